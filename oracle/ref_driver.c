@@ -1,0 +1,105 @@
+/*
+ * oracle/ref_driver.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Thin C-ABI around the reference's OWN compiled ac/ac.c and wu/wu.c
+ * (linked from /root/reference by oracle/Makefile into oracle/_ref/libref.so).
+ * It does what main.c does around the hot path and nothing more:
+ *   - table allocation / initialisation conventions  main.c:410-420, 429-449
+ *   - m_nBitsInShift = 2                             main.c:431
+ *   - preproc then search, timed separately          main.c:125-157, 268-298
+ * Pattern buffers are m+1 bytes, zero padded, because ac_addstring evaluates
+ * string[m] after a fully existing path (ac/ac.c:136-143).
+ */
+#include "smatcher.h" /* the reference's header, found with -I/root/reference */
+#include <time.h>
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+unsigned int ref_shiftsize(int alphabet)
+{
+    wu_determine_shiftsize(alphabet);
+    return shiftsize;
+}
+
+/* tables are caller-owned, sized as main.c:410-420; they are initialised here */
+unsigned long long ref_run_ac(const unsigned char *pat_flat, int m, int p_size, int alphabet,
+                              const unsigned char *text, int n, int *state_transition,
+                              unsigned int *state_supply, unsigned int *state_final,
+                              unsigned int *idcounter, unsigned int *patterncounter,
+                              double *t_preproc, double *t_search)
+{
+    size_t rows = (size_t)m * p_size + 1;
+    memset(state_transition, -1, rows * alphabet * sizeof(int));
+    memset(state_supply, 0, rows * sizeof(unsigned int));
+    memset(state_final, 0, rows * sizeof(unsigned int));
+
+    unsigned char **pattern = (unsigned char **)malloc((size_t)p_size * sizeof(unsigned char *));
+    for (int j = 0; j < p_size; j++) {
+        pattern[j] = (unsigned char *)calloc((size_t)m + 1, 1);
+        memcpy(pattern[j], pat_flat + (size_t)j * m, (size_t)m);
+    }
+    double t0 = now_s();
+    struct ac_table *table = preproc_ac(pattern, m, p_size, alphabet, state_transition,
+                                        state_supply, state_final);
+    double t1 = now_s();
+    unsigned int matches = text ? search_ac((unsigned char *)text, n, table) : 0;
+    double t2 = now_s();
+    if (idcounter) *idcounter = table->idcounter;
+    if (patterncounter) *patterncounter = table->patterncounter;
+    if (t_preproc) *t_preproc = t1 - t0;
+    if (t_search) *t_search = t2 - t1;
+    free_ac(table, alphabet);
+    for (int j = 0; j < p_size; j++) free(pattern[j]);
+    free(pattern);
+    return matches;
+}
+
+/* which: 0 = preproc_wu/search_wu (char**), 1 = preproc_wu2/search_wu2 (flat) */
+unsigned long long ref_run_wu(const unsigned char *pat_flat, int m, int p_size, int alphabet,
+                              const unsigned char *text, int n, int *SHIFT, int *PREFIX_value,
+                              int *PREFIX_index, int *PREFIX_size, int which,
+                              double *t_preproc, double *t_search)
+{
+    const int B = 3; /* main.c:335 */
+    wu_determine_shiftsize(alphabet);
+    m_nBitsInShift = 2;
+    for (unsigned int i = 0; i < shiftsize; i++) {
+        SHIFT[i] = m - B + 1;
+        PREFIX_size[i] = 0;
+    }
+    unsigned int matches = 0;
+    double t0, t1, t2;
+    if (which == 0) {
+        unsigned char **pattern = (unsigned char **)malloc((size_t)p_size * sizeof(unsigned char *));
+        for (int j = 0; j < p_size; j++) {
+            pattern[j] = (unsigned char *)malloc((size_t)m);
+            memcpy(pattern[j], pat_flat + (size_t)j * m, (size_t)m);
+        }
+        t0 = now_s();
+        preproc_wu(pattern, m, p_size, alphabet, B, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
+        t1 = now_s();
+        if (text)
+            matches = search_wu(pattern, m, p_size, (unsigned char *)text, n, SHIFT, PREFIX_value,
+                                PREFIX_index, PREFIX_size);
+        t2 = now_s();
+        for (int j = 0; j < p_size; j++) free(pattern[j]);
+        free(pattern);
+    } else {
+        t0 = now_s();
+        preproc_wu2((unsigned char *)pat_flat, m, p_size, alphabet, B, SHIFT, PREFIX_value,
+                    PREFIX_index, PREFIX_size);
+        t1 = now_s();
+        if (text)
+            matches = search_wu2((unsigned char *)pat_flat, m, p_size, (unsigned char *)text, n,
+                                 SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
+        t2 = now_s();
+    }
+    if (t_preproc) *t_preproc = t1 - t0;
+    if (t_search) *t_search = t2 - t1;
+    return matches;
+}
