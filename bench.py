@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbit/s of text scanned by the MI355X multi-pattern matcher.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+through torch.distributed.run, one rank per GPU, RCCL (backend "nccl").  Rank 0 prints ONE JSON
+line.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 1 GiB of synthetic
+4-letter DNA text per GPU, resident in HBM before the timed region, 1 000 patterns per set with
+pattern lengths 8-32.  The reference API carries ONE pattern length per run (smatcher.h:89-106),
+so "len 8-32" is a sweep of fixed-length sets, m = 8, 16, 32; one STEP = one
+Aho-Corasick pass over the rank's text for each of the three sets (3 GiB of text scanned per GPU
+per step), and for N > 1 one RCCL all-reduce of the three 64-bit counts (the reference's
+MPI_Reduce, main.c:656).  value = bits scanned by all ranks / wall time of the K steps.
+
+N > 1 is weak scaling: every rank holds its own 1 GiB byte range (+ m-1 halo) of one N GiB text
+(shard formula main.c:467-477); there is no data-path collective.
+
+Extra objects on the JSON line: `roofline` (HBM bound; achieved = algorithmic bytes per launch,
+1 byte per text symbol, / mean launch duration measured with events on the launch stream),
+`cpu_baseline` (the reference's own compiled search_ac, oracle/_ref, or the oracle port when that
+is absent, single thread, on a bounded prefix of the same text), `ac` / `wm` per-configuration
+rates (WM = BASELINE configs[2]: same text, 10 000 patterns of length 8) and `parity`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd")
+sys.path.insert(0, PKG)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+TEXT_SEED, PAT_SEED, SIGMA = 42, 7, 4
+AC_LENGTHS = (8, 16, 32)
+AC_PATTERNS = 1000
+WM_PATTERNS, WM_LENGTH = 10000, 8
+
+
+def cpu_baseline(text_prefix, pats):
+    """Reference CPU path timed on this box's host cores (rank 0, N = 1 only).  Checker code:
+    the only place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    kind = "reference" if O.have_ref() else "port"
+    secs, counts = 0.0, {}
+    for m, pat in pats.items():
+        if kind == "reference":
+            cnt, _, _, ts = O.ref_ac(pat, m, AC_PATTERNS, SIGMA, text_prefix)
+        else:
+            t0 = time.perf_counter()
+            _, tabs = O.oracle_ac(pat, m, AC_PATTERNS, SIGMA)
+            t0 = time.perf_counter()
+            cnt = O.oracle_ac_search_tables(text_prefix, SIGMA, tabs)
+            ts = time.perf_counter() - t0
+        secs += ts
+        counts[m] = cnt
+    bits = 8.0 * len(text_prefix) * len(pats)
+    return dict(value=bits / secs / 1e9, unit="Gbit/s", cores=1, kind=kind,
+                sample="search_ac (ac/ac.c:198-222) over the first %d MiB of the same text, m=%s, %d patterns each, "
+                       "1 thread, %.1f s" % (len(text_prefix) >> 20, "/".join(str(m) for m in pats), AC_PATTERNS, secs)), counts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mib-per-gpu", type=int, default=1024, help="text bytes per GPU in MiB (BASELINE: 1024)")
+    ap.add_argument("--cpu-sample-mib", type=int, default=96)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-wm", action="store_true", help="skip the WM (configs[2]) side measurement")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import smatcher_hip as S
+    import sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available() or S.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the scan path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    per_gpu = args.mib_per_gpu << 20
+    n_total = per_gpu * world
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # ---- pattern sets (host) and compiled automata
+    pats = {m: S.corpus_patterns(m, AC_PATTERNS, PAT_SEED, SIGMA, TEXT_SEED, n_total, 2) for m in AC_LENGTHS}
+    acs = {m: S.AcAutomaton.from_patterns(pats[m], m, AC_PATTERNS, SIGMA) for m in AC_LENGTHS}
+    halo = max(AC_LENGTHS) - 1
+
+    # ---- this rank's byte range of the N GiB text, generated in HBM (never crosses PCIe)
+    begin = rank * per_gpu
+    shard_ends = {m: sharded.shard_for_rank(n_total, world, rank, m) for m in AC_LENGTHS}
+    for m in AC_LENGTHS:
+        assert shard_ends[m][0] == begin
+    n_alloc = min(per_gpu + halo, n_total - begin)
+    text = torch.empty(n_alloc + 64, dtype=torch.uint8, device=dev)
+    rc = S.lib.smh_corpus_text_device(C.c_void_p(text.data_ptr()), n_alloc, begin, TEXT_SEED, SIGMA, C.c_void_p(stream))
+    if rc != 0:
+        raise SystemExit("corpus generation failed: " + S.lib.smh_last_error().decode())
+    counts = torch.zeros(len(AC_LENGTHS), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def shard_len(m):
+        b, e = shard_ends[m]
+        return e - b
+
+    def step(events=None):
+        counts.zero_()
+        for i, m in enumerate(AC_LENGTHS):
+            if events is not None:
+                events[i][0].record()
+            acs[m].scan_device(text.data_ptr(), shard_len(m), counts.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
+            if events is not None:
+                events[i][1].record()
+        sharded.reduce_count(counts)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in AC_LENGTHS]
+           for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_counts = [int(x) for x in counts.tolist()]
+
+    # per-launch durations (ms) from the events on the launch stream
+    kern_ms = {m: [evs[k][i][0].elapsed_time(evs[k][i][1]) for k in range(args.steps)] for i, m in enumerate(AC_LENGTHS)}
+    bits_per_step = 8.0 * sum(shard_len(m) for m in AC_LENGTHS)
+    if world > 1:
+        t = torch.tensor([bits_per_step], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        bits_per_step = float(t.item())
+    value = bits_per_step * args.steps / elapsed / 1e9
+
+    out = None
+    if rank == 0:
+        mean = lambda xs: sum(xs) / len(xs)
+        ac_detail = {}
+        for m in AC_LENGTHS:
+            info = acs[m].info()
+            ms = mean(kern_ms[m])
+            gbs = shard_len(m) / (ms * 1e-3) / 1e9
+            ac_detail["m%d" % m] = dict(kernel_ms=round(ms, 4), min_ms=round(min(kern_ms[m]), 4), GBps=round(gbs, 1),
+                                        Gbit_s=round(8 * gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
+                                        dfa_rows=info.rows, lds_rows=info.lds_rows, lds_bytes=info.lds_bytes,
+                                        matches=total_counts[AC_LENGTHS.index(m)])
+        dom = max(AC_LENGTHS, key=lambda m: mean(kern_ms[m]))
+        dom_ms = mean(kern_ms[dom])
+        achieved = shard_len(dom) / (dom_ms * 1e-3) / 1e9
+        roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        kernel="ac_dfa_kernel (m=%d set)" % dom, launch_ms=round(dom_ms, 4),
+                        algorithmic_bytes_per_launch=shard_len(dom))
+        out = {
+            "metric": "Gbit/s text scanned (AC and WM) at 1/2/4/8 MI355X; % HBM roofline",
+            "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "AC on MI355X: %d MiB synthetic DNA text per GPU resident in HBM, %d patterns per set, "
+                                   "pattern lengths 8-32 as fixed-length sets m=8/16/32 (BASELINE configs[1]); "
+                                   "step = 3 scans + count all-reduce" % (args.mib_per_gpu, AC_PATTERNS),
+                       "text_bytes_per_gpu": per_gpu, "alphabet": SIGMA, "patterns": AC_PATTERNS,
+                       "pattern_lengths": list(AC_LENGTHS), "text_seed": TEXT_SEED, "pattern_seed": PAT_SEED,
+                       "sharding": "byte-range x%d, m-1 halo, RCCL sum of counts" % world},
+            "roofline": roofline, "ac": ac_detail, "device": S.device_name(),
+        }
+
+    # ---- WM side measurement (BASELINE configs[2]: same text, 10 000 patterns of length 8)
+    if not args.no_wm:
+        wpat = S.corpus_patterns(WM_LENGTH, WM_PATTERNS, PAT_SEED + 1, SIGMA, TEXT_SEED, n_total, 2)
+        wm = S.WmTables.from_patterns(wpat, WM_LENGTH, WM_PATTERNS, SIGMA)
+        wb, we = sharded.shard_for_rank(n_total, world, rank, WM_LENGTH)
+        wcount = torch.zeros(1, dtype=torch.int64, device=dev)
+        wm.scan_device(text.data_ptr(), we - wb, wcount.data_ptr(), S.VARIANT_TUNED, stream)
+        torch.cuda.synchronize()
+        wev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for a, b in wev:
+            wcount.zero_()
+            a.record()
+            wm.scan_device(text.data_ptr(), we - wb, wcount.data_ptr(), S.VARIANT_TUNED, stream)
+            b.record()
+        torch.cuda.synchronize()
+        wms = [a.elapsed_time(b) for a, b in wev]
+        sharded.reduce_count(wcount)
+        if rank == 0:
+            wi = wm.info()
+            ms = sum(wms) / len(wms)
+            gbs = (we - wb) / (ms * 1e-3) / 1e9
+            out["wm"] = dict(workload="WM: same text, %d patterns of length %d (BASELINE configs[2]); per-GPU kernel rate"
+                                      % (WM_PATTERNS, WM_LENGTH),
+                             kernel_ms=round(ms, 4), min_ms=round(min(wms), 4), GBps=round(gbs, 1), Gbit_s=round(8 * gbs, 1),
+                             hbm_frac=round(gbs / HBM_PEAK_GBS, 4), matches=int(wcount.item()),
+                             block_symbols=wi.block_symbols, filter_log2=wi.filter_log2, filter_exact=wi.filter_exact,
+                             shift_zero="%d/%d" % (wi.shift_zero, wi.shiftsize))
+
+    # ---- CPU baseline + bit-exact parity on a bounded prefix (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sample = min(args.cpu_sample_mib << 20, per_gpu)
+        prefix = S.corpus_text(sample, TEXT_SEED, SIGMA, offset=0)
+        assert np.array_equal(prefix[:4096], text[:4096].cpu().numpy()), "device and host corpus differ"
+        base, cpu_counts = cpu_baseline(prefix, pats)
+        gpu_counts = {}
+        c1 = torch.zeros(1, dtype=torch.int64, device=dev)
+        for m in AC_LENGTHS:
+            c1.zero_()
+            acs[m].scan_device(text.data_ptr(), sample, c1.data_ptr(), S.VARIANT_TUNED, stream)
+            torch.cuda.synchronize()
+            gpu_counts[m] = int(c1.item())
+        out["cpu_baseline"] = base
+        out["parity"] = dict(bit_exact=all(gpu_counts[m] == cpu_counts[m] for m in AC_LENGTHS),
+                             gpu_counts=gpu_counts, cpu_counts=cpu_counts, sample_bytes=sample)
+        if not out["parity"]["bit_exact"]:
+            print(json.dumps(out))
+            raise SystemExit("PARITY FAILURE: GPU counts differ from the CPU reference")
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,393 @@
+/*
+ * csrc/ac_host.c -- host side of the Aho-Corasick path (plain C).
+ *
+ *   preproc_ac / free_ac      drop-in for ac/ac.c:224-252: fills the caller's
+ *                             state_transition / state_supply / state_final
+ *                             exactly as the reference does.
+ *   smh_ac_compile_tables     goto/supply/final tables -> complete DFA laid out
+ *                             for the gfx950 kernels (smh_internal.h).
+ *
+ * Design notes (how this differs from the reference, not what it computes):
+ *   - the trie lives directly in the caller's flat state_transition table
+ *     (-1 = no edge; row 0: 0 = no edge), no node structs or per-node malloc
+ *     (reference: ac/ac.c:148-171);
+ *   - failure links come from an array-queue BFS, O(states * alphabet)
+ *     (reference: list_append walks the whole queue, ac/list.h:57-74 -> quadratic);
+ *   - search never runs on the host: search_ac (smh_runtime.hip) launches the kernel.
+ */
+#include "smh_internal.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ errors */
+static __thread char g_err[512];
+
+void smh_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+const char *smh_last_error(void) { return g_err; }
+const char *smh_version(void) { return "mi355x-smatcher 0.1 (gfx950)"; }
+
+/* reference: fail() from the absent ../helper2.h -- message, then exit */
+void fail(const char *msg)
+{
+    fputs(msg, stderr);
+    exit(1);
+}
+
+/* ------------------------------------------------------------------ preproc_ac */
+static inline int has_edge(const int *trans, uint32_t state, int32_t v)
+{
+    (void)trans;
+    return state == 0 ? v > 0 : v != -1;
+}
+
+struct ac_table *preproc_ac(unsigned char **pattern, int m, int p_size, int alphabet,
+                            int *state_transition, unsigned int *state_supply,
+                            unsigned int *state_final)
+{
+    if (m < 1 || p_size < 0 || alphabet < 1 || alphabet > 256)
+        fail("preproc_ac: bad arguments\n");
+    struct smh_ac_table_box *box = (struct smh_ac_table_box *)calloc(1, sizeof *box);
+    if (!box) fail("Could not initialize table\n");
+
+    const size_t A = (size_t)alphabet;
+    /* ac_init, ac/ac.c:59-62: row 0 of the flat table is all zero */
+    for (int c = 0; c < alphabet; ++c) state_transition[c] = 0;
+    uint32_t idcounter = 1, patterncounter = 0;
+
+    /* ac_addstring, ac/ac.c:127-196: new state id = creation order */
+    for (int j = 0; j < p_size; ++j) {
+        const unsigned char *s = pattern[j];
+        uint32_t state = 0;
+        for (int i = 0; i < m; ++i) {
+            unsigned c = s[i];
+            if ((int)c >= alphabet) fail("preproc_ac: pattern symbol outside the alphabet\n");
+            int32_t nx = state_transition[state * A + c];
+            if (!has_edge(state_transition, state, nx)) {
+                nx = (int32_t)idcounter++;
+                state_transition[state * A + c] = nx;
+            }
+            state = (uint32_t)nx;
+        }
+        if (!state_final[state]) {
+            state_final[state] = 1;
+            ++patterncounter;
+        }
+    }
+
+    /* ac_maketree, ac/ac.c:79-124: breadth-first failure links; like the reference they are
+     * kept privately (struct ac_state.fail there, failv[] here) and exported to
+     * state_supply[] for depth >= 2 states only (ac/ac.c:114) */
+    uint32_t *queue = (uint32_t *)malloc((size_t)idcounter * sizeof(uint32_t));
+    uint32_t *failv = (uint32_t *)calloc((size_t)idcounter, sizeof(uint32_t));
+    if (!queue || !failv) fail("Could not allocate memory\n");
+    size_t head = 0, tail = 0;
+    for (int c = 0; c < alphabet; ++c)
+        if (state_transition[c] > 0) queue[tail++] = (uint32_t)state_transition[c];
+    while (head < tail) {
+        uint32_t cur = queue[head++];
+        for (int c = 0; c < alphabet; ++c) {
+            int32_t s = state_transition[cur * A + c];
+            if (s == -1) continue;
+            queue[tail++] = (uint32_t)s;
+            uint32_t st = failv[cur];
+            int32_t t;
+            for (;;) {
+                t = state_transition[st * A + c];
+                if (st == 0 || t != -1) break;
+                st = failv[st];
+            }
+            /* at the root a missing edge reads 0 == the root itself (ac/ac.c:86-88) */
+            failv[s] = (uint32_t)t;
+            state_supply[s] = (uint32_t)t;
+        }
+    }
+    free(queue);
+    free(failv);
+
+    box->pub.idcounter = idcounter;
+    box->pub.patterncounter = patterncounter;
+    box->root.id = 0;
+    box->root.keywordline = 0;
+    box->root.output = NULL;
+    box->root.fail = &box->root;
+    box->root.next = (struct ac_state **)malloc(A * sizeof(struct ac_state *));
+    if (!box->root.next) fail("Could not allocate memory\n");
+    for (int c = 0; c < alphabet; ++c) box->root.next[c] = &box->root;
+    box->pub.zerostate = &box->root;
+    box->magic = SMH_MAGIC_AC;
+    box->ac = smh_ac_compile_tables_impl(state_transition, state_supply, state_final,
+                                         (uint64_t)idcounter, alphabet, m);
+    if (!box->ac) {
+        fputs(smh_last_error(), stderr);
+        fail("\npreproc_ac: could not compile the automaton\n");
+    }
+    return &box->pub;
+}
+
+void free_ac(struct ac_table *table, int alphabet)
+{
+    (void)alphabet;
+    if (!table) return;
+    struct smh_ac_table_box *box = (struct smh_ac_table_box *)table;
+    if (box->magic != SMH_MAGIC_AC) fail("free_ac: not a table from preproc_ac\n");
+    smh_ac_free(box->ac);
+    free(box->root.next);
+    box->magic = 0;
+    free(box);
+}
+
+/* ------------------------------------------------------------------ DFA compile */
+void smh_ac_host_free(struct smh_ac *ac)
+{
+    if (!ac) return;
+    free(ac->table);
+    free(ac->depth_first);
+    free(ac->g_transition);
+    free(ac->g_supply);
+    free(ac->g_final);
+    ac->magic = 0;
+    free(ac);
+}
+
+struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *supply,
+                                          const unsigned int *final, uint64_t rows_in,
+                                          int alphabet, int m)
+{
+    if (!trans || !supply || !final || rows_in < 1 || alphabet < 1 || alphabet > 256 || m < 1) {
+        smh_set_error("smh_ac_compile_tables: bad arguments");
+        return NULL;
+    }
+    if (rows_in > 0x7FFFFFFFull) {
+        smh_set_error("smh_ac_compile_tables: more than 2^31 states");
+        return NULL;
+    }
+    const size_t A = (size_t)alphabet;
+    const uint32_t R = (uint32_t)rows_in;
+
+    /* 1. breadth-first sweep over goto edges: order, depth, leaf flag */
+    uint32_t *order = (uint32_t *)malloc((size_t)R * sizeof(uint32_t));
+    uint32_t *depth = (uint32_t *)malloc((size_t)R * sizeof(uint32_t));
+    uint8_t *seen = (uint8_t *)calloc(R, 1);
+    uint8_t *leaf = (uint8_t *)malloc(R);
+    uint32_t *canon = (uint32_t *)malloc((size_t)R * sizeof(uint32_t));
+    uint32_t *newid = (uint32_t *)malloc((size_t)R * sizeof(uint32_t));
+    struct smh_ac *ac = (struct smh_ac *)calloc(1, sizeof *ac);
+    uint32_t *full = NULL;
+    if (!order || !depth || !seen || !leaf || !canon || !newid || !ac) goto oom;
+
+    size_t head = 0, tail = 0;
+    order[tail++] = 0;
+    depth[0] = 0;
+    seen[0] = 1;
+    uint32_t max_id = 0;
+    while (head < tail) {
+        uint32_t cur = order[head++];
+        int kids = 0;
+        for (int c = 0; c < alphabet; ++c) {
+            int32_t s = trans[cur * A + c];
+            if (!has_edge(trans, cur, s)) continue;
+            if ((uint32_t)s >= R || seen[s]) {
+                smh_set_error("smh_ac_compile_tables: state_transition is not a trie "
+                              "(edge %u -> %d)", cur, s);
+                goto bad;
+            }
+            seen[s] = 1;
+            depth[s] = depth[cur] + 1;
+            order[tail++] = (uint32_t)s;
+            if ((uint32_t)s > max_id) max_id = (uint32_t)s;
+            ++kids;
+        }
+        leaf[cur] = kids == 0;
+    }
+    const uint32_t nstates = (uint32_t)tail;
+
+    /* 2. fold leaves onto their supply chain; number the kept states breadth-first */
+    uint32_t rows = 0, finals = 0;
+    int fixed_ok = 1;
+    for (uint32_t k = 0; k < nstates; ++k) {
+        uint32_t u = order[k];
+        uint32_t sup = depth[u] <= 1 ? 0u : supply[u];
+        if (u != 0 && (sup >= R || !seen[sup] || depth[sup] >= depth[u])) {
+            smh_set_error("smh_ac_compile_tables: bad supply link %u -> %u", u, sup);
+            goto bad;
+        }
+        if (final[u]) {
+            ++finals;
+            if (!leaf[u] || depth[u] != (uint32_t)m) fixed_ok = 0;
+        } else if (leaf[u] && u != 0) {
+            fixed_ok = 0; /* a non-accepting leaf cannot come from preproc_ac */
+        }
+        if (u == 0 || !leaf[u]) {
+            canon[u] = u;
+            newid[u] = rows++;
+        } else {
+            canon[u] = canon[sup];
+            newid[u] = 0xFFFFFFFFu;
+        }
+    }
+
+    /* 3. complete the transition function over kept states, breadth-first:
+     *    delta(s,c) = goto(s,c) if defined, else delta(supply(s),c)   (ac/ac.c:209-211) */
+    full = (uint32_t *)malloc((size_t)rows * A * sizeof(uint32_t));
+    if (!full) goto oom;
+    for (uint32_t k = 0; k < nstates; ++k) {
+        uint32_t u = order[k];
+        if (canon[u] != u) continue;
+        uint32_t *row = full + (size_t)newid[u] * A;
+        if (u == 0) {
+            for (int c = 0; c < alphabet; ++c) {
+                int32_t s = trans[c];
+                row[c] = has_edge(trans, 0, s) ? (uint32_t)s : 0u;
+            }
+        } else {
+            uint32_t sup = depth[u] <= 1 ? 0u : supply[u];
+            const uint32_t *srow = full + (size_t)newid[canon[sup]] * A;
+            for (int c = 0; c < alphabet; ++c) {
+                int32_t s = trans[u * A + c];
+                row[c] = s != -1 ? (uint32_t)s : srow[c];
+            }
+        }
+    }
+
+    /* 4. encode: entry = row(canon(target)) | FLAG(final[target]) */
+    ac->magic = SMH_MAGIC_AC;
+    ac->alphabet = alphabet;
+    ac->m = m;
+    ac->states = nstates;
+    ac->finals = finals;
+    ac->rows = rows;
+    ac->fixed_length_ok = fixed_ok;
+    ac->entry_bytes = rows <= 32768u ? 2 : 4;
+    ac->table_bytes = (uint64_t)rows * A * (uint64_t)ac->entry_bytes;
+    ac->table = malloc((size_t)ac->table_bytes);
+    if (!ac->table) goto oom;
+    for (size_t i = 0; i < (size_t)rows * A; ++i) {
+        uint32_t t = full[i];
+        uint32_t r = newid[canon[t]];
+        if (ac->entry_bytes == 2)
+            ((uint16_t *)ac->table)[i] = (uint16_t)(r | (final[t] ? 0x8000u : 0u));
+        else
+            ((uint32_t *)ac->table)[i] = r | (final[t] ? 0x80000000u : 0u);
+    }
+
+    /* 5. depth_first[d] = first row whose depth >= d (rows are in BFS order) */
+    int max_depth = 0;
+    for (uint32_t k = 0; k < nstates; ++k)
+        if (canon[order[k]] == order[k] && (int)depth[order[k]] > max_depth)
+            max_depth = (int)depth[order[k]];
+    ac->max_depth = max_depth;
+    ac->depth_first = (uint32_t *)malloc((size_t)(max_depth + 2) * sizeof(uint32_t));
+    if (!ac->depth_first) goto oom;
+    {
+        int d = 0;
+        uint32_t r = 0;
+        for (uint32_t k = 0; k < nstates; ++k) {
+            uint32_t u = order[k];
+            if (canon[u] != u) continue;
+            while (d <= (int)depth[u]) ac->depth_first[d++] = r;
+            ++r;
+        }
+        while (d <= max_depth + 1) ac->depth_first[d++] = rows;
+    }
+
+    /* 6. reference-layout copy, truncated to the ids in use, for SMH_VARIANT_TABLE */
+    {
+        size_t keep = (size_t)max_id + 1;
+        ac->g_transition = (int32_t *)malloc(keep * A * sizeof(int32_t));
+        ac->g_supply = (uint32_t *)malloc(keep * sizeof(uint32_t));
+        ac->g_final = (uint32_t *)malloc(keep * sizeof(uint32_t));
+        if (!ac->g_transition || !ac->g_supply || !ac->g_final) goto oom;
+        memcpy(ac->g_transition, trans, keep * A * sizeof(int32_t));
+        for (size_t u = 0; u < keep; ++u) {
+            /* depth <= 1 states: the reference never writes their supply entry; the walk needs 0 */
+            ac->g_supply[u] = (seen[u] && depth[u] >= 2) ? supply[u] : 0u;
+            ac->g_final[u] = seen[u] ? (final[u] ? 1u : 0u) : 0u;
+        }
+        ac->states = (uint32_t)keep; /* == idcounter when the tables came from preproc_ac */
+    }
+
+    free(order); free(depth); free(seen); free(leaf); free(canon); free(newid); free(full);
+    return ac;
+
+oom:
+    smh_set_error("smh_ac_compile_tables: out of memory");
+bad:
+    free(order); free(depth); free(seen); free(leaf); free(canon); free(newid); free(full);
+    smh_ac_host_free(ac);
+    return NULL;
+}
+
+smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *state_supply,
+                              const unsigned int *state_final, uint64_t rows, int alphabet, int m)
+{
+    return smh_ac_compile_tables_impl(state_transition, state_supply, state_final, rows, alphabet, m);
+}
+
+smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet)
+{
+    if (!pattern_flat || m < 1 || p_size < 1 || alphabet < 1 || alphabet > 256) {
+        smh_set_error("smh_ac_compile_patterns: bad arguments");
+        return NULL;
+    }
+    for (size_t i = 0; i < (size_t)m * p_size; ++i)
+        if ((int)pattern_flat[i] >= alphabet) {
+            smh_set_error("smh_ac_compile_patterns: symbol %u >= alphabet %d", pattern_flat[i], alphabet);
+            return NULL;
+        }
+    /* the reference-layout tables, sized and initialised as main.c:410-420 does */
+    size_t rows = (size_t)m * p_size + 1;
+    int *trans = (int *)malloc(rows * alphabet * sizeof(int));
+    unsigned int *supply = (unsigned int *)calloc(rows, sizeof(unsigned int));
+    unsigned int *final = (unsigned int *)calloc(rows, sizeof(unsigned int));
+    unsigned char **ptrs = (unsigned char **)malloc((size_t)p_size * sizeof(unsigned char *));
+    if (!trans || !supply || !final || !ptrs) {
+        free(trans); free(supply); free(final); free(ptrs);
+        smh_set_error("smh_ac_compile_patterns: out of memory");
+        return NULL;
+    }
+    memset(trans, -1, rows * alphabet * sizeof(int));
+    for (int j = 0; j < p_size; ++j) ptrs[j] = (unsigned char *)pattern_flat + (size_t)j * m;
+    struct ac_table *t = preproc_ac(ptrs, m, p_size, alphabet, trans, supply, final);
+    struct smh_ac_table_box *box = (struct smh_ac_table_box *)t;
+    smh_ac *ac = box->ac;
+    box->ac = NULL;
+    free_ac(t, alphabet);
+    free(trans); free(supply); free(final); free(ptrs);
+    return ac;
+}
+
+int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC || !out) {
+        smh_set_error("smh_ac_get_info: bad handle");
+        return SMH_EINVAL;
+    }
+    memset(out, 0, sizeof *out);
+    out->alphabet = (uint32_t)ac->alphabet;
+    out->m = (uint32_t)ac->m;
+    out->states = ac->states;
+    out->finals = ac->finals;
+    out->rows = ac->rows;
+    out->entry_bytes = (uint32_t)ac->entry_bytes;
+    out->table_bytes = ac->table_bytes;
+    extern void smh_ac_lds_plan(const struct smh_ac *ac, uint32_t *lds_rows, uint32_t *lds_bytes);
+    smh_ac_lds_plan(ac, &out->lds_rows, &out->lds_bytes);
+    return SMH_OK;
+}
+
+void smh_ac_free(smh_ac *ac)
+{
+    if (!ac) return;
+    if (ac->dev) smh_ac_dev_free(ac->dev);
+    ac->dev = NULL;
+    smh_ac_host_free(ac);
+}

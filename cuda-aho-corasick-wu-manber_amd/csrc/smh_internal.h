@@ -1,0 +1,134 @@
+/*
+ * csrc/smh_internal.h -- layouts shared by the C host code (ac_host.c, wm_host.c,
+ * corpus.c) and the HIP side (smh_runtime.hip, *_kernels.hip).  Not installed.
+ */
+#ifndef SMH_INTERNAL_H
+#define SMH_INTERNAL_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/smatcher.h"
+#include "../../include/smatcher_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMH_MAGIC_AC 0x41434446u /* "ACDF" */
+#define SMH_MAGIC_WM 0x574d424cu /* "WMBL" */
+
+void smh_set_error(const char *fmt, ...);
+
+/* ------------------------------------------------------------------ AC
+ * Device DFA (DESIGN.md "AC layout"): one row per kept state, `alphabet`
+ * entries per row, entry = next row | FLAG.  FLAG (top bit) says the
+ * reference automaton is in an accepting state after this transition.
+ * Accepting leaves have no row: a transition into leaf f is stored as
+ * (row of supply*(f)) | FLAG, exact because a leaf's goto is undefined for
+ * every symbol and the walk continues from its supply state (ac/ac.c:209-211).
+ * Rows are numbered breadth-first, so row id order == depth order.
+ */
+struct smh_ac_dev; /* opaque to C: device buffers, owned by smh_runtime.hip */
+
+struct smh_ac {
+    uint32_t magic;
+    int alphabet;
+    int m;
+    uint32_t states;      /* reachable states, reference numbering */
+    uint32_t finals;      /* accepting states */
+    uint32_t rows;        /* kept states == DFA rows */
+    int entry_bytes;      /* 2: FLAG = 0x8000, rows <= 32768; 4: FLAG = 0x80000000 */
+    void *table;          /* rows * alphabet entries, host copy */
+    uint64_t table_bytes;
+    int max_depth;        /* depth of the deepest kept row */
+    uint32_t *depth_first; /* [max_depth + 2]: first row with depth >= d; [max_depth+1] = rows */
+    int fixed_length_ok;  /* every accepting state is a leaf at depth m (chunked scans are exact) */
+    /* reference-layout tables truncated to `states` rows, for SMH_VARIANT_TABLE */
+    int32_t *g_transition; /* states * alphabet, -1 = no edge, row 0 as ac_init leaves it */
+    uint32_t *g_supply;
+    uint32_t *g_final;
+    struct smh_ac_dev *dev;
+};
+
+/* private wrapper handed out by preproc_ac: the public struct first, so a
+ * struct ac_table* from the caller can be cast back */
+struct smh_ac_table_box {
+    struct ac_table pub;
+    uint32_t magic;
+    struct smh_ac *ac;
+    struct ac_state root;
+};
+
+/* host-side builders (ac_host.c) */
+struct smh_ac *smh_ac_compile_tables_impl(const int *state_transition, const unsigned int *state_supply,
+                                          const unsigned int *state_final, uint64_t rows,
+                                          int alphabet, int m);
+void smh_ac_host_free(struct smh_ac *ac);
+void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
+
+/* ------------------------------------------------------------------ WM
+ * Device tables (DESIGN.md "WM layout"):
+ *   filter   : bit set in LDS indexed by the code of the window's last
+ *              `block_symbols` symbols (bits_per_symbol each) -- the device
+ *              SHIFT table: bit = 1  <=>  SHIFT_dev[block] == 0.  Either direct
+ *              (index = code) or hashed (two bits of one 32-bit word, picked by a
+ *              multiplicative hash of the code).
+ *   verify   : open-addressing table in HBM keyed by FNV-1a of the whole window,
+ *              {tag, pattern+1}; the device HASH/PREFIX stage.  Absent when the
+ *              filter is exact (block == whole pattern, direct index).
+ *   patterns : distinct patterns, sorted, m bytes each.
+ *   legacy   : the reference tables (SHIFT, PREFIX_* as CSR) for SMH_VARIANT_TABLE.
+ */
+struct smh_wm_dev;
+
+struct smh_wm {
+    uint32_t magic;
+    int alphabet;
+    int m;
+    int patterns;
+    int distinct;
+    int bits_per_symbol;
+    /* tuned path */
+    int block_symbols;
+    int filter_log2;      /* bits in the filter = 1 << filter_log2 (>= 5) */
+    int filter_exact;
+    int filter_hashed;
+    uint32_t *filter;     /* (1 << filter_log2) / 32 words */
+    double filter_density; /* fraction of windows expected to pass on uniform text */
+    int verify_log2;      /* slots = 1 << verify_log2; 0 slots when exact */
+    uint32_t *verify;     /* 2 words per slot: tag, pattern index + 1 (0 = empty) */
+    unsigned char *pat_sorted; /* distinct * m */
+    /* reference-layout tables */
+    uint32_t shiftsize;
+    uint32_t shift_zero;
+    int32_t *l_shift;       /* shiftsize */
+    uint32_t *l_bucket_off; /* shiftsize + 1 */
+    int32_t *l_bucket;      /* 2 ints per entry: PREFIX_value, PREFIX_index */
+    unsigned char *pat_orig; /* patterns * m, original order (PREFIX_index refers to it) */
+    struct smh_wm_dev *dev;
+};
+
+struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int p_size, int alphabet,
+                                   const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
+                                   const int *PREFIX_size);
+void smh_wm_host_free(struct smh_wm *wm);
+void smh_wm_dev_free(struct smh_wm_dev *dev); /* smh_runtime.hip */
+
+/* hashes shared by host table build and device lookup -- keep in sync with wm_kernels.hip */
+#define SMH_HASH_MUL 0x9E3779B1u
+static inline uint32_t smh_fnv1a32(const unsigned char *s, int len)
+{
+    uint32_t h = 0x811C9DC5u;
+    for (int i = 0; i < len; ++i) {
+        h ^= s[i];
+        h *= 0x01000193u;
+    }
+    return h;
+}
+
+uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

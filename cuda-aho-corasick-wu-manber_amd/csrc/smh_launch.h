@@ -1,0 +1,80 @@
+/*
+ * csrc/smh_launch.h -- launch entry points of the kernel translation units,
+ * called by smh_runtime.hip.  All take a hipStream_t and return hipError_t.
+ */
+#ifndef SMH_LAUNCH_H
+#define SMH_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SMH_BLOCK_THREADS 1024
+#define SMH_LDS_BUDGET (156u * 1024u) /* of the 160 KiB per CU; the rest is left to the runtime */
+#define SMH_MAX_HALO_CHUNKS 4          /* fast paths cover m - 1 <= 64 */
+#define SMH_DEPTH_FIRST_LEN 72         /* padded depth_first[] the AC kernels index with h + 1 <= 65 */
+
+struct smh_ac_launch {
+    const uint8_t *d_text;
+    uint64_t n;
+    int m;
+    int alphabet;
+    int entry_bytes;
+    const void *d_table;        /* rows * alphabet entries */
+    uint32_t rows;
+    uint32_t lds_rows;
+    uint32_t lds_bytes;         /* multiple of 16 */
+    const uint32_t *d_depth_first; /* SMH_DEPTH_FIRST_LEN entries */
+    uint64_t *d_count;
+    int n_cus;
+};
+hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream);
+
+struct smh_ac_table_launch {
+    const uint8_t *d_text;
+    uint64_t n;
+    int m;
+    int alphabet;
+    const int32_t *d_transition;
+    const uint32_t *d_supply;
+    const uint32_t *d_final;
+    uint64_t *d_count;
+    int n_cus;
+};
+hipError_t smh_launch_ac_table(const smh_ac_table_launch &L, hipStream_t stream);
+
+struct smh_wm_launch {
+    const uint8_t *d_text;
+    uint64_t n;
+    int m;
+    int bits;
+    int block_symbols;
+    int filter_log2;
+    int filter_hashed;
+    int filter_exact;
+    const uint32_t *d_filter;
+    int verify_log2;
+    const uint32_t *d_verify;
+    const uint8_t *d_pat_sorted;
+    uint64_t *d_count;
+    int n_cus;
+};
+hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream);
+
+struct smh_wm_table_launch {
+    const uint8_t *d_text;
+    uint64_t n;
+    int m;
+    uint32_t shiftsize;
+    const uint16_t *d_shift;     /* SHIFT narrowed to 16 bits */
+    const uint32_t *d_bucket_off;
+    const int32_t *d_bucket;
+    const uint8_t *d_pat_orig;
+    uint64_t *d_count;
+    int n_cus;
+};
+hipError_t smh_launch_wm_table(const smh_wm_table_launch &L, hipStream_t stream);
+
+hipError_t smh_launch_corpus_text(uint8_t *d_out, uint64_t n, uint64_t offset, uint64_t seed,
+                                  int alphabet, hipStream_t stream);
+
+#endif

@@ -1,0 +1,485 @@
+/*
+ * csrc/smh_runtime.hip -- the C-ABI shim between the C host code and the HIP kernels.
+ *
+ *   - device-side copies of the compiled tables (uploaded lazily, once per handle)
+ *   - smh_ac_scan / smh_wm_scan: asynchronous launches on the caller's stream
+ *   - the blocking *_count_host helpers (upload text, scan, download the count)
+ *   - the legacy entry points with the reference's shapes: search_ac, search_wu,
+ *     search_wu2 (smatcher.h:90,105-106) and cuda_ac1..5 / cuda_wm1..5
+ *     (cuda/cuda_ac.cu:594-1072, cuda/cuda_wm.cu:183-1180)
+ *
+ * There is no CPU search path here: when no HIP device is usable the extended
+ * API returns SMH_ENODEV and the legacy names print the reason and exit(1).
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "smh_internal.h"
+#include "smh_launch.h"
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            smh_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SMH_ENODEV;                                                            \
+        }                                                                                 \
+    } while (0)
+
+struct smh_ac_dev {
+    int device;
+    void *d_table;
+    uint32_t *d_depth_first;
+    int32_t *d_transition;
+    uint32_t *d_supply;
+    uint32_t *d_final;
+    uint32_t lds_rows, lds_bytes;
+};
+
+struct smh_wm_dev {
+    int device;
+    uint32_t *d_filter;
+    uint32_t *d_verify;
+    uint8_t *d_pat_sorted;
+    uint16_t *d_shift;
+    uint32_t *d_bucket_off;
+    int32_t *d_bucket;
+    uint8_t *d_pat_orig;
+};
+
+static int g_n_cus = 0;
+static int g_n_cus_dev = -1;
+
+static int current_cus(int *n_cus)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev != g_n_cus_dev) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        g_n_cus = prop.multiProcessorCount;
+        g_n_cus_dev = dev;
+    }
+    *n_cus = g_n_cus > 0 ? g_n_cus : 256;
+    return SMH_OK;
+}
+
+/* ------------------------------------------------------------------ runtime wrappers */
+extern "C" int smh_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+extern "C" int smh_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return SMH_OK;
+}
+
+extern "C" int smh_device_name(char *buf, size_t cap)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, cap, "%s %s (%d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return SMH_OK;
+}
+
+extern "C" int smh_device_malloc(void **dptr, uint64_t bytes)
+{
+    if (!dptr) { smh_set_error("smh_device_malloc: NULL"); return SMH_EINVAL; }
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return SMH_OK;
+}
+
+extern "C" int smh_device_free(void *dptr)
+{
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return SMH_OK;
+}
+
+extern "C" int smh_device_memset(void *dptr, int value, uint64_t bytes, void *stream)
+{
+    HIP_TRY(hipMemsetAsync(dptr, value, bytes, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_copy_to_device(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_copy_to_host(void *dst, const void *src, uint64_t bytes, void *stream)
+{
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_stream_synchronize(void *stream)
+{
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_corpus_text_device(unsigned char *d_out, uint64_t n, uint64_t offset, uint64_t seed,
+                                      int alphabet, void *stream)
+{
+    if (!d_out || alphabet < 1 || alphabet > 256) { smh_set_error("smh_corpus_text_device: bad arguments"); return SMH_EINVAL; }
+    if (((uintptr_t)d_out & 15u) != 0) { smh_set_error("smh_corpus_text_device: buffer must be 16-byte aligned"); return SMH_EINVAL; }
+    HIP_TRY(smh_launch_corpus_text(d_out, n, offset, seed, alphabet, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+/* upload `bytes` of host data into a fresh device buffer padded to `pad_to` extra readable bytes */
+static int upload(void **d, const void *h, size_t bytes, size_t pad)
+{
+    size_t total = ((bytes + pad + 15) / 16) * 16;
+    if (total < 16) total = 16;
+    HIP_TRY(hipMalloc(d, total));
+    HIP_TRY(hipMemset(*d, 0, total));
+    if (bytes) HIP_TRY(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+    return SMH_OK;
+}
+
+/* ------------------------------------------------------------------ AC */
+/* rows staged in LDS: as many whole rows as fit the budget (all of them when the DFA is small) */
+extern "C" void smh_ac_lds_plan(const struct smh_ac *ac, uint32_t *lds_rows, uint32_t *lds_bytes)
+{
+    const uint64_t row_bytes = (uint64_t)ac->alphabet * (uint64_t)ac->entry_bytes;
+    uint64_t rows = SMH_LDS_BUDGET / row_bytes;
+    if (rows > ac->rows) rows = ac->rows;
+    if (rows < 1) rows = 1;
+    uint64_t bytes = (rows * row_bytes + 15u) & ~(uint64_t)15u;
+    *lds_rows = (uint32_t)rows;
+    *lds_bytes = (uint32_t)bytes;
+}
+
+extern "C" void smh_ac_dev_free(struct smh_ac_dev *dev)
+{
+    if (!dev) return;
+    (void)hipFree(dev->d_table);
+    (void)hipFree(dev->d_depth_first);
+    (void)hipFree(dev->d_transition);
+    (void)hipFree(dev->d_supply);
+    (void)hipFree(dev->d_final);
+    delete dev;
+}
+
+static int ac_ensure_device(struct smh_ac *ac)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (ac->dev && ac->dev->device == dev) return SMH_OK;
+    if (ac->dev) { smh_ac_dev_free(ac->dev); ac->dev = NULL; }
+    smh_ac_dev *d = new smh_ac_dev();
+    memset(d, 0, sizeof *d);
+    d->device = dev;
+    ac->dev = d;
+    smh_ac_lds_plan(ac, &d->lds_rows, &d->lds_bytes);
+    int rc;
+    /* 256 entries of slack: a text byte >= alphabet may index just past the last row */
+    if ((rc = upload(&d->d_table, ac->table, (size_t)ac->table_bytes, 256 * 4)) != SMH_OK) return rc;
+    std::vector<uint32_t> df(SMH_DEPTH_FIRST_LEN, ac->rows);
+    for (int i = 0; i <= ac->max_depth + 1 && i < SMH_DEPTH_FIRST_LEN; ++i) df[i] = ac->depth_first[i];
+    if ((rc = upload((void **)&d->d_depth_first, df.data(), df.size() * 4, 0)) != SMH_OK) return rc;
+    const size_t A = (size_t)ac->alphabet;
+    if ((rc = upload((void **)&d->d_transition, ac->g_transition, (size_t)ac->states * A * 4, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_supply, ac->g_supply, (size_t)ac->states * 4, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_final, ac->g_final, (size_t)ac->states * 4, 0)) != SMH_OK) return rc;
+    return SMH_OK;
+}
+
+extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
+                           void *stream)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC || !d_count || (n && !d_text)) {
+        smh_set_error("smh_ac_scan: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (((uintptr_t)d_text & 15u) != 0) {
+        smh_set_error("smh_ac_scan: d_text must be 16-byte aligned");
+        return SMH_EINVAL;
+    }
+    if (!ac->fixed_length_ok) {
+        smh_set_error("smh_ac_scan: the automaton's accepting states are not all leaves at depth m = %d; "
+                      "the segmented scan is exact only for patterns of one length (as is the reference's "
+                      "GPU path, cuda/cuda_ac.cu:31-34)", ac->m);
+        return SMH_EUNSUP;
+    }
+    if (n < (uint64_t)ac->m) return SMH_OK;
+    int rc = ac_ensure_device(ac);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    if (variant == SMH_VARIANT_TABLE) {
+        smh_ac_table_launch L;
+        L.d_text = d_text; L.n = n; L.m = ac->m; L.alphabet = ac->alphabet;
+        L.d_transition = ac->dev->d_transition; L.d_supply = ac->dev->d_supply; L.d_final = ac->dev->d_final;
+        L.d_count = d_count; L.n_cus = n_cus;
+        HIP_TRY(smh_launch_ac_table(L, (hipStream_t)stream));
+    } else if (variant == SMH_VARIANT_TUNED) {
+        smh_ac_launch L;
+        L.d_text = d_text; L.n = n; L.m = ac->m; L.alphabet = ac->alphabet; L.entry_bytes = ac->entry_bytes;
+        L.d_table = ac->dev->d_table; L.rows = ac->rows; L.lds_rows = ac->dev->lds_rows;
+        L.lds_bytes = ac->dev->lds_bytes; L.d_depth_first = ac->dev->d_depth_first; L.d_count = d_count;
+        L.n_cus = n_cus;
+        HIP_TRY(smh_launch_ac_dfa(L, (hipStream_t)stream));
+    } else {
+        smh_set_error("smh_ac_scan: unknown variant %d", variant);
+        return SMH_EINVAL;
+    }
+    return SMH_OK;
+}
+
+/* shared by the two *_count_host helpers: text up, zeroed counter, timed launch, count down */
+template <typename Launch>
+static int count_host(const unsigned char *text, uint64_t n, uint64_t *count, double *kernel_seconds, Launch launch)
+{
+    if (!count || (n && !text)) { smh_set_error("count_host: bad arguments"); return SMH_EINVAL; }
+    *count = 0;
+    if (kernel_seconds) *kernel_seconds = 0.0;
+    unsigned char *d_text = NULL;
+    uint64_t *d_count = NULL;
+    hipEvent_t ev0 = NULL, ev1 = NULL;
+    int rc = SMH_OK;
+    float ms = 0.f;
+#define CH_TRY(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            smh_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            rc = SMH_ENODEV;                                                               \
+            goto done;                                                                     \
+        }                                                                                  \
+    } while (0)
+    CH_TRY(hipMalloc((void **)&d_text, ((n + 15) / 16) * 16 + 16));
+    CH_TRY(hipMalloc((void **)&d_count, 16));
+    CH_TRY(hipMemset(d_count, 0, 16));
+    if (n) CH_TRY(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
+    CH_TRY(hipEventCreate(&ev0));
+    CH_TRY(hipEventCreate(&ev1));
+    CH_TRY(hipEventRecord(ev0, 0));
+    rc = launch(d_text, d_count);
+    if (rc != SMH_OK) goto done;
+    CH_TRY(hipEventRecord(ev1, 0));
+    CH_TRY(hipEventSynchronize(ev1));
+    CH_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    CH_TRY(hipMemcpy(count, d_count, 8, hipMemcpyDeviceToHost));
+    if (kernel_seconds) *kernel_seconds = (double)ms / 1000.0;
+done:
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    (void)hipFree(d_text);
+    (void)hipFree(d_count);
+    return rc;
+#undef CH_TRY
+}
+
+extern "C" int smh_ac_count_host(smh_ac *ac, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
+                                 double *kernel_seconds)
+{
+    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
+        return smh_ac_scan(ac, d_text, n, d_count, variant, NULL);
+    });
+}
+
+/* ------------------------------------------------------------------ WM */
+extern "C" void smh_wm_dev_free(struct smh_wm_dev *dev)
+{
+    if (!dev) return;
+    (void)hipFree(dev->d_filter);
+    (void)hipFree(dev->d_verify);
+    (void)hipFree(dev->d_pat_sorted);
+    (void)hipFree(dev->d_shift);
+    (void)hipFree(dev->d_bucket_off);
+    (void)hipFree(dev->d_bucket);
+    (void)hipFree(dev->d_pat_orig);
+    delete dev;
+}
+
+static int wm_ensure_device(struct smh_wm *wm)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (wm->dev && wm->dev->device == dev) return SMH_OK;
+    if (wm->dev) { smh_wm_dev_free(wm->dev); wm->dev = NULL; }
+    smh_wm_dev *d = new smh_wm_dev();
+    memset(d, 0, sizeof *d);
+    d->device = dev;
+    wm->dev = d;
+    int rc;
+    const size_t fbytes = ((size_t)1 << wm->filter_log2) / 8;
+    if ((rc = upload((void **)&d->d_filter, wm->filter, fbytes, 0)) != SMH_OK) return rc;
+    if (!wm->filter_exact) {
+        if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 8, 0)) != SMH_OK) return rc;
+    }
+    if ((rc = upload((void **)&d->d_pat_sorted, wm->pat_sorted, (size_t)wm->distinct * wm->m, 0)) != SMH_OK) return rc;
+    std::vector<uint16_t> sh(wm->shiftsize);
+    for (uint32_t i = 0; i < wm->shiftsize; ++i) {
+        int32_t v = wm->l_shift[i];
+        sh[i] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
+    }
+    if ((rc = upload((void **)&d->d_shift, sh.data(), sh.size() * 2, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_bucket_off, wm->l_bucket_off, ((size_t)wm->shiftsize + 1) * 4, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_bucket, wm->l_bucket, (size_t)wm->l_bucket_off[wm->shiftsize] * 8, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_pat_orig, wm->pat_orig, (size_t)wm->patterns * wm->m, 0)) != SMH_OK) return rc;
+    return SMH_OK;
+}
+
+extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
+                           void *stream)
+{
+    if (!wm || wm->magic != SMH_MAGIC_WM || !d_count || (n && !d_text)) {
+        smh_set_error("smh_wm_scan: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (((uintptr_t)d_text & 15u) != 0) {
+        smh_set_error("smh_wm_scan: d_text must be 16-byte aligned");
+        return SMH_EINVAL;
+    }
+    if (n < (uint64_t)wm->m) return SMH_OK;
+    int rc = wm_ensure_device(wm);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    if (variant == SMH_VARIANT_TABLE) {
+        smh_wm_table_launch L;
+        L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = wm->dev->d_shift;
+        L.d_bucket_off = wm->dev->d_bucket_off; L.d_bucket = wm->dev->d_bucket; L.d_pat_orig = wm->dev->d_pat_orig;
+        L.d_count = d_count; L.n_cus = n_cus;
+        HIP_TRY(smh_launch_wm_table(L, (hipStream_t)stream));
+    } else if (variant == SMH_VARIANT_TUNED) {
+        smh_wm_launch L;
+        L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
+        L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_exact = wm->filter_exact;
+        L.d_filter = wm->dev->d_filter; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
+        L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_count = d_count; L.n_cus = n_cus;
+        HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
+    } else {
+        smh_set_error("smh_wm_scan: unknown variant %d", variant);
+        return SMH_EINVAL;
+    }
+    return SMH_OK;
+}
+
+extern "C" int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
+                                 double *kernel_seconds)
+{
+    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
+        return smh_wm_scan(wm, d_text, n, d_count, variant, NULL);
+    });
+}
+
+/* ------------------------------------------------------------------ legacy names (smatcher.h) */
+static void die_with_error(const char *where)
+{
+    fprintf(stderr, "%s: %s\n", where, smh_last_error());
+    exit(1);
+}
+
+/* smatcher.h:90 / ac/ac.c:198-222 -- same count, computed by ac_dfa_kernel */
+extern "C" unsigned search_ac(unsigned char *text, int n, struct ac_table *table)
+{
+    struct smh_ac_table_box *box = (struct smh_ac_table_box *)table;
+    if (!box || box->magic != SMH_MAGIC_AC) fail("search_ac: not a table from preproc_ac\n");
+    uint64_t count = 0;
+    if (smh_ac_count_host(box->ac, text, n < 0 ? 0 : (uint64_t)n, SMH_VARIANT_TUNED, &count, NULL) != SMH_OK)
+        die_with_error("search_ac");
+    return (unsigned)count;
+}
+
+static void cuda_ac_any(int k, int variant, int m, unsigned char *text, int n, int p_size, int alphabet,
+                        int *state_transition, unsigned int *state_supply, unsigned int *state_final)
+{
+    smh_ac *ac = smh_ac_compile_tables(state_transition, state_supply, state_final, (uint64_t)m * p_size + 1,
+                                       alphabet, m);
+    if (!ac) die_with_error("cuda_ac");
+    uint64_t count = 0;
+    double secs = 0.0;
+    if (smh_ac_count_host(ac, text, n < 0 ? 0 : (uint64_t)n, variant, &count, &secs) != SMH_OK)
+        die_with_error("cuda_ac");
+    /* cuda/cuda_ac.cu:675 */
+    printf("Kernel %d matches \t%i\t time \t%f\n", k, (int)count, secs);
+    smh_ac_free(ac);
+}
+
+#define SMH_CUDA_AC(K, VARIANT)                                                                            \
+    extern "C" void cuda_ac##K(int m, unsigned char *text, int n, int p_size, int alphabet,                \
+                               int *state_transition, unsigned int *state_supply, unsigned int *state_final) \
+    {                                                                                                      \
+        cuda_ac_any(K, VARIANT, m, text, n, p_size, alphabet, state_transition, state_supply, state_final); \
+    }
+SMH_CUDA_AC(1, SMH_VARIANT_TABLE)
+SMH_CUDA_AC(2, SMH_VARIANT_TABLE)
+SMH_CUDA_AC(3, SMH_VARIANT_TUNED)
+SMH_CUDA_AC(4, SMH_VARIANT_TUNED)
+SMH_CUDA_AC(5, SMH_VARIANT_TUNED)
+
+/* the caller's alphabet is not an argument of search_wu*: recover it from the global
+ * shiftsize = (alphabet-1)*21+1 that wu_determine_shiftsize set (wu/wu.c:18-47) */
+static int alphabet_from_shiftsize(void)
+{
+    static const int known[] = {2, 4, 8, 20, 128, 256, 512, 1024};
+    for (size_t i = 0; i < sizeof known / sizeof known[0]; ++i)
+        if (smh_wu_shiftsize_for(known[i]) == shiftsize) return known[i];
+    fail("search_wu: call wu_determine_shiftsize first\n");
+    return 0;
+}
+
+static unsigned int wm_any(const unsigned char *flat, int m, int p_size, int alphabet, unsigned char *text, int n,
+                           int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size, int variant,
+                           double *secs)
+{
+    smh_wm *wm = smh_wm_compile_tables(flat, m, p_size, alphabet, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
+    if (!wm) die_with_error("wu-manber");
+    uint64_t count = 0;
+    if (smh_wm_count_host(wm, text, n < 0 ? 0 : (uint64_t)n, variant, &count, secs) != SMH_OK)
+        die_with_error("wu-manber");
+    smh_wm_free(wm);
+    return (unsigned int)count;
+}
+
+/* smatcher.h:106 / wu/wu.c:151-209 */
+extern "C" unsigned int search_wu2(unsigned char *pattern_flat, int m, int p_size, unsigned char *text, int n,
+                                   int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size)
+{
+    return wm_any(pattern_flat, m, p_size, alphabet_from_shiftsize(), text, n, SHIFT, PREFIX_value, PREFIX_index,
+                  PREFIX_size, SMH_VARIANT_TUNED, NULL);
+}
+
+/* smatcher.h:105 / wu/wu.c:49-107 */
+extern "C" unsigned int search_wu(unsigned char **pattern, int m, int p_size, unsigned char *text, int n,
+                                  int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size)
+{
+    std::vector<unsigned char> flat((size_t)m * (size_t)p_size);
+    for (int j = 0; j < p_size; ++j) memcpy(flat.data() + (size_t)j * m, pattern[j], (size_t)m);
+    return wm_any(flat.data(), m, p_size, alphabet_from_shiftsize(), text, n, SHIFT, PREFIX_value, PREFIX_index,
+                  PREFIX_size, SMH_VARIANT_TUNED, NULL);
+}
+
+#define SMH_CUDA_WM(K, VARIANT)                                                                              \
+    extern "C" int cuda_wm##K(unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size,    \
+                              int alphabet, int B, int *SHIFT, int *PREFIX_value, int *PREFIX_index,         \
+                              int *PREFIX_size, double *gpuTime)                                             \
+    {                                                                                                        \
+        (void)B;                                                                                             \
+        double secs = 0.0;                                                                                   \
+        unsigned int c = wm_any(pattern_flat, m, p_size, alphabet, text, n, SHIFT, PREFIX_value, PREFIX_index, \
+                                PREFIX_size, VARIANT, &secs);                                                \
+        if (gpuTime) *gpuTime = secs; /* cuda/cuda_wm.cu:302 */                                              \
+        return (int)c;                                                                                       \
+    }
+SMH_CUDA_WM(1, SMH_VARIANT_TABLE)
+SMH_CUDA_WM(2, SMH_VARIANT_TABLE)
+SMH_CUDA_WM(3, SMH_VARIANT_TUNED)
+SMH_CUDA_WM(4, SMH_VARIANT_TUNED)
+SMH_CUDA_WM(5, SMH_VARIANT_TUNED)

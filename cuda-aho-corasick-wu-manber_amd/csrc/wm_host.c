@@ -1,0 +1,361 @@
+/*
+ * csrc/wm_host.c -- host side of the Wu-Manber path (plain C).
+ *
+ *   wu_determine_shiftsize / preproc_wu / preproc_wu2
+ *        drop-ins for wu/wu.c:18-47, :109-149, :211-251: the caller's SHIFT and
+ *        PREFIX_* arrays are filled exactly as the reference fills them.
+ *   smh_wm_compile / smh_wm_compile_tables
+ *        patterns (+ reference tables) -> device layout of DESIGN.md "WM layout":
+ *        an LDS block filter (the device SHIFT table), an HBM verify table (the
+ *        device HASH/PREFIX stage) and the reference tables as CSR buckets.
+ *
+ * How the device layout differs from the reference's (not what it computes):
+ *   - PREFIX_value / PREFIX_index are dense [shiftsize x p_size] arrays in the
+ *     reference (main.c:436-439: 2 x 2.1 GB at alphabet 256, 100 000 patterns);
+ *     here they are packed into CSR buckets before they leave the host;
+ *   - the reference's block is fixed at 3 symbols with a 2-bit shift hash
+ *     (wu/wu.c:63-67), which on a 4-letter alphabet makes every SHIFT entry 0
+ *     from ~1000 patterns up; the device block is as wide as the LDS allows
+ *     (up to the whole pattern), so its SHIFT == 0 test actually filters.
+ */
+#include "smh_internal.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+unsigned short m_nBitsInShift = 2; /* smatcher.h:71; main.c:431 sets 2 */
+unsigned int shiftsize = 0;        /* smatcher.h:73 */
+
+/* wu/wu.c:18-47: (alphabet-1)*21 + 1 for the alphabets the reference lists */
+uint32_t smh_wu_shiftsize_for(int alphabet)
+{
+    static const int known[] = {2, 4, 8, 20, 128, 256, 512, 1024};
+    for (size_t i = 0; i < sizeof known / sizeof known[0]; ++i)
+        if (alphabet == known[i]) return (uint32_t)(alphabet - 1) * 21u + 1u;
+    return 0;
+}
+
+void wu_determine_shiftsize(int alphabet)
+{
+    uint32_t s = smh_wu_shiftsize_for(alphabet);
+    if (!s) fail("The alphabet size is not supported by wu-manber\n");
+    shiftsize = s;
+}
+
+/* one table build for both pattern representations: stride = m for the flat
+ * form, rows[] for the pointer form */
+static void wu_fill(const unsigned char *flat, unsigned char *const *rows, int m, int p_size, int B,
+                    int nbits, int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size)
+{
+    if (B != 3) fail("preproc_wu: the block hash covers 3 symbols, B must be 3\n");
+    if (m < 3) fail("preproc_wu: patterns must have at least 3 symbols\n");
+    for (int j = 0; j < p_size; ++j) {
+        const unsigned char *P = rows ? rows[j] : flat + (size_t)j * m;
+        /* blocks ending at offsets m-1 (shift 0) down to B-1 (shift m-B): wu/wu.c:119-131 */
+        for (int end = m - 1; end >= B - 1; --end) {
+            unsigned h = (((unsigned)P[end - 2] << nbits) + P[end - 1] << nbits) + P[end];
+            int shiftlen = m - 1 - end;
+            if (shiftlen < SHIFT[h]) SHIFT[h] = shiftlen;
+            if (shiftlen == 0) {
+                size_t slot = (size_t)h * p_size + (size_t)PREFIX_size[h];
+                PREFIX_value[slot] = (int)(((unsigned)P[0] << nbits) + P[1]); /* wu/wu.c:136-138 */
+                PREFIX_index[slot] = j;
+                PREFIX_size[h]++;
+            }
+        }
+    }
+}
+
+void preproc_wu(unsigned char **pattern, int m, int p_size, int alphabet, int B, int *SHIFT,
+                int *PREFIX_value, int *PREFIX_index, int *PREFIX_size)
+{
+    (void)alphabet; /* the reference ignores it too */
+    wu_fill(NULL, pattern, m, p_size, B, m_nBitsInShift, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
+}
+
+void preproc_wu2(unsigned char *pattern_flat, int m, int p_size, int alphabet, int B, int *SHIFT,
+                 int *PREFIX_value, int *PREFIX_index, int *PREFIX_size)
+{
+    (void)alphabet;
+    wu_fill(pattern_flat, NULL, m, p_size, B, m_nBitsInShift, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
+}
+
+/* ------------------------------------------------------------------ device layout */
+void smh_wm_host_free(struct smh_wm *wm)
+{
+    if (!wm) return;
+    free(wm->filter);
+    free(wm->verify);
+    free(wm->pat_sorted);
+    free(wm->l_shift);
+    free(wm->l_bucket_off);
+    free(wm->l_bucket);
+    free(wm->pat_orig);
+    wm->magic = 0;
+    free(wm);
+}
+
+static int g_sort_m;
+static int cmp_rows(const void *a, const void *b) { return memcmp(a, b, (size_t)g_sort_m); }
+
+static int ceil_log2_u32(uint32_t v)
+{
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+
+/* code of the `w` symbols ending at s[0], oldest symbol in the highest bits --
+ * the value the kernels hold in their rolling register (wm_kernels.hip) */
+static uint32_t block_code(const unsigned char *s_last, int w, int bits)
+{
+    uint64_t code = 0;
+    for (int i = w - 1; i >= 0; --i) code = (code << bits) | s_last[-i];
+    return (uint32_t)code;
+}
+
+#define SMH_WM_FILTER_LOG2_MAX 20 /* 2^20 bits = 128 KiB of LDS */
+
+struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int p_size, int alphabet,
+                                   const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
+                                   const int *PREFIX_size)
+{
+    if (!pattern_flat || m < 3 || p_size < 1 || alphabet < 2 || alphabet > 256) {
+        smh_set_error("smh_wm_compile: bad arguments (need m >= 3, p_size >= 1, 2 <= alphabet <= 256)");
+        return NULL;
+    }
+    uint32_t ssz = smh_wu_shiftsize_for(alphabet);
+    if (!ssz) {
+        smh_set_error("The alphabet size is not supported by wu-manber");
+        return NULL;
+    }
+    for (size_t i = 0; i < (size_t)m * p_size; ++i)
+        if ((int)pattern_flat[i] >= alphabet) {
+            smh_set_error("smh_wm_compile: symbol %u >= alphabet %d", pattern_flat[i], alphabet);
+            return NULL;
+        }
+    struct smh_wm *wm = (struct smh_wm *)calloc(1, sizeof *wm);
+    if (!wm) goto oom;
+    wm->magic = SMH_MAGIC_WM;
+    wm->alphabet = alphabet;
+    wm->m = m;
+    wm->patterns = p_size;
+    wm->shiftsize = ssz;
+    wm->bits_per_symbol = ceil_log2_u32((uint32_t)alphabet);
+
+    /* ---- reference-layout tables ----
+     * caller's dense tables (preproc_wu / preproc_wu2 output)  ->  CSR buckets, or
+     * built here straight into CSR: same SHIFT values and the same bucket order
+     * (pattern index ascending, wu/wu.c:140-143) without the dense
+     * [shiftsize x p_size] arrays of main.c:436-439 */
+    wm->l_shift = (int32_t *)malloc((size_t)ssz * sizeof(int32_t));
+    wm->l_bucket_off = (uint32_t *)calloc((size_t)ssz + 1, sizeof(uint32_t));
+    if (!wm->l_shift || !wm->l_bucket_off) goto oom;
+    if (SHIFT) {
+        uint64_t total = 0;
+        for (uint32_t h = 0; h < ssz; ++h) {
+            wm->l_shift[h] = SHIFT[h];
+            if (PREFIX_size[h] < 0 || PREFIX_size[h] > p_size) {
+                smh_set_error("smh_wm_compile_tables: PREFIX_size[%u] = %d out of range", h, PREFIX_size[h]);
+                goto bad;
+            }
+            wm->l_bucket_off[h] = (uint32_t)total;
+            total += (uint64_t)PREFIX_size[h];
+        }
+        wm->l_bucket_off[ssz] = (uint32_t)total;
+        wm->l_bucket = (int32_t *)malloc((size_t)(total ? total : 1) * 2 * sizeof(int32_t));
+        if (!wm->l_bucket) goto oom;
+        for (uint32_t h = 0; h < ssz; ++h)
+            for (int i = 0; i < PREFIX_size[h]; ++i) {
+                size_t src = (size_t)h * p_size + (size_t)i;
+                size_t dst = (size_t)wm->l_bucket_off[h] + (size_t)i;
+                if (PREFIX_index[src] < 0 || PREFIX_index[src] >= p_size) {
+                    smh_set_error("smh_wm_compile_tables: PREFIX_index out of range");
+                    goto bad;
+                }
+                wm->l_bucket[2 * dst] = PREFIX_value[src];
+                wm->l_bucket[2 * dst + 1] = PREFIX_index[src];
+            }
+    } else {
+        const int nbits = 2, B = 3;
+        for (uint32_t h = 0; h < ssz; ++h) wm->l_shift[h] = m - B + 1; /* main.c:444-449 */
+        uint32_t *fillpos = (uint32_t *)calloc(ssz, sizeof(uint32_t));
+        wm->l_bucket = (int32_t *)malloc((size_t)p_size * 2 * sizeof(int32_t));
+        if (!fillpos || !wm->l_bucket) { free(fillpos); goto oom; }
+        for (int j = 0; j < p_size; ++j) {
+            const unsigned char *P = pattern_flat + (size_t)j * m;
+            for (int end = m - 1; end >= B - 1; --end) {
+                unsigned h = (((unsigned)P[end - 2] << nbits) + P[end - 1] << nbits) + P[end];
+                if (m - 1 - end < wm->l_shift[h]) wm->l_shift[h] = m - 1 - end;
+            }
+            unsigned hs = (((unsigned)P[m - 3] << nbits) + P[m - 2] << nbits) + P[m - 1];
+            wm->l_bucket_off[hs + 1]++;
+        }
+        for (uint32_t h = 0; h < ssz; ++h) wm->l_bucket_off[h + 1] += wm->l_bucket_off[h];
+        for (int j = 0; j < p_size; ++j) {
+            const unsigned char *P = pattern_flat + (size_t)j * m;
+            unsigned hs = (((unsigned)P[m - 3] << nbits) + P[m - 2] << nbits) + P[m - 1];
+            size_t dst = (size_t)wm->l_bucket_off[hs] + fillpos[hs]++;
+            wm->l_bucket[2 * dst] = (int32_t)(((unsigned)P[0] << nbits) + P[1]);
+            wm->l_bucket[2 * dst + 1] = j;
+        }
+        free(fillpos);
+    }
+    for (uint32_t h = 0; h < ssz; ++h)
+        if (wm->l_shift[h] == 0) wm->shift_zero++;
+    wm->pat_orig = (unsigned char *)malloc((size_t)p_size * m);
+    if (!wm->pat_orig) goto oom;
+    memcpy(wm->pat_orig, pattern_flat, (size_t)p_size * m);
+
+    /* ---- distinct patterns, sorted ---- */
+    wm->pat_sorted = (unsigned char *)malloc((size_t)p_size * m);
+    if (!wm->pat_sorted) goto oom;
+    memcpy(wm->pat_sorted, pattern_flat, (size_t)p_size * m);
+    g_sort_m = m;
+    qsort(wm->pat_sorted, (size_t)p_size, (size_t)m, cmp_rows);
+    int d = 0;
+    for (int j = 0; j < p_size; ++j)
+        if (j == 0 || memcmp(wm->pat_sorted + (size_t)j * m, wm->pat_sorted + (size_t)(d - 1) * m, (size_t)m) != 0) {
+            if (d != j) memmove(wm->pat_sorted + (size_t)d * m, wm->pat_sorted + (size_t)j * m, (size_t)m);
+            ++d;
+        }
+    wm->distinct = d;
+
+    /* ---- block filter (device SHIFT table, one bit per block code: 1 <=> SHIFT_dev == 0) ----
+     * direct : block = last W symbols, W*bits <= 20, bit index = code
+     * hashed : block = last min(m, 32/bits) symbols, two bits of one word chosen by a
+     *          multiplicative hash (blocked Bloom filter, k = 2)
+     * exact  : direct and W == m  ->  a set bit IS a match, no verify stage            */
+    const int bits = wm->bits_per_symbol;
+    int Wd = SMH_WM_FILTER_LOG2_MAX / bits;
+    if (Wd > m) Wd = m;
+    if (Wd < 1) Wd = 1;
+    int Td = Wd * bits;
+    if (Td < 5) Td = 5;
+    /* density of the direct filter = distinct block codes / 2^Td */
+    uint32_t *direct = (uint32_t *)calloc((size_t)1 << (Td - 5), sizeof(uint32_t));
+    if (!direct) goto oom;
+    uint64_t dset = 0;
+    for (int j = 0; j < d; ++j) {
+        uint32_t code = block_code(wm->pat_sorted + (size_t)j * m + (m - 1), Wd, bits);
+        uint32_t w = code >> 5, b = 1u << (code & 31);
+        if (!(direct[w] & b)) { direct[w] |= b; ++dset; }
+    }
+    double direct_density = (double)dset / (double)(1ull << Td);
+    int exact = (Wd == m);
+    int Wh = 32 / bits;
+    if (Wh > m) Wh = m;
+    int use_hashed = !exact && Wh > Wd && direct_density > 1.0 / 64.0;
+    if (use_hashed) {
+        const int Th = SMH_WM_FILTER_LOG2_MAX;
+        uint32_t *hashed = (uint32_t *)calloc((size_t)1 << (Th - 5), sizeof(uint32_t));
+        if (!hashed) { free(direct); goto oom; }
+        const int wbits = Wh * bits;
+        const uint32_t kmask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
+        for (int j = 0; j < d; ++j) {
+            uint32_t key = block_code(wm->pat_sorted + (size_t)j * m + (m - 1), Wh, bits) & kmask;
+            uint32_t h = key * SMH_HASH_MUL;
+            uint32_t w = h >> (32 - (Th - 5));
+            uint32_t b1 = (h >> (32 - (Th - 5) - 5)) & 31u, b2 = (h >> (32 - (Th - 5) - 10)) & 31u;
+            hashed[w] |= (1u << b1) | (1u << b2);
+        }
+        /* pass probability of a random key: mean over words of P(both picked bits set) */
+        double acc = 0;
+        for (size_t w = 0; w < ((size_t)1 << (Th - 5)); ++w) {
+            double f = (double)__builtin_popcount(hashed[w]) / 32.0;
+            acc += f * f;
+        }
+        double hashed_density = acc / (double)((size_t)1 << (Th - 5));
+        if (hashed_density < direct_density) {
+            free(direct);
+            wm->filter = hashed;
+            wm->filter_hashed = 1;
+            wm->filter_log2 = Th;
+            wm->block_symbols = Wh;
+            wm->filter_density = hashed_density;
+        } else {
+            free(hashed);
+            use_hashed = 0;
+        }
+    }
+    if (!use_hashed) {
+        wm->filter = direct;
+        wm->filter_hashed = 0;
+        wm->filter_log2 = Td;
+        wm->block_symbols = Wd;
+        wm->filter_density = direct_density;
+        wm->filter_exact = exact;
+    }
+
+    /* ---- verify table (device HASH/PREFIX stage): FNV-1a(window) -> {tag, pattern + 1} ---- */
+    if (!wm->filter_exact) {
+        int lg = ceil_log2_u32((uint32_t)d * 2u);
+        if (lg < 4) lg = 4;
+        wm->verify_log2 = lg;
+        size_t slots = (size_t)1 << lg;
+        wm->verify = (uint32_t *)calloc(slots * 2, sizeof(uint32_t));
+        if (!wm->verify) goto oom;
+        for (int j = 0; j < d; ++j) {
+            uint32_t tag = smh_fnv1a32(wm->pat_sorted + (size_t)j * m, m);
+            size_t s = (size_t)((tag * SMH_HASH_MUL) >> (32 - lg));
+            while (wm->verify[2 * s + 1]) s = (s + 1) & (slots - 1);
+            wm->verify[2 * s] = tag;
+            wm->verify[2 * s + 1] = (uint32_t)j + 1u;
+        }
+    }
+
+    return wm;
+
+oom:
+    smh_set_error("smh_wm_compile: out of memory");
+bad:
+    smh_wm_host_free(wm);
+    return NULL;
+}
+
+smh_wm *smh_wm_compile(const unsigned char *pattern_flat, int m, int p_size, int alphabet)
+{
+    return smh_wm_compile_impl(pattern_flat, m, p_size, alphabet, NULL, NULL, NULL, NULL);
+}
+
+smh_wm *smh_wm_compile_tables(const unsigned char *pattern_flat, int m, int p_size, int alphabet,
+                              const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
+                              const int *PREFIX_size)
+{
+    if (!SHIFT || !PREFIX_value || !PREFIX_index || !PREFIX_size) {
+        smh_set_error("smh_wm_compile_tables: NULL table");
+        return NULL;
+    }
+    return smh_wm_compile_impl(pattern_flat, m, p_size, alphabet, SHIFT, PREFIX_value, PREFIX_index,
+                               PREFIX_size);
+}
+
+int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
+{
+    if (!wm || wm->magic != SMH_MAGIC_WM || !out) {
+        smh_set_error("smh_wm_get_info: bad handle");
+        return SMH_EINVAL;
+    }
+    memset(out, 0, sizeof *out);
+    out->alphabet = (uint32_t)wm->alphabet;
+    out->m = (uint32_t)wm->m;
+    out->patterns = (uint32_t)wm->patterns;
+    out->distinct = (uint32_t)wm->distinct;
+    out->shiftsize = wm->shiftsize;
+    out->shift_zero = wm->shift_zero;
+    out->block_symbols = (uint32_t)wm->block_symbols;
+    out->filter_log2 = (uint32_t)wm->filter_log2;
+    out->filter_exact = (uint32_t)wm->filter_exact;
+    out->filter_hashed = (uint32_t)wm->filter_hashed;
+    out->verify_slots = wm->filter_exact ? 0u : (1u << wm->verify_log2);
+    out->lds_bytes = (uint32_t)(((size_t)1 << wm->filter_log2) / 8);
+    return SMH_OK;
+}
+
+void smh_wm_free(smh_wm *wm)
+{
+    if (!wm) return;
+    if (wm->dev) smh_wm_dev_free(wm->dev);
+    wm->dev = NULL;
+    smh_wm_host_free(wm);
+}

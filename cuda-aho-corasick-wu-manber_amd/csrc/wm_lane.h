@@ -1,0 +1,241 @@
+/*
+ * csrc/wm_lane.h -- what one lane of the Wu-Manber kernels does.
+ *
+ * Replaces the per-thread skip loops of the reference's wm_kernel1..5
+ * (cuda/cuda_wm.cu:60-1058).  The quantity computed is the one search_wu
+ * returns (wu/wu.c:49-107): the number of END columns e in [m-1, n) at which
+ * at least one pattern equals text[e-m+1 .. e].  That count is a property of
+ * each column alone -- a shift only skips columns that provably end no match --
+ * so columns can be tested independently (cuda/cuda_wm.cu:69-70,136 splits the
+ * columns over threads on the same grounds).
+ *
+ * Tuned path = the Wu-Manber stages with a device-sized block:
+ *   SHIFT stage : rolling code of the last W symbols -> one bit of the LDS
+ *                 filter; bit clear  <=>  SHIFT_dev[block] > 0  <=>  no pattern
+ *                 ends in this block, column rejected
+ *   HASH/PREFIX : surviving columns probe the HBM verify table with a hash of
+ *                 the whole window and compare the pattern bytes (absent when
+ *                 the block is the whole pattern and directly indexed: then a
+ *                 set bit IS a match)
+ * Table path = the reference tables as given: SHIFT lookup (LDS), skip loop,
+ * bucket scan over {PREFIX_value, PREFIX_index}, byte compare.
+ */
+#ifndef SMH_WM_LANE_H
+#define SMH_WM_LANE_H
+
+#include "lane_common.h"
+
+#define SMH_WM_HASH_MUL 0x9E3779B1u /* == SMH_HASH_MUL in smh_internal.h */
+
+struct smh_wm_params {
+    int m;
+    int bits;            /* bits per symbol */
+    uint32_t code_mask;  /* low block_symbols*bits bits of the rolling register */
+    int filter_log2;     /* hashed filter: log2 of its bit count */
+    int verify_log2;     /* slots = 1 << verify_log2 */
+    const uint32_t *verify;      /* HBM: {tag, pattern + 1} per slot */
+    const uint8_t *pat_sorted;   /* HBM: distinct patterns, m bytes each */
+};
+
+/* device HASH/PREFIX stage: is text[e-m+1 .. e] one of the patterns? */
+SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_params &P)
+{
+    const uint8_t *w = text + (e + 1 - (uint64_t)P.m);
+    uint32_t tag = 0x811C9DC5u;
+    for (int i = 0; i < P.m; ++i) {
+        tag ^= w[i];
+        tag *= 0x01000193u;
+    }
+    const uint32_t mask = (1u << P.verify_log2) - 1u;
+    uint32_t s = (tag * SMH_WM_HASH_MUL) >> (32 - P.verify_log2);
+    for (;;) {
+        const uint32_t stag = P.verify[2 * s];
+        const uint32_t sidx = P.verify[2 * s + 1];
+        if (sidx == 0) return 0;
+        if (stag == tag) {
+            const uint8_t *q = P.pat_sorted + (uint64_t)(sidx - 1) * (uint32_t)P.m;
+            int i = 0;
+            while (i < P.m && q[i] == w[i]) ++i;
+            if (i == P.m) return 1;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+/* SHIFT stage for one column: returns 1 when the block's filter bit(s) are set */
+template <bool HASHED>
+SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh_wm_params &P)
+{
+    const uint32_t key = code & P.code_mask;
+    if (HASHED) {
+        const uint32_t h = key * SMH_WM_HASH_MUL;
+        const int wl = P.filter_log2 - 5;
+        const uint32_t word = filter[h >> (32 - wl)];
+        const uint32_t b1 = (h >> (32 - wl - 5)) & 31u, b2 = (h >> (32 - wl - 10)) & 31u;
+        return (word >> b1) & (word >> b2) & 1u;
+    } else {
+        return (filter[key >> 5] >> (key & 31u)) & 1u;
+    }
+}
+
+/*
+ * Fast path: the lane owns the 64 END columns of the segment at byte offset a
+ * (a multiple of 64) and reads the 16*HC bytes in front of it to prime the
+ * rolling block code; the caller guarantees a >= 16*HC, a + 64 <= n and
+ * 16*HC >= m-1, so every column has a full window.
+ */
+template <bool HASHED, bool EXACT, int HC>
+SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32_t *filter,
+                                   const smh_wm_params &P)
+{
+    uint32_t w[4 * HC + 16];
+#pragma unroll
+    for (int q = 0; q < HC + 4; ++q) {
+        const smh_u32x4 t = smh_load16(text + (a - 16u * HC) + 16u * q);
+        w[4 * q + 0] = t.v[0];
+        w[4 * q + 1] = t.v[1];
+        w[4 * q + 2] = t.v[2];
+        w[4 * q + 3] = t.v[3];
+    }
+    uint32_t code = 0, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 16 * HC; ++i) code = (code << P.bits) | smh_byte_of(w[i >> 2], i & 3);
+    /* SHIFT stage over the 64 columns; survivors are only recorded (one bit each) so that the
+     * unrolled loop stays branch-free and the rarely taken verify code exists once */
+    uint32_t surv_lo = 0, surv_hi = 0;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+        code = (code << P.bits) | smh_byte_of(w[4 * HC + (i >> 2)], i & 3);
+        const uint32_t hit = smh_wm_filter<HASHED>(code, filter, P);
+        if (EXACT)
+            cnt += hit;
+        else if (i < 32)
+            surv_lo |= hit << i;
+        else
+            surv_hi |= hit << (i - 32);
+    }
+    if (!EXACT) {
+        /* HASH/PREFIX stage */
+        while (surv_lo) {
+            const int i = __builtin_ctz(surv_lo);
+            surv_lo &= surv_lo - 1;
+            cnt += smh_wm_verify(text, a + (uint64_t)i, P);
+        }
+        while (surv_hi) {
+            const int i = __builtin_ctz(surv_hi);
+            surv_hi &= surv_hi - 1;
+            cnt += smh_wm_verify(text, a + 32u + (uint64_t)i, P);
+        }
+    }
+    return cnt;
+}
+
+/* Slow path: any segment of END columns, bounds checked, no pre-halo requirement. */
+template <bool HASHED, bool EXACT>
+SMH_LANE uint32_t smh_wm_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const uint32_t *filter,
+                                   const smh_wm_params &P, int block_symbols)
+{
+    if (a >= n) return 0;
+    uint64_t end = a + SMH_SEG;
+    if (end > n) end = n;
+    uint64_t e0 = a;
+    if (e0 < (uint64_t)(P.m - 1)) e0 = (uint64_t)(P.m - 1);
+    if (e0 >= end) return 0;
+    /* prime with the block_symbols - 1 symbols in front of the first column (they exist: e0 >= m-1) */
+    uint32_t code = 0, cnt = 0;
+    for (uint64_t i = e0 - (uint64_t)(block_symbols - 1); i < e0; ++i) code = (code << P.bits) | text[i];
+    for (uint64_t e = e0; e < end; ++e) {
+        code = (code << P.bits) | text[e];
+        const uint32_t hit = smh_wm_filter<HASHED>(code, filter, P);
+        if (EXACT)
+            cnt += hit;
+        else if (hit)
+            cnt += smh_wm_verify(text, e, P);
+    }
+    return cnt;
+}
+
+/*
+ * SMH_VARIANT_TABLE: the reference's loop (wu/wu.c:61-104, cuda/cuda_wm.cu:1012-1057)
+ * over the END columns [a, a + span) with the reference tables as given:
+ * shift[] (LDS copy of SHIFT), CSR buckets of {PREFIX_value, PREFIX_index}.
+ */
+template <typename SHIFT_T>
+SMH_LANE uint32_t smh_wm_lane_table(const uint8_t *text, uint64_t n, uint64_t a, uint64_t span,
+                                    const SHIFT_T *shift, uint32_t shiftsize, const uint32_t *bucket_off,
+                                    const int32_t *bucket, const uint8_t *pat_orig, int m, int nbits)
+{
+    uint64_t end = a + span;
+    if (end > n) end = n;
+    uint64_t column = a;
+    if (column < (uint64_t)(m - 1)) column = (uint64_t)(m - 1);
+    uint32_t cnt = 0;
+    while (column < end) {
+        uint32_t hash1 = text[column - 2];
+        hash1 <<= nbits;
+        hash1 += text[column - 1];
+        hash1 <<= nbits;
+        hash1 += text[column];
+        /* a byte >= alphabet can push hash1 past the table; such a column ends no match */
+        const uint32_t sh = hash1 < shiftsize ? shift[hash1] : 1u;
+        if (sh == 0) {
+            uint32_t hash2 = text[column - (uint64_t)m + 1];
+            hash2 <<= nbits;
+            hash2 += text[column - (uint64_t)m + 2];
+            const uint32_t b0 = bucket_off[hash1], b1 = bucket_off[hash1 + 1];
+            for (uint32_t k = b0; k < b1; ++k) {
+                if ((uint32_t)bucket[2 * k] != hash2) continue;
+                const uint8_t *q = pat_orig + (uint64_t)(uint32_t)bucket[2 * k + 1] * (uint32_t)m;
+                const uint8_t *w = text + (column + 1 - (uint64_t)m);
+                int i = 0;
+                while (i < m && q[i] == w[i]) ++i;
+                if (i == m) {
+                    ++cnt;
+                    break;
+                }
+            }
+            ++column;
+        } else {
+            column += sh;
+        }
+    }
+    return cnt;
+}
+
+/* whole-grid work distribution for one lane; HC == 0: no fast path (m - 1 > 64) */
+template <bool HASHED, bool EXACT, int HC>
+SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n,
+                                const uint32_t *filter, const smh_wm_params &P, int block_symbols)
+{
+    if (n < (uint64_t)P.m) return 0;
+    const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
+    const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
+    const uint32_t lane = (uint32_t)(gthread & 63u);
+    const uint64_t wave = gthread >> 6, nwaves = nthreads >> 6;
+    uint32_t cnt = 0;
+    for (uint64_t k = wave; k < n_chunks; k += nwaves) {
+        const uint64_t base = k * chunk_bytes;
+        const uint64_t a = base + (uint64_t)lane * SMH_SEG;
+        if (HC > 0 && base >= 16u * HC && base + chunk_bytes <= n)
+            cnt += smh_wm_lane_fast<HASHED, EXACT, (HC > 0 ? HC : 1)>(text, a, filter, P);
+        else
+            cnt += smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols);
+    }
+    return cnt;
+}
+
+#define SMH_WM_TABLE_SPAN 256u /* END columns per lane in the table-walking kernel */
+template <typename SHIFT_T>
+SMH_LANE uint32_t smh_wm_table_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n,
+                                      const SHIFT_T *shift, uint32_t shiftsize, const uint32_t *bucket_off,
+                                      const int32_t *bucket, const uint8_t *pat_orig, int m, int nbits)
+{
+    if (n < (uint64_t)m) return 0;
+    uint32_t cnt = 0;
+    for (uint64_t a = gthread * SMH_WM_TABLE_SPAN; a < n; a += nthreads * SMH_WM_TABLE_SPAN)
+        cnt += smh_wm_lane_table<SHIFT_T>(text, n, a, SMH_WM_TABLE_SPAN, shift, shiftsize, bucket_off, bucket,
+                                          pat_orig, m, nbits);
+    return cnt;
+}
+
+#endif

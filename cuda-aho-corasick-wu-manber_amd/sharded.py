@@ -1,0 +1,28 @@
+"""Byte-range sharding over ranks: one process per GPU, counts summed with one all-reduce.
+
+Mirrors what the reference driver does with MPI (main.c:375-378 shard length,
+main.c:464-477 displacements with the m-1 halo, main.c:654-657 MPI_Reduce of the
+count), with two differences: every rank works on its TRUE shard length (the
+reference passes the padded length, main.c:376,630) and the count is 64-bit.
+
+The data path has no collective: shards are independent; the only exchange is
+the 8-byte sum.  With backend "nccl" that is RCCL over xGMI; the CPU tests run
+the same code over "gloo".
+"""
+import torch
+import torch.distributed as dist
+
+import smatcher_hip as S
+
+
+def shard_for_rank(n_total, world_size, rank, m):
+    """[begin, end) of this rank's bytes, halo included (smh_shard_range = main.c:467-477)."""
+    return S.shard_range(n_total, world_size, rank, m)
+
+
+def reduce_count(local_count):
+    """Sum a per-rank match count over all ranks; `local_count` is a 1-element int64 tensor
+    (device tensor under nccl/RCCL, CPU tensor under gloo).  Returns the same tensor."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(local_count, op=dist.ReduceOp.SUM)
+    return local_count

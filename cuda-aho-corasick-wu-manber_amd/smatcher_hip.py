@@ -1,0 +1,275 @@
+"""ctypes mirror of libsmatcher_hip.so (include/smatcher.h + include/smatcher_hip.h).
+
+This is harness plumbing for tests/ and bench.py: it adds nothing to the hot
+path, which is C host code + gfx950 kernels inside the shared library.  The
+library is built in-tree by `make -C cuda-aho-corasick-wu-manber_amd` (or
+__graft_entry__.build()); a missing library is a hard error -- there is no
+Python or CPU fallback for the search entry points.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsmatcher_hip.so")
+
+SMH_OK = 0
+VARIANT_TUNED = 0
+VARIANT_TABLE = 1
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int)
+u32p = C.POINTER(C.c_uint)
+u64p = C.POINTER(C.c_uint64)
+dblp = C.POINTER(C.c_double)
+
+
+class SmhError(RuntimeError):
+    pass
+
+
+class AcInfo(C.Structure):
+    _fields_ = [("alphabet", C.c_uint32), ("m", C.c_uint32), ("states", C.c_uint32),
+                ("finals", C.c_uint32), ("rows", C.c_uint32), ("entry_bytes", C.c_uint32),
+                ("lds_rows", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_bytes", C.c_uint64)]
+
+
+class WmInfo(C.Structure):
+    _fields_ = [("alphabet", C.c_uint32), ("m", C.c_uint32), ("patterns", C.c_uint32),
+                ("distinct", C.c_uint32), ("shiftsize", C.c_uint32), ("shift_zero", C.c_uint32),
+                ("block_symbols", C.c_uint32), ("filter_log2", C.c_uint32),
+                ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
+                ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32)]
+
+
+class AcTable(C.Structure):
+    """struct ac_table (include/smatcher.h)"""
+    _fields_ = [("idcounter", C.c_uint), ("patterncounter", C.c_uint), ("zerostate", C.c_void_p)]
+
+
+# every symbol include/smatcher.h and include/smatcher_hip.h declare
+LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_shiftsize",
+                   "preproc_wu", "preproc_wu2", "search_wu", "search_wu2", "m_nBitsInShift",
+                   "shiftsize"]
+                  + ["cuda_ac%d" % k for k in range(1, 6)] + ["cuda_wm%d" % k for k in range(1, 6)])
+EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
+               "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
+               "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize",
+               "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
+               "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
+               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_scan", "smh_ac_count_host",
+               "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info",
+               "smh_wm_scan", "smh_wm_count_host", "smh_wm_free"]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SmhError("libsmatcher_hip.so is not built (%s); run `make -C %s` -- there is no "
+                       "fallback path" % (LIB_PATH, HERE))
+    lib = C.CDLL(LIB_PATH)
+    lib.smh_version.restype = C.c_char_p
+    lib.smh_last_error.restype = C.c_char_p
+    lib.smh_device_count.restype = C.c_int
+    lib.smh_set_device.argtypes = [C.c_int]
+    lib.smh_device_name.argtypes = [C.c_char_p, C.c_size_t]
+    lib.smh_device_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
+    lib.smh_device_free.argtypes = [C.c_void_p]
+    lib.smh_device_memset.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
+    lib.smh_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.smh_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    lib.smh_stream_synchronize.argtypes = [C.c_void_p]
+    lib.smh_splitmix64_at.restype = C.c_uint64
+    lib.smh_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
+    lib.smh_corpus_text_host.restype = None
+    lib.smh_corpus_text_host.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    lib.smh_corpus_text_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+    lib.smh_corpus_patterns.restype = None
+    lib.smh_corpus_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+    lib.smh_shard_range.restype = None
+    lib.smh_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, u64p, u64p]
+    lib.smh_ac_compile_tables.restype = C.c_void_p
+    lib.smh_ac_compile_tables.argtypes = [i32p, u32p, u32p, C.c_uint64, C.c_int, C.c_int]
+    lib.smh_ac_compile_patterns.restype = C.c_void_p
+    lib.smh_ac_compile_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
+    lib.smh_ac_get_info.argtypes = [C.c_void_p, C.POINTER(AcInfo)]
+    lib.smh_ac_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+    lib.smh_ac_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, u64p, dblp]
+    lib.smh_ac_free.restype = None
+    lib.smh_ac_free.argtypes = [C.c_void_p]
+    lib.smh_wm_compile.restype = C.c_void_p
+    lib.smh_wm_compile.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
+    lib.smh_wm_compile_tables.restype = C.c_void_p
+    lib.smh_wm_compile_tables.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p]
+    lib.smh_wm_get_info.argtypes = [C.c_void_p, C.POINTER(WmInfo)]
+    lib.smh_wm_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+    lib.smh_wm_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, u64p, dblp]
+    lib.smh_wm_free.restype = None
+    lib.smh_wm_free.argtypes = [C.c_void_p]
+    # legacy names, with the reference's argument lists (smatcher.h)
+    lib.preproc_ac.restype = C.POINTER(AcTable)
+    lib.preproc_ac.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p, u32p, u32p]
+    lib.search_ac.restype = C.c_uint
+    lib.search_ac.argtypes = [u8p, C.c_int, C.POINTER(AcTable)]
+    lib.free_ac.restype = None
+    lib.free_ac.argtypes = [C.POINTER(AcTable), C.c_int]
+    lib.wu_determine_shiftsize.restype = None
+    lib.wu_determine_shiftsize.argtypes = [C.c_int]
+    tabs = [i32p, i32p, i32p, i32p]
+    lib.preproc_wu.restype = None
+    lib.preproc_wu.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int] + tabs
+    lib.preproc_wu2.restype = None
+    lib.preproc_wu2.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int] + tabs
+    lib.search_wu.restype = C.c_uint
+    lib.search_wu.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, u8p, C.c_int] + tabs
+    lib.search_wu2.restype = C.c_uint
+    lib.search_wu2.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int] + tabs
+    for k in range(1, 6):
+        f = getattr(lib, "cuda_ac%d" % k)
+        f.restype = None
+        f.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_int, i32p, u32p, u32p]
+        g = getattr(lib, "cuda_wm%d" % k)
+        g.restype = C.c_int
+        g.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int] + tabs + [dblp]
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc, what):
+    if rc != SMH_OK:
+        raise SmhError("%s failed (%d): %s" % (what, rc, lib.smh_last_error().decode()))
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a, a.ctypes.data_as(u8p)
+
+
+def shiftsize_global():
+    return C.c_uint.in_dll(lib, "shiftsize").value
+
+
+def device_count():
+    return int(lib.smh_device_count())
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    _check(lib.smh_device_name(buf, 256), "smh_device_name")
+    return buf.value.decode()
+
+
+def corpus_text(n, seed=42, alphabet=4, offset=0):
+    out = np.empty(n, dtype=np.uint8)
+    lib.smh_corpus_text_host(out.ctypes.data_as(u8p), n, offset, seed, alphabet)
+    return out
+
+
+def corpus_patterns(m, p, seed=7, alphabet=4, text_seed=42, n_text=0, every=2):
+    out = np.empty(m * p, dtype=np.uint8)
+    lib.smh_corpus_patterns(out.ctypes.data_as(u8p), m, p, seed, alphabet, text_seed, n_text, every)
+    return out
+
+
+def shard_range(n, shards, i, m):
+    b, e = C.c_uint64(), C.c_uint64()
+    lib.smh_shard_range(n, shards, i, m, C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+class AcAutomaton:
+    """smh_ac handle: compiled Aho-Corasick automaton."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise SmhError("AC compile failed: %s" % lib.smh_last_error().decode())
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def from_patterns(cls, pat_flat, m, p, alphabet):
+        a, ptr = _u8(pat_flat)
+        return cls(lib.smh_ac_compile_patterns(ptr, m, p, alphabet))
+
+    @classmethod
+    def from_tables(cls, state_transition, state_supply, state_final, rows, alphabet, m):
+        return cls(lib.smh_ac_compile_tables(state_transition.ctypes.data_as(i32p),
+                                             state_supply.ctypes.data_as(u32p),
+                                             state_final.ctypes.data_as(u32p), rows, alphabet, m))
+
+    def info(self):
+        out = AcInfo()
+        _check(lib.smh_ac_get_info(self.h, C.byref(out)), "smh_ac_get_info")
+        return out
+
+    def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
+        _check(lib.smh_ac_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,
+                               C.c_void_p(stream or 0)), "smh_ac_scan")
+
+    def count_host(self, text, variant=VARIANT_TUNED):
+        t, ptr = _u8(text)
+        cnt, secs = C.c_uint64(), C.c_double()
+        _check(lib.smh_ac_count_host(self.h, ptr, len(t), variant, C.byref(cnt), C.byref(secs)),
+               "smh_ac_count_host")
+        return cnt.value, secs.value
+
+    def close(self):
+        if self.h:
+            lib.smh_ac_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class WmTables:
+    """smh_wm handle: compiled Wu-Manber tables."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise SmhError("WM compile failed: %s" % lib.smh_last_error().decode())
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def from_patterns(cls, pat_flat, m, p, alphabet):
+        a, ptr = _u8(pat_flat)
+        return cls(lib.smh_wm_compile(ptr, m, p, alphabet))
+
+    @classmethod
+    def from_tables(cls, pat_flat, m, p, alphabet, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size):
+        a, ptr = _u8(pat_flat)
+        return cls(lib.smh_wm_compile_tables(ptr, m, p, alphabet, SHIFT.ctypes.data_as(i32p),
+                                             PREFIX_value.ctypes.data_as(i32p),
+                                             PREFIX_index.ctypes.data_as(i32p),
+                                             PREFIX_size.ctypes.data_as(i32p)))
+
+    def info(self):
+        out = WmInfo()
+        _check(lib.smh_wm_get_info(self.h, C.byref(out)), "smh_wm_get_info")
+        return out
+
+    def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
+        _check(lib.smh_wm_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,
+                               C.c_void_p(stream or 0)), "smh_wm_scan")
+
+    def count_host(self, text, variant=VARIANT_TUNED):
+        t, ptr = _u8(text)
+        cnt, secs = C.c_uint64(), C.c_double()
+        _check(lib.smh_wm_count_host(self.h, ptr, len(t), variant, C.byref(cnt), C.byref(secs)),
+               "smh_wm_count_host")
+        return cnt.value, secs.value
+
+    def close(self):
+        if self.h:
+            lib.smh_wm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,129 @@
+/*
+ * include/smatcher.h -- drop-in host API of the MI355X multi-pattern matcher.
+ *
+ * This header replaces the reference's smatcher.h for the Aho-Corasick and
+ * Wu-Manber path.  Every declaration below keeps the reference's name,
+ * argument order, argument meaning, ownership and error behaviour so that the
+ * reference driver (main.c) compiles and links against libsmatcher_hip.so
+ * unchanged; the citation after each item is the reference line it replaces.
+ *
+ * What is different underneath: preproc_* build the same caller-owned tables
+ * on the host (bit-identical contents), search_* and cuda_* run hand-written
+ * gfx950 kernels on the current HIP device and return the same match count
+ * the reference's CPU loops (ac/ac.c:198-222, wu/wu.c:49-107) return.
+ * There is no CPU search fallback: without a usable GPU these entry points
+ * print a message and exit(1), which is the reference's own error convention
+ * (cuda/cuda.h:26-47, fail()).
+ *
+ * The sibling algorithms of the reference (Set-Horspool, SBOM, SOG, KMP, BM;
+ * smatcher.h:93-99,108-133) are outside this library's scope and not declared.
+ *
+ * 64-bit text lengths / counts, resident-text handles, streams and the
+ * multi-GPU shard helpers live in smatcher_hip.h.
+ */
+#ifndef SMATCHER_H
+#define SMATCHER_H
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <string.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: ../helper2.h (absent upstream) supplied these to every caller of smatcher.h */
+#ifndef MIN
+#define MIN(a, b) (((a) < (b)) ? (a) : (b))
+#endif
+#ifndef MAX
+#define MAX(a, b) (((a) > (b)) ? (a) : (b))
+#endif
+void fail(const char *msg); /* print msg, exit(1) */
+
+/* smatcher.h:41-47 -- trie node as the reference declares it.  Callers only ever
+ * hold it through struct ac_table.zerostate; this library keeps one root node
+ * there (id 0, fail = itself, every next[] edge a self loop). */
+struct ac_state {
+    unsigned int id;
+    unsigned int keywordline;
+    unsigned char *output;
+    struct ac_state *fail;
+    struct ac_state **next;
+};
+
+/* smatcher.h:49-53 -- idcounter = number of automaton states, patterncounter =
+ * number of distinct patterns, as the reference leaves them after preproc_ac. */
+struct ac_table {
+    unsigned int idcounter;
+    unsigned int patterncounter;
+    struct ac_state *zerostate;
+};
+
+/* smatcher.h:71,73 -- the reference DEFINES these in the header (needs -fcommon);
+ * here they are declared and defined once inside the library. */
+extern unsigned short m_nBitsInShift; /* must be 2 (main.c:431); preset to 2 */
+extern unsigned int shiftsize;        /* set by wu_determine_shiftsize */
+
+/* ---- Aho-Corasick: smatcher.h:89-91, ac/ac.c:224-252 ----
+ * pattern: p_size pointers to m symbols each (values < alphabet).
+ * state_transition[(m*p_size+1)*alphabet] pre-filled with -1, state_supply and
+ * state_final [(m*p_size+1)] pre-filled with 0 by the caller (main.c:410-420);
+ * filled exactly as the reference fills them.  Returned table is released by free_ac. */
+struct ac_table *preproc_ac(unsigned char **pattern, int m, int p_size, int alphabet,
+                            int *state_transition, unsigned int *state_supply,
+                            unsigned int *state_final);
+/* number of text end positions whose AC state is accepting (ac/ac.c:198-222), computed on the GPU */
+unsigned search_ac(unsigned char *text, int n, struct ac_table *table);
+void free_ac(struct ac_table *table, int alphabet);
+
+/* ---- Wu-Manber: smatcher.h:101-106, wu/wu.c ----
+ * SHIFT[shiftsize] pre-filled with m-B+1, PREFIX_size[shiftsize] with 0,
+ * PREFIX_value / PREFIX_index [shiftsize*p_size] (main.c:429-449); B must be 3. */
+void wu_determine_shiftsize(int alphabet);
+void preproc_wu(unsigned char **pattern, int m, int p_size, int alphabet, int B, int *SHIFT,
+                int *PREFIX_value, int *PREFIX_index, int *PREFIX_size);
+void preproc_wu2(unsigned char *pattern_flat, int m, int p_size, int alphabet, int B, int *SHIFT,
+                 int *PREFIX_value, int *PREFIX_index, int *PREFIX_size);
+unsigned int search_wu(unsigned char **pattern, int m, int p_size, unsigned char *text, int n,
+                       int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size);
+unsigned int search_wu2(unsigned char *pattern_flat, int m, int p_size, unsigned char *text, int n,
+                        int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size);
+
+/* ---- GPU entry points with the reference's shapes ----
+ * cuda/cuda_ac.cu:594,691,788,885,983: print "Kernel K matches \t%i\t time \t%f\n".
+ * cuda/cuda_wm.cu:183,438,652,854,1060: return the count, *gpuTime = kernel seconds.
+ * K = 1,2 run the table-faithful kernels (goto/supply/final rows, dense-bucket
+ * scan); K = 3,4,5 run the tuned kernels (LDS-resident DFA / block filter).
+ * Unlike the reference there is no minimum text size and no dropped tail. */
+void cuda_ac1(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_supply, unsigned int *state_final);
+void cuda_ac2(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_supply, unsigned int *state_final);
+void cuda_ac3(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_supply, unsigned int *state_final);
+void cuda_ac4(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_supply, unsigned int *state_final);
+void cuda_ac5(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_supply, unsigned int *state_final);
+int cuda_wm1(unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size,
+             int alphabet, int B, int *SHIFT, int *PREFIX_value, int *PREFIX_index,
+             int *PREFIX_size, double *gpuTime);
+int cuda_wm2(unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size,
+             int alphabet, int B, int *SHIFT, int *PREFIX_value, int *PREFIX_index,
+             int *PREFIX_size, double *gpuTime);
+int cuda_wm3(unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size,
+             int alphabet, int B, int *SHIFT, int *PREFIX_value, int *PREFIX_index,
+             int *PREFIX_size, double *gpuTime);
+int cuda_wm4(unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size,
+             int alphabet, int B, int *SHIFT, int *PREFIX_value, int *PREFIX_index,
+             int *PREFIX_size, double *gpuTime);
+int cuda_wm5(unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size,
+             int alphabet, int B, int *SHIFT, int *PREFIX_value, int *PREFIX_index,
+             int *PREFIX_size, double *gpuTime);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,139 @@
+/*
+ * include/smatcher_hip.h -- extended C ABI of libsmatcher_hip.so.
+ *
+ * smatcher.h keeps the reference's host API verbatim (int n, unsigned count,
+ * one blocking call per scan that re-uploads the text, as cuda/cuda_ac.cu:627
+ * and cuda/cuda_wm.cu:232 do).  This header is the documented superset the
+ * BASELINE configurations need and the reference cannot express:
+ *
+ *   - 64-bit text lengths and match counts (reference: int n smatcher.h:90,105;
+ *     unsigned / int results; MPI_INT reduce main.c:656);
+ *   - text that is already resident in GPU memory (device pointer in, device
+ *     counter out, caller's stream) so one upload serves AC and WM scans and
+ *     the timed region contains the kernel only (what the reference times:
+ *     cuda/cuda_ac.cu:642-663, cuda/cuda_wm.cu:263-286);
+ *   - compiled, reusable automaton / table handles (the reference rebuilds
+ *     device state in every cuda_* call, cuda/cuda_ac.cu:594-689);
+ *   - the byte-range shard formula of main.c:375-378,464-477 with true shard
+ *     lengths, for one-process-per-GPU drivers that sum counts with RCCL.
+ *
+ * Plain C types only; `stream` arguments are hipStream_t passed as void*
+ * (NULL = the default stream).  Functions returning int return SMH_OK (0) or a
+ * negative SMH_E* code and leave a message for smh_last_error(); nothing here
+ * exits the process (the legacy names in smatcher.h do, like the reference).
+ */
+#ifndef SMATCHER_HIP_H
+#define SMATCHER_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMH_OK 0
+#define SMH_EINVAL (-1)  /* bad argument (symbol >= alphabet, m < 1, unaligned text, ...) */
+#define SMH_ENODEV (-2)  /* no usable HIP device / HIP runtime error */
+#define SMH_ENOMEM (-3)
+#define SMH_EUNSUP (-4)  /* outside the supported envelope */
+
+/* kernel families selectable per scan */
+#define SMH_VARIANT_TUNED 0 /* LDS-resident DFA (AC) / block-filter + verify (WM) */
+#define SMH_VARIANT_TABLE 1 /* walks the reference-layout tables as given (goto/supply/final; SHIFT/PREFIX buckets) */
+
+const char *smh_version(void);
+const char *smh_last_error(void);
+
+/* ---- runtime / device memory (so that C callers need no HIP headers) ---- */
+int smh_device_count(void); /* 0 when there is no GPU or no HIP runtime */
+int smh_set_device(int device);
+int smh_device_name(char *buf, size_t cap);
+int smh_device_malloc(void **dptr, uint64_t bytes);
+int smh_device_free(void *dptr);
+int smh_device_memset(void *dptr, int value, uint64_t bytes, void *stream);
+int smh_copy_to_device(void *dst, const void *src, uint64_t bytes, void *stream);
+int smh_copy_to_host(void *dst, const void *src, uint64_t bytes, void *stream);
+int smh_stream_synchronize(void *stream);
+
+/* ---- synthetic corpus (clean-room stand-in for the reference's missing helper.c:
+ *      load_files / create_multiple_pattern_with_hits, main.c:49,453) ----
+ * Counter-based splitmix64: symbol i = mix(seed + (i+1)*0x9E3779B97F4A7C15) % alphabet,
+ * so any slice [offset, offset+n) can be produced independently on host or device. */
+uint64_t smh_splitmix64_at(uint64_t seed, uint64_t index);
+void smh_corpus_text_host(unsigned char *out, uint64_t n, uint64_t offset, uint64_t seed, int alphabet);
+int smh_corpus_text_device(unsigned char *d_out, uint64_t n, uint64_t offset, uint64_t seed,
+                           int alphabet, void *stream);
+/* p patterns of m symbols, flat; every `from_text_every`-th one is a substring of the
+ * synthetic text (text_seed, n_text) so that matches exist; <= 0: all uniform random */
+void smh_corpus_patterns(unsigned char *out, int m, int p_size, uint64_t seed, int alphabet,
+                         uint64_t text_seed, uint64_t n_text, int from_text_every);
+
+/* ---- byte-range shards: main.c:375-378,464-477 with the true length of the last shard ---- */
+void smh_shard_range(uint64_t n, int n_shards, int shard, int m, uint64_t *begin, uint64_t *end);
+
+/* ---- Aho-Corasick ---- */
+typedef struct smh_ac smh_ac;
+
+typedef struct smh_ac_info {
+    uint32_t alphabet;
+    uint32_t m;            /* pattern length the automaton was compiled for */
+    uint32_t states;       /* reachable states in the reference numbering (== ac_table.idcounter) */
+    uint32_t finals;       /* accepting states (== ac_table.patterncounter) */
+    uint32_t rows;         /* DFA rows kept on the device (accepting leaves are folded away) */
+    uint32_t entry_bytes;  /* 2 or 4 */
+    uint32_t lds_rows;     /* rows staged in LDS by the tuned kernel; rows beyond come from HBM/L2 */
+    uint32_t lds_bytes;
+    uint64_t table_bytes;  /* full DFA size in HBM */
+} smh_ac_info;
+
+/* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
+smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *state_supply,
+                              const unsigned int *state_final, uint64_t rows, int alphabet, int m);
+/* from patterns: builds the reference tables internally, then compiles them */
+smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
+int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out);
+/* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).
+ * d_text must be 16-byte aligned; n may exceed 2^32. */
+int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count,
+                int variant, void *stream);
+/* blocking convenience: upload host text, scan, return count and kernel-only seconds */
+int smh_ac_count_host(smh_ac *ac, const unsigned char *text, uint64_t n, int variant,
+                      uint64_t *count, double *kernel_seconds);
+void smh_ac_free(smh_ac *ac);
+
+/* ---- Wu-Manber ---- */
+typedef struct smh_wm smh_wm;
+
+typedef struct smh_wm_info {
+    uint32_t alphabet;
+    uint32_t m;
+    uint32_t patterns;        /* as given */
+    uint32_t distinct;        /* after de-duplication */
+    uint32_t shiftsize;       /* reference SHIFT table length (wu/wu.c:18-47) */
+    uint32_t shift_zero;      /* reference SHIFT entries equal to 0 */
+    uint32_t block_symbols;   /* device block size (symbols hashed by the LDS filter) */
+    uint32_t filter_log2;     /* log2 of the LDS filter's bit count */
+    uint32_t filter_exact;    /* 1: a filter hit IS a match (block == whole pattern, direct index) */
+    uint32_t filter_hashed;   /* 1: block code is hashed into the filter, 0: indexes it directly */
+    uint32_t verify_slots;    /* open-addressing slots of the HBM verify table (0 when exact) */
+    uint32_t lds_bytes;
+} smh_wm_info;
+
+/* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */
+smh_wm *smh_wm_compile(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
+/* from the caller's reference-layout tables (as preproc_wu / preproc_wu2 filled them) */
+smh_wm *smh_wm_compile_tables(const unsigned char *pattern_flat, int m, int p_size, int alphabet,
+                              const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
+                              const int *PREFIX_size);
+int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out);
+int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count,
+                int variant, void *stream);
+int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int variant,
+                      uint64_t *count, double *kernel_seconds);
+void smh_wm_free(smh_wm *wm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

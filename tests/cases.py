@@ -1,0 +1,108 @@
+"""Seeded test inputs shared by the golden-vector generator and the parity tests.
+
+A case is a small dict; the text and patterns are regenerated from it with the
+oracle's splitmix64 generator (the product's own generator is checked equal to
+it in test_host_tables.py), so only seeds, sizes and expected results are
+committed under tests/golden/.
+"""
+import numpy as np
+
+import oracle_lib as O
+
+SIGMAS = [2, 4, 8, 20, 128, 256]
+LENGTHS = [3, 4, 8, 16, 32]
+COUNTS = [1, 2, 100, 1000]
+
+
+def matrix_cases():
+    """SURVEY.md 8c fixture matrix: m x sigma x p, patterns half sampled from the text."""
+    out = []
+    k = 0
+    for sigma in SIGMAS:
+        for m in LENGTHS:
+            for p in COUNTS:
+                # odd sizes so that tails / partial segments are always exercised
+                n = 60000 + 4099 * (k % 7) + (k % 16)
+                out.append(dict(name="mx_s%d_m%d_p%d" % (sigma, m, p), n=n, p=p, m=m, sigma=sigma,
+                                text="uniform", pat="mixed", text_seed=42 + k, pat_seed=7 + k))
+                k += 1
+    return out
+
+
+def special_cases():
+    out = []
+    # SURVEY.md 8c known answers (uniform random patterns, text seed 42, pattern seed 7)
+    out.append(dict(name="kat_1m_100x8", n=1 << 20, p=100, m=8, sigma=4, text="uniform", pat="uniform",
+                    text_seed=42, pat_seed=7))
+    out.append(dict(name="kat_1m003_r3", n=1000003, p=100, m=8, sigma=4, text="uniform", pat="uniform",
+                    text_seed=42, pat_seed=7))
+    # duplicates in the pattern set count once (ac/ac.c:183, wu/wu.c:91-95)
+    out.append(dict(name="dups", n=70001, p=200, m=8, sigma=4, text="uniform", pat="dups",
+                    text_seed=3, pat_seed=4))
+    # overlapping matches: constant text, the all-zero pattern among others
+    out.append(dict(name="overlap_zeros", n=50021, p=20, m=8, sigma=4, text="zeros", pat="with_zero",
+                    text_seed=5, pat_seed=6))
+    out.append(dict(name="overlap_zeros_m32", n=40009, p=20, m=32, sigma=2, text="zeros", pat="with_zero",
+                    text_seed=5, pat_seed=6))
+    # text shorter than / equal to / barely longer than the pattern
+    out.append(dict(name="n_lt_m", n=5, p=10, m=8, sigma=4, text="uniform", pat="uniform", text_seed=8, pat_seed=9))
+    out.append(dict(name="n_eq_m", n=8, p=10, m=8, sigma=4, text="uniform", pat="first_window",
+                    text_seed=8, pat_seed=9))
+    out.append(dict(name="n_eq_m_plus1", n=9, p=10, m=8, sigma=4, text="uniform", pat="first_window",
+                    text_seed=8, pat_seed=9))
+    # sizes around the kernels' geometry: 64-byte segments, 4 KiB / 8 KiB wave-chunks, 16-byte loads
+    for n in (63, 64, 65, 4095, 4096, 4097, 4103, 8191, 8192, 8193, 8200, 8207, 8208, 12288 + 15, 16384 + 7,
+              3 * 8192 + 16 + 6):
+        out.append(dict(name="edge_n%d" % n, n=n, p=64, m=8, sigma=4, text="uniform", pat="mixed",
+                        text_seed=100 + n, pat_seed=200 + n))
+    for m in (17, 18, 33, 34, 64, 65, 66, 80):
+        out.append(dict(name="edge_m%d" % m, n=40000 + m, p=50, m=m, sigma=4, text="uniform", pat="mixed",
+                        text_seed=300 + m, pat_seed=400 + m))
+    # dense hits: many short patterns on a small alphabet (every SHIFT entry 0)
+    out.append(dict(name="dense_dna", n=120007, p=3000, m=8, sigma=4, text="uniform", pat="uniform",
+                    text_seed=11, pat_seed=12))
+    out.append(dict(name="dense_bin", n=90001, p=500, m=12, sigma=2, text="uniform", pat="uniform",
+                    text_seed=13, pat_seed=14))
+    # automaton too big for 16-bit rows (> 32768 kept states) and for the LDS budget
+    out.append(dict(name="big_dfa", n=100003, p=2500, m=32, sigma=4, text="uniform", pat="mixed",
+                    text_seed=15, pat_seed=16))
+    out.append(dict(name="ascii_5_20", n=150001, p=3000, m=20, sigma=256, text="uniform", pat="mixed",
+                    text_seed=17, pat_seed=18))
+    out.append(dict(name="ascii_m5", n=150001, p=5000, m=5, sigma=256, text="uniform", pat="mixed",
+                    text_seed=19, pat_seed=20))
+    return out
+
+
+def all_cases():
+    return special_cases() + matrix_cases()
+
+
+def build(case):
+    """-> (text uint8[n], pat_flat uint8[p*m])"""
+    n, p, m, sigma = case["n"], case["p"], case["m"], case["sigma"]
+    if case["text"] == "uniform":
+        text = O.gen_text(n, case["text_seed"], sigma)
+    elif case["text"] == "zeros":
+        text = np.zeros(n, dtype=np.uint8)
+    else:
+        raise ValueError(case["text"])
+    kind = case["pat"]
+    if kind == "uniform":
+        pat = O.gen_patterns(m, p, case["pat_seed"], sigma)
+    elif kind == "mixed":
+        pat = O.gen_patterns_mixed(m, p, case["pat_seed"], sigma, case["text_seed"], n, 2)
+    elif kind == "dups":
+        pat = O.gen_patterns_mixed(m, p, case["pat_seed"], sigma, case["text_seed"], n, 2).reshape(p, m)
+        pat[p // 2:] = pat[:p - p // 2]
+        pat = pat.reshape(-1)
+    elif kind == "with_zero":
+        pat = O.gen_patterns(m, p, case["pat_seed"], sigma).reshape(p, m)
+        pat[p // 3] = 0
+        pat = pat.reshape(-1)
+    elif kind == "first_window":
+        pat = O.gen_patterns(m, p, case["pat_seed"], sigma).reshape(p, m)
+        pat[p - 1] = text[:m]
+        pat = pat.reshape(-1)
+    else:
+        raise ValueError(kind)
+    return text, np.ascontiguousarray(pat, dtype=np.uint8)

@@ -1,0 +1,172 @@
+/*
+ * tests/emu/emu_kernels.cpp -- TEST HARNESS ONLY, never linked into the product.
+ *
+ * Compiles the kernels' lane code (csrc/ac_lane.h, csrc/wm_lane.h) for the CPU
+ * with -DSMH_HOST_EMU and runs it thread by thread over the same grid the
+ * launchers would use.  This is how tiling, halo, tail and early-exit logic is
+ * exercised in the GPU-less authoring container; the -m gpu tests then run
+ * the real kernels through the C ABI.  The text is copied into a buffer whose
+ * last valid 16-byte piece ends at a PROT_NONE guard page (and, in a second
+ * pass, starts right after one), so an out-of-bounds vector load in a fast
+ * path crashes the test instead of passing silently.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include "smh_internal.h"
+#include "ac_lane.h"
+#include "wm_lane.h"
+
+#define EMU_BLOCK_THREADS 1024
+#define EMU_AC_NCH 2 /* == SMH_AC_NCH in ac_kernels.hip */
+
+struct guarded {
+    uint8_t *map;
+    size_t map_len;
+    uint8_t *text;
+};
+
+/* mode 0: buffer ends at a guard page; mode 1: buffer starts right after one */
+static guarded guard_copy(const uint8_t *src, uint64_t n, int mode)
+{
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t padded = ((n + 15) / 16) * 16; /* the runtime pads device text to 16 bytes */
+    const size_t body = ((padded + page - 1) / page) * page;
+    guarded g;
+    g.map_len = body + 2 * page;
+    g.map = (uint8_t *)mmap(NULL, g.map_len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (g.map == MAP_FAILED) abort();
+    mprotect(g.map, page, PROT_NONE);
+    mprotect(g.map + page + body, page, PROT_NONE);
+    g.text = mode == 0 ? g.map + page + body - padded : g.map + page;
+    memcpy(g.text, src, n);
+    return g;
+}
+
+static void guard_free(guarded &g) { munmap(g.map, g.map_len); }
+
+/* ------------------------------------------------------------------ AC */
+template <typename E, int SIGMA, int HC, bool ALLHOT>
+static uint64_t ac_grid(const smh_ac *ac, const uint8_t *text, uint64_t n, uint32_t hot_rows, uint64_t blocks,
+                        const uint32_t *df)
+{
+    const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
+    uint64_t total = 0;
+    for (uint64_t t = 0; t < nthreads; ++t)
+        total += smh_ac_thread<E, SIGMA, HC, EMU_AC_NCH, ALLHOT>(t, nthreads, text, n, ac->m, (const E *)ac->table,
+                                                                 (const E *)ac->table, hot_rows, ac->alphabet, df);
+    return total;
+}
+
+template <typename E, int SIGMA, int HC>
+static uint64_t ac_hot(const smh_ac *ac, const uint8_t *text, uint64_t n, uint32_t hot_rows, uint64_t blocks,
+                       const uint32_t *df)
+{
+    return hot_rows >= ac->rows ? ac_grid<E, SIGMA, HC, true>(ac, text, n, hot_rows, blocks, df)
+                                : ac_grid<E, SIGMA, HC, false>(ac, text, n, hot_rows, blocks, df);
+}
+
+template <typename E, int SIGMA>
+static uint64_t ac_halo(const smh_ac *ac, const uint8_t *text, uint64_t n, uint32_t hot_rows, uint64_t blocks,
+                        const uint32_t *df)
+{
+    const int halo = ac->m - 1;
+    if (halo <= 16) return ac_hot<E, SIGMA, 1>(ac, text, n, hot_rows, blocks, df);
+    if (halo <= 32) return ac_hot<E, SIGMA, 2>(ac, text, n, hot_rows, blocks, df);
+    if (halo <= 64) return ac_hot<E, SIGMA, 4>(ac, text, n, hot_rows, blocks, df);
+    return ac_hot<E, SIGMA, 0>(ac, text, n, hot_rows, blocks, df);
+}
+
+/* hot_rows: rows the emulated LDS holds (0 = all); blocks: grid size (0 = 4) */
+extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64_t n, int variant,
+                                uint32_t hot_rows, uint32_t blocks)
+{
+    if (n < (uint64_t)ac->m) return 0;
+    if (!blocks) blocks = 4;
+    if (!hot_rows || hot_rows > ac->rows) hot_rows = ac->rows;
+    uint32_t df[72];
+    for (int i = 0; i < 72; ++i) df[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+    uint64_t result[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        const uint8_t *text = g.text;
+        uint64_t total = 0;
+        if (variant == SMH_VARIANT_TABLE) {
+            const uint64_t nthreads = (uint64_t)blocks * 256;
+            for (uint64_t t = 0; t < nthreads; ++t)
+                total += smh_ac_table_thread(t, nthreads, text, n, ac->m, ac->g_transition, ac->g_supply,
+                                             ac->g_final, ac->alphabet);
+        } else if (ac->entry_bytes == 2) {
+            total = ac->alphabet == 4 ? ac_halo<uint16_t, 4>(ac, text, n, hot_rows, blocks, df)
+                                      : ac_halo<uint16_t, 0>(ac, text, n, hot_rows, blocks, df);
+        } else {
+            total = ac->alphabet == 4 ? ac_halo<uint32_t, 4>(ac, text, n, hot_rows, blocks, df)
+                                      : ac_halo<uint32_t, 0>(ac, text, n, hot_rows, blocks, df);
+        }
+        guard_free(g);
+        result[mode] = total;
+    }
+    return result[0] == result[1] ? result[0] : ~0ull;
+}
+
+/* ------------------------------------------------------------------ WM */
+template <bool HASHED, bool EXACT, int HC>
+static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks)
+{
+    smh_wm_params P;
+    P.m = wm->m;
+    P.bits = wm->bits_per_symbol;
+    const int wbits = wm->block_symbols * wm->bits_per_symbol;
+    P.code_mask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
+    P.filter_log2 = wm->filter_log2;
+    P.verify_log2 = wm->verify_log2;
+    P.verify = wm->verify;
+    P.pat_sorted = wm->pat_sorted;
+    const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
+    uint64_t total = 0;
+    for (uint64_t t = 0; t < nthreads; ++t)
+        total += smh_wm_thread<HASHED, EXACT, HC>(t, nthreads, text, n, wm->filter, P, wm->block_symbols);
+    return total;
+}
+
+template <bool HASHED, bool EXACT>
+static uint64_t wm_halo(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks)
+{
+    const int halo = wm->m - 1;
+    if (halo <= 16) return wm_grid<HASHED, EXACT, 1>(wm, text, n, blocks);
+    if (halo <= 32) return wm_grid<HASHED, EXACT, 2>(wm, text, n, blocks);
+    if (halo <= 64) return wm_grid<HASHED, EXACT, 4>(wm, text, n, blocks);
+    return wm_grid<HASHED, EXACT, 0>(wm, text, n, blocks);
+}
+
+extern "C" uint64_t emu_wm_scan(const smh_wm *wm, const uint8_t *text_in, uint64_t n, int variant, uint32_t blocks)
+{
+    if (n < (uint64_t)wm->m) return 0;
+    if (!blocks) blocks = 4;
+    uint64_t result[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        const uint8_t *text = g.text;
+        uint64_t total = 0;
+        if (variant == SMH_VARIANT_TABLE) {
+            uint16_t *sh = (uint16_t *)malloc(wm->shiftsize * 2);
+            for (uint32_t i = 0; i < wm->shiftsize; ++i) sh[i] = (uint16_t)wm->l_shift[i];
+            const uint64_t nthreads = (uint64_t)blocks * 256;
+            for (uint64_t t = 0; t < nthreads; ++t)
+                total += smh_wm_table_thread<uint16_t>(t, nthreads, text, n, sh, wm->shiftsize, wm->l_bucket_off,
+                                                       wm->l_bucket, wm->pat_orig, wm->m, 2);
+            free(sh);
+        } else if (wm->filter_hashed) {
+            total = wm_halo<true, false>(wm, text, n, blocks);
+        } else if (wm->filter_exact) {
+            total = wm_halo<false, true>(wm, text, n, blocks);
+        } else {
+            total = wm_halo<false, false>(wm, text, n, blocks);
+        }
+        guard_free(g);
+        result[mode] = total;
+    }
+    return result[0] == result[1] ? result[0] : ~0ull;
+}

@@ -1,0 +1,32 @@
+"""ctypes binding of tests/emu/libsmh_emu.so: the kernels' lane code compiled for the CPU
+(TEST HARNESS ONLY -- see tests/emu/emu_kernels.cpp)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd")
+sys.path.insert(0, PKG)
+import smatcher_hip as S  # noqa: E402
+
+_PATH = os.path.join(ROOT, "tests", "emu", "libsmh_emu.so")
+if not os.path.exists(_PATH):
+    subprocess.check_call(["make", "-s", "-C", PKG, "emu"])
+_emu = C.CDLL(_PATH)
+_emu.emu_ac_scan.restype = C.c_uint64
+_emu.emu_ac_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32]
+_emu.emu_wm_scan.restype = C.c_uint64
+_emu.emu_wm_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_int, C.c_uint32]
+
+
+def ac_scan(ac, text, variant=S.VARIANT_TUNED, hot_rows=0, blocks=0):
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    return int(_emu.emu_ac_scan(ac.h, text.ctypes.data_as(S.u8p), len(text), variant, hot_rows, blocks))
+
+
+def wm_scan(wm, text, variant=S.VARIANT_TUNED, blocks=0):
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    return int(_emu.emu_wm_scan(wm.h, text.ctypes.data_as(S.u8p), len(text), variant, blocks))

@@ -1,0 +1,53 @@
+"""Generates tests/golden/ref_vectors.json by RUNNING THE REFERENCE ITSELF.
+
+Run in the authoring container (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+For every seeded case of tests/cases.py it calls the reference's own compiled
+ac/ac.c and wu/wu.c (oracle/_ref/libref.so; build recipe oracle/Makefile) and
+records what they produce: the match counts of search_ac / search_wu /
+search_wu2, struct ac_table.idcounter / patterncounter, and FNV-1a digests of
+every table the reference fills (state_transition, state_supply, state_final,
+SHIFT, PREFIX_size, PREFIX_value / PREFIX_index bucket heads).  Inputs are not
+stored: they are regenerated from the seeds.  The file is data (expected
+outputs), not reference source.
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+
+import cases  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+
+def main():
+    if not O.have_ref():
+        raise SystemExit("oracle/_ref/libref.so missing: run `make -C oracle ref` where /root/reference exists")
+    out = []
+    for case in cases.all_cases():
+        text, pat = cases.build(case)
+        n, p, m, sigma = case["n"], case["p"], case["m"], case["sigma"]
+        c_ac, t_ac, _, _ = O.ref_ac(pat, m, p, sigma, text)
+        c_w2, t_w2, _, _ = O.ref_wu(pat, m, p, sigma, text, flat=True)
+        c_w1, t_w1, _, _ = O.ref_wu(pat, m, p, sigma, text, flat=False)
+        assert t_w1.digest() == t_w2.digest()
+        rec = dict(case)
+        rec.update(count_ac=c_ac, count_wu=c_w1, count_wu2=c_w2, idcounter=t_ac.idcounter,
+                   patterncounter=t_ac.patterncounter,
+                   fnv_transition="%016x" % O.fnv(t_ac.state_transition[:t_ac.idcounter * sigma]),
+                   fnv_supply="%016x" % O.fnv(t_ac.state_supply[:t_ac.idcounter]),
+                   fnv_final="%016x" % O.fnv(t_ac.state_final[:t_ac.idcounter]),
+                   fnv_wm=["%016x" % d for d in t_w2.digest()])
+        out.append(rec)
+        print(case["name"], c_ac, c_w1, c_w2, t_ac.idcounter, flush=True)
+    with open(os.path.join(HERE, "ref_vectors.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("wrote", len(out), "vectors")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,216 @@
+"""Parity tests proper: the real gfx950 kernels, called through the C ABI of libsmatcher_hip.so,
+against (i) the reference's golden counts, (ii) the oracle on fresh inputs, and (iii) at BASELINE
+sizes, size-independent properties (AC == WM, shard sums == whole, table-walk == tuned kernels).
+Integer work: every comparison is bit-exact."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd"))
+import smatcher_hip as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+with open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")) as f:
+    VECTORS = json.load(f)
+BY_NAME = {v["name"]: v for v in VECTORS}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if S.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests must run on the MI355X box")
+
+
+@pytest.mark.parametrize("vec", VECTORS, ids=[v["name"] for v in VECTORS])
+def test_kernels_match_reference_vectors(vec):
+    text, pat = cases.build(vec)
+    p, m, sigma, want = vec["p"], vec["m"], vec["sigma"], vec["count_ac"]
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    assert ac.count_host(text, S.VARIANT_TUNED)[0] == want
+    assert ac.count_host(text, S.VARIANT_TABLE)[0] == want
+    assert wm.count_host(text, S.VARIANT_TUNED)[0] == want == vec["count_wu2"]
+    assert wm.count_host(text, S.VARIANT_TABLE)[0] == want
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_kernels_match_oracle_on_fresh_inputs(seed):
+    rng = np.random.RandomState(1234 + seed)
+    sigma = [2, 4, 8, 20, 128, 256][seed % 6]
+    m = int(rng.randint(3, 66))
+    p = int(rng.randint(1, 3000))
+    n = int(rng.randint(m, 3_000_000))
+    text = O.gen_text(n, 500 + seed, sigma)
+    pat = O.gen_patterns_mixed(m, p, 600 + seed, sigma, 500 + seed, n, 2)
+    want_ac, _ = O.oracle_ac(pat, m, p, sigma, text)
+    want_wm, _ = O.oracle_wu(pat, m, p, sigma, text)
+    assert want_ac == want_wm
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    for variant in (S.VARIANT_TUNED, S.VARIANT_TABLE):
+        assert ac.count_host(text, variant)[0] == want_ac
+        assert wm.count_host(text, variant)[0] == want_wm
+
+
+def test_legacy_api_reads_like_the_reference_driver(capfd):
+    """preproc_* / search_* / cuda_* exactly as main.c:125-157, 268-298, 582-648 calls them."""
+    vec = BY_NAME["dense_dna"]
+    text, pat = cases.build(vec)
+    n, p, m, sigma, want = vec["n"], vec["p"], vec["m"], vec["sigma"], vec["count_ac"]
+    tp = text.ctypes.data_as(S.u8p)
+    # --- multiac
+    t = O.ACTables(m, p, sigma)
+    rows = np.zeros((p, m + 1), dtype=np.uint8)
+    rows[:, :m] = pat.reshape(p, m)
+    arr = (S.u8p * p)()
+    for j in range(p):
+        arr[j] = C.cast(rows[j].ctypes.data, S.u8p)
+    tab = S.lib.preproc_ac(arr, m, p, sigma, t.state_transition.ctypes.data_as(S.i32p),
+                           t.state_supply.ctypes.data_as(S.u32p), t.state_final.ctypes.data_as(S.u32p))
+    assert S.lib.search_ac(tp, n, tab) == want
+    S.lib.free_ac(tab, sigma)
+    capfd.readouterr()
+    for k in range(1, 6):
+        getattr(S.lib, "cuda_ac%d" % k)(m, tp, n, p, sigma, t.state_transition.ctypes.data_as(S.i32p),
+                                        t.state_supply.ctypes.data_as(S.u32p), t.state_final.ctypes.data_as(S.u32p))
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("Kernel")]
+    assert len(lines) == 5
+    for k, ln in enumerate(lines, 1):
+        parts = ln.split("\t")  # "Kernel K matches \t%i\t time \t%f"  (cuda/cuda_ac.cu:675)
+        assert parts[0] == "Kernel %d matches " % k and int(parts[1]) == want and float(parts[3]) > 0
+    # --- multiwm2 / multiwm
+    S.lib.wu_determine_shiftsize(sigma)
+    w = O.WMTables(m, p, sigma, S.shiftsize_global())
+    S.lib.preproc_wu2(pat.ctypes.data_as(S.u8p), m, p, sigma, 3, *w.ptrs())
+    assert S.lib.search_wu2(pat.ctypes.data_as(S.u8p), m, p, tp, n, *w.ptrs()) == want
+    prow = np.ascontiguousarray(pat.reshape(p, m))
+    parr = (S.u8p * p)()
+    for j in range(p):
+        parr[j] = C.cast(prow[j].ctypes.data, S.u8p)
+    assert S.lib.search_wu(parr, m, p, tp, n, *w.ptrs()) == want
+    for k in range(1, 6):
+        secs = C.c_double(0)
+        got = getattr(S.lib, "cuda_wm%d" % k)(pat.ctypes.data_as(S.u8p), m, tp, n, p, sigma, 3, *w.ptrs(), C.byref(secs))
+        assert got == want and secs.value > 0
+
+
+def test_device_resident_text_and_streams():
+    import torch
+    dev = torch.device("cuda", 0)
+    n, sigma, m, p = (1 << 24) + 37, 4, 8, 1000
+    text = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert S.lib.smh_corpus_text_device(C.c_void_p(text.data_ptr()), n, 0, 42, sigma, C.c_void_p(stream)) == 0
+    host = S.corpus_text(n, 42, sigma)
+    assert np.array_equal(text[:n].cpu().numpy(), host)  # device generator == host generator == oracle generator
+    assert np.array_equal(host, O.gen_text(n, 42, sigma))
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
+    want, _ = O.oracle_ac(pat, m, p, sigma, host)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream()
+    ac.scan_device(text.data_ptr(), n, cnt.data_ptr(), S.VARIANT_TUNED, stream)
+    ac.scan_device(text.data_ptr(), n, cnt.data_ptr(), S.VARIANT_TUNED, stream)        # counts accumulate
+    wm.scan_device(text.data_ptr(), n, cnt.data_ptr() + 8, S.VARIANT_TUNED, stream)
+    with torch.cuda.stream(side):
+        ac.scan_device(text.data_ptr(), n, cnt.data_ptr() + 16, S.VARIANT_TABLE, side.cuda_stream)
+        wm.scan_device(text.data_ptr(), n, cnt.data_ptr() + 24, S.VARIANT_TABLE, side.cuda_stream)
+    torch.cuda.synchronize()
+    assert cnt.tolist() == [2 * want, want, want, want]
+    # unaligned device pointer is refused, not mis-scanned
+    with pytest.raises(S.SmhError):
+        ac.scan_device(text.data_ptr() + 4, n - 4, cnt.data_ptr(), S.VARIANT_TUNED, stream)
+
+
+@pytest.mark.parametrize("name", ["big_dfa", "ascii_5_20", "mx_s256_m32_p1000"])
+def test_dfa_larger_than_lds(name):
+    """Rows beyond the LDS budget are served from HBM/L2 (hot/cold split) -- same counts."""
+    vec = BY_NAME[name]
+    text, pat = cases.build(vec)
+    ac = S.AcAutomaton.from_patterns(pat, vec["m"], vec["p"], vec["sigma"])
+    info = ac.info()
+    assert info.lds_rows < info.rows
+    assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"]
+
+
+def test_baseline_size_properties():
+    """BASELINE configs[1]/[2] size: 1 GiB DNA text in HBM.  The oracle cannot scan that in seconds,
+    so: (a) oracle on a 32 MiB slice, (b) AC == WM on the full text, (c) sum over the 8 byte-range
+    shards (main.c:467-477) == whole, (d) table-walking kernels == tuned kernels on a 128 MiB slice."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, sigma = 1 << 30, 4
+    text = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert S.lib.smh_corpus_text_device(C.c_void_p(text.data_ptr()), n, 0, 42, sigma, C.c_void_p(stream)) == 0
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def run(obj, off, length, variant=S.VARIANT_TUNED):
+        cnt.zero_()
+        obj.scan_device(text.data_ptr() + off, length, cnt.data_ptr(), variant, stream)
+        torch.cuda.synchronize()
+        return int(cnt.item())
+
+    for m, p in ((8, 1000), (16, 1000), (32, 1000), (8, 10000)):
+        pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
+        ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+        wm = S.WmTables.from_patterns(pat, m, p, sigma)
+        slice_n = 32 << 20
+        host = S.corpus_text(slice_n, 42, sigma)
+        want, _ = O.oracle_ac(pat, m, p, sigma, host)
+        assert run(ac, 0, slice_n) == want and run(wm, 0, slice_n) == want
+        whole = run(ac, 0, n)
+        assert whole == run(wm, 0, n)
+        assert whole >= p // 2  # every pattern sampled from the text occurs at least once
+        parts = 0
+        for i in range(8):
+            b, e = S.shard_range(n, 8, i, m)
+            parts += run(ac if i % 2 == 0 else wm, b, e - b)
+        assert parts == whole
+        t_n = 128 << 20
+        tuned = run(ac, 0, t_n)
+        assert run(ac, 0, t_n, S.VARIANT_TABLE) == tuned and run(wm, 0, t_n, S.VARIANT_TABLE) == tuned
+
+
+def test_text_longer_than_4gib():
+    """64-bit lengths (the reference's int n stops at 2 GiB, smatcher.h:90): a 4 GiB + 12345 byte text,
+    whole == two halves that overlap by m-1."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n, sigma, m, p = (1 << 32) + 12345, 4, 8, 1000
+    text = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert S.lib.smh_corpus_text_device(C.c_void_p(text.data_ptr()), n, 0, 42, sigma, C.c_void_p(stream)) == 0
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def run(obj, off, length):
+        cnt.zero_()
+        obj.scan_device(text.data_ptr() + off, length, cnt.data_ptr(), S.VARIANT_TUNED, stream)
+        torch.cuda.synchronize()
+        return int(cnt.item())
+
+    whole = run(ac, 0, n)
+    assert whole == run(wm, 0, n)
+    b0, e0 = S.shard_range(n, 2, 0, m)
+    b1, e1 = S.shard_range(n, 2, 1, m)
+    b1a = b1 - (b1 % 16)  # keep the device pointer 16-byte aligned: start a little earlier ...
+    extra = run(ac, b1a, b1 - b1a + m - 1) if b1a != b1 else 0  # ... and subtract what the overlap adds
+    assert run(ac, b0, e0 - b0) + run(wm, b1a, e1 - b1a) - extra == whole
+    # the tail of the text (beyond 2^32) really is scanned: plant-free check against the oracle
+    tail_off = (1 << 32) - 4096
+    host_tail = S.corpus_text(n - tail_off, 42, sigma, offset=tail_off)
+    want_tail, _ = O.oracle_ac(pat, m, p, sigma, host_tail)
+    assert run(ac, tail_off, n - tail_off) == want_tail

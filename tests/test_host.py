@@ -1,0 +1,172 @@
+"""Host side of the product (C code in libsmatcher_hip.so) on the CPU: the library loads and
+exports every declared symbol, preproc_* fill the caller's tables exactly as the reference does
+(golden digests), the compiled device layouts are self-consistent, and the search entry points
+refuse to run without a GPU instead of falling back."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd")
+sys.path.insert(0, PKG)
+import smatcher_hip as S  # noqa: E402
+
+with open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")) as f:
+    VECTORS = json.load(f)
+FAST = [v for v in VECTORS if v["n"] <= 200000]
+
+
+def hx(x):
+    return "%016x" % x
+
+
+def test_library_exports_every_declared_symbol():
+    declared = set()
+    for hdr in ("smatcher.h", "smatcher_hip.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        declared |= set(re.findall(r"\b((?:smh_|cuda_ac|cuda_wm|preproc_|search_|free_ac|wu_determine|fail)\w*)\s*\(", src))
+    declared |= {"m_nBitsInShift", "shiftsize"}
+    assert declared >= set(S.LEGACY_SYMBOLS + S.EXT_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(S.lib, name), "libsmatcher_hip.so does not export " + name
+    assert C.c_ushort.in_dll(S.lib, "m_nBitsInShift").value == 2  # main.c:431
+
+
+def test_corpus_and_shards_match_oracle():
+    for sigma in (2, 4, 20, 256):
+        assert np.array_equal(S.corpus_text(5000, 42, sigma, offset=123), O.gen_text(5000, 42, sigma, offset=123))
+        assert np.array_equal(S.corpus_patterns(9, 77, 7, sigma, 42, 5000, 2),
+                              O.gen_patterns_mixed(9, 77, 7, sigma, 42, 5000, 2))
+    for n, R, m in ((1 << 20, 8, 8), (1000003, 3, 8), (17, 8, 5), (100, 1, 32)):
+        for i in range(R):
+            assert S.shard_range(n, R, i, m) == O.shard_range(n, R, i, m)
+
+
+def _legacy_preproc_ac(pat, m, p, sigma):
+    t = O.ACTables(m, p, sigma)  # allocated and initialised as main.c:410-420
+    rows = np.zeros((p, m + 1), dtype=np.uint8)
+    rows[:, :m] = pat.reshape(p, m)
+    arr = (S.u8p * p)()
+    for j in range(p):
+        arr[j] = C.cast(rows[j].ctypes.data, S.u8p)
+    tab = S.lib.preproc_ac(arr, m, p, sigma, t.state_transition.ctypes.data_as(S.i32p),
+                           t.state_supply.ctypes.data_as(S.u32p), t.state_final.ctypes.data_as(S.u32p))
+    t.idcounter, t.patterncounter = tab.contents.idcounter, tab.contents.patterncounter
+    assert tab.contents.zerostate
+    S.lib.free_ac(tab, sigma)
+    return t
+
+
+@pytest.mark.parametrize("vec", FAST, ids=[v["name"] for v in FAST])
+def test_preproc_tables_match_reference_vectors(vec):
+    text, pat = cases.build(vec)
+    p, m, sigma = vec["p"], vec["m"], vec["sigma"]
+    t = _legacy_preproc_ac(pat, m, p, sigma)
+    assert (t.idcounter, t.patterncounter) == (vec["idcounter"], vec["patterncounter"])
+    assert hx(O.fnv(t.state_transition[:t.idcounter * sigma])) == vec["fnv_transition"]
+    assert hx(O.fnv(t.state_supply[:t.idcounter])) == vec["fnv_supply"]
+    assert hx(O.fnv(t.state_final[:t.idcounter])) == vec["fnv_final"]
+    # rows past idcounter are left exactly as the caller initialised them
+    assert (t.state_transition[t.idcounter * sigma:] == -1).all()
+    S.lib.wu_determine_shiftsize(sigma)
+    assert S.shiftsize_global() == O.lib.ora_wu_determine_shiftsize(sigma)
+    for flat in (True, False):
+        w = O.WMTables(m, p, sigma, S.shiftsize_global())  # main.c:429-449
+        if flat:
+            S.lib.preproc_wu2(pat.ctypes.data_as(S.u8p), m, p, sigma, 3, *w.ptrs())
+        else:
+            rows = np.ascontiguousarray(pat.reshape(p, m))
+            arr = (S.u8p * p)()
+            for j in range(p):
+                arr[j] = C.cast(rows[j].ctypes.data, S.u8p)
+            S.lib.preproc_wu(arr, m, p, sigma, 3, *w.ptrs())
+        assert [hx(d) for d in w.digest()] == vec["fnv_wm"]
+
+
+@pytest.mark.parametrize("name", ["kat_1m_100x8", "dups", "big_dfa", "ascii_5_20", "mx_s4_m32_p1000",
+                                  "mx_s20_m8_p1000", "mx_s2_m16_p100"])
+def test_compiled_layouts(name):
+    vec = next(v for v in VECTORS if v["name"] == name)
+    text, pat = cases.build(vec)
+    p, m, sigma = vec["p"], vec["m"], vec["sigma"]
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    info = ac.info()
+    assert info.states == vec["idcounter"] and info.finals == vec["patterncounter"]
+    # accepting leaves are folded away: one row per non-accepting state
+    assert info.rows == info.states - info.finals
+    assert info.entry_bytes == (2 if info.rows <= 32768 else 4)
+    assert info.table_bytes == info.rows * sigma * info.entry_bytes
+    assert 1 <= info.lds_rows <= info.rows and info.lds_bytes <= 160 * 1024 and info.lds_bytes % 16 == 0
+    # compiling from the legacy tables gives the same automaton as compiling from patterns
+    _, t = O.oracle_ac(pat, m, p, sigma)
+    ac2 = S.AcAutomaton.from_tables(t.state_transition, t.state_supply, t.state_final, m * p + 1, sigma, m)
+    i2 = ac2.info()
+    assert (i2.states, i2.finals, i2.rows, i2.table_bytes) == (info.states, info.finals, info.rows, info.table_bytes)
+    wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    wi = wm.info()
+    distinct = len({bytes(r) for r in pat.reshape(p, m)})
+    assert wi.distinct == distinct == vec["patterncounter"] and wi.patterns == p
+    assert wi.shiftsize == O.lib.ora_wu_determine_shiftsize(sigma)
+    _, tw = O.oracle_wu(pat, m, p, sigma)
+    assert wi.shift_zero == int((tw.SHIFT == 0).sum())
+    assert wi.block_symbols <= m and wi.filter_log2 <= 20 and wi.lds_bytes <= 128 * 1024
+    if wi.filter_exact:
+        assert wi.block_symbols == m and not wi.filter_hashed and wi.verify_slots == 0
+    else:
+        assert wi.verify_slots >= 2 * distinct
+    wm2 = S.WmTables.from_tables(pat, m, p, sigma, tw.SHIFT, tw.PREFIX_value, tw.PREFIX_index, tw.PREFIX_size)
+    w2 = wm2.info()
+    assert (w2.distinct, w2.shift_zero, w2.block_symbols, w2.filter_log2) == \
+           (wi.distinct, wi.shift_zero, wi.block_symbols, wi.filter_log2)
+
+
+def test_bad_arguments_are_reported():
+    pat = np.zeros(8, dtype=np.uint8)
+    pat[3] = 9
+    with pytest.raises(S.SmhError):
+        S.AcAutomaton.from_patterns(pat, 8, 1, 4)      # symbol >= alphabet
+    with pytest.raises(S.SmhError):
+        S.WmTables.from_patterns(np.zeros(8, dtype=np.uint8), 8, 1, 5)  # alphabet unsupported by wu-manber
+    with pytest.raises(S.SmhError):
+        S.WmTables.from_patterns(np.zeros(2, dtype=np.uint8), 2, 1, 4)  # m < 3 (block of 3 symbols)
+
+
+def _run_snippet(code):
+    env = dict(os.environ, PYTHONPATH=PKG + os.pathsep + os.path.join(ROOT, "tests"))
+    return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_unsupported_alphabet_exits_like_the_reference():
+    r = _run_snippet("import smatcher_hip as S; S.lib.wu_determine_shiftsize(5); print('survived')")
+    assert r.returncode == 1 and "not supported by wu-manber" in r.stderr and "survived" not in r.stdout
+
+
+@pytest.mark.skipif(S.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_search_without_gpu_fails_loudly():
+    """No CPU fallback: the extended API reports SMH_ENODEV, the legacy names exit(1)."""
+    pat = S.corpus_patterns(8, 10, 7, 4, 42, 1000, 2)
+    text = S.corpus_text(1000, 42, 4)
+    ac = S.AcAutomaton.from_patterns(pat, 8, 10, 4)
+    with pytest.raises(S.SmhError):
+        ac.count_host(text)
+    wm = S.WmTables.from_patterns(pat, 8, 10, 4)
+    with pytest.raises(S.SmhError):
+        wm.count_host(text)
+    code = ("import numpy as np, ctypes as C, smatcher_hip as S, oracle_lib as O\n"
+            "pat=S.corpus_patterns(8,10,7,4,42,1000,2); text=S.corpus_text(1000,42,4)\n"
+            "S.lib.wu_determine_shiftsize(4); w=O.WMTables(8,10,4,64)\n"
+            "S.lib.preproc_wu2(pat.ctypes.data_as(S.u8p),8,10,4,3,*w.ptrs())\n"
+            "S.lib.search_wu2(pat.ctypes.data_as(S.u8p),8,10,text.ctypes.data_as(S.u8p),1000,*w.ptrs())\n"
+            "print('survived')\n")
+    r = _run_snippet(code)
+    assert r.returncode == 1 and "survived" not in r.stdout
