@@ -409,6 +409,7 @@ static void cuda_ac_any(int k, int variant, int m, unsigned char *text, int n, i
         die_with_error("cuda_ac");
     /* cuda/cuda_ac.cu:675 */
     printf("Kernel %d matches \t%i\t time \t%f\n", k, (int)count, secs);
+    fflush(stdout);
     smh_ac_free(ac);
 }
 
