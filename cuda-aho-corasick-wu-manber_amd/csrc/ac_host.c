@@ -16,6 +16,7 @@
  *   - search never runs on the host: search_ac (smh_runtime.hip) launches the kernel.
  */
 #include "smh_internal.h"
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -150,6 +151,10 @@ void smh_ac_host_free(struct smh_ac *ac)
 {
     if (!ac) return;
     free(ac->table);
+    free(ac->row_depth);
+    free(ac->row_fail);
+    if (ac->trunc1_table != ac->scan_table) free(ac->trunc1_table);
+    free(ac->scan_table);
     free(ac->depth_first);
     free(ac->g_transition);
     free(ac->g_supply);
@@ -299,6 +304,17 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
         while (d <= max_depth + 1) ac->depth_first[d++] = rows;
     }
 
+    ac->row_depth = (uint8_t *)malloc(rows ? rows : 1);
+    ac->row_fail = (uint32_t *)malloc((size_t)(rows ? rows : 1) * sizeof(uint32_t));
+    if (!ac->row_depth || !ac->row_fail) goto oom;
+    for (uint32_t k = 0; k < nstates; ++k) {
+        uint32_t u = order[k];
+        if (canon[u] != u) continue;
+        uint32_t sup = depth[u] <= 1 ? 0u : supply[u];
+        ac->row_depth[newid[u]] = (uint8_t)(depth[u] > 255 ? 255 : depth[u]);
+        ac->row_fail[newid[u]] = newid[canon[sup]];
+    }
+
     /* 6. reference-layout copy, truncated to the ids in use, for SMH_VARIANT_TABLE */
     {
         size_t keep = (size_t)max_id + 1;
@@ -316,6 +332,9 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
     }
 
     free(order); free(depth); free(seen); free(leaf); free(canon); free(newid); free(full);
+    order = depth = canon = newid = full = NULL;
+    seen = leaf = NULL;
+    if (ac->fixed_length_ok && smh_ac_plan_scan(ac, SMH_AC_LDS_BUDGET, 0, 0) != SMH_OK) goto bad;
     return ac;
 
 oom:
@@ -324,6 +343,126 @@ bad:
     free(order); free(depth); free(seen); free(leaf); free(canon); free(newid); free(full);
     smh_ac_host_free(ac);
     return NULL;
+}
+
+
+/* ------------------------------------------------------------------ scan-table plan
+ * The kernels never leave LDS in their inner loop, so the automaton the lanes walk must fit
+ * there whole.  Cutting the DFA at depth K keeps exactly the rows [0, depth_first[K+1]) (BFS
+ * numbering) and is again an Aho-Corasick automaton -- of the K-symbol prefixes.  Two layouts:
+ * stride 1 (one lookup per symbol) and, for the 4-letter alphabet, stride 2 (one lookup per two
+ * symbols; LDS random-lookup rate is the kernel's bound, see profiles/).  A crude cost model in
+ * "scan steps per text byte" picks between them.  With candidate rate r per byte a wave-step
+ * (64 lanes x 2 chains x stride bytes) takes the queue-push path with probability
+ * p = 1 - exp(-128 * stride * r); that path costs several plain steps, so K is worth much more
+ * than stride once candidates stop being rare:
+ *     cost = (1 + p * SMH_PUSH_COST) / stride + r * SMH_VERIFY_COST                            */
+#define SMH_PUSH_COST 6.0
+#define SMH_VERIFY_COST 10.0
+
+static uint32_t entry_get(const void *t, int eb, size_t i)
+{
+    return eb == 2 ? ((const uint16_t *)t)[i] : ((const uint32_t *)t)[i];
+}
+
+/* target row and candidate flag of the depth-K automaton for (row, c) */
+static inline uint32_t trunc_step(const struct smh_ac *ac, int K, uint32_t row, int c, int *flag)
+{
+    const uint32_t mask = ac->entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu;
+    uint32_t e = entry_get(ac->table, ac->entry_bytes, (size_t)row * ac->alphabet + c);
+    uint32_t t = e & mask;
+    if (K >= ac->m) {
+        *flag = (int)(e >> (ac->entry_bytes == 2 ? 15 : 31));
+        return t;
+    }
+    if (ac->row_depth[t] > K) t = ac->row_fail[t]; /* depth K+1 -> its supply state, depth <= K */
+    *flag = ac->row_depth[t] == K;
+    return t;
+}
+
+static double candidate_rate(const struct smh_ac *ac, int K)
+{
+    if (K >= ac->m) return 0.0;
+    double states_at_k = (double)(ac->depth_first[K + 1] - ac->depth_first[K]);
+    double r = states_at_k;
+    for (int i = 0; i < K; ++i) r /= (double)ac->alphabet;
+    return r > 1.0 ? 1.0 : r;
+}
+
+int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth)
+{
+    const int A = ac->alphabet;
+    const int kmax = ac->m < SMH_AC_MAX_SCAN_DEPTH ? ac->m : SMH_AC_MAX_SCAN_DEPTH;
+    int best_k[3] = {0, 0, 0};
+    double best_cost = 1e30;
+    int best_s = 0;
+    for (int s = 1; s <= 2; ++s) {
+        if (s == 2 && A != 4) continue;
+        if (force_stride && s != force_stride) continue;
+        for (int K = kmax; K >= 1; --K) {
+            if (force_depth && K != force_depth) continue;
+            uint64_t rk = ac->depth_first[K + 1 <= ac->max_depth + 1 ? K + 1 : ac->max_depth + 1];
+            if (K >= ac->m) rk = ac->rows;
+            uint64_t per_row = s == 1 ? (uint64_t)A * (rk <= 32768 ? 2u : 4u) : (uint64_t)A * A * 2u;
+            if (s == 2 && rk > 16384) continue;
+            if (rk * per_row > lds_budget) continue;
+            const double r = candidate_rate(ac, K);
+            const double ppush = 1.0 - exp(-128.0 * s * r);
+            double cost = (1.0 + ppush * SMH_PUSH_COST) / s + r * SMH_VERIFY_COST;
+            if (cost < best_cost) { best_cost = cost; best_s = s; best_k[s] = K; }
+            if (!force_depth) break; /* the deepest K that fits is the best for this stride */
+        }
+    }
+    if (!best_s) {
+        smh_set_error("smh_ac_plan_scan: no depth-K automaton fits %u bytes of LDS (alphabet %d)", lds_budget, A);
+        return SMH_EUNSUP;
+    }
+    const int K = best_k[best_s];
+    const uint32_t rk = K >= ac->m ? ac->rows : ac->depth_first[K + 1];
+    if (ac->trunc1_table != ac->scan_table) free(ac->trunc1_table);
+    free(ac->scan_table);
+    ac->scan_table = ac->trunc1_table = NULL;
+    ac->scan_depth = K;
+    ac->scan_stride = best_s;
+    ac->scan_exact = K >= ac->m;
+    ac->scan_rows = rk;
+    ac->scan_candidate_rate = candidate_rate(ac, K);
+    /* stride-1 depth-K table */
+    const int eb1 = rk <= 32768 ? 2 : 4;
+    const size_t n1 = (size_t)rk * A;
+    void *t1 = calloc(n1 * eb1 + 16, 1);
+    if (!t1) { smh_set_error("smh_ac_plan_scan: out of memory"); return SMH_ENOMEM; }
+    for (uint32_t r = 0; r < rk; ++r)
+        for (int c = 0; c < A; ++c) {
+            int flag;
+            uint32_t t = trunc_step(ac, K, r, c, &flag);
+            if (eb1 == 2) ((uint16_t *)t1)[(size_t)r * A + c] = (uint16_t)(t | (flag ? 0x8000u : 0u));
+            else ((uint32_t *)t1)[(size_t)r * A + c] = t | (flag ? 0x80000000u : 0u);
+        }
+    ac->trunc1_table = t1;
+    ac->trunc1_entry_bytes = eb1;
+    ac->trunc1_bytes = (uint64_t)n1 * eb1;
+    if (best_s == 1) {
+        ac->scan_table = t1;
+        ac->scan_entry_bytes = eb1;
+        ac->scan_bytes = (uint32_t)((n1 * eb1 + 15) & ~(size_t)15);
+    } else {
+        const size_t n2 = (size_t)rk * 16;
+        uint16_t *t2 = (uint16_t *)calloc(n2 * 2 + 16, 1);
+        if (!t2) { smh_set_error("smh_ac_plan_scan: out of memory"); return SMH_ENOMEM; }
+        for (uint32_t r = 0; r < rk; ++r)
+            for (int c1 = 0; c1 < 4; ++c1)
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    int f1, f2;
+                    uint32_t r1 = trunc_step(ac, K, r, c1, &f1);
+                    uint32_t r2 = trunc_step(ac, K, r1, c2, &f2);
+                    t2[(size_t)r * 16 + c1 * 4 + c2] = (uint16_t)(r2 | (f1 ? 0x4000u : 0u) | (f2 ? 0x8000u : 0u));
+                }
+        ac->scan_table = t2;
+        ac->scan_entry_bytes = 2;
+        ac->scan_bytes = (uint32_t)((n2 * 2 + 15) & ~(size_t)15);
+    }
+    return SMH_OK;
 }
 
 smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *state_supply,
@@ -379,9 +518,27 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->rows = ac->rows;
     out->entry_bytes = (uint32_t)ac->entry_bytes;
     out->table_bytes = ac->table_bytes;
-    extern void smh_ac_lds_plan(const struct smh_ac *ac, uint32_t *lds_rows, uint32_t *lds_bytes);
-    smh_ac_lds_plan(ac, &out->lds_rows, &out->lds_bytes);
+    out->lds_rows = ac->scan_rows;
+    out->lds_bytes = ac->scan_bytes;
+    out->scan_depth = (uint32_t)ac->scan_depth;
+    out->scan_stride = (uint32_t)ac->scan_stride;
+    out->scan_exact = (uint32_t)ac->scan_exact;
     return SMH_OK;
+}
+
+int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC || stride < 0 || stride > 2 || depth < 0) {
+        smh_set_error("smh_ac_set_scan_plan: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (!ac->fixed_length_ok) {
+        smh_set_error("smh_ac_set_scan_plan: patterns are not all of length m");
+        return SMH_EUNSUP;
+    }
+    if (ac->dev) smh_ac_dev_free(ac->dev); /* device copies are rebuilt on the next scan */
+    ac->dev = NULL;
+    return smh_ac_plan_scan(ac, SMH_AC_LDS_BUDGET, stride, depth);
 }
 
 void smh_ac_free(smh_ac *ac)

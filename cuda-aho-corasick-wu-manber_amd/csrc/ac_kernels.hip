@@ -1,12 +1,15 @@
 /*
  * csrc/ac_kernels.hip -- Aho-Corasick scan kernels for gfx950 (MI355X).
  *
- * ac_dfa_kernel    tuned path: complete DFA, hot rows staged in LDS once per
- *                  workgroup, 64-byte text segments streamed straight into
- *                  registers, NCH automata per lane, wave-level reduction and
- *                  one 64-bit atomic per wave.  Replaces ac_kernel3..5b
- *                  (cuda/cuda_ac.cu:23-532) -- no textures, no per-thread
- *                  counters copied back to the host (cuda/cuda_ac.cu:667-673).
+ * ac_dfa_kernel    tuned path: the depth-K automaton staged in LDS once per
+ *                  workgroup (stride 1 or 2 symbols per lookup), 64-byte text
+ *                  segments streamed straight into registers, NCH automata per
+ *                  lane, candidates compacted into a per-wave queue (ballot +
+ *                  prefix count) and verified against the full DFA in HBM,
+ *                  wave-level reduction and one 64-bit atomic per wave.
+ *                  Replaces ac_kernel3..5b (cuda/cuda_ac.cu:23-532) -- no
+ *                  textures, no per-thread counters copied back to the host
+ *                  (cuda/cuda_ac.cu:667-673).
  * ac_table_kernel  walks the reference-layout goto/supply/final tables from
  *                  HBM/L2 as given; replaces ac_kernel1/2 (cuda/cuda_ac.cu:535-592).
  *
@@ -26,24 +29,23 @@ __device__ __forceinline__ void smh_wave_add(uint32_t cnt, uint64_t *count)
     if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd((unsigned long long *)count, (unsigned long long)cnt);
 }
 
-template <typename E, int SIGMA, int HC, bool ALLHOT>
-__global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(
-    const uint8_t *__restrict__ text, uint64_t n, int m, const E *__restrict__ table, uint32_t hot_rows,
-    uint32_t lds_bytes, int sigma_rt, const uint32_t *__restrict__ depth_first, uint64_t *count)
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT>
+__global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__restrict__ scan_table, uint32_t lds_bytes,
+                                                                  smh_ac_verify_ctx V, uint64_t *queue_base,
+                                                                  uint64_t *count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smh_lds[];
-    /* stage the hot rows: 16 bytes per lane per step, coalesced */
+    /* stage the depth-K automaton: 16 bytes per lane per step, coalesced */
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(table);
+        const uint4 *src = reinterpret_cast<const uint4 *>(scan_table);
         uint4 *dst = reinterpret_cast<uint4 *>(smh_lds);
         for (uint32_t i = threadIdx.x; i < lds_bytes / 16u; i += blockDim.x) dst[i] = src[i];
     }
     __syncthreads();
-    const E *hot = reinterpret_cast<const E *>(smh_lds);
+    const E *tab = reinterpret_cast<const E *>(smh_lds);
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t cnt = smh_ac_thread<E, SIGMA, HC, SMH_AC_NCH, ALLHOT>(gthread, nthreads, text, n, m, hot, table,
-                                                                        hot_rows, sigma_rt, depth_first);
+    const uint32_t cnt = smh_ac_thread<E, SIGMA, STRIDE, HC, SMH_AC_NCH, EXACT>(gthread, nthreads, tab, V, queue_base);
     smh_wave_add(cnt, count);
 }
 
@@ -60,10 +62,12 @@ __global__ __launch_bounds__(256) void ac_table_kernel(const uint8_t *__restrict
 }
 
 /* ------------------------------------------------------------------ launch */
-template <typename E, int SIGMA, int HC, bool ALLHOT>
+uint32_t smh_ac_max_blocks(int n_cus) { return (uint32_t)n_cus * 2u; }
+
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT>
 static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
 {
-    auto kern = ac_dfa_kernel<E, SIGMA, HC, ALLHOT>;
+    auto kern = ac_dfa_kernel<E, SIGMA, STRIDE, HC, EXACT>;
     hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
     if (err != hipSuccess) return err;
@@ -71,41 +75,45 @@ static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
     err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SMH_BLOCK_THREADS, L.lds_bytes);
     if (err != hipSuccess) return err;
     if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
     /* enough wave-chunks for every wave?  shrink the grid for small texts */
     const uint64_t chunk = (uint64_t)SMH_SEG * 64u * SMH_AC_NCH;
-    const uint64_t n_chunks = (L.n + chunk - 1) / chunk;
+    const uint64_t n_chunks = (L.V.n + chunk - 1) / chunk;
     uint64_t blocks = (uint64_t)L.n_cus * (uint64_t)per_cu;
     const uint64_t want = (n_chunks + (SMH_BLOCK_THREADS / 64) - 1) / (SMH_BLOCK_THREADS / 64);
     if (blocks > want) blocks = want;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), L.lds_bytes, stream, L.d_text, L.n,
-                       L.m, reinterpret_cast<const E *>(L.d_table), L.lds_rows, L.lds_bytes, L.alphabet,
-                       L.d_depth_first, L.d_count);
+    if (blocks > smh_ac_max_blocks(L.n_cus)) blocks = smh_ac_max_blocks(L.n_cus); /* the queue workspace is sized for this */
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), L.lds_bytes, stream,
+                       reinterpret_cast<const E *>(L.d_scan_table), L.lds_bytes, L.V, L.d_queue, L.d_count);
     return hipGetLastError();
 }
 
-template <typename E, int SIGMA, int HC>
-static hipError_t launch_hot(const smh_ac_launch &L, hipStream_t stream)
+template <typename E, int SIGMA, int STRIDE, int HC>
+static hipError_t launch_exact(const smh_ac_launch &L, hipStream_t stream)
 {
-    return L.lds_rows >= L.rows ? launch_one<E, SIGMA, HC, true>(L, stream)
-                                : launch_one<E, SIGMA, HC, false>(L, stream);
+    return L.exact ? launch_one<E, SIGMA, STRIDE, HC, true>(L, stream) : launch_one<E, SIGMA, STRIDE, HC, false>(L, stream);
 }
 
-template <typename E, int SIGMA>
+template <typename E, int SIGMA, int STRIDE>
 static hipError_t launch_halo(const smh_ac_launch &L, hipStream_t stream)
 {
-    const int halo = L.m - 1;
-    if (halo <= 16) return launch_hot<E, SIGMA, 1>(L, stream);
-    if (halo <= 32) return launch_hot<E, SIGMA, 2>(L, stream);
-    if (halo <= 64) return launch_hot<E, SIGMA, 4>(L, stream);
-    return launch_hot<E, SIGMA, 0>(L, stream);
+    const int halo = L.V.K - 1;
+    if (halo <= 16) return launch_exact<E, SIGMA, STRIDE, 1>(L, stream);
+    if (halo <= 32) return launch_exact<E, SIGMA, STRIDE, 2>(L, stream);
+    return launch_exact<E, SIGMA, STRIDE, 4>(L, stream);
 }
 
 hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream)
 {
-    if (L.entry_bytes == 2)
-        return L.alphabet == 4 ? launch_halo<uint16_t, 4>(L, stream) : launch_halo<uint16_t, 0>(L, stream);
-    return L.alphabet == 4 ? launch_halo<uint32_t, 4>(L, stream) : launch_halo<uint32_t, 0>(L, stream);
+    if (L.V.K - 1 > 64) return hipErrorInvalidValue;
+    if (L.stride == 2) {
+        if (L.V.sigma != 4 || L.scan_entry_bytes != 2) return hipErrorInvalidValue;
+        return launch_halo<uint16_t, 4, 2>(L, stream);
+    }
+    if (L.scan_entry_bytes == 2)
+        return L.V.sigma == 4 ? launch_halo<uint16_t, 4, 1>(L, stream) : launch_halo<uint16_t, 0, 1>(L, stream);
+    return L.V.sigma == 4 ? launch_halo<uint32_t, 4, 1>(L, stream) : launch_halo<uint32_t, 0, 1>(L, stream);
 }
 
 hipError_t smh_launch_ac_table(const smh_ac_table_launch &L, hipStream_t stream)

@@ -52,6 +52,39 @@ SMH_LANE smh_u32x4 smh_load16(const uint8_t *p)
 }
 #endif
 
+/*
+ * Dword `q` of the text that FOLLOWS a lane's 64-byte segment (its post-halo), without loading
+ * it again: those bytes are the first bytes of the next lane's segment, already sitting in that
+ * lane's registers, so they are pulled across with one DPP move (wave_shl:1 = "lane i reads lane
+ * i+1").  Lane 63 has no right-hand neighbour in the wave; it receives `edge`, which the caller
+ * sets to the wave-uniform value that follows the wave's last segment.  Re-loading the halo from
+ * memory instead (a 16-byte load per lane at +64) makes every wave touch all 32 cache lines of
+ * its chunk a second time, long after the first pass -- measured as 1.9x HBM read traffic.
+ * Must be called with all 64 lanes active.  The CPU emulation reads the same bytes from memory.
+ */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+SMH_LANE uint32_t smh_next_lane_word(uint32_t mine, uint32_t edge, const uint8_t *, uint64_t)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)mine, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+SMH_LANE uint32_t smh_first_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+SMH_LANE uint64_t smh_uniform64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+#else
+SMH_LANE uint32_t smh_next_lane_word(uint32_t, uint32_t, const uint8_t *text, uint64_t byte_offset)
+{
+    uint32_t v;
+    memcpy(&v, text + byte_offset, 4);
+    return v;
+}
+SMH_LANE uint32_t smh_first_lane(uint32_t v) { return v; }
+SMH_LANE uint64_t smh_uniform64(uint64_t v) { return v; }
+#endif
+
 SMH_LANE uint32_t smh_byte_of(uint32_t word, int k) { return (word >> (8 * k)) & 0xFFu; }
 
 #endif

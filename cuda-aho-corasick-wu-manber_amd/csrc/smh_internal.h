@@ -20,13 +20,27 @@ extern "C" {
 void smh_set_error(const char *fmt, ...);
 
 /* ------------------------------------------------------------------ AC
- * Device DFA (DESIGN.md "AC layout"): one row per kept state, `alphabet`
- * entries per row, entry = next row | FLAG.  FLAG (top bit) says the
- * reference automaton is in an accepting state after this transition.
- * Accepting leaves have no row: a transition into leaf f is stored as
- * (row of supply*(f)) | FLAG, exact because a leaf's goto is undefined for
- * every symbol and the walk continues from its supply state (ac/ac.c:209-211).
- * Rows are numbered breadth-first, so row id order == depth order.
+ * Device automaton (DESIGN.md "AC layout").
+ *
+ * full DFA   : one row per kept state, `alphabet` entries per row, entry = next
+ *              row | FLAG.  FLAG (top bit) says the reference automaton is in an
+ *              accepting state after this transition.  Accepting leaves have no
+ *              row: a transition into leaf f is stored as (row of supply*(f)) |
+ *              FLAG, exact because a leaf's goto is undefined for every symbol
+ *              and the walk continues from its supply state (ac/ac.c:209-211).
+ *              Rows are numbered breadth-first: row id order == depth order.
+ *              Lives in HBM; only the verify stage reads it.
+ * scan table : the same automaton cut at depth K <= m (the Aho-Corasick machine
+ *              of the patterns' K-symbol prefixes), small enough to sit in LDS
+ *              whole.  Its rows are rows [0, rows_k) of the full DFA; an entry
+ *              that would leave depth K is bent to the supply state.  FLAG now
+ *              means "a K-symbol pattern prefix ends here".  K == m: FLAG is a
+ *              match and there is no verify stage.  K < m: the position is a
+ *              candidate; it is queued with its depth-K row and later walked
+ *              down the goto edges of the full DFA for the remaining m-K symbols.
+ *              stride 1: entry = next row | FLAG            (alphabet entries/row)
+ *              stride 2: entry = row after TWO symbols | F1<<14 | F2<<15
+ *                        (alphabet^2 entries/row, 16-bit, alphabet 4 only)
  */
 struct smh_ac_dev; /* opaque to C: device buffers, owned by smh_runtime.hip */
 
@@ -43,6 +57,22 @@ struct smh_ac {
     int max_depth;        /* depth of the deepest kept row */
     uint32_t *depth_first; /* [max_depth + 2]: first row with depth >= d; [max_depth+1] = rows */
     int fixed_length_ok;  /* every accepting state is a leaf at depth m (chunked scans are exact) */
+    uint8_t *row_depth;   /* [rows] */
+    uint32_t *row_fail;   /* [rows] supply state of each kept row, as a row id */
+    /* scan table (LDS image) and its plan */
+    int scan_depth;       /* K */
+    int scan_stride;      /* 1 or 2 symbols per lookup */
+    int scan_exact;       /* K == m */
+    uint32_t scan_rows;   /* rows with depth <= K */
+    int scan_entry_bytes; /* 2 or 4 (stride 2: always 2) */
+    void *scan_table;     /* scan_rows * alphabet^stride entries */
+    uint32_t scan_bytes;  /* padded to 16 */
+    double scan_candidate_rate; /* expected candidates per text byte on uniform text (0 when exact) */
+    /* stride-1 depth-K table in HBM: the slow path and the resolution of stride-2 "first symbol"
+     * candidates read it; identical to scan_table when scan_stride == 1 */
+    void *trunc1_table;
+    int trunc1_entry_bytes;
+    uint64_t trunc1_bytes;
     /* reference-layout tables truncated to `states` rows, for SMH_VARIANT_TABLE */
     int32_t *g_transition; /* states * alphabet, -1 = no edge, row 0 as ac_init leaves it */
     uint32_t *g_supply;
@@ -64,6 +94,10 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *state_transition, const uns
                                           const unsigned int *state_final, uint64_t rows,
                                           int alphabet, int m);
 void smh_ac_host_free(struct smh_ac *ac);
+/* choose K / stride for an LDS budget and build scan_table (+ trunc1_table); force_stride 0 = auto */
+int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth);
+#define SMH_AC_LDS_BUDGET (160u * 1024u - 512u)
+#define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
 
 /* ------------------------------------------------------------------ WM

@@ -7,26 +7,25 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ac_lane.h"
 
 #define SMH_BLOCK_THREADS 1024
 #define SMH_LDS_BUDGET (156u * 1024u) /* of the 160 KiB per CU; the rest is left to the runtime */
 #define SMH_MAX_HALO_CHUNKS 4          /* fast paths cover m - 1 <= 64 */
-#define SMH_DEPTH_FIRST_LEN 72         /* padded depth_first[] the AC kernels index with h + 1 <= 65 */
+#define SMH_DEPTH_FIRST_MIN 72         /* depth_first[] is padded to max(this, m + 2): indexed with h + 1 <= 65 and t + 1 <= m */
 
 struct smh_ac_launch {
-    const uint8_t *d_text;
-    uint64_t n;
-    int m;
-    int alphabet;
-    int entry_bytes;
-    const void *d_table;        /* rows * alphabet entries */
-    uint32_t rows;
-    uint32_t lds_rows;
+    smh_ac_verify_ctx V;        /* text, n, m, K, sigma, full DFA, depth_first, trunc1 (device pointers) */
+    int stride;                 /* 1 or 2 */
+    int exact;                  /* K == m: flags are matches, no queue */
+    int scan_entry_bytes;
+    const void *d_scan_table;   /* LDS image */
     uint32_t lds_bytes;         /* multiple of 16 */
-    const uint32_t *d_depth_first; /* SMH_DEPTH_FIRST_LEN entries */
+    uint64_t *d_queue;          /* smh_ac_max_blocks * 16 waves * SMH_AC_QCAP entries (NULL when exact) */
     uint64_t *d_count;
     int n_cus;
 };
+uint32_t smh_ac_max_blocks(int n_cus);
 hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream);
 
 struct smh_ac_table_launch {

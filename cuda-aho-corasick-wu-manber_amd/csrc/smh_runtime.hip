@@ -31,11 +31,13 @@
 struct smh_ac_dev {
     int device;
     void *d_table;
+    void *d_scan;
+    void *d_trunc1;
+    uint64_t *d_queue;
     uint32_t *d_depth_first;
     int32_t *d_transition;
     uint32_t *d_supply;
     uint32_t *d_final;
-    uint32_t lds_rows, lds_bytes;
 };
 
 struct smh_wm_dev {
@@ -151,22 +153,13 @@ static int upload(void **d, const void *h, size_t bytes, size_t pad)
 }
 
 /* ------------------------------------------------------------------ AC */
-/* rows staged in LDS: as many whole rows as fit the budget (all of them when the DFA is small) */
-extern "C" void smh_ac_lds_plan(const struct smh_ac *ac, uint32_t *lds_rows, uint32_t *lds_bytes)
-{
-    const uint64_t row_bytes = (uint64_t)ac->alphabet * (uint64_t)ac->entry_bytes;
-    uint64_t rows = SMH_LDS_BUDGET / row_bytes;
-    if (rows > ac->rows) rows = ac->rows;
-    if (rows < 1) rows = 1;
-    uint64_t bytes = (rows * row_bytes + 15u) & ~(uint64_t)15u;
-    *lds_rows = (uint32_t)rows;
-    *lds_bytes = (uint32_t)bytes;
-}
-
 extern "C" void smh_ac_dev_free(struct smh_ac_dev *dev)
 {
     if (!dev) return;
     (void)hipFree(dev->d_table);
+    if (dev->d_trunc1 != dev->d_scan) (void)hipFree(dev->d_trunc1);
+    (void)hipFree(dev->d_scan);
+    (void)hipFree(dev->d_queue);
     (void)hipFree(dev->d_depth_first);
     (void)hipFree(dev->d_transition);
     (void)hipFree(dev->d_supply);
@@ -184,12 +177,25 @@ static int ac_ensure_device(struct smh_ac *ac)
     memset(d, 0, sizeof *d);
     d->device = dev;
     ac->dev = d;
-    smh_ac_lds_plan(ac, &d->lds_rows, &d->lds_bytes);
     int rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     /* 256 entries of slack: a text byte >= alphabet may index just past the last row */
     if ((rc = upload(&d->d_table, ac->table, (size_t)ac->table_bytes, 256 * 4)) != SMH_OK) return rc;
-    std::vector<uint32_t> df(SMH_DEPTH_FIRST_LEN, ac->rows);
-    for (int i = 0; i <= ac->max_depth + 1 && i < SMH_DEPTH_FIRST_LEN; ++i) df[i] = ac->depth_first[i];
+    if ((rc = upload(&d->d_scan, ac->scan_table, (size_t)ac->scan_bytes, 0)) != SMH_OK) return rc;
+    if (ac->trunc1_table == ac->scan_table) {
+        d->d_trunc1 = d->d_scan;
+    } else if ((rc = upload(&d->d_trunc1, ac->trunc1_table, (size_t)ac->trunc1_bytes, 256 * 4)) != SMH_OK) {
+        return rc;
+    }
+    if (!ac->scan_exact) {
+        const size_t qbytes = (size_t)smh_ac_max_blocks(n_cus) * (SMH_BLOCK_THREADS / 64) * SMH_AC_QCAP * 8;
+        HIP_TRY(hipMalloc((void **)&d->d_queue, qbytes));
+    }
+    size_t dflen = (size_t)ac->m + 2;
+    if (dflen < SMH_DEPTH_FIRST_MIN) dflen = SMH_DEPTH_FIRST_MIN;
+    std::vector<uint32_t> df(dflen, ac->rows);
+    for (int i = 0; i <= ac->max_depth + 1 && (size_t)i < dflen; ++i) df[i] = ac->depth_first[i];
     if ((rc = upload((void **)&d->d_depth_first, df.data(), df.size() * 4, 0)) != SMH_OK) return rc;
     const size_t A = (size_t)ac->alphabet;
     if ((rc = upload((void **)&d->d_transition, ac->g_transition, (size_t)ac->states * A * 4, 0)) != SMH_OK) return rc;
@@ -228,10 +234,12 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         HIP_TRY(smh_launch_ac_table(L, (hipStream_t)stream));
     } else if (variant == SMH_VARIANT_TUNED) {
         smh_ac_launch L;
-        L.d_text = d_text; L.n = n; L.m = ac->m; L.alphabet = ac->alphabet; L.entry_bytes = ac->entry_bytes;
-        L.d_table = ac->dev->d_table; L.rows = ac->rows; L.lds_rows = ac->dev->lds_rows;
-        L.lds_bytes = ac->dev->lds_bytes; L.d_depth_first = ac->dev->d_depth_first; L.d_count = d_count;
-        L.n_cus = n_cus;
+        L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
+        L.V.full = ac->dev->d_table; L.V.full_entry_bytes = ac->entry_bytes; L.V.depth_first = ac->dev->d_depth_first;
+        L.V.trunc1 = ac->dev->d_trunc1; L.V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+        L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
+        L.d_scan_table = ac->dev->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = ac->dev->d_queue;
+        L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_ac_dfa(L, (hipStream_t)stream));
     } else {
         smh_set_error("smh_ac_scan: unknown variant %d", variant);

@@ -32,7 +32,9 @@ class SmhError(RuntimeError):
 class AcInfo(C.Structure):
     _fields_ = [("alphabet", C.c_uint32), ("m", C.c_uint32), ("states", C.c_uint32),
                 ("finals", C.c_uint32), ("rows", C.c_uint32), ("entry_bytes", C.c_uint32),
-                ("lds_rows", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_bytes", C.c_uint64)]
+                ("lds_rows", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_bytes", C.c_uint64),
+                ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class WmInfo(C.Structure):
@@ -58,7 +60,7 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
-               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_scan", "smh_ac_count_host",
+               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_scan", "smh_ac_count_host",
                "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info",
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free"]
 
@@ -93,6 +95,7 @@ def _load():
     lib.smh_ac_compile_patterns.restype = C.c_void_p
     lib.smh_ac_compile_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
     lib.smh_ac_get_info.argtypes = [C.c_void_p, C.POINTER(AcInfo)]
+    lib.smh_ac_set_scan_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.smh_ac_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
     lib.smh_ac_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, u64p, dblp]
     lib.smh_ac_free.restype = None
@@ -202,6 +205,9 @@ class AcAutomaton:
         out = AcInfo()
         _check(lib.smh_ac_get_info(self.h, C.byref(out)), "smh_ac_get_info")
         return out
+
+    def set_scan_plan(self, stride=0, depth=0):
+        _check(lib.smh_ac_set_scan_plan(self.h, stride, depth), "smh_ac_set_scan_plan")
 
     def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
         _check(lib.smh_ac_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,

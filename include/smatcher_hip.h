@@ -82,9 +82,13 @@ typedef struct smh_ac_info {
     uint32_t finals;       /* accepting states (== ac_table.patterncounter) */
     uint32_t rows;         /* DFA rows kept on the device (accepting leaves are folded away) */
     uint32_t entry_bytes;  /* 2 or 4 */
-    uint32_t lds_rows;     /* rows staged in LDS by the tuned kernel; rows beyond come from HBM/L2 */
+    uint32_t lds_rows;     /* rows of the depth-K scan automaton staged in LDS by the tuned kernel */
     uint32_t lds_bytes;
     uint64_t table_bytes;  /* full DFA size in HBM */
+    uint32_t scan_depth;   /* K: the LDS automaton is the Aho-Corasick machine of the K-symbol prefixes */
+    uint32_t scan_stride;  /* text symbols consumed per LDS lookup (1 or 2) */
+    uint32_t scan_exact;   /* 1: K == m, a flagged transition is a match; 0: candidates are verified in HBM */
+    uint32_t reserved;
 } smh_ac_info;
 
 /* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
@@ -93,8 +97,13 @@ smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *s
 /* from patterns: builds the reference tables internally, then compiles them */
 smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
 int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out);
+/* tuning / test knob: rebuild the LDS scan automaton with a forced stride (1 or 2; 0 = choose) and
+ * a forced depth K (1..min(m,65); 0 = the deepest that fits).  SMH_EUNSUP when it does not fit LDS. */
+int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth);
 /* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).
- * d_text must be 16-byte aligned; n may exceed 2^32. */
+ * d_text must be 16-byte aligned; n may exceed 2^32.  A handle owns one candidate-queue workspace
+ * per device: scans of the SAME handle must not overlap in time (use one stream per handle, or
+ * one handle per stream). */
 int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count,
                 int variant, void *stream);
 /* blocking convenience: upload host text, scan, return count and kernel-only seconds */

@@ -48,46 +48,39 @@ static guarded guard_copy(const uint8_t *src, uint64_t n, int mode)
 static void guard_free(guarded &g) { munmap(g.map, g.map_len); }
 
 /* ------------------------------------------------------------------ AC */
-template <typename E, int SIGMA, int HC, bool ALLHOT>
-static uint64_t ac_grid(const smh_ac *ac, const uint8_t *text, uint64_t n, uint32_t hot_rows, uint64_t blocks,
-                        const uint32_t *df)
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT>
+static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t blocks)
 {
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t)
-        total += smh_ac_thread<E, SIGMA, HC, EMU_AC_NCH, ALLHOT>(t, nthreads, text, n, ac->m, (const E *)ac->table,
-                                                                 (const E *)ac->table, hot_rows, ac->alphabet, df);
+        total += smh_ac_thread<E, SIGMA, STRIDE, HC, EMU_AC_NCH, EXACT>(t, nthreads, (const E *)ac->scan_table, V, nullptr);
     return total;
 }
 
-template <typename E, int SIGMA, int HC>
-static uint64_t ac_hot(const smh_ac *ac, const uint8_t *text, uint64_t n, uint32_t hot_rows, uint64_t blocks,
-                       const uint32_t *df)
+template <typename E, int SIGMA, int STRIDE, int HC>
+static uint64_t ac_exact(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t blocks)
 {
-    return hot_rows >= ac->rows ? ac_grid<E, SIGMA, HC, true>(ac, text, n, hot_rows, blocks, df)
-                                : ac_grid<E, SIGMA, HC, false>(ac, text, n, hot_rows, blocks, df);
+    return ac->scan_exact ? ac_grid<E, SIGMA, STRIDE, HC, true>(ac, V, blocks) : ac_grid<E, SIGMA, STRIDE, HC, false>(ac, V, blocks);
 }
 
-template <typename E, int SIGMA>
-static uint64_t ac_halo(const smh_ac *ac, const uint8_t *text, uint64_t n, uint32_t hot_rows, uint64_t blocks,
-                        const uint32_t *df)
+template <typename E, int SIGMA, int STRIDE>
+static uint64_t ac_halo(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t blocks)
 {
-    const int halo = ac->m - 1;
-    if (halo <= 16) return ac_hot<E, SIGMA, 1>(ac, text, n, hot_rows, blocks, df);
-    if (halo <= 32) return ac_hot<E, SIGMA, 2>(ac, text, n, hot_rows, blocks, df);
-    if (halo <= 64) return ac_hot<E, SIGMA, 4>(ac, text, n, hot_rows, blocks, df);
-    return ac_hot<E, SIGMA, 0>(ac, text, n, hot_rows, blocks, df);
+    const int halo = ac->scan_depth - 1;
+    if (halo <= 16) return ac_exact<E, SIGMA, STRIDE, 1>(ac, V, blocks);
+    if (halo <= 32) return ac_exact<E, SIGMA, STRIDE, 2>(ac, V, blocks);
+    return ac_exact<E, SIGMA, STRIDE, 4>(ac, V, blocks);
 }
 
-/* hot_rows: rows the emulated LDS holds (0 = all); blocks: grid size (0 = 4) */
-extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64_t n, int variant,
-                                uint32_t hot_rows, uint32_t blocks)
+/* blocks: grid size (0 = 4); the scan plan (stride, depth K) is whatever the handle holds */
+extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64_t n, int variant, uint32_t blocks)
 {
     if (n < (uint64_t)ac->m) return 0;
     if (!blocks) blocks = 4;
-    if (!hot_rows || hot_rows > ac->rows) hot_rows = ac->rows;
-    uint32_t df[72];
-    for (int i = 0; i < 72; ++i) df[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+    size_t dflen = (size_t)ac->m + 2 < 72 ? 72 : (size_t)ac->m + 2;
+    uint32_t *df = (uint32_t *)malloc(dflen * 4);
+    for (size_t i = 0; i < dflen; ++i) df[i] = (int)i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
     uint64_t result[2];
     for (int mode = 0; mode < 2; ++mode) {
         guarded g = guard_copy(text_in, n, mode);
@@ -98,16 +91,22 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
             for (uint64_t t = 0; t < nthreads; ++t)
                 total += smh_ac_table_thread(t, nthreads, text, n, ac->m, ac->g_transition, ac->g_supply,
                                              ac->g_final, ac->alphabet);
-        } else if (ac->entry_bytes == 2) {
-            total = ac->alphabet == 4 ? ac_halo<uint16_t, 4>(ac, text, n, hot_rows, blocks, df)
-                                      : ac_halo<uint16_t, 0>(ac, text, n, hot_rows, blocks, df);
         } else {
-            total = ac->alphabet == 4 ? ac_halo<uint32_t, 4>(ac, text, n, hot_rows, blocks, df)
-                                      : ac_halo<uint32_t, 0>(ac, text, n, hot_rows, blocks, df);
+            smh_ac_verify_ctx V;
+            V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
+            V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
+            V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+            if (ac->scan_stride == 2)
+                total = ac_halo<uint16_t, 4, 2>(ac, V, blocks);
+            else if (ac->scan_entry_bytes == 2)
+                total = ac->alphabet == 4 ? ac_halo<uint16_t, 4, 1>(ac, V, blocks) : ac_halo<uint16_t, 0, 1>(ac, V, blocks);
+            else
+                total = ac->alphabet == 4 ? ac_halo<uint32_t, 4, 1>(ac, V, blocks) : ac_halo<uint32_t, 0, 1>(ac, V, blocks);
         }
         guard_free(g);
         result[mode] = total;
     }
+    free(df);
     return result[0] == result[1] ? result[0] : ~0ull;
 }
 

@@ -17,14 +17,15 @@ if not os.path.exists(_PATH):
     subprocess.check_call(["make", "-s", "-C", PKG, "emu"])
 _emu = C.CDLL(_PATH)
 _emu.emu_ac_scan.restype = C.c_uint64
-_emu.emu_ac_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_int, C.c_uint32, C.c_uint32]
+_emu.emu_ac_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_int, C.c_uint32]
 _emu.emu_wm_scan.restype = C.c_uint64
 _emu.emu_wm_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_int, C.c_uint32]
 
 
-def ac_scan(ac, text, variant=S.VARIANT_TUNED, hot_rows=0, blocks=0):
+def ac_scan(ac, text, variant=S.VARIANT_TUNED, blocks=0):
+    """Scan with whatever stride / depth plan the handle currently holds (AcAutomaton.set_scan_plan)."""
     text = np.ascontiguousarray(text, dtype=np.uint8)
-    return int(_emu.emu_ac_scan(ac.h, text.ctypes.data_as(S.u8p), len(text), variant, hot_rows, blocks))
+    return int(_emu.emu_ac_scan(ac.h, text.ctypes.data_as(S.u8p), len(text), variant, blocks))
 
 
 def wm_scan(wm, text, variant=S.VARIANT_TUNED, blocks=0):

@@ -44,7 +44,7 @@ def _worker(rank, world, port, name, out_dir):
     b, e = sharded.shard_for_rank(len(text), world, rank, m)
     ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
     wm = S.WmTables.from_patterns(pat, m, p, sigma)
-    local = torch.tensor([E.ac_scan(ac, text[b:e], 0, 0, 1), E.wm_scan(wm, text[b:e], 0, 1)], dtype=torch.int64)
+    local = torch.tensor([E.ac_scan(ac, text[b:e], 0, 1), E.wm_scan(wm, text[b:e], 0, 1)], dtype=torch.int64)
     mine = local.clone()
     sharded.reduce_count(local)
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([mine[0], mine[1], local[0], local[1], b, e]))

@@ -18,15 +18,35 @@ with open(os.path.join(ROOT, "tests", "golden", "ref_vectors.json")) as f:
     VECTORS = json.load(f)
 
 
+def scan_plans(ac, m, sigma):
+    """(stride, depth) plans worth exercising for an automaton: exact and cut, both strides."""
+    plans = []
+    for stride in ((1, 2) if sigma == 4 else (1,)):
+        for depth in sorted({m, max(1, m - 1), max(1, m // 2), min(m, 2), min(m, 65)}):
+            if depth > 65:
+                continue
+            try:
+                ac.set_scan_plan(stride, depth)
+            except S.SmhError:
+                continue  # does not fit LDS at this depth / stride
+            plans.append((stride, depth))
+    ac.set_scan_plan(0, 0)
+    return plans
+
+
 @pytest.mark.parametrize("vec", VECTORS, ids=[v["name"] for v in VECTORS])
 def test_emulated_kernels_match_reference_counts(vec):
     text, pat = cases.build(vec)
     p, m, sigma, want = vec["p"], vec["m"], vec["sigma"], vec["count_ac"]
     ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
-    rows = ac.info().rows
-    assert E.ac_scan(ac, text, S.VARIANT_TUNED, 0, 3) == want           # whole DFA in "LDS"
-    assert E.ac_scan(ac, text, S.VARIANT_TUNED, max(1, rows // 3), 1) == want  # hot/cold split
-    assert E.ac_scan(ac, text, S.VARIANT_TABLE, 0, 2) == want           # goto/supply/final walk
+    assert E.ac_scan(ac, text, S.VARIANT_TUNED, 3) == want              # the plan the host chose
+    assert E.ac_scan(ac, text, S.VARIANT_TABLE, 2) == want              # goto/supply/final walk
+    # every scan plan must give the same count: stride 1 / 2, exact (K = m) and depth-cut (K < m)
+    for stride, depth in scan_plans(ac, m, sigma):
+        ac.set_scan_plan(stride, depth)
+        info = ac.info()
+        assert info.scan_stride == stride and info.scan_depth == depth and info.scan_exact == (depth == m)
+        assert E.ac_scan(ac, text, S.VARIANT_TUNED, 1) == want, (stride, depth)
     wm = S.WmTables.from_patterns(pat, m, p, sigma)
     assert E.wm_scan(wm, text, S.VARIANT_TUNED, 3) == want == vec["count_wu2"]
     assert E.wm_scan(wm, text, S.VARIANT_TABLE, 2) == want
@@ -45,9 +65,11 @@ def test_every_boundary_offset():
     for off in offsets:
         text = np.zeros(n, dtype=np.uint8)
         text[off:off + m] = pat
-        for got in (E.ac_scan(ac, text, 0, 0, 1), E.ac_scan(ac, text, 1, 0, 1), E.wm_scan(wm, text, 0, 1),
-                    E.wm_scan(wm, text, 1, 1)):
-            assert got == 1, off
+        got = [E.ac_scan(ac, text, 1, 1), E.wm_scan(wm, text, 0, 1), E.wm_scan(wm, text, 1, 1)]
+        for stride, depth in ((1, 8), (2, 8), (1, 5), (2, 5), (2, 4), (1, 1)):
+            ac.set_scan_plan(stride, depth)
+            got.append(E.ac_scan(ac, text, 0, 1))
+        assert got == [1] * len(got), (off, got)
 
 
 @pytest.mark.parametrize("m", [9, 24, 40, 70])
@@ -63,8 +85,9 @@ def test_long_patterns_straddling_segments(m):
         text[off:off + m] = pat
         want = O.count_bruteforce(pat, m, 1, text)
         assert want >= 1
-        assert E.ac_scan(ac, text, 0, 0, 1) == want
-        assert E.ac_scan(ac, text, 0, 5, 1) == want
+        for stride, depth in ((0, 0), (1, min(m, 65)), (2, min(m, 65)), (1, 7), (2, 7), (2, 6), (1, 3)):
+            ac.set_scan_plan(stride, depth)
+            assert E.ac_scan(ac, text, 0, 1) == want, (stride, depth)
         assert E.wm_scan(wm, text, 0, 1) == want
         assert E.wm_scan(wm, text, 1, 1) == want
 
@@ -75,5 +98,5 @@ def test_grid_size_does_not_change_the_count():
     ac = S.AcAutomaton.from_patterns(pat, vec["m"], vec["p"], vec["sigma"])
     wm = S.WmTables.from_patterns(pat, vec["m"], vec["p"], vec["sigma"])
     for blocks in (1, 2, 5, 16):
-        assert E.ac_scan(ac, text, 0, 0, blocks) == vec["count_ac"]
+        assert E.ac_scan(ac, text, 0, blocks) == vec["count_ac"]
         assert E.wm_scan(wm, text, 0, blocks) == vec["count_ac"]

@@ -134,13 +134,36 @@ def test_device_resident_text_and_streams():
 
 @pytest.mark.parametrize("name", ["big_dfa", "ascii_5_20", "mx_s256_m32_p1000"])
 def test_dfa_larger_than_lds(name):
-    """Rows beyond the LDS budget are served from HBM/L2 (hot/cold split) -- same counts."""
+    """Automata that do not fit LDS are cut at depth K; candidates are verified in HBM -- same counts."""
     vec = BY_NAME[name]
     text, pat = cases.build(vec)
     ac = S.AcAutomaton.from_patterns(pat, vec["m"], vec["p"], vec["sigma"])
     info = ac.info()
-    assert info.lds_rows < info.rows
+    assert info.lds_rows < info.rows and not info.scan_exact and info.scan_depth < vec["m"]
     assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"]
+
+
+@pytest.mark.parametrize("name", ["dense_dna", "kat_1m_100x8", "mx_s4_m16_p1000", "mx_s4_m32_p100", "edge_m65",
+                                  "overlap_zeros", "mx_s20_m8_p1000", "big_dfa"])
+def test_every_scan_plan_gives_the_same_count(name):
+    """Stride 1 / 2, exact (K = m) and depth-cut (K < m) automata, down to K = 1 where nearly every
+    position is a candidate and the per-wave queue overflows and drains constantly."""
+    vec = BY_NAME[name]
+    text, pat = cases.build(vec)
+    m, sigma = vec["m"], vec["sigma"]
+    ac = S.AcAutomaton.from_patterns(pat, m, vec["p"], sigma)
+    tried = 0
+    for stride in ((1, 2) if sigma == 4 else (1,)):
+        for depth in sorted({1, 2, 3, max(1, m // 2), max(1, m - 1), min(m, 65)}):
+            if depth > min(m, 65):
+                continue
+            try:
+                ac.set_scan_plan(stride, depth)
+            except S.SmhError:
+                continue
+            tried += 1
+            assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"], (stride, depth)
+    assert tried >= 3
 
 
 def test_baseline_size_properties():

@@ -107,6 +107,10 @@ def test_compiled_layouts(name):
     assert info.entry_bytes == (2 if info.rows <= 32768 else 4)
     assert info.table_bytes == info.rows * sigma * info.entry_bytes
     assert 1 <= info.lds_rows <= info.rows and info.lds_bytes <= 160 * 1024 and info.lds_bytes % 16 == 0
+    assert 1 <= info.scan_depth <= min(m, 65) and info.scan_stride in (1, 2)
+    assert info.scan_exact == (info.scan_depth == m)
+    if info.scan_exact:
+        assert info.lds_rows == info.rows
     # compiling from the legacy tables gives the same automaton as compiling from patterns
     _, t = O.oracle_ac(pat, m, p, sigma)
     ac2 = S.AcAutomaton.from_tables(t.state_transition, t.state_supply, t.state_final, m * p + 1, sigma, m)
