@@ -17,10 +17,12 @@
  * is one dependent table lookup per byte.
  */
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
 #include "smh_launch.h"
 #include "ac_lane.h"
 
-#define SMH_AC_NCH 2
+#define SMH_AC_NCH 1 /* text segments (automata) per lane; measured best with the prefetch: profiles/ */
 
 __device__ __forceinline__ void smh_wave_add(uint32_t cnt, uint64_t *count)
 {
@@ -29,23 +31,40 @@ __device__ __forceinline__ void smh_wave_add(uint32_t cnt, uint64_t *count)
     if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd((unsigned long long *)count, (unsigned long long)cnt);
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT>
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__restrict__ scan_table, uint32_t lds_bytes,
-                                                                  smh_ac_verify_ctx V, uint64_t *queue_base,
-                                                                  uint64_t *count)
+                                                                  smh_ac_verify_ctx V, smh_ac_df df,
+                                                                  uint64_t *queue_base, uint64_t *count)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smh_lds[];
-    /* stage the depth-K automaton: 16 bytes per lane per step, coalesced */
+    /* stage the depth-K automaton: 16 bytes per lane per step, coalesced; four loads in flight per
+     * lane so that the staging costs about one memory round trip per 64 KiB, not one per 16 KiB */
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(scan_table);
         uint4 *dst = reinterpret_cast<uint4 *>(smh_lds);
-        for (uint32_t i = threadIdx.x; i < lds_bytes / 16u; i += blockDim.x) dst[i] = src[i];
+        const uint32_t n16 = lds_bytes / 16u;
+        uint32_t i = threadIdx.x;
+        for (; i + 3u * SMH_BLOCK_THREADS < n16; i += 4u * SMH_BLOCK_THREADS) {
+            const uint4 t0 = src[i], t1 = src[i + SMH_BLOCK_THREADS], t2 = src[i + 2u * SMH_BLOCK_THREADS],
+                        t3 = src[i + 3u * SMH_BLOCK_THREADS];
+            dst[i] = t0;
+            dst[i + SMH_BLOCK_THREADS] = t1;
+            dst[i + 2u * SMH_BLOCK_THREADS] = t2;
+            dst[i + 3u * SMH_BLOCK_THREADS] = t3;
+        }
+        for (; i < n16; i += SMH_BLOCK_THREADS) dst[i] = src[i];
     }
     __syncthreads();
-    const E *tab = reinterpret_cast<const E *>(smh_lds);
+    /* the lane code addresses the table by LDS byte offset: it must sit at offset 0 (dynamic LDS only) */
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t cnt = smh_ac_thread<E, SIGMA, STRIDE, HC, SMH_AC_NCH, EXACT>(gthread, nthreads, tab, V, queue_base);
+    uint32_t cnt;
+    if constexpr (STRIDE == 2) {
+        cnt = smh_ac_thread<smh_fmt_s2, HC, NCH, EXACT, PF>(smh_fmt_s2{}, gthread, nthreads, smh_lds, V, df, queue_base);
+    } else {
+        const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
+        cnt = smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, NCH, EXACT, PF>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
+    }
     smh_wave_add(cnt, count);
 }
 
@@ -64,20 +83,40 @@ __global__ __launch_bounds__(256) void ac_table_kernel(const uint8_t *__restrict
 /* ------------------------------------------------------------------ launch */
 uint32_t smh_ac_max_blocks(int n_cus) { return (uint32_t)n_cus * 2u; }
 
-template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT>
+/* development knobs (not part of the API): SMH_AC_TUNE="nch=1|2|4,pf=0|1,bpc=1|2" */
+static int tune_get(const char *key, int dflt)
+{
+    const char *t = getenv("SMH_AC_TUNE");
+    if (!t) return dflt;
+    const char *p = strstr(t, key);
+    if (!p) return dflt;
+    return atoi(p + strlen(key) + 1);
+}
+
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true>
 static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
 {
-    auto kern = ac_dfa_kernel<E, SIGMA, STRIDE, HC, EXACT>;
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
-    if (err != hipSuccess) return err;
-    int per_cu = 0;
-    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SMH_BLOCK_THREADS, L.lds_bytes);
-    if (err != hipSuccess) return err;
+    auto kern = ac_dfa_kernel<E, SIGMA, STRIDE, HC, EXACT, NCH, PF>;
+    /* the attribute call and the occupancy query cost tens of microseconds of host time, during
+     * which the GPU idles between the caller's events: do them once per (kernel, LDS size) */
+    static uint32_t cached_lds = 0xFFFFFFFFu;
+    static int cached_per_cu = 0;
+    if (cached_lds != L.lds_bytes) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.lds_bytes);
+        if (err != hipSuccess) return err;
+        int q = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, SMH_BLOCK_THREADS, L.lds_bytes);
+        if (err != hipSuccess) return err;
+        cached_per_cu = q;
+        cached_lds = L.lds_bytes;
+    }
+    int per_cu = cached_per_cu;
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
+    if (per_cu > tune_get("bpc", 2)) per_cu = tune_get("bpc", 2);
     /* enough wave-chunks for every wave?  shrink the grid for small texts */
-    const uint64_t chunk = (uint64_t)SMH_SEG * 64u * SMH_AC_NCH;
+    const uint64_t chunk = (uint64_t)SMH_SEG * 64u * NCH;
     const uint64_t n_chunks = (L.V.n + chunk - 1) / chunk;
     uint64_t blocks = (uint64_t)L.n_cus * (uint64_t)per_cu;
     const uint64_t want = (n_chunks + (SMH_BLOCK_THREADS / 64) - 1) / (SMH_BLOCK_THREADS / 64);
@@ -85,13 +124,27 @@ static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
     if (blocks < 1) blocks = 1;
     if (blocks > smh_ac_max_blocks(L.n_cus)) blocks = smh_ac_max_blocks(L.n_cus); /* the queue workspace is sized for this */
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), L.lds_bytes, stream,
-                       reinterpret_cast<const E *>(L.d_scan_table), L.lds_bytes, L.V, L.d_queue, L.d_count);
+                       reinterpret_cast<const E *>(L.d_scan_table), L.lds_bytes, L.V, L.df, L.d_queue, L.d_count);
     return hipGetLastError();
 }
 
 template <typename E, int SIGMA, int STRIDE, int HC>
 static hipError_t launch_exact(const smh_ac_launch &L, hipStream_t stream)
 {
+    if constexpr (SIGMA == 4 && HC <= 2 && sizeof(E) == 2) {
+        if (getenv("SMH_AC_TUNE")) {
+            const int nch = tune_get("nch", SMH_AC_NCH), pf = tune_get("pf", 1);
+            if (L.exact) {
+                if (nch == 1 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, true, 1, false>(L, stream);
+                if (nch == 2 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, true, 2, false>(L, stream);
+                if (nch == 2 && pf == 1) return launch_one<E, SIGMA, STRIDE, HC, true, 2, true>(L, stream);
+            } else {
+                if (nch == 1 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, false, 1, false>(L, stream);
+                if (nch == 2 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, false, 2, false>(L, stream);
+                if (nch == 2 && pf == 1) return launch_one<E, SIGMA, STRIDE, HC, false, 2, true>(L, stream);
+            }
+        }
+    }
     return L.exact ? launch_one<E, SIGMA, STRIDE, HC, true>(L, stream) : launch_one<E, SIGMA, STRIDE, HC, false>(L, stream);
 }
 

@@ -51,6 +51,15 @@ struct smh_ac_verify_ctx {
     int trunc1_entry_bytes;
 };
 
+/* depth_first[0..71] BY VALUE: as a kernel argument it is read with scalar loads from the kernarg
+ * segment.  Read through a pointer it becomes a vector load as soon as the kernel also stores to
+ * global memory (the candidate queue), and the s_waitcnt vmcnt(0) in front of its use would then
+ * also wait for the prefetched next chunk -- measured as a 30 % slowdown. */
+#define SMH_AC_DF_LEN 72
+struct smh_ac_df {
+    uint32_t v[SMH_AC_DF_LEN];
+};
+
 SMH_LANE uint32_t smh_entry_at(const void *t, int eb, uint64_t i)
 {
     return eb == 2 ? (uint32_t)((const uint16_t *)t)[i] : ((const uint32_t *)t)[i];
@@ -131,88 +140,103 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
 }
 #endif
 
-/* ------------------------------------------------------------------ scan building blocks */
-template <typename E, int SIGMA>
-SMH_LANE uint32_t smh_ac_step1(uint32_t &row, uint32_t c, const E *tab, int sigma_rt)
-{
-    const uint32_t sigma = SIGMA ? (uint32_t)SIGMA : (uint32_t)sigma_rt;
-    /* symbols must be < alphabet (as in the reference, which indexes next[] with the raw
-     * byte: ac/ac.c:209); an out-of-range byte is folded so it can never index past the table */
-    if (SIGMA && (SIGMA & (SIGMA - 1)) == 0)
-        c &= (uint32_t)(SIGMA - 1);
-    else if (c >= sigma)
-        c = 0;
-    const uint32_t e = tab[row * sigma + c];
-    row = e & smh_ac_entry<E>::MASK;
-    return e >> smh_ac_entry<E>::FLAG_SHIFT;
-}
-
-/* symbol pair code c1*4+c2 of bytes (2k, 2k+1) of a text word, alphabet 4 */
-SMH_LANE uint32_t smh_pair_code(uint32_t word, int k)
-{
-    const uint32_t h = word >> (16 * k);
-    return ((h & 3u) << 2) | ((h >> 8) & 3u);
-}
-
-template <typename E, int SIGMA, int STRIDE, int HC, int NCH, bool EXACT> struct smh_ac_scan_ctx {
-    const E *tab;   /* LDS: depth-K automaton */
+/* ------------------------------------------------------------------ scan table formats
+ * A format says how a lane turns (state, text dword) into the next LDS address with as few VALU
+ * ops as possible.  The lane state is the raw table ENTRY (next row + flag bits), not the row.
+ *   prep(w)        once per text dword
+ *   next(e, x, k)  entry after consuming byte k (stride 1) or byte pair k (stride 2) of the dword
+ *   flags(e)       stride 1: bit 0; stride 2: bit 0 = after the first symbol, bit 1 = after the second
+ *   row(e)         row id (for the early-exit test and for queue entries)
+ *   any(e)         nonzero iff a flag is set (used on an OR of many entries)
+ */
+template <typename E, int SIGMA> struct smh_fmt_s1 { /* stride 1: entry = row | FLAG (top bit) */
+    static constexpr int STRIDE = 1;
+    static constexpr uint32_t FSHIFT = smh_ac_entry<E>::FLAG_SHIFT, MASK = smh_ac_entry<E>::MASK;
     int sigma_rt;
-    int halo;       /* K - 1 */
-    const uint32_t *depth_first;
+    SMH_MEMBER uint32_t prep(uint32_t w) const { return SIGMA == 4 ? w << (sizeof(E) == 2 ? 1 : 2) : w; }
+    SMH_MEMBER uint32_t next(uint32_t e, uint32_t x, int k, const void *tab) const
+    {
+        if (SIGMA == 4) {
+            /* x = w << log2(sizeof(E)): the symbol's byte offset inside the row is a bit field of x */
+            const uint32_t c = smh_bfe(x, 8 * k, sizeof(E) == 2 ? 3 : 4);
+            const uint32_t addr = ((e & MASK) << (sizeof(E) == 2 ? 3 : 4)) | c;
+            return sizeof(E) == 2 ? smh_lds_u16(tab, addr) : smh_lds_u32(tab, addr);
+        } else {
+            const uint32_t sigma = SIGMA ? (uint32_t)SIGMA : (uint32_t)sigma_rt;
+            /* symbols must be < alphabet (as in the reference, which indexes next[] with the raw
+             * byte: ac/ac.c:209); an out-of-range byte is folded so it cannot index past the table */
+            uint32_t c = smh_byte_of(x, k);
+            if (c >= sigma) c = 0;
+            const uint32_t addr = ((e & MASK) * sigma + c) * (uint32_t)sizeof(E);
+            return sizeof(E) == 2 ? smh_lds_u16(tab, addr) : smh_lds_u32(tab, addr);
+        }
+    }
+    SMH_MEMBER uint32_t flags(uint32_t e) const { return e >> FSHIFT; }
+    SMH_MEMBER uint32_t row(uint32_t e) const { return e & MASK; }
+    SMH_MEMBER uint32_t any(uint32_t e) const { return e >> FSHIFT; }
+};
+
+struct smh_fmt_s2 { /* stride 2, alphabet 4: entry = row | F1 << 14 | F2 << 15, 16 entries per row */
+    static constexpr int STRIDE = 2;
+    /* pair codes * 2 land at bits 1..4 (bytes 0,1) and 17..20 (bytes 2,3) */
+    SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 3) | (w >> 7); }
+    SMH_MEMBER uint32_t next(uint32_t e, uint32_t x, int k, const void *tab) const
+    {
+        const uint32_t c = k == 0 ? (x & 0x1Eu) : smh_bfe(x, 16, 5);
+        return smh_lds_u16(tab, ((e & 0x3FFFu) << 5) | c);
+    }
+    SMH_MEMBER uint32_t flags(uint32_t e) const { return e >> 14; }
+    SMH_MEMBER uint32_t row(uint32_t e) const { return e & 0x3FFFu; }
+    SMH_MEMBER uint32_t any(uint32_t e) const { return e >> 14; }
+};
+
+template <typename FMT, int HC, int NCH, bool EXACT> struct smh_ac_scan_ctx {
+    FMT fmt;
+    const void *tab; /* LDS: depth-K automaton */
+    int halo;        /* K - 1 */
+    const smh_ac_df *df;
     const uint8_t *text;
     const uint64_t *a;    /* segment offsets of the NCH chains */
-    const uint32_t *tail; /* wave-uniform: the bytes that follow the wave-chunk */
+    const uint32_t *tail; /* 4*HC words, same in every lane: the bytes that follow the wave-chunk */
     const smh_ac_verify_ctx *V;
     smh_ac_queue *Q;
 };
 
-/* one scan step of all NCH chains on bytes taken from `word[j]` at byte index `b` (stride 1) or
- * byte pair (b, b+1) (stride 2); `pos0[j] + b` is the text position of the first byte.
- * second_valid: whether a flag on the second byte of a pair may be used (false on the odd tail of
- * the halo, where that byte already belongs to the next lane's starts). */
-template <typename E, int SIGMA, int STRIDE, int HC, int NCH, bool EXACT>
-SMH_LANE void smh_ac_scan_step(const smh_ac_scan_ctx<E, SIGMA, STRIDE, HC, NCH, EXACT> &c, const uint32_t (&word)[NCH],
-                               int b, const uint64_t (&pos0)[NCH], bool second_valid, uint32_t (&row)[NCH],
-                               uint32_t &cnt)
+/* queue the candidates flagged by entry `e` (reached from `prev`) for the byte (pair) at `pos` */
+template <typename FMT, int HC, int NCH, bool EXACT>
+SMH_LANE void smh_ac_emit_flags(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, uint32_t f, uint32_t prev, uint32_t e,
+                                uint64_t pos)
 {
-    if (STRIDE == 1) {
-        uint32_t f[NCH];
-        uint32_t anyf = 0;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            f[j] = smh_ac_step1<E, SIGMA>(row[j], smh_byte_of(word[j], b), c.tab, c.sigma_rt);
-            anyf |= f[j];
-        }
-        if (EXACT) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) cnt += f[j];
-        } else if (SMH_WAVE_ANY(anyf != 0)) {
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) smh_ac_emit(*c.Q, *c.V, f[j] != 0, pos0[j] + (uint64_t)b, row[j], false);
-        }
+    if (FMT::STRIDE == 1) {
+        smh_ac_emit(*c.Q, *c.V, f != 0, pos, c.fmt.row(e), false);
     } else {
-        uint32_t f[NCH], prev[NCH];
-        uint32_t anyf = 0;
+        /* first symbol of the pair: the depth-K row is not in the entry -> resolved lazily */
+        smh_ac_emit(*c.Q, *c.V, (f & 1u) != 0, pos, c.fmt.row(prev), true);
+        smh_ac_emit(*c.Q, *c.V, (f & 2u) != 0, pos + 1u, c.fmt.row(e), false);
+    }
+}
+
+/* one step of all chains with full flag handling: the halo steps and the replay of a flagged piece */
+template <typename FMT, int HC, int NCH, bool EXACT>
+SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, const uint32_t (&x)[NCH], int k,
+                               const uint64_t (&pos)[NCH], bool second_valid, uint32_t (&e)[NCH], uint32_t &cnt)
+{
+    uint32_t f[NCH], prev[NCH];
+    uint32_t anyf = 0;
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            prev[j] = row[j];
-            const uint32_t e = c.tab[row[j] * 16u + smh_pair_code(word[j], b >> 1)];
-            row[j] = e & 0x3FFFu;
-            f[j] = e >> 14;
-            if (!second_valid) f[j] &= 1u;
-            anyf |= f[j];
-        }
-        if (EXACT) {
+    for (int j = 0; j < NCH; ++j) {
+        prev[j] = e[j];
+        e[j] = c.fmt.next(e[j], x[j], k, c.tab);
+        f[j] = c.fmt.flags(e[j]);
+        if (FMT::STRIDE == 2 && !second_valid) f[j] &= 1u;
+        anyf |= f[j];
+    }
+    if (EXACT) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) cnt += (f[j] & 1u) + (f[j] >> 1);
-        } else if (SMH_WAVE_ANY(anyf != 0)) {
+        for (int j = 0; j < NCH; ++j) cnt += (uint32_t)__builtin_popcount(f[j]);
+    } else if (SMH_WAVE_ANY(anyf != 0)) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                /* first symbol of the pair: the depth-K row is not in the entry -> resolved lazily */
-                smh_ac_emit(*c.Q, *c.V, (f[j] & 1u) != 0, pos0[j] + (uint64_t)b, prev[j], true);
-                smh_ac_emit(*c.Q, *c.V, (f[j] & 2u) != 0, pos0[j] + (uint64_t)b + 1u, row[j], false);
-            }
-        }
+        for (int j = 0; j < NCH; ++j) smh_ac_emit_flags(c, f[j], prev[j], e[j], pos[j]);
     }
 }
 
@@ -229,17 +253,16 @@ SMH_LANE void smh_ac_scan_step(const smh_ac_scan_ctx<E, SIGMA, STRIDE, HC, NCH, 
  * are past that point keep stepping with the rest of the wave (it is harmless: they cannot reach
  * depth K inside the halo), which keeps the step free of divergence.
  */
-template <int H, typename E, int SIGMA, int STRIDE, int HC, int NCH, bool EXACT>
-SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<E, SIGMA, STRIDE, HC, NCH, EXACT> &c,
-                               const uint32_t (&w)[NCH][16], uint32_t (&hw)[NCH], uint32_t (&row)[NCH],
-                               uint32_t &cnt)
+template <int H, typename FMT, int HC, int NCH, bool EXACT>
+SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, const uint32_t (&w)[NCH][16],
+                               uint32_t (&hx)[NCH], uint32_t (&e)[NCH], uint32_t &cnt)
 {
-    if (H % STRIDE != 0) return true; /* stride 2 consumes bytes H and H+1 at even H */
+    if (H % FMT::STRIDE != 0) return true; /* stride 2 consumes bytes H and H+1 at even H */
     if (H >= c.halo) return false;
-    const uint32_t need = c.depth_first[H + 1];
+    const uint32_t need = c.df->v[H + 1];
     bool any = false;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) any |= row[j] >= need;
+    for (int j = 0; j < NCH; ++j) any |= c.fmt.row(e[j]) >= need;
     if (!SMH_WAVE_ANY(any)) return false;
     if ((H & 3) == 0) {
         /* next halo dword: the neighbour lane's segment word H/4 (all lanes active here: every
@@ -247,34 +270,41 @@ SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<E, SIGMA, STRIDE, HC, NCH, 
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const uint32_t edge = j + 1 < NCH ? smh_first_lane(w[j + 1 < NCH ? j + 1 : j][H >> 2]) : c.tail[H >> 2];
-            hw[j] = smh_next_lane_word(w[j][H >> 2], edge, c.text, c.a[j] + SMH_SEG + (uint64_t)H);
+            hx[j] = c.fmt.prep(smh_next_lane_word(w[j][H >> 2], edge, c.text, c.a[j] + SMH_SEG + (uint64_t)H));
         }
     }
-    uint64_t pos0[NCH];
+    uint64_t pos[NCH];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) pos0[j] = c.a[j] + SMH_SEG + (uint64_t)(H & ~3);
-    smh_ac_scan_step(c, hw, H & 3, pos0, H + 1 < c.halo, row, cnt);
+    for (int j = 0; j < NCH; ++j) pos[j] = c.a[j] + SMH_SEG + (uint64_t)H;
+    smh_ac_step_full(c, hx, (H & 3) / FMT::STRIDE, pos, H + 1 < c.halo, e, cnt);
     return true;
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC, int NCH, bool EXACT, int... Hs>
-SMH_LANE void smh_ac_halo_all(const smh_ac_scan_ctx<E, SIGMA, STRIDE, HC, NCH, EXACT> &c, const uint32_t (&w)[NCH][16],
-                              uint32_t (&row)[NCH], uint32_t &cnt, std::integer_sequence<int, Hs...>)
+template <typename FMT, int HC, int NCH, bool EXACT, int... Hs>
+SMH_LANE void smh_ac_halo_all(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, const uint32_t (&w)[NCH][16],
+                              uint32_t (&e)[NCH], uint32_t &cnt, std::integer_sequence<int, Hs...>)
 {
-    uint32_t hw[NCH];
+    uint32_t hx[NCH];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) hw[j] = 0;
-    (void)(smh_ac_halo_step<Hs>(c, w, hw, row, cnt) && ...);
+    for (int j = 0; j < NCH; ++j) hx[j] = 0;
+    (void)(smh_ac_halo_step<Hs>(c, w, hx, e, cnt) && ...);
 }
 
-/*
- * Fast path: NCH segments per lane, each fully inside the text together with
- * 16*HC bytes after it (the caller guarantees a[j] + 64 + 16*HC <= n and
- * 16*HC >= K-1).  Only the 64 segment bytes are loaded; the halo bytes come out
- * of the neighbouring lane's registers (smh_next_lane_word).  The NCH automata
- * are independent dependency chains stepped in lock-step, so the LDS latency of
- * one hides behind the others.
- */
+/* the 16*HC bytes that follow a wave-chunk (the post-halo of its last lane), loaded by every lane
+ * from the same address together with the segments, so that the halo steps touch no memory */
+template <int HC>
+SMH_LANE void smh_ac_load_tail(const uint8_t *p, uint32_t (&t)[4 * HC])
+{
+#pragma unroll
+    for (int q = 0; q < HC; ++q) {
+        const smh_u32x4 v = smh_load16(p + 16u * q);
+        t[4 * q + 0] = v.v[0];
+        t[4 * q + 1] = v.v[1];
+        t[4 * q + 2] = v.v[2];
+        t[4 * q + 3] = v.v[3];
+    }
+}
+
 template <int NCH>
 SMH_LANE void smh_ac_load_segments(const uint8_t *text, const uint64_t (&a)[NCH], uint32_t (&w)[NCH][16])
 {
@@ -290,28 +320,73 @@ SMH_LANE void smh_ac_load_segments(const uint8_t *text, const uint64_t (&a)[NCH]
         }
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC, int NCH, bool EXACT>
-SMH_LANE uint32_t smh_ac_lane_fast(const uint8_t *text, const uint64_t (&a)[NCH], const uint32_t (&w)[NCH][16],
-                                   const uint32_t *tail, const E *tab, int sigma_rt, int K,
-                                   const uint32_t *depth_first, const smh_ac_verify_ctx &V, smh_ac_queue &Q)
+/*
+ * Fast path: NCH segments per lane (already in registers), each fully inside the text together
+ * with 16*HC bytes after it (the caller guarantees a[j] + 64 + 16*HC <= n and 16*HC >= K-1).
+ * The halo bytes come out of the neighbouring lane's registers (smh_next_lane_word).  The NCH
+ * automata are independent dependency chains stepped in lock-step, so the LDS latency of one
+ * hides behind the others.
+ *
+ * K == m: every lookup adds its match flags to the count.  K < m: candidates are rare, so the
+ * inner loop only ORs the entries together; the OR is examined once per 16-byte piece with a
+ * wave-wide vote, and a piece that holds a candidate anywhere in the wave is walked again from a
+ * snapshot of the states, this time queueing the candidates.
+ */
+template <typename FMT, int HC, int NCH, bool EXACT>
+SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const uint64_t (&a)[NCH],
+                                   const uint32_t (&w)[NCH][16], const uint32_t (&tail)[4 * HC], const void *tab,
+                                   int K, const smh_ac_df &df, const smh_ac_verify_ctx &V, smh_ac_queue &Q)
 {
-    uint32_t row[NCH], cnt = 0;
+    uint32_t e[NCH], snap[NCH], cnt = 0, anyf = 0;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) row[j] = 0;
-    smh_ac_scan_ctx<E, SIGMA, STRIDE, HC, NCH, EXACT> ctx{tab, sigma_rt, K - 1, depth_first, text, a, tail, &V, &Q};
+    for (int j = 0; j < NCH; ++j) e[j] = snap[j] = 0;
+    smh_ac_scan_ctx<FMT, HC, NCH, EXACT> ctx{fmt, tab, K - 1, &df, text, a, tail, &V, &Q};
+    constexpr int SPD = 4 / FMT::STRIDE; /* steps per text dword */
 
 #pragma unroll
-    for (int i = 0; i < 64; i += STRIDE) {
-        uint32_t word[NCH];
-        uint64_t pos0[NCH];
+    for (int piece = 0; piece < 4; ++piece) {
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            word[j] = w[j][i >> 2];
-            pos0[j] = a[j] + (uint64_t)(i & ~3);
+        for (int q = 4 * piece; q < 4 * piece + 4; ++q) {
+            uint32_t x[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) x[j] = fmt.prep(w[j][q]);
+#pragma unroll
+            for (int k = 0; k < SPD; ++k)
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) {
+                    e[j] = fmt.next(e[j], x[j], k, tab);
+                    if (EXACT)
+                        cnt += (uint32_t)__builtin_popcount(fmt.flags(e[j]));
+                    else
+                        anyf |= e[j];
+                }
         }
-        smh_ac_scan_step(ctx, word, i & 3, pos0, true, row, cnt);
+        if (!EXACT) {
+            if (SMH_WAVE_ANY(fmt.any(anyf) != 0)) {
+                /* replay the piece from the snapshot, with flag handling */
+                uint32_t r[NCH];
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) r[j] = snap[j];
+#pragma unroll
+                for (int q = 4 * piece; q < 4 * piece + 4; ++q) {
+                    uint32_t x[NCH];
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) x[j] = fmt.prep(w[j][q]);
+#pragma unroll
+                    for (int k = 0; k < SPD; ++k) {
+                        uint64_t pos[NCH];
+#pragma unroll
+                        for (int j = 0; j < NCH; ++j) pos[j] = a[j] + (uint64_t)(4 * q + k * FMT::STRIDE);
+                        smh_ac_step_full(ctx, x, k, pos, true, r, cnt);
+                    }
+                }
+            }
+            anyf = 0;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) snap[j] = e[j];
+        }
     }
-    smh_ac_halo_all(ctx, w, row, cnt, std::make_integer_sequence<int, 16 * HC>{});
+    smh_ac_halo_all(ctx, w, e, cnt, std::make_integer_sequence<int, 16 * HC>{});
     return cnt;
 }
 
@@ -370,9 +445,9 @@ SMH_LANE uint32_t smh_ac_lane_table(const uint8_t *text, uint64_t n, uint64_t n_
  * 64 lanes per wave): wave-chunks of NCH*4 KiB are dealt round-robin to waves,
  * so at any moment the resident waves stream one contiguous window of text.
  */
-template <typename E, int SIGMA, int STRIDE, int HC, int NCH, bool EXACT>
-SMH_LANE uint32_t smh_ac_thread(uint64_t gthread, uint64_t nthreads, const E *tab, const smh_ac_verify_ctx &V,
-                                uint64_t *queue_base)
+template <typename FMT, int HC, int NCH, bool EXACT, bool PREFETCH = true>
+SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthreads, const void *tab,
+                                const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base)
 {
     if (V.n < (uint64_t)V.m) return 0;
     const uint64_t n_starts = V.n - (uint64_t)V.m + 1;
@@ -387,7 +462,7 @@ SMH_LANE uint32_t smh_ac_thread(uint64_t gthread, uint64_t nthreads, const E *ta
     uint32_t cnt = 0;
     /* software pipeline: the segments of the wave's NEXT chunk are requested before the current
      * chunk is scanned, so the HBM latency of a chunk hides behind a whole chunk of lookups */
-    uint32_t cur[NCH][16], nxt[NCH][16];
+    uint32_t cur[NCH][16], nxt[NCH][16], cur_tail[4 * HC], nxt_tail[4 * HC];
     uint64_t k = wave;
     bool cur_fast = false;
     if (k < n_chunks) {
@@ -398,6 +473,7 @@ SMH_LANE uint32_t smh_ac_thread(uint64_t gthread, uint64_t nthreads, const E *ta
 #pragma unroll
             for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SMH_SEG;
             smh_ac_load_segments<NCH>(V.text, a, cur);
+            smh_ac_load_tail<HC>(V.text + base + chunk_bytes, cur_tail);
         }
     }
     while (k < n_chunks) {
@@ -405,28 +481,37 @@ SMH_LANE uint32_t smh_ac_thread(uint64_t gthread, uint64_t nthreads, const E *ta
         const uint64_t kn = k + nwaves;
         const uint64_t base_n = smh_uniform64(kn * chunk_bytes);
         const bool nxt_fast = kn < n_chunks && base_n + chunk_bytes + 16u * HC <= V.n;
-        if (nxt_fast) {
+        if (PREFETCH && nxt_fast) {
             uint64_t an[NCH];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) an[j] = base_n + ((uint64_t)j * 64u + lane) * SMH_SEG;
             smh_ac_load_segments<NCH>(V.text, an, nxt);
+            smh_ac_load_tail<HC>(V.text + base_n + chunk_bytes, nxt_tail);
         }
         if (cur_fast) {
             uint64_t a[NCH];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SMH_SEG;
-            const uint32_t *tail = reinterpret_cast<const uint32_t *>(V.text + base + chunk_bytes);
-            cnt += smh_ac_lane_fast<E, SIGMA, STRIDE, HC, NCH, EXACT>(V.text, a, cur, tail, tab, V.sigma, V.K,
-                                                                      V.depth_first, V, Q);
+            cnt += smh_ac_lane_fast<FMT, HC, NCH, EXACT>(fmt, V.text, a, cur, cur_tail, tab, V.K, df, V, Q);
         } else {
             for (int j = 0; j < NCH; ++j)
                 cnt += smh_ac_lane_slow(V, n_starts, base + ((uint64_t)j * 64u + lane) * SMH_SEG);
         }
         if (nxt_fast) {
+            if (PREFETCH) {
 #pragma unroll
-            for (int j = 0; j < NCH; ++j)
+                for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) cur[j][q] = nxt[j][q];
+                    for (int q = 0; q < 16; ++q) cur[j][q] = nxt[j][q];
+#pragma unroll
+                for (int q = 0; q < 4 * HC; ++q) cur_tail[q] = nxt_tail[q];
+            } else {
+                uint64_t an[NCH];
+#pragma unroll
+                for (int j = 0; j < NCH; ++j) an[j] = base_n + ((uint64_t)j * 64u + lane) * SMH_SEG;
+                smh_ac_load_segments<NCH>(V.text, an, cur);
+                smh_ac_load_tail<HC>(V.text + base_n + chunk_bytes, cur_tail);
+            }
         }
         cur_fast = nxt_fast;
         k = kn;

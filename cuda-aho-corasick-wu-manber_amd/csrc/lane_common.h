@@ -31,6 +31,7 @@
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 #define SMH_LANE __device__ __forceinline__
+#define SMH_MEMBER __device__ __forceinline__
 #define SMH_WAVE_ANY(x) (__any((int)(x)) != 0)
 struct smh_u32x4 { uint32_t v[4]; };
 SMH_LANE smh_u32x4 smh_load16(const uint8_t *p)
@@ -42,6 +43,7 @@ SMH_LANE smh_u32x4 smh_load16(const uint8_t *p)
 }
 #else
 #define SMH_LANE static inline
+#define SMH_MEMBER inline
 #define SMH_WAVE_ANY(x) (x)
 struct smh_u32x4 { uint32_t v[4]; };
 SMH_LANE smh_u32x4 smh_load16(const uint8_t *p)
@@ -83,6 +85,41 @@ SMH_LANE uint32_t smh_next_lane_word(uint32_t, uint32_t, const uint8_t *text, ui
 }
 SMH_LANE uint32_t smh_first_lane(uint32_t v) { return v; }
 SMH_LANE uint64_t smh_uniform64(uint64_t v) { return v; }
+#endif
+
+/*
+ * Instruction-level helpers.  The scan kernels are VALU-issue bound (every VALU op holds a SIMD's
+ * issue port for 4 cycles: profiles/r01_v2_dpp_prefetch), so the inner loops are written as the
+ * exact op sequences we want and these helpers pin the instruction choice:
+ *   smh_bfe      -> v_bfe_u32
+ *   smh_lds_u16  -> ds_read_u16 from a BYTE OFFSET inside the workgroup's LDS allocation.  The
+ *                   tables are staged at LDS offset 0 (the kernels use only dynamic LDS), so the
+ *                   offset is the address and no base has to be added per lookup.
+ */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+SMH_LANE uint32_t smh_bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
+SMH_LANE uint32_t smh_lds_u16(const void *, uint32_t byte_off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(byte_off);
+}
+SMH_LANE uint32_t smh_lds_u32(const void *, uint32_t byte_off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(byte_off);
+}
+#else
+SMH_LANE uint32_t smh_bfe(uint32_t x, uint32_t off, uint32_t width) { return (x >> off) & ((1u << width) - 1u); }
+SMH_LANE uint32_t smh_lds_u16(const void *base, uint32_t byte_off)
+{
+    uint16_t v;
+    memcpy(&v, (const uint8_t *)base + byte_off, 2);
+    return v;
+}
+SMH_LANE uint32_t smh_lds_u32(const void *base, uint32_t byte_off)
+{
+    uint32_t v;
+    memcpy(&v, (const uint8_t *)base + byte_off, 4);
+    return v;
+}
 #endif
 
 SMH_LANE uint32_t smh_byte_of(uint32_t word, int k) { return (word >> (8 * k)) & 0xFFu; }

@@ -16,6 +16,7 @@
 
 struct smh_ac_launch {
     smh_ac_verify_ctx V;        /* text, n, m, K, sigma, full DFA, depth_first, trunc1 (device pointers) */
+    smh_ac_df df;               /* depth_first[0..71] by value (kernel argument) */
     int stride;                 /* 1 or 2 */
     int exact;                  /* K == m: flags are matches, no queue */
     int scan_entry_bytes;

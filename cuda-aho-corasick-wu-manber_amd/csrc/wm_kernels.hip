@@ -66,12 +66,19 @@ static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
     auto kern = wm_block_kernel<HASHED, EXACT, HC>;
     uint32_t lds_bytes = (uint32_t)(((uint64_t)1 << L.filter_log2) / 8u);
     if (lds_bytes < 16u) lds_bytes = 16u;
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (err != hipSuccess) return err;
-    int per_cu = 0;
-    err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, SMH_BLOCK_THREADS, lds_bytes);
-    if (err != hipSuccess) return err;
+    static uint32_t cached_lds = 0xFFFFFFFFu;
+    static int cached_per_cu = 0;
+    if (cached_lds != lds_bytes) { /* once per (kernel, LDS size): see ac_kernels.hip */
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (err != hipSuccess) return err;
+        int q = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, SMH_BLOCK_THREADS, lds_bytes);
+        if (err != hipSuccess) return err;
+        cached_per_cu = q;
+        cached_lds = lds_bytes;
+    }
+    int per_cu = cached_per_cu;
     if (per_cu < 1) per_cu = 1;
     const uint64_t chunk = (uint64_t)SMH_SEG * 64u;
     const uint64_t n_chunks = (L.n + chunk - 1) / chunk;

@@ -20,7 +20,7 @@
 #include "wm_lane.h"
 
 #define EMU_BLOCK_THREADS 1024
-#define EMU_AC_NCH 2 /* == SMH_AC_NCH in ac_kernels.hip */
+#define EMU_AC_NCH 1 /* == SMH_AC_NCH in ac_kernels.hip */
 
 struct guarded {
     uint8_t *map;
@@ -51,10 +51,18 @@ static void guard_free(guarded &g) { munmap(g.map, g.map_len); }
 template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT>
 static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t blocks)
 {
+    smh_ac_df df;
+    for (int i = 0; i < SMH_AC_DF_LEN; ++i) df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
-    for (uint64_t t = 0; t < nthreads; ++t)
-        total += smh_ac_thread<E, SIGMA, STRIDE, HC, EMU_AC_NCH, EXACT>(t, nthreads, (const E *)ac->scan_table, V, nullptr);
+    for (uint64_t t = 0; t < nthreads; ++t) {
+        if constexpr (STRIDE == 2) {
+            total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT>(smh_fmt_s2{}, t, nthreads, ac->scan_table, V, df, nullptr);
+        } else {
+            const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
+            total += smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, EMU_AC_NCH, EXACT>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
+        }
+    }
     return total;
 }
 
