@@ -40,6 +40,24 @@ AC_PATTERNS = 1000
 WM_PATTERNS, WM_LENGTH = 10000, 8
 
 
+def measured_traffic(info):
+    """HBM bytes per launch of the AC kernel instance that `info` (smh_ac_info) selects, from the
+    committed rocprofv3 --pmc passes (profiles/hbm_traffic.json: FETCH_SIZE x2 + WRITE_SIZE per the
+    gfx950 corrections of MI355X_MICROARCH.md).  bench.py cannot read PMC counters itself; the file
+    is produced from the same command under rocprofv3 (tools/pmc_summary.py, profiles/README)."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    kernels = json.load(open(path)).get("kernels", {})
+    halo = info.scan_depth - 1
+    hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
+    name = "ac_dfa_kernel<%s, 4, %d, %d, %s, 1, true>" % ("unsigned short" if info.lds_bytes and info.entry_bytes == 2 or
+                                                           info.scan_stride == 2 else "unsigned int", info.scan_stride,
+                                                           hc, "true" if info.scan_exact else "false")
+    rec = kernels.get(name)
+    return rec["hbm_bytes"] if rec else None
+
+
 def cpu_baseline(text_prefix, pats):
     """Reference CPU path timed on this box's host cores (rank 0, N = 1 only).  Checker code:
     the only place bench.py touches oracle/."""
@@ -174,12 +192,14 @@ def main():
             ac_detail["m%d" % m] = dict(kernel_ms=round(ms, 4), min_ms=round(min(kern_ms[m]), 4), GBps=round(gbs, 1),
                                         Gbit_s=round(8 * gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                                         dfa_rows=info.rows, lds_rows=info.lds_rows, lds_bytes=info.lds_bytes,
+                                        scan_stride=info.scan_stride, scan_depth=info.scan_depth,
+                                        scan_exact=info.scan_exact,
                                         matches=total_counts[AC_LENGTHS.index(m)])
         dom = max(AC_LENGTHS, key=lambda m: mean(kern_ms[m]))
         dom_ms = mean(kern_ms[dom])
         achieved = shard_len(dom) / (dom_ms * 1e-3) / 1e9
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 4), traffic=measured_traffic(acs[dom].info()),
                         kernel="ac_dfa_kernel (m=%d set)" % dom, launch_ms=round(dom_ms, 4),
                         algorithmic_bytes_per_launch=shard_len(dom))
         out = {

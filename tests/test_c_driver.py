@@ -1,0 +1,53 @@
+"""A plain C program written against the reference's API (tests/c_driver/legacy_driver.c, the call
+sequence of main.c:125-157, 268-298, 410-449, 582-648) compiles with gcc and links against
+libsmatcher_hip.so unchanged.  CPU: it builds, preproc_ac runs on the host and the first GPU call
+exits(1) with a message (no fallback).  GPU (-m gpu): every count equals the oracle's."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd")
+sys.path.insert(0, PKG)
+import smatcher_hip as S  # noqa: E402
+
+SRC = os.path.join(ROOT, "tests", "c_driver", "legacy_driver.c")
+EXE = os.path.join(ROOT, "tests", "c_driver", "legacy_driver")
+
+
+def build_driver():
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), SRC, "-o", EXE,
+                           "-L" + PKG, "-lsmatcher_hip", "-Wl,-rpath," + PKG, "-lm"])
+
+
+def test_c_driver_builds_and_has_no_cpu_fallback():
+    build_driver()
+    r = subprocess.run([EXE, "8", "100", "100000", "4"], capture_output=True, text=True, timeout=120)
+    lines = r.stdout.splitlines()
+    assert lines and lines[0].startswith("preproc_ac states")  # host-side preprocessing works anywhere
+    text = S.corpus_text(100000, 42, 4)
+    pat = S.corpus_patterns(8, 100, 7, 4, 42, 100000, 2)
+    _, t = O.oracle_ac(pat, 8, 100, 4)
+    assert lines[0].split("\t")[1] == str(t.idcounter) and lines[0].split("\t")[3] == str(t.patterncounter)
+    if S.device_count() == 0:
+        assert r.returncode == 1 and "search_ac" in r.stderr and len(lines) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,p,n,sigma", [(8, 100, 1 << 20, 4), (16, 500, 3000001, 4), (12, 300, 777777, 20)])
+def test_c_driver_counts_match_oracle(m, p, n, sigma):
+    build_driver()
+    r = subprocess.run([EXE, str(m), str(p), str(n), str(sigma)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    text = S.corpus_text(n, 42, sigma)
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
+    want, _ = O.oracle_ac(pat, m, p, sigma, text)
+    out = r.stdout
+    assert "search_ac matches \t%d\n" % want in out
+    assert "search_wm2 matches \t%d\n" % want in out
+    assert "Kernel 1 matches \t%d\t" % want in out and "Kernel 5 matches \t%d\t" % want in out
+    assert "cuda_wm1 matches \t%d\t cuda_wm5 matches \t%d\n" % (want, want) in out
