@@ -51,9 +51,9 @@ def measured_traffic(info):
     kernels = json.load(open(path)).get("kernels", {})
     halo = info.scan_depth - 1
     hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
-    name = "ac_dfa_kernel<%s, 4, %d, %d, %s, 1, true>" % ("unsigned short" if info.lds_bytes and info.entry_bytes == 2 or
-                                                           info.scan_stride == 2 else "unsigned int", info.scan_stride,
-                                                           hc, "true" if info.scan_exact else "false")
+    entry = "unsigned short" if (info.scan_stride == 2 or info.lds_rows <= 32768) else "unsigned int"
+    name = "ac_dfa_kernel<%s, 4, %d, %d, %s, 1, true>" % (entry, info.scan_stride, hc,
+                                                          "true" if info.scan_exact else "false")
     rec = kernels.get(name)
     return rec["hbm_bytes"] if rec else None
 
