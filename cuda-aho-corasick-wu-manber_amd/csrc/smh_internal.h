@@ -132,6 +132,12 @@ struct smh_wm {
     int verify_log2;      /* slots = 1 << verify_log2; 0 slots when exact */
     uint32_t *verify;     /* 2 words per slot: tag, pattern index + 1 (0 = empty) */
     unsigned char *pat_sorted; /* distinct * m */
+    /* pair filter (alphabet 4, m <= 8, exact): indexed by the code of NINE consecutive symbols
+     * (18 bits, oldest symbol highest); word i>>5 of two interleaved bit maps: bit (i&31) of
+     * pair_table[2*(i>>5)] = "the m symbols ending at the 8th symbol are a pattern", of
+     * pair_table[2*(i>>5)+1] = "the m symbols ending at the 9th symbol are a pattern".  One LDS
+     * lookup answers two end columns.  64 KiB. */
+    uint32_t *pair_table;
     /* reference-layout tables */
     uint32_t shiftsize;
     uint32_t shift_zero;

@@ -52,6 +52,7 @@ struct smh_wm_launch {
     int filter_hashed;
     int filter_exact;
     const uint32_t *d_filter;
+    const uint32_t *d_pair; /* pair filter (alphabet 4, m <= 8, exact), else NULL */
     int verify_log2;
     const uint32_t *d_verify;
     const uint8_t *d_pat_sorted;

@@ -43,6 +43,7 @@ struct smh_ac_dev {
 struct smh_wm_dev {
     int device;
     uint32_t *d_filter;
+    uint32_t *d_pair;
     uint32_t *d_verify;
     uint8_t *d_pat_sorted;
     uint16_t *d_shift;
@@ -306,6 +307,7 @@ extern "C" void smh_wm_dev_free(struct smh_wm_dev *dev)
 {
     if (!dev) return;
     (void)hipFree(dev->d_filter);
+    (void)hipFree(dev->d_pair);
     (void)hipFree(dev->d_verify);
     (void)hipFree(dev->d_pat_sorted);
     (void)hipFree(dev->d_shift);
@@ -328,6 +330,7 @@ static int wm_ensure_device(struct smh_wm *wm)
     int rc;
     const size_t fbytes = ((size_t)1 << wm->filter_log2) / 8;
     if ((rc = upload((void **)&d->d_filter, wm->filter, fbytes, 0)) != SMH_OK) return rc;
+    if (wm->pair_table && (rc = upload((void **)&d->d_pair, wm->pair_table, 65536, 0)) != SMH_OK) return rc;
     if (!wm->filter_exact) {
         if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 8, 0)) != SMH_OK) return rc;
     }
@@ -370,7 +373,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         smh_wm_launch L;
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_exact = wm->filter_exact;
-        L.d_filter = wm->dev->d_filter; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
+        L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
         L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
     } else {

@@ -85,6 +85,7 @@ void smh_wm_host_free(struct smh_wm *wm)
 {
     if (!wm) return;
     free(wm->filter);
+    free(wm->pair_table);
     free(wm->verify);
     free(wm->pat_sorted);
     free(wm->l_shift);
@@ -285,6 +286,19 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         wm->block_symbols = Wd;
         wm->filter_density = direct_density;
         wm->filter_exact = exact;
+    }
+
+    /* ---- pair filter: one lookup for two end columns (see smh_internal.h) ---- */
+    if (wm->filter_exact && alphabet == 4 && m <= 8 && !wm->filter_hashed) {
+        wm->pair_table = (uint32_t *)calloc(2u * 8192u, sizeof(uint32_t));
+        if (!wm->pair_table) goto oom;
+        const uint32_t mmask = (1u << (2 * m)) - 1u;
+        for (uint32_t i = 0; i < (1u << 18); ++i) {
+            /* the exact direct filter is indexed by the m-symbol code, oldest symbol highest */
+            const uint32_t c1 = (i >> 2) & mmask, c2 = i & mmask;
+            if ((wm->filter[c1 >> 5] >> (c1 & 31u)) & 1u) wm->pair_table[2u * (i >> 5)] |= 1u << (i & 31u);
+            if ((wm->filter[c2 >> 5] >> (c2 & 31u)) & 1u) wm->pair_table[2u * (i >> 5) + 1u] |= 1u << (i & 31u);
+        }
     }
 
     /* ---- verify table (device HASH/PREFIX stage): FNV-1a(window) -> {tag, pattern + 1} ---- */

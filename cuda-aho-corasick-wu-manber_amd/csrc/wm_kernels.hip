@@ -42,6 +42,31 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     smh_wave_add_wm(cnt, count);
 }
 
+/* alphabet 4, m <= 8: pair filter (two end columns per LDS lookup), 64 KiB of LDS */
+__global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_pair_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,
+                                                                   const uint32_t *__restrict__ pair_g,
+                                                                   const uint32_t *__restrict__ filter_g,
+                                                                   uint64_t *count)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smh_lds[];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(pair_g);
+        uint4 *dst = reinterpret_cast<uint4 *>(smh_lds);
+        /* 65536 bytes = 4096 x 16 B = 4 per thread, all four loads in flight */
+        const uint4 t0 = src[threadIdx.x], t1 = src[threadIdx.x + 1024], t2 = src[threadIdx.x + 2048],
+                    t3 = src[threadIdx.x + 3072];
+        dst[threadIdx.x] = t0;
+        dst[threadIdx.x + 1024] = t1;
+        dst[threadIdx.x + 2048] = t2;
+        dst[threadIdx.x + 3072] = t3;
+    }
+    __syncthreads();
+    const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t cnt = smh_wm_pair_thread<true>(gthread, nthreads, text, n, m, smh_lds, filter_g);
+    smh_wave_add_wm(cnt, count);
+}
+
 __global__ __launch_bounds__(256) void wm_table_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,
                                                       const uint16_t *__restrict__ shift_g, uint32_t shiftsize,
                                                       const uint32_t *__restrict__ bucket_off,
@@ -110,8 +135,33 @@ static hipError_t launch_halo(const smh_wm_launch &L, hipStream_t stream)
     return launch_one<HASHED, EXACT, 0>(L, stream);
 }
 
+static hipError_t launch_pair(const smh_wm_launch &L, hipStream_t stream)
+{
+    const uint32_t lds_bytes = 65536u;
+    static int cached_per_cu = 0;
+    if (!cached_per_cu) {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(wm_pair_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (err != hipSuccess) return err;
+        int q = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, wm_pair_kernel, SMH_BLOCK_THREADS, lds_bytes);
+        if (err != hipSuccess) return err;
+        cached_per_cu = q < 1 ? 1 : q;
+    }
+    const uint64_t chunk = (uint64_t)SMH_SEG * 64u;
+    const uint64_t n_chunks = (L.n + chunk - 1) / chunk;
+    uint64_t blocks = (uint64_t)L.n_cus * (uint64_t)cached_per_cu;
+    const uint64_t want = (n_chunks + (SMH_BLOCK_THREADS / 64) - 1) / (SMH_BLOCK_THREADS / 64);
+    if (blocks > want) blocks = want;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wm_pair_kernel, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), lds_bytes, stream, L.d_text,
+                       L.n, L.m, L.d_pair, L.d_filter, L.d_count);
+    return hipGetLastError();
+}
+
 hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream)
 {
+    if (L.d_pair) return launch_pair(L, stream);
     if (L.filter_hashed) return launch_halo<true, false>(L, stream);
     if (L.filter_exact) return launch_halo<false, true>(L, stream);
     return launch_halo<false, false>(L, stream);

@@ -238,4 +238,149 @@ SMH_LANE uint32_t smh_wm_table_thread(uint64_t gthread, uint64_t nthreads, const
     return cnt;
 }
 
+/* ------------------------------------------------------------------ pair filter (alphabet 4, m <= 8)
+ * One LDS lookup decides TWO end columns: the lookup key is the 18-bit code of the nine symbols
+ * ending at the second column (smh_internal.h "pair filter").  Per pair of text bytes: one
+ * v_bfe (pair code), one v_lshl_or (rolling code), two ops for the address, one ds_read_b64,
+ * two v_bfe with the code's low 5 bits as bit index, one v_add3.  The eight symbols in front of
+ * the segment come from the previous lane's registers (DPP wave_shr:1); lane 0 takes the
+ * wave-uniform `edge` words loaded from the 8 bytes in front of the wave-chunk.
+ */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+SMH_LANE uint32_t smh_prev_lane_word(uint32_t mine, uint32_t edge, const uint8_t *, uint64_t)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)edge, (int)mine, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+SMH_LANE void smh_lds_u32x2(const void *, uint32_t byte_off, uint32_t &lo, uint32_t &hi)
+{
+    typedef uint32_t smh_v2u __attribute__((ext_vector_type(2)));
+    const smh_v2u v = *reinterpret_cast<const __attribute__((address_space(3))) smh_v2u *>(byte_off);
+    lo = v.x;
+    hi = v.y;
+}
+#else
+SMH_LANE uint32_t smh_prev_lane_word(uint32_t, uint32_t, const uint8_t *text, uint64_t byte_offset)
+{
+    uint32_t v;
+    memcpy(&v, text + byte_offset, 4);
+    return v;
+}
+SMH_LANE void smh_lds_u32x2(const void *base, uint32_t byte_off, uint32_t &lo, uint32_t &hi)
+{
+    memcpy(&lo, (const uint8_t *)base + byte_off, 4);
+    memcpy(&hi, (const uint8_t *)base + byte_off + 4, 4);
+}
+#endif
+
+/* pair codes (4 bits: first symbol high) of a text dword: x = (w << 3) | (w >> 7) puts them at bits 1..4 and 17..20 */
+SMH_LANE uint32_t smh_wm_pairs_prep(uint32_t w) { return (w << 3) | (w >> 7); }
+
+SMH_LANE uint32_t smh_wm_pair_step(uint32_t &code, uint32_t x, int k, const void *tab)
+{
+    code = (code << 4) | smh_bfe(x, k == 0 ? 1 : 17, 4);
+    uint32_t lo, hi;
+    smh_lds_u32x2(tab, (code >> 2) & 0xFFF8u, lo, hi); /* ((code & 0x3FFFF) >> 5) * 8 */
+    return smh_bfe(lo, code & 31u, 1) + smh_bfe(hi, code & 31u, 1);
+}
+
+/* fast path: the 64 END columns of the segment at a (a >= 8, a + 64 <= n, first column >= m-1) */
+SMH_LANE uint32_t smh_wm_pair_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16],
+                                        const uint32_t (&edge)[2], const void *tab)
+{
+    /* prime the rolling code with the 8 symbols in front of the segment */
+    uint32_t code = 0, cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t pw = smh_prev_lane_word(w[14 + q], edge[q], text, a - 8u + 4u * q);
+        const uint32_t x = smh_wm_pairs_prep(pw);
+        code = (code << 4) | smh_bfe(x, 1, 4);
+        code = (code << 4) | smh_bfe(x, 17, 4);
+    }
+    /* `code` now holds symbols a-8 .. a-1; the lookup after the pair (a+2i, a+2i+1) sees a+2i-7 .. a+2i+1 */
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t x = smh_wm_pairs_prep(w[q]);
+        cnt += smh_wm_pair_step(code, x, 0, tab);
+        cnt += smh_wm_pair_step(code, x, 1, tab);
+    }
+    return cnt;
+}
+
+/* slow path of the pair kernel: per-column test against the exact m-symbol filter held in HBM */
+SMH_LANE uint32_t smh_wm_pair_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const uint32_t *filter_g, int m)
+{
+    if (a >= n) return 0;
+    uint64_t end = a + SMH_SEG;
+    if (end > n) end = n;
+    uint64_t e0 = a;
+    if (e0 < (uint64_t)(m - 1)) e0 = (uint64_t)(m - 1);
+    if (e0 >= end) return 0;
+    const uint32_t mask = (1u << (2 * m)) - 1u;
+    uint32_t code = 0, cnt = 0;
+    for (uint64_t i = e0 - (uint64_t)(m - 1); i < e0; ++i) code = (code << 2) | (text[i] & 3u);
+    for (uint64_t e = e0; e < end; ++e) {
+        code = (code << 2) | (text[e] & 3u);
+        const uint32_t key = code & mask;
+        cnt += (filter_g[key >> 5] >> (key & 31u)) & 1u;
+    }
+    return cnt;
+}
+
+template <bool PREFETCH>
+SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n, int m,
+                                     const void *tab, const uint32_t *filter_g)
+{
+    if (n < (uint64_t)m) return 0;
+    const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
+    const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
+    const uint32_t lane = (uint32_t)(gthread & 63u);
+    const uint64_t wave = gthread >> 6, nwaves = nthreads >> 6;
+    uint32_t cnt = 0;
+    uint32_t cur[16], nxt[16], cur_edge[2], nxt_edge[2];
+    uint64_t k = wave;
+    /* chunk 0 has no text in front of it and columns < m-1 without a window: slow path */
+    auto is_fast = [&](uint64_t kk) { return kk >= 1 && kk < n_chunks && (kk + 1) * chunk_bytes <= n; };
+    auto load = [&](uint64_t kk, uint32_t (&w)[16], uint32_t (&edge)[2]) {
+        const uint64_t base = smh_uniform64(kk * chunk_bytes);
+        const uint8_t *p = text + base + (uint64_t)lane * SMH_SEG;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const smh_u32x4 t = smh_load16(p + 16u * q);
+            w[4 * q + 0] = t.v[0];
+            w[4 * q + 1] = t.v[1];
+            w[4 * q + 2] = t.v[2];
+            w[4 * q + 3] = t.v[3];
+        }
+        /* the 8 bytes in front of the wave-chunk, same address in every lane (16-byte aligned load) */
+        const smh_u32x4 t = smh_load16(text + base - 16u);
+        edge[0] = t.v[2];
+        edge[1] = t.v[3];
+    };
+    bool cur_fast = is_fast(k);
+    if (cur_fast) load(k, cur, cur_edge);
+    while (k < n_chunks) {
+        const uint64_t kn = k + nwaves;
+        const bool nxt_fast = is_fast(kn);
+        if (PREFETCH && nxt_fast) load(kn, nxt, nxt_edge);
+        const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
+        if (cur_fast)
+            cnt += smh_wm_pair_lane_fast(text, a, cur, cur_edge, tab);
+        else
+            cnt += smh_wm_pair_lane_slow(text, n, a, filter_g, m);
+        if (nxt_fast) {
+            if (PREFETCH) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
+                cur_edge[0] = nxt_edge[0];
+                cur_edge[1] = nxt_edge[1];
+            } else {
+                load(kn, cur, cur_edge);
+            }
+        }
+        cur_fast = nxt_fast;
+        k = kn;
+    }
+    return cnt;
+}
+
 #endif

@@ -5,6 +5,10 @@ path, which is C host code + gfx950 kernels inside the shared library.  The
 library is built in-tree by `make -C cuda-aho-corasick-wu-manber_amd` (or
 __graft_entry__.build()); a missing library is a hard error -- there is no
 Python or CPU fallback for the search entry points.
+
+Processes that also use torch must import torch BEFORE this module: torch loads its bundled HIP
+runtime by path, this library requests libamdhip64.so.7 by SONAME and then shares torch's copy;
+the other order puts two HIP runtimes into one process and torch then finds no GPU.
 """
 import ctypes as C
 import os

@@ -75,5 +75,6 @@ int main(int argc, char **argv)
     free(pattern); free(pattern2); free(text);
     free(state_transition); free(state_supply); free(state_final);
     free(SHIFT); free(PREFIX_value); free(PREFIX_index); free(PREFIX_size);
+    fflush(stdout);
     return 0;
 }

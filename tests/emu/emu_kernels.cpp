@@ -165,6 +165,10 @@ extern "C" uint64_t emu_wm_scan(const smh_wm *wm, const uint8_t *text_in, uint64
                 total += smh_wm_table_thread<uint16_t>(t, nthreads, text, n, sh, wm->shiftsize, wm->l_bucket_off,
                                                        wm->l_bucket, wm->pat_orig, wm->m, 2);
             free(sh);
+        } else if (wm->pair_table) {
+            const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
+            for (uint64_t t = 0; t < nthreads; ++t)
+                total += smh_wm_pair_thread<true>(t, nthreads, text, n, wm->m, wm->pair_table, wm->filter);
         } else if (wm->filter_hashed) {
             total = wm_halo<true, false>(wm, text, n, blocks);
         } else if (wm->filter_exact) {

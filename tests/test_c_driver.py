@@ -1,7 +1,10 @@
 """A plain C program written against the reference's API (tests/c_driver/legacy_driver.c, the call
 sequence of main.c:125-157, 268-298, 410-449, 582-648) compiles with gcc and links against
-libsmatcher_hip.so unchanged.  CPU: it builds, preproc_ac runs on the host and the first GPU call
-exits(1) with a message (no fallback).  GPU (-m gpu): every count equals the oracle's."""
+libsmatcher_hip.so unchanged.  CPU: it builds as an executable, preproc_ac runs on the host and the
+first GPU call exits(1) with a message (no fallback).  GPU (-m gpu): the same translation unit,
+built as a shared object with main renamed, is called in-process (a process that has touched the
+GPU must not fork+exec on the GPU pool) and every count equals the oracle's."""
+import ctypes as C
 import os
 import subprocess
 import sys
@@ -17,6 +20,7 @@ import smatcher_hip as S  # noqa: E402
 
 SRC = os.path.join(ROOT, "tests", "c_driver", "legacy_driver.c")
 EXE = os.path.join(ROOT, "tests", "c_driver", "legacy_driver")
+DSO = os.path.join(ROOT, "tests", "c_driver", "legacy_driver.so")
 
 
 def build_driver():
@@ -24,6 +28,13 @@ def build_driver():
                            "-L" + PKG, "-lsmatcher_hip", "-Wl,-rpath," + PKG, "-lm"])
 
 
+def build_driver_dso():
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-shared", "-fPIC", "-Dmain=legacy_driver_main",
+                           "-I" + os.path.join(ROOT, "include"), SRC, "-o", DSO,
+                           "-L" + PKG, "-lsmatcher_hip", "-Wl,-rpath," + PKG, "-lm"])
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="spawns a process; only run where no GPU can have been initialised")
 def test_c_driver_builds_and_has_no_cpu_fallback():
     build_driver()
     r = subprocess.run([EXE, "8", "100", "100000", "4"], capture_output=True, text=True, timeout=120)
@@ -39,10 +50,19 @@ def test_c_driver_builds_and_has_no_cpu_fallback():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("m,p,n,sigma", [(8, 100, 1 << 20, 4), (16, 500, 3000001, 4), (12, 300, 777777, 20)])
-def test_c_driver_counts_match_oracle(m, p, n, sigma):
-    build_driver()
-    r = subprocess.run([EXE, str(m), str(p), str(n), str(sigma)], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
+def test_c_driver_counts_match_oracle(m, p, n, sigma, capfd):
+    if not os.path.exists(DSO):
+        pytest.fail("tests/c_driver/legacy_driver.so missing: __graft_entry__.build() compiles it (no compiler runs "
+                    "from a GPU-initialised process)")
+    drv = C.CDLL(DSO)
+    args = [b"legacy_driver", str(m).encode(), str(p).encode(), str(n).encode(), str(sigma).encode()]
+    argv = (C.c_char_p * len(args))(*args)
+    capfd.readouterr()
+    assert drv.legacy_driver_main(len(args), argv) == 0
+
+    class R:
+        stdout = capfd.readouterr().out
+    r = R()
     text = S.corpus_text(n, 42, sigma)
     pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
     want, _ = O.oracle_ac(pat, m, p, sigma, text)
