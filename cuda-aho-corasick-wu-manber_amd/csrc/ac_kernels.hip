@@ -31,6 +31,27 @@ __device__ __forceinline__ void smh_wave_add(uint32_t cnt, uint64_t *count)
     if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd((unsigned long long *)count, (unsigned long long)cnt);
 }
 
+/* Workgroup-level count: wave sums meet in LDS and ONE 64-bit atomic per workgroup reaches HBM.
+ * With one atomic per wave, 4096 same-address atomics (~12 ns each, serialised at the memory side)
+ * queued up when the balanced waves all finish together: a ~45 us tail on a 240 us kernel whenever
+ * every wave has matches.  `lds` may be the table region: the first barrier makes sure every wave
+ * is done reading it. */
+__device__ __forceinline__ void smh_block_add(uint32_t cnt, uint64_t *count, unsigned char *lds)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    __syncthreads();
+    uint32_t *part = reinterpret_cast<uint32_t *>(lds);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint64_t v = threadIdx.x < (blockDim.x >> 6) ? part[threadIdx.x] : 0u;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0 && v) atomicAdd((unsigned long long *)count, (unsigned long long)v);
+    }
+}
+
 template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__restrict__ scan_table, uint32_t lds_bytes,
                                                                   smh_ac_verify_ctx V, smh_ac_df df,
@@ -65,7 +86,7 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__re
         const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
         cnt = smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, NCH, EXACT, PF>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
     }
-    smh_wave_add(cnt, count);
+    smh_block_add(cnt, count, smh_lds);
 }
 
 __global__ __launch_bounds__(256) void ac_table_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,

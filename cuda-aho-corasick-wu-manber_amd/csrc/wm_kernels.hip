@@ -23,6 +23,23 @@ __device__ __forceinline__ void smh_wave_add_wm(uint32_t cnt, uint64_t *count)
     if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd((unsigned long long *)count, (unsigned long long)cnt);
 }
 
+/* one atomic per workgroup instead of one per wave: see smh_block_add in ac_kernels.hip */
+__device__ __forceinline__ void smh_block_add_wm(uint32_t cnt, uint64_t *count, unsigned char *lds)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    __syncthreads();
+    uint32_t *part = reinterpret_cast<uint32_t *>(lds);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint64_t v = threadIdx.x < (blockDim.x >> 6) ? part[threadIdx.x] : 0u;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (threadIdx.x == 0 && v) atomicAdd((unsigned long long *)count, (unsigned long long)v);
+    }
+}
+
 template <bool HASHED, bool EXACT, int HC>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ filter_g, uint32_t lds_bytes,
@@ -39,7 +56,7 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t cnt = smh_wm_thread<HASHED, EXACT, HC>(gthread, nthreads, text, n, filter, P, block_symbols);
-    smh_wave_add_wm(cnt, count);
+    smh_block_add_wm(cnt, count, smh_lds);
 }
 
 /* alphabet 4, m <= 8: pair filter (two end columns per LDS lookup), 64 KiB of LDS */
@@ -64,7 +81,7 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_pair_kernel(const uint8_
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t cnt = smh_wm_pair_thread<true>(gthread, nthreads, text, n, m, smh_lds, filter_g);
-    smh_wave_add_wm(cnt, count);
+    smh_block_add_wm(cnt, count, smh_lds);
 }
 
 __global__ __launch_bounds__(256) void wm_table_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,
