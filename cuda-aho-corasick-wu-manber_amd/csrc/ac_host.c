@@ -351,14 +351,12 @@ bad:
  * there whole.  Cutting the DFA at depth K keeps exactly the rows [0, depth_first[K+1]) (BFS
  * numbering) and is again an Aho-Corasick automaton -- of the K-symbol prefixes.  Two layouts:
  * stride 1 (one lookup per symbol) and, for the 4-letter alphabet, stride 2 (one lookup per two
- * symbols; LDS random-lookup rate is the kernel's bound, see profiles/).  A crude cost model in
- * "scan steps per text byte" picks between them.  With candidate rate r per byte a wave-step
- * (64 lanes x 2 chains x stride bytes) takes the queue-push path with probability
- * p = 1 - exp(-128 * stride * r); that path costs several plain steps, so K is worth much more
- * than stride once candidates stop being rare:
- *     cost = (1 + p * SMH_PUSH_COST) / stride + r * SMH_VERIFY_COST                            */
-#define SMH_PUSH_COST 6.0
-#define SMH_VERIFY_COST 10.0
+ * symbols).  Measured on MI355X (profiles/): stride 2 with K = m runs ~5.0 TB/s,
+ * stride 1 ~3.6 TB/s (LDS lookup rate), stride 1 with K < m ~3.35 TB/s while candidates are rare;
+ * stride 2 with K < m has to verify every candidate from the root and only pays when candidates are
+ * very rare (it measured 2.0 TB/s at one candidate per 260 bytes).  Relative cost per text byte:
+ *     stride 1:  1 + 0.08 [K < m] + 3 * P(a 16-byte piece of a wave holds a candidate)
+ *     stride 2:  0.72 + 300 * r [K < m]                       r = candidates per text byte      */
 
 static uint32_t entry_get(const void *t, int eb, size_t i)
 {
@@ -407,8 +405,11 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
             if (s == 2 && rk > 16384) continue;
             if (rk * per_row > lds_budget) continue;
             const double r = candidate_rate(ac, K);
-            const double ppush = 1.0 - exp(-128.0 * s * r);
-            double cost = (1.0 + ppush * SMH_PUSH_COST) / s + r * SMH_VERIFY_COST;
+            double cost;
+            if (s == 1)
+                cost = 1.0 + (K < ac->m ? 0.08 : 0.0) + 3.0 * (1.0 - exp(-16.0 * 64.0 * r));
+            else
+                cost = 0.72 + 300.0 * r;
             if (cost < best_cost) { best_cost = cost; best_s = s; best_k[s] = K; }
             if (!force_depth) break; /* the deepest K that fits is the best for this stride */
         }

@@ -66,25 +66,38 @@ SMH_LANE uint32_t smh_entry_at(const void *t, int eb, uint64_t i)
 }
 
 /*
- * A K-symbol pattern prefix ends at text[q] and corresponds to depth-K row `row` of the DFA.
- * Follow goto edges for the remaining m-K symbols: an edge exists iff the next row is one level
- * deeper (rows are numbered breadth-first, so depth(r) >= d  <=>  r >= depth_first[d]); the
- * last edge, into an accepting leaf, is the FLAG bit.  lazy: `row` is the row BEFORE text[q] was
- * consumed (stride-2 scan, candidate on the first symbol of a pair) -- one stride-1 step first.
+ * A K-symbol pattern prefix ends at text[q].  Follow goto edges of the full DFA for the remaining
+ * symbols: an edge exists iff the next row is one level deeper (rows are numbered breadth-first,
+ * so depth(r) >= d  <=>  r >= depth_first[d]); the last edge, into an accepting leaf, is the FLAG
+ * bit.  What the scan knew about the candidate decides where the walk starts:
+ *   SMH_CAND_ROW   `row` is the depth-K row reached at text[q]: walk symbols K .. m-1
+ *   SMH_CAND_LAZY  `row` is the row BEFORE text[q] was consumed (stride-2 scan, candidate on the
+ *                  first symbol of a pair): one stride-1 step of the depth-K table first
+ *   SMH_CAND_ROOT  only the position is known (stride-2 scan that records candidates as bits):
+ *                  walk all m symbols from the root, starting at q - K + 1
  */
-SMH_LANE uint32_t smh_ac_deep_walk(const smh_ac_verify_ctx &V, uint64_t q, uint32_t row, bool lazy)
+#define SMH_CAND_ROW 0u
+#define SMH_CAND_LAZY 1u
+#define SMH_CAND_ROOT 2u
+
+SMH_LANE uint32_t smh_ac_deep_walk(const smh_ac_verify_ctx &V, uint64_t q, uint32_t row, uint32_t kind)
 {
-    if (lazy) {
+    int t0 = V.K;
+    uint64_t start = q + 1 - (uint64_t)V.K; /* text position of the pattern's first symbol */
+    if (kind == SMH_CAND_LAZY) {
         uint32_t c0 = V.text[q];
         if (c0 >= (uint32_t)V.sigma) c0 = 0;
         const uint32_t e = smh_entry_at(V.trunc1, V.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c0);
         row = e & (V.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu);
+    } else if (kind == SMH_CAND_ROOT) {
+        row = 0;
+        t0 = 0;
     }
-    if (q + (uint64_t)(V.m - V.K) >= V.n) return 0;
+    if (start + (uint64_t)V.m > V.n) return 0;
     const uint32_t fshift = V.full_entry_bytes == 2 ? 15u : 31u;
     const uint32_t fmask = (1u << fshift) - 1u;
-    for (int t = V.K; t < V.m; ++t) {
-        const uint32_t c = V.text[q + 1 + (uint64_t)(t - V.K)];
+    for (int t = t0; t < V.m; ++t) {
+        const uint32_t c = V.text[start + (uint64_t)t];
         if (c >= (uint32_t)V.sigma) return 0;
         const uint32_t e = smh_entry_at(V.full, V.full_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
         if (e >> fshift) return 1;
@@ -112,14 +125,14 @@ SMH_LANE void smh_ac_drain(smh_ac_queue &Q, const smh_ac_verify_ctx &V)
     for (uint32_t i = lane; i < Q.count; i += 64u) {
         const uint64_t ent = __hip_atomic_load(Q.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t rl = (uint32_t)(ent >> 40);
-        Q.matches += smh_ac_deep_walk(V, ent & 0xFFFFFFFFFFull, rl & 0x7FFFFFu, (rl >> 23) != 0);
+        Q.matches += smh_ac_deep_walk(V, ent & 0xFFFFFFFFFFull, rl & 0x3FFFFFu, rl >> 22);
     }
     Q.count = 0;
 }
 
 /* wavefront-level compaction: lanes with `cond` append {position, row} to the wave's queue.
  * Must be called in wave-uniform control flow. */
-SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, bool lazy)
+SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, uint32_t kind)
 {
     const uint64_t mask = __ballot(cond);
     if (mask == 0) return;
@@ -127,16 +140,16 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
     if (Q.count + np > SMH_AC_QCAP) smh_ac_drain(Q, V);
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (cond) {
-        const uint64_t ent = pos | ((uint64_t)(row | (lazy ? 0x800000u : 0u)) << 40);
+        const uint64_t ent = pos | ((uint64_t)(row | (kind << 22)) << 40);
         __hip_atomic_store(Q.slots + Q.count + before, ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     Q.count += np;
 }
 #else
 SMH_LANE void smh_ac_drain(smh_ac_queue &, const smh_ac_verify_ctx &) {}
-SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, bool lazy)
+SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, uint32_t kind)
 {
-    if (cond) Q.matches += smh_ac_deep_walk(V, pos, row, lazy);
+    if (cond) Q.matches += smh_ac_deep_walk(V, pos, row, kind);
 }
 #endif
 
@@ -200,6 +213,7 @@ template <typename FMT, int HC, int NCH, bool EXACT> struct smh_ac_scan_ctx {
     const uint32_t *tail; /* 4*HC words, same in every lane: the bytes that follow the wave-chunk */
     const smh_ac_verify_ctx *V;
     smh_ac_queue *Q;
+    uint32_t *hmask; /* stride-2 bit-recording mode: halo flags are OR-ed in here (NCH words), else NULL */
 };
 
 /* queue the candidates flagged by entry `e` (reached from `prev`) for the byte (pair) at `pos` */
@@ -208,18 +222,19 @@ SMH_LANE void smh_ac_emit_flags(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, u
                                 uint64_t pos)
 {
     if (FMT::STRIDE == 1) {
-        smh_ac_emit(*c.Q, *c.V, f != 0, pos, c.fmt.row(e), false);
+        smh_ac_emit(*c.Q, *c.V, f != 0, pos, c.fmt.row(e), SMH_CAND_ROW);
     } else {
         /* first symbol of the pair: the depth-K row is not in the entry -> resolved lazily */
-        smh_ac_emit(*c.Q, *c.V, (f & 1u) != 0, pos, c.fmt.row(prev), true);
-        smh_ac_emit(*c.Q, *c.V, (f & 2u) != 0, pos + 1u, c.fmt.row(e), false);
+        smh_ac_emit(*c.Q, *c.V, (f & 1u) != 0, pos, c.fmt.row(prev), SMH_CAND_LAZY);
+        smh_ac_emit(*c.Q, *c.V, (f & 2u) != 0, pos + 1u, c.fmt.row(e), SMH_CAND_ROW);
     }
 }
 
 /* one step of all chains with full flag handling: the halo steps and the replay of a flagged piece */
 template <typename FMT, int HC, int NCH, bool EXACT>
 SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, const uint32_t (&x)[NCH], int k,
-                               const uint64_t (&pos)[NCH], bool second_valid, uint32_t (&e)[NCH], uint32_t &cnt)
+                               const uint64_t (&pos)[NCH], bool second_valid, uint32_t (&e)[NCH], uint32_t &cnt,
+                               int hbit = 0)
 {
     uint32_t f[NCH], prev[NCH];
     uint32_t anyf = 0;
@@ -234,6 +249,9 @@ SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, co
     if (EXACT) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) cnt += (uint32_t)__builtin_popcount(f[j]);
+    } else if (c.hmask) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) c.hmask[j] |= f[j] << hbit;
     } else if (SMH_WAVE_ANY(anyf != 0)) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) smh_ac_emit_flags(c, f[j], prev[j], e[j], pos[j]);
@@ -276,7 +294,7 @@ SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, co
     uint64_t pos[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) pos[j] = c.a[j] + SMH_SEG + (uint64_t)H;
-    smh_ac_step_full(c, hx, (H & 3) / FMT::STRIDE, pos, H + 1 < c.halo, e, cnt);
+    smh_ac_step_full(c, hx, (H & 3) / FMT::STRIDE, pos, H + 1 < c.halo, e, cnt, H);
     return true;
 }
 
@@ -340,7 +358,15 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
     uint32_t e[NCH], snap[NCH], cnt = 0, anyf = 0;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) e[j] = snap[j] = 0;
-    smh_ac_scan_ctx<FMT, HC, NCH, EXACT> ctx{fmt, tab, K - 1, &df, text, a, tail, &V, &Q};
+    /* stride 2 with K < m: candidates are too frequent for "vote and replay" (a 16-byte piece of a
+     * wave holds 2048 positions); every lookup instead drops its two flag bits into a per-lane bit
+     * mask (one bit per text byte) and the set bits are queued after the segment, position only --
+     * the verify stage then walks the pattern from the root (SMH_CAND_ROOT). */
+    constexpr bool BITS = !EXACT && FMT::STRIDE == 2 && HC == 1;
+    uint32_t mlo[NCH], mhi[NCH], mhalo[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) mlo[j] = mhi[j] = mhalo[j] = 0;
+    smh_ac_scan_ctx<FMT, HC, NCH, EXACT> ctx{fmt, tab, K - 1, &df, text, a, tail, &V, &Q, BITS ? mhalo : nullptr};
     constexpr int SPD = 4 / FMT::STRIDE; /* steps per text dword */
 
 #pragma unroll
@@ -355,13 +381,20 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     e[j] = fmt.next(e[j], x[j], k, tab);
-                    if (EXACT)
+                    if (EXACT) {
                         cnt += (uint32_t)__builtin_popcount(fmt.flags(e[j]));
-                    else
+                    } else if (BITS) {
+                        const int bit = 4 * q + 2 * k;
+                        if (bit < 32)
+                            mlo[j] |= fmt.flags(e[j]) << bit;
+                        else
+                            mhi[j] |= fmt.flags(e[j]) << (bit - 32);
+                    } else {
                         anyf |= e[j];
+                    }
                 }
         }
-        if (!EXACT) {
+        if (!EXACT && !BITS) {
             if (SMH_WAVE_ANY(fmt.any(anyf) != 0)) {
                 /* replay the piece from the snapshot, with flag handling */
                 uint32_t r[NCH];
@@ -387,6 +420,23 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
         }
     }
     smh_ac_halo_all(ctx, w, e, cnt, std::make_integer_sequence<int, 16 * HC>{});
+    if (BITS) {
+        /* compaction: one queue entry per set bit, as many rounds as the busiest lane has bits */
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            uint32_t *const masks[3] = {&mlo[j], &mhi[j], &mhalo[j]};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                uint32_t msk = *masks[g];
+                while (SMH_WAVE_ANY(msk != 0)) {
+                    const bool have = msk != 0;
+                    const uint32_t b = have ? (uint32_t)__builtin_ctz(msk) : 0u;
+                    smh_ac_emit(Q, V, have, a[j] + 32u * g + b, 0u, SMH_CAND_ROOT);
+                    msk &= msk - 1u;
+                }
+            }
+        }
+    }
     return cnt;
 }
 
@@ -409,7 +459,7 @@ SMH_LANE uint32_t smh_ac_lane_slow(const smh_ac_verify_ctx &V, uint64_t n_starts
         if (c >= (uint32_t)V.sigma) c = 0;
         const uint32_t e = smh_entry_at(V.trunc1, V.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
         row = e & tmask;
-        if (e >> tshift) cnt += V.K >= V.m ? 1u : smh_ac_deep_walk(V, i, row, false);
+        if (e >> tshift) cnt += V.K >= V.m ? 1u : smh_ac_deep_walk(V, i, row, SMH_CAND_ROW);
     }
     return cnt;
 }
