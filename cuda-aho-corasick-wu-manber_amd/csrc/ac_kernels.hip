@@ -101,6 +101,27 @@ __global__ __launch_bounds__(256) void ac_table_kernel(const uint8_t *__restrict
     smh_wave_add(cnt, count);
 }
 
+__global__ __launch_bounds__(256) void ac_positions_kernel(smh_ac_verify_ctx V, uint64_t *positions, uint64_t capacity,
+                                                          uint64_t *cursor)
+{
+    const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    smh_ac_positions_thread(gthread, nthreads, V, positions, capacity, cursor);
+}
+
+hipError_t smh_launch_ac_positions(const smh_ac_verify_ctx &V, uint64_t *d_positions, uint64_t capacity,
+                                   uint64_t *d_cursor, int n_cus, hipStream_t stream)
+{
+    const uint64_t per_block = 256ull * SMH_SEG;
+    uint64_t blocks = (V.n + per_block - 1) / per_block;
+    const uint64_t cap = (uint64_t)n_cus * 8u;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ac_positions_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, V, d_positions, capacity,
+                       d_cursor);
+    return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------ launch */
 uint32_t smh_ac_max_blocks(int n_cus) { return (uint32_t)n_cus * 2u; }
 

@@ -584,4 +584,67 @@ SMH_LANE uint32_t smh_ac_table_thread(uint64_t gthread, uint64_t nthreads, const
     return cnt;
 }
 
+/* ------------------------------------------------------------------ match positions
+ * The reference only ever printed positions from commented-out code (ac/ac.c:217 "match at %i"
+ * with the END column); this path appends the END columns of all matches to a device buffer.
+ * One lane scans the starts of one 64-byte segment with the stride-1 depth-K table read from
+ * HBM/L2 (candidates verified on the spot), collecting a 64-bit mask of matching starts; the wave
+ * then compacts: prefix sum of the per-lane counts, one atomic on the cursor, coalesced-ish
+ * stores.  Order of the output is unspecified (sort to compare).  Entries beyond `capacity` are
+ * dropped; the cursor still counts them, so cursor > capacity tells the caller to retry bigger.
+ */
+SMH_LANE uint64_t smh_ac_segment_match_mask(const smh_ac_verify_ctx &V, uint64_t n_starts, uint64_t a)
+{
+    if (a >= n_starts) return 0;
+    uint64_t own_end = a + SMH_SEG;
+    if (own_end > n_starts) own_end = n_starts;
+    uint64_t stop = own_end + (uint64_t)(V.K - 1);
+    if (stop > V.n) stop = V.n;
+    const uint32_t tmask = V.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu;
+    const uint32_t tshift = V.trunc1_entry_bytes == 2 ? 15u : 31u;
+    uint32_t row = 0;
+    uint64_t mask = 0;
+    for (uint64_t i = a; i < stop; ++i) {
+        uint32_t c = V.text[i];
+        if (c >= (uint32_t)V.sigma) c = 0;
+        const uint32_t e = smh_entry_at(V.trunc1, V.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
+        row = e & tmask;
+        if (e >> tshift) {
+            const uint32_t hit = V.K >= V.m ? 1u : smh_ac_deep_walk(V, i, row, SMH_CAND_ROW);
+            /* the K-symbol prefix that ends at i starts at i - K + 1, inside [a, own_end) */
+            if (hit) mask |= 1ull << (i + 1 - (uint64_t)V.K - a);
+        }
+    }
+    return mask;
+}
+
+/* append END columns (start + m - 1) of the set bits; returns the number of matches */
+SMH_LANE uint32_t smh_append_positions(uint64_t mask, uint64_t a, int m, uint64_t *positions, uint64_t capacity,
+                                       uint64_t *cursor)
+{
+    const uint32_t mine = (uint32_t)__builtin_popcountll(mask);
+    uint64_t slot = smh_wave_reserve(cursor, mine);
+    while (mask) {
+        const int b = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (slot < capacity) positions[slot] = a + (uint64_t)b + (uint64_t)(m - 1);
+        ++slot;
+    }
+    return mine;
+}
+
+SMH_LANE void smh_ac_positions_thread(uint64_t gthread, uint64_t nthreads, const smh_ac_verify_ctx &V,
+                                      uint64_t *positions, uint64_t capacity, uint64_t *cursor)
+{
+    if (V.n < (uint64_t)V.m) return;
+    const uint64_t n_starts = V.n - (uint64_t)V.m + 1;
+    const uint64_t n_segs = (n_starts + SMH_SEG - 1) / SMH_SEG;
+    const uint64_t n_rounds = (n_segs + nthreads - 1) / nthreads; /* same trip count for every lane of a wave */
+    for (uint64_t r = 0; r < n_rounds; ++r) {
+        const uint64_t a = (r * nthreads + gthread) * SMH_SEG;
+        const uint64_t mask = smh_ac_segment_match_mask(V, n_starts, a);
+        smh_append_positions(mask, a, V.m, positions, capacity, cursor);
+    }
+}
+
 #endif

@@ -122,6 +122,36 @@ SMH_LANE uint32_t smh_lds_u32(const void *base, uint32_t byte_off)
 }
 #endif
 
+/*
+ * Wavefront-level compaction for position output: every lane announces how many entries it will
+ * append; the wave computes an exclusive prefix sum over its 64 lanes, ONE lane advances the global
+ * cursor by the wave total with a single atomic, and each lane gets the slot where its own entries
+ * start.  Must be called by all 64 lanes.  The CPU emulation appends lane by lane.
+ */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+SMH_LANE uint64_t smh_wave_reserve(uint64_t *cursor, uint32_t mine)
+{
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if ((threadIdx.x & 63u) >= (uint32_t)off) incl += up;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    uint64_t base = 0;
+    if ((threadIdx.x & 63u) == 0 && total) base = atomicAdd((unsigned long long *)cursor, (unsigned long long)total);
+    base = ((uint64_t)__shfl((uint32_t)(base >> 32), 0, 64) << 32) | __shfl((uint32_t)base, 0, 64);
+    return base + (incl - mine);
+}
+#else
+SMH_LANE uint64_t smh_wave_reserve(uint64_t *cursor, uint32_t mine)
+{
+    const uint64_t base = *cursor;
+    *cursor += mine;
+    return base;
+}
+#endif
+
 SMH_LANE uint32_t smh_byte_of(uint32_t word, int k) { return (word >> (8 * k)) & 0xFFu; }
 
 #endif

@@ -41,6 +41,8 @@ struct smh_ac_table_launch {
     int n_cus;
 };
 hipError_t smh_launch_ac_table(const smh_ac_table_launch &L, hipStream_t stream);
+hipError_t smh_launch_ac_positions(const smh_ac_verify_ctx &V, uint64_t *d_positions, uint64_t capacity,
+                                   uint64_t *d_cursor, int n_cus, hipStream_t stream);
 
 struct smh_wm_launch {
     const uint8_t *d_text;
@@ -74,6 +76,8 @@ struct smh_wm_table_launch {
     int n_cus;
 };
 hipError_t smh_launch_wm_table(const smh_wm_table_launch &L, hipStream_t stream);
+hipError_t smh_launch_wm_positions(const smh_wm_table_launch &L, uint64_t *d_positions, uint64_t capacity,
+                                   uint64_t *d_cursor, hipStream_t stream);
 
 hipError_t smh_launch_corpus_text(uint8_t *d_out, uint64_t n, uint64_t offset, uint64_t seed,
                                   int alphabet, hipStream_t stream);

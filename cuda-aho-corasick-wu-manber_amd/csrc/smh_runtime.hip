@@ -250,6 +250,30 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
     return SMH_OK;
 }
 
+extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_positions,
+                                uint64_t capacity, uint64_t *d_cursor, void *stream)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC || !d_cursor || (capacity && !d_positions) || (n && !d_text)) {
+        smh_set_error("smh_ac_positions: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (!ac->fixed_length_ok) {
+        smh_set_error("smh_ac_positions: patterns are not all of length m");
+        return SMH_EUNSUP;
+    }
+    if (n < (uint64_t)ac->m) return SMH_OK;
+    int rc = ac_ensure_device(ac);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_ac_verify_ctx V;
+    V.text = d_text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
+    V.full = ac->dev->d_table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = ac->dev->d_depth_first;
+    V.trunc1 = ac->dev->d_trunc1; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    HIP_TRY(smh_launch_ac_positions(V, d_positions, capacity, d_cursor, n_cus, (hipStream_t)stream));
+    return SMH_OK;
+}
+
 /* shared by the two *_count_host helpers: text up, zeroed counter, timed launch, count down */
 template <typename Launch>
 static int count_host(const unsigned char *text, uint64_t n, uint64_t *count, double *kernel_seconds, Launch launch)
@@ -380,6 +404,26 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         smh_set_error("smh_wm_scan: unknown variant %d", variant);
         return SMH_EINVAL;
     }
+    return SMH_OK;
+}
+
+extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_positions,
+                                uint64_t capacity, uint64_t *d_cursor, void *stream)
+{
+    if (!wm || wm->magic != SMH_MAGIC_WM || !d_cursor || (capacity && !d_positions) || (n && !d_text)) {
+        smh_set_error("smh_wm_positions: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (n < (uint64_t)wm->m) return SMH_OK;
+    int rc = wm_ensure_device(wm);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_wm_table_launch L;
+    L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = wm->dev->d_shift;
+    L.d_bucket_off = wm->dev->d_bucket_off; L.d_bucket = wm->dev->d_bucket; L.d_pat_orig = wm->dev->d_pat_orig;
+    L.d_count = NULL; L.n_cus = n_cus;
+    HIP_TRY(smh_launch_wm_positions(L, d_positions, capacity, d_cursor, (hipStream_t)stream));
     return SMH_OK;
 }
 

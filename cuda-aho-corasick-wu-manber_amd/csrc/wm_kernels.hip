@@ -101,6 +101,38 @@ __global__ __launch_bounds__(256) void wm_table_kernel(const uint8_t *__restrict
     smh_wave_add_wm(cnt, count);
 }
 
+__global__ __launch_bounds__(256) void wm_positions_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,
+                                                          const uint16_t *__restrict__ shift_g, uint32_t shiftsize,
+                                                          const uint32_t *__restrict__ bucket_off,
+                                                          const int32_t *__restrict__ bucket,
+                                                          const uint8_t *__restrict__ pat_orig, uint64_t *positions,
+                                                          uint64_t capacity, uint64_t *cursor)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smh_lds[];
+    uint16_t *shift = reinterpret_cast<uint16_t *>(smh_lds);
+    for (uint32_t i = threadIdx.x; i < shiftsize; i += blockDim.x) shift[i] = shift_g[i];
+    __syncthreads();
+    const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    smh_wm_positions_thread<uint16_t>(gthread, nthreads, text, n, shift, shiftsize, bucket_off, bucket, pat_orig, m, 2,
+                                      positions, capacity, cursor);
+}
+
+hipError_t smh_launch_wm_positions(const smh_wm_table_launch &L, uint64_t *d_positions, uint64_t capacity,
+                                   uint64_t *d_cursor, hipStream_t stream)
+{
+    const uint64_t per_block = 256ull * SMH_SEG;
+    uint64_t blocks = (L.n + per_block - 1) / per_block;
+    const uint64_t cap = (uint64_t)L.n_cus * 8u;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    const uint32_t lds = (L.shiftsize * 2u + 15u) & ~15u;
+    hipLaunchKernelGGL(wm_positions_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, L.d_text, L.n, L.m,
+                       L.d_shift, L.shiftsize, L.d_bucket_off, L.d_bucket, L.d_pat_orig, d_positions, capacity,
+                       d_cursor);
+    return hipGetLastError();
+}
+
 /* ------------------------------------------------------------------ launch */
 template <bool HASHED, bool EXACT, int HC>
 static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)

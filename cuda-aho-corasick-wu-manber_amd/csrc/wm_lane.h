@@ -383,4 +383,77 @@ SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, uint64_t nthreads, const 
     return cnt;
 }
 
+/* ------------------------------------------------------------------ match positions
+ * END columns of all matches (wu/wu.c:93 printed "Match of pattern index %i at %i" for the end
+ * column, in commented-out code).  One lane tests the 64 end columns of a segment with the
+ * reference-layout tables as given (SHIFT skip loop, bucket scan, byte compare) and the wave
+ * compacts the hits into the output buffer (smh_append_positions semantics, see ac_lane.h).
+ */
+template <typename SHIFT_T>
+SMH_LANE uint64_t smh_wm_segment_match_mask(const uint8_t *text, uint64_t n, uint64_t a, const SHIFT_T *shift,
+                                            uint32_t shiftsize, const uint32_t *bucket_off, const int32_t *bucket,
+                                            const uint8_t *pat_orig, int m, int nbits)
+{
+    uint64_t end = a + SMH_SEG;
+    if (end > n) end = n;
+    uint64_t column = a;
+    if (column < (uint64_t)(m - 1)) column = (uint64_t)(m - 1);
+    uint64_t mask = 0;
+    while (column < end) {
+        uint32_t hash1 = text[column - 2];
+        hash1 <<= nbits;
+        hash1 += text[column - 1];
+        hash1 <<= nbits;
+        hash1 += text[column];
+        const uint32_t sh = hash1 < shiftsize ? shift[hash1] : 1u;
+        if (sh == 0) {
+            uint32_t hash2 = text[column - (uint64_t)m + 1];
+            hash2 <<= nbits;
+            hash2 += text[column - (uint64_t)m + 2];
+            const uint32_t b0 = bucket_off[hash1], b1 = bucket_off[hash1 + 1];
+            for (uint32_t k = b0; k < b1; ++k) {
+                if ((uint32_t)bucket[2 * k] != hash2) continue;
+                const uint8_t *q = pat_orig + (uint64_t)(uint32_t)bucket[2 * k + 1] * (uint32_t)m;
+                const uint8_t *w = text + (column + 1 - (uint64_t)m);
+                int i = 0;
+                while (i < m && q[i] == w[i]) ++i;
+                if (i == m) {
+                    mask |= 1ull << (column - a);
+                    break;
+                }
+            }
+            ++column;
+        } else {
+            column += sh;
+        }
+    }
+    return mask;
+}
+
+template <typename SHIFT_T>
+SMH_LANE void smh_wm_positions_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n,
+                                      const SHIFT_T *shift, uint32_t shiftsize, const uint32_t *bucket_off,
+                                      const int32_t *bucket, const uint8_t *pat_orig, int m, int nbits,
+                                      uint64_t *positions, uint64_t capacity, uint64_t *cursor)
+{
+    if (n < (uint64_t)m) return;
+    const uint64_t n_segs = (n + SMH_SEG - 1) / SMH_SEG;
+    const uint64_t n_rounds = (n_segs + nthreads - 1) / nthreads;
+    for (uint64_t r = 0; r < n_rounds; ++r) {
+        const uint64_t a = (r * nthreads + gthread) * SMH_SEG;
+        uint64_t mask = a < n ? smh_wm_segment_match_mask<SHIFT_T>(text, n, a, shift, shiftsize, bucket_off, bucket,
+                                                                  pat_orig, m, nbits)
+                              : 0ull;
+        /* bit b = END column a + b */
+        const uint32_t mine = (uint32_t)__builtin_popcountll(mask);
+        uint64_t slot = smh_wave_reserve(cursor, mine);
+        while (mask) {
+            const int b = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            if (slot < capacity) positions[slot] = a + (uint64_t)b;
+            ++slot;
+        }
+    }
+}
+
 #endif

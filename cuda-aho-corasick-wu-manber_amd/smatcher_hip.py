@@ -64,7 +64,7 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
-               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_scan", "smh_ac_count_host",
+               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
                "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info",
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free"]
 
@@ -101,6 +101,8 @@ def _load():
     lib.smh_ac_get_info.argtypes = [C.c_void_p, C.POINTER(AcInfo)]
     lib.smh_ac_set_scan_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.smh_ac_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+    lib.smh_ac_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.smh_wm_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.smh_ac_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, u64p, dblp]
     lib.smh_ac_free.restype = None
     lib.smh_ac_free.argtypes = [C.c_void_p]
@@ -217,6 +219,10 @@ class AcAutomaton:
         _check(lib.smh_ac_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,
                                C.c_void_p(stream or 0)), "smh_ac_scan")
 
+    def positions_device(self, d_text_ptr, n, d_positions_ptr, capacity, d_cursor_ptr, stream=None):
+        _check(lib.smh_ac_positions(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_positions_ptr), capacity,
+                                    C.c_void_p(d_cursor_ptr), C.c_void_p(stream or 0)), "smh_ac_positions")
+
     def count_host(self, text, variant=VARIANT_TUNED):
         t, ptr = _u8(text)
         cnt, secs = C.c_uint64(), C.c_double()
@@ -265,6 +271,10 @@ class WmTables:
     def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
         _check(lib.smh_wm_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,
                                C.c_void_p(stream or 0)), "smh_wm_scan")
+
+    def positions_device(self, d_text_ptr, n, d_positions_ptr, capacity, d_cursor_ptr, stream=None):
+        _check(lib.smh_wm_positions(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_positions_ptr), capacity,
+                                    C.c_void_p(d_cursor_ptr), C.c_void_p(stream or 0)), "smh_wm_positions")
 
     def count_host(self, text, variant=VARIANT_TUNED):
         t, ptr = _u8(text)

@@ -106,6 +106,13 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth);
  * one handle per stream). */
 int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count,
                 int variant, void *stream);
+/* match positions (the reference only has commented-out printf's, ac/ac.c:217):
+ * appends the END column of every match in d_text[0, n) to d_positions[*d_cursor ...] (device
+ * uint64 array of `capacity` entries) and advances the device counter *d_cursor by the number of
+ * matches.  Output order is unspecified.  Entries that do not fit are dropped but still counted:
+ * *d_cursor > capacity afterwards means "call again with a bigger buffer". */
+int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_positions,
+                     uint64_t capacity, uint64_t *d_cursor, void *stream);
 /* blocking convenience: upload host text, scan, return count and kernel-only seconds */
 int smh_ac_count_host(smh_ac *ac, const unsigned char *text, uint64_t n, int variant,
                       uint64_t *count, double *kernel_seconds);
@@ -138,6 +145,10 @@ smh_wm *smh_wm_compile_tables(const unsigned char *pattern_flat, int m, int p_si
 int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out);
 int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count,
                 int variant, void *stream);
+/* END columns of all matches (wu/wu.c:93 printed them from commented-out code); same contract as
+ * smh_ac_positions */
+int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_positions,
+                     uint64_t capacity, uint64_t *d_cursor, void *stream);
 int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int variant,
                       uint64_t *count, double *kernel_seconds);
 void smh_wm_free(smh_wm *wm);

@@ -181,3 +181,37 @@ extern "C" uint64_t emu_wm_scan(const smh_wm *wm, const uint8_t *text_in, uint64
     }
     return result[0] == result[1] ? result[0] : ~0ull;
 }
+
+/* ------------------------------------------------------------------ positions */
+extern "C" uint64_t emu_ac_positions(const smh_ac *ac, const uint8_t *text, uint64_t n, uint64_t *out, uint64_t capacity,
+                                     uint32_t blocks)
+{
+    if (!blocks) blocks = 2;
+    size_t dflen = (size_t)ac->m + 2 < 72 ? 72 : (size_t)ac->m + 2;
+    uint32_t *df = (uint32_t *)malloc(dflen * 4);
+    for (size_t i = 0; i < dflen; ++i) df[i] = (int)i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+    smh_ac_verify_ctx V;
+    V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
+    V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
+    V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    uint64_t cursor = 0;
+    const uint64_t nthreads = (uint64_t)blocks * 256;
+    for (uint64_t t = 0; t < nthreads; ++t) smh_ac_positions_thread(t, nthreads, V, out, capacity, &cursor);
+    free(df);
+    return cursor;
+}
+
+extern "C" uint64_t emu_wm_positions(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t *out, uint64_t capacity,
+                                     uint32_t blocks)
+{
+    if (!blocks) blocks = 2;
+    uint16_t *sh = (uint16_t *)malloc(wm->shiftsize * 2);
+    for (uint32_t i = 0; i < wm->shiftsize; ++i) sh[i] = (uint16_t)wm->l_shift[i];
+    uint64_t cursor = 0;
+    const uint64_t nthreads = (uint64_t)blocks * 256;
+    for (uint64_t t = 0; t < nthreads; ++t)
+        smh_wm_positions_thread<uint16_t>(t, nthreads, text, n, sh, wm->shiftsize, wm->l_bucket_off, wm->l_bucket,
+                                          wm->pat_orig, wm->m, 2, out, capacity, &cursor);
+    free(sh);
+    return cursor;
+}

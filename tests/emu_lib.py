@@ -31,3 +31,24 @@ def ac_scan(ac, text, variant=S.VARIANT_TUNED, blocks=0):
 def wm_scan(wm, text, variant=S.VARIANT_TUNED, blocks=0):
     text = np.ascontiguousarray(text, dtype=np.uint8)
     return int(_emu.emu_wm_scan(wm.h, text.ctypes.data_as(S.u8p), len(text), variant, blocks))
+
+
+_emu.emu_ac_positions.restype = C.c_uint64
+_emu.emu_ac_positions.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32]
+_emu.emu_wm_positions.restype = C.c_uint64
+_emu.emu_wm_positions.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32]
+
+
+def _positions(fn, handle, text, capacity, blocks):
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    out = np.zeros(max(capacity, 1), dtype=np.uint64)
+    total = int(fn(handle, text.ctypes.data_as(S.u8p), len(text), out.ctypes.data_as(C.POINTER(C.c_uint64)), capacity, blocks))
+    return total, out[:min(total, capacity)]
+
+
+def ac_positions(ac, text, capacity, blocks=0):
+    return _positions(_emu.emu_ac_positions, ac.h, text, capacity, blocks)
+
+
+def wm_positions(wm, text, capacity, blocks=0):
+    return _positions(_emu.emu_wm_positions, wm.h, text, capacity, blocks)
