@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "ac_lane.h"
+#include "wm_lane.h"
 
 #define SMH_BLOCK_THREADS 1024
 #define SMH_LDS_BUDGET (156u * 1024u) /* of the 160 KiB per CU; the rest is left to the runtime */
@@ -58,9 +59,11 @@ struct smh_wm_launch {
     int verify_log2;
     const uint32_t *d_verify;
     const uint8_t *d_pat_sorted;
+    uint64_t *d_queue; /* smh_wm_max_blocks * 16 waves * SMH_WM_QCAP columns (NULL when exact) */
     uint64_t *d_count;
     int n_cus;
 };
+uint32_t smh_wm_max_blocks(int n_cus);
 hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream);
 
 struct smh_wm_table_launch {

@@ -44,6 +44,7 @@ struct smh_wm_dev {
     int device;
     uint32_t *d_filter;
     uint32_t *d_pair;
+    uint64_t *d_queue;
     uint32_t *d_verify;
     uint8_t *d_pat_sorted;
     uint16_t *d_shift;
@@ -332,6 +333,7 @@ extern "C" void smh_wm_dev_free(struct smh_wm_dev *dev)
     if (!dev) return;
     (void)hipFree(dev->d_filter);
     (void)hipFree(dev->d_pair);
+    (void)hipFree(dev->d_queue);
     (void)hipFree(dev->d_verify);
     (void)hipFree(dev->d_pat_sorted);
     (void)hipFree(dev->d_shift);
@@ -358,7 +360,13 @@ static int wm_ensure_device(struct smh_wm *wm)
     if (!wm->filter_exact) {
         if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 8, 0)) != SMH_OK) return rc;
     }
-    if ((rc = upload((void **)&d->d_pat_sorted, wm->pat_sorted, (size_t)wm->distinct * wm->m, 0)) != SMH_OK) return rc;
+    {
+        /* distinct patterns, each zero-padded to whole dwords (the verify stage compares dwords) */
+        const size_t row = (size_t)((wm->m + 3) / 4) * 4;
+        std::vector<unsigned char> padded((size_t)wm->distinct * row + 16, 0);
+        for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);
+        if ((rc = upload((void **)&d->d_pat_sorted, padded.data(), (size_t)wm->distinct * row, 16)) != SMH_OK) return rc;
+    }
     std::vector<uint16_t> sh(wm->shiftsize);
     for (uint32_t i = 0; i < wm->shiftsize; ++i) {
         int32_t v = wm->l_shift[i];
@@ -398,7 +406,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_exact = wm->filter_exact;
         L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
-        L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_count = d_count; L.n_cus = n_cus;
+        L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_queue = wm->dev->d_queue; L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
     } else {
         smh_set_error("smh_wm_scan: unknown variant %d", variant);

@@ -96,6 +96,27 @@ void smh_wm_host_free(struct smh_wm *wm)
     free(wm);
 }
 
+/* block hash of the hashed filter; the kernels compute the same value with two 24-bit
+ * multiplies (smh_wm_block_hash in wm_lane.h) */
+static uint32_t smh_wm_block_hash(uint32_t key)
+{
+    return (uint32_t)((uint64_t)(key & 0xFFFFFFu) * 0x9E3779u) + (uint32_t)((uint64_t)((key >> 8) & 0xFFFFFFu) * 0x85EBCBu);
+}
+
+/* hash of a pattern as zero-padded little-endian dwords; the kernels compute it over the text
+ * window the same way (smh_wm_mix / smh_window_dword in wm_lane.h) */
+static uint32_t smh_wm_tag(const unsigned char *p, int m)
+{
+    uint32_t h = 0x811C9DC5u;
+    for (int j = 0; j < (m + 3) / 4; ++j) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4 && 4 * j + b < m; ++b) v |= (uint32_t)p[4 * j + b] << (8 * b);
+        h = (h ^ v) * 0x9E3779B1u;
+        h ^= h >> 15;
+    }
+    return h;
+}
+
 static int g_sort_m;
 static int cmp_rows(const void *a, const void *b) { return memcmp(a, b, (size_t)g_sort_m); }
 
@@ -255,7 +276,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         const uint32_t kmask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
         for (int j = 0; j < d; ++j) {
             uint32_t key = block_code(wm->pat_sorted + (size_t)j * m + (m - 1), Wh, bits) & kmask;
-            uint32_t h = key * SMH_HASH_MUL;
+            uint32_t h = smh_wm_block_hash(key);
             uint32_t w = h >> (32 - (Th - 5));
             uint32_t b1 = (h >> (32 - (Th - 5) - 5)) & 31u, b2 = (h >> (32 - (Th - 5) - 10)) & 31u;
             hashed[w] |= (1u << b1) | (1u << b2);
@@ -310,7 +331,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         wm->verify = (uint32_t *)calloc(slots * 2, sizeof(uint32_t));
         if (!wm->verify) goto oom;
         for (int j = 0; j < d; ++j) {
-            uint32_t tag = smh_fnv1a32(wm->pat_sorted + (size_t)j * m, m);
+            uint32_t tag = smh_wm_tag(wm->pat_sorted + (size_t)j * m, m);
             size_t s = (size_t)((tag * SMH_HASH_MUL) >> (32 - lg));
             while (wm->verify[2 * s + 1]) s = (s + 1) & (slots - 1);
             wm->verify[2 * s] = tag;

@@ -55,7 +55,10 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     const uint32_t *filter = reinterpret_cast<const uint32_t *>(smh_lds);
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t cnt = smh_wm_thread<HASHED, EXACT, HC>(gthread, nthreads, text, n, filter, P, block_symbols);
+    /* survivor queues: 1 KiB per wave right behind the filter */
+    uint64_t *queue = EXACT ? nullptr
+                            : reinterpret_cast<uint64_t *>(smh_lds + lds_bytes) + (threadIdx.x >> 6) * SMH_WM_QCAP;
+    const uint32_t cnt = smh_wm_thread<HASHED, EXACT, HC>(gthread, nthreads, text, n, filter, P, block_symbols, queue);
     smh_block_add_wm(cnt, count, smh_lds);
 }
 
@@ -134,20 +137,23 @@ hipError_t smh_launch_wm_positions(const smh_wm_table_launch &L, uint64_t *d_pos
 }
 
 /* ------------------------------------------------------------------ launch */
+uint32_t smh_wm_max_blocks(int n_cus) { return (uint32_t)n_cus * 2u; }
+
 template <bool HASHED, bool EXACT, int HC>
 static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
 {
     auto kern = wm_block_kernel<HASHED, EXACT, HC>;
     uint32_t lds_bytes = (uint32_t)(((uint64_t)1 << L.filter_log2) / 8u);
     if (lds_bytes < 16u) lds_bytes = 16u;
+    const uint32_t lds_total = lds_bytes + (EXACT ? 0u : (SMH_BLOCK_THREADS / 64) * SMH_WM_QCAP * 8u);
     static uint32_t cached_lds = 0xFFFFFFFFu;
     static int cached_per_cu = 0;
     if (cached_lds != lds_bytes) { /* once per (kernel, LDS size): see ac_kernels.hip */
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
         if (err != hipSuccess) return err;
         int q = 0;
-        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, SMH_BLOCK_THREADS, lds_bytes);
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, SMH_BLOCK_THREADS, lds_total);
         if (err != hipSuccess) return err;
         cached_per_cu = q;
         cached_lds = lds_bytes;
@@ -169,7 +175,7 @@ static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
     P.verify_log2 = L.verify_log2;
     P.verify = L.d_verify;
     P.pat_sorted = L.d_pat_sorted;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), lds_bytes, stream, L.d_text, L.n,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), lds_total, stream, L.d_text, L.n,
                        L.d_filter, lds_bytes, P, L.block_symbols, L.d_count);
     return hipGetLastError();
 }

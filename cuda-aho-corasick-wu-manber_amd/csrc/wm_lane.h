@@ -34,32 +34,67 @@ struct smh_wm_params {
     int filter_log2;     /* hashed filter: log2 of its bit count */
     int verify_log2;     /* slots = 1 << verify_log2 */
     const uint32_t *verify;      /* HBM: {tag, pattern + 1} per slot */
-    const uint8_t *pat_sorted;   /* HBM: distinct patterns, m bytes each */
+    const uint8_t *pat_sorted;   /* HBM: distinct patterns, each zero-padded to ((m+3)/4)*4 bytes */
 };
 
-/* device HASH/PREFIX stage: is text[e-m+1 .. e] one of the patterns? */
+/* window dword j of the m-byte window that starts at byte offset s: built from ALIGNED dword loads
+ * and a funnel shift, so the stage never issues unaligned or byte-granular loads; the bytes past the
+ * window in its last dword are cleared (patterns are stored zero-padded to whole dwords) */
+SMH_LANE uint32_t smh_window_dword(const uint32_t *aligned, uint32_t shift_bits, int j, int m)
+{
+    const int rest = m - 4 * j; /* bytes of the window in this dword */
+    const uint32_t lo = aligned[j];
+    uint32_t v = lo >> shift_bits;
+    /* the next aligned dword is touched only when the window really extends into it, so the stage
+     * never reads past the aligned dword that holds the window's last byte */
+    if (shift_bits && rest > 4 - (int)(shift_bits >> 3)) v |= aligned[j + 1] << (32u - shift_bits);
+    if (rest < 4) v &= (1u << (8 * rest)) - 1u;
+    return v;
+}
+
+/* hash of a pattern / window given as zero-padded little-endian dwords; mirrored by wm_host.c */
+SMH_LANE uint32_t smh_wm_mix(uint32_t h, uint32_t v)
+{
+    h = (h ^ v) * 0x9E3779B1u;
+    return h ^ (h >> 15);
+}
+
+/* device HASH/PREFIX stage: is text[e-m+1 .. e] one of the patterns?  Three dependent memory
+ * phases (window dwords, one table slot, pattern dwords) instead of byte loops.  Kept small on
+ * purpose: it is inlined into the scan kernel and must not raise its register pressure. */
 SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_params &P)
 {
-    const uint8_t *w = text + (e + 1 - (uint64_t)P.m);
-    uint32_t tag = 0x811C9DC5u;
-    for (int i = 0; i < P.m; ++i) {
-        tag ^= w[i];
-        tag *= 0x01000193u;
-    }
+    const uint64_t s0 = e + 1 - (uint64_t)P.m;
+    const uint32_t *aligned = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
+    const uint32_t shift_bits = (uint32_t)(s0 & 3u) * 8u;
+    const int nd = (P.m + 3) >> 2;
     const uint32_t mask = (1u << P.verify_log2) - 1u;
+    uint32_t tag = 0x811C9DC5u;
+    for (int j = 0; j < nd; ++j) tag = smh_wm_mix(tag, smh_window_dword(aligned, shift_bits, j, P.m));
     uint32_t s = (tag * SMH_WM_HASH_MUL) >> (32 - P.verify_log2);
     for (;;) {
         const uint32_t stag = P.verify[2 * s];
         const uint32_t sidx = P.verify[2 * s + 1];
         if (sidx == 0) return 0;
         if (stag == tag) {
-            const uint8_t *q = P.pat_sorted + (uint64_t)(sidx - 1) * (uint32_t)P.m;
-            int i = 0;
-            while (i < P.m && q[i] == w[i]) ++i;
-            if (i == P.m) return 1;
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx - 1) * (uint32_t)nd;
+            uint32_t diff = 0;
+            for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(aligned, shift_bits, j, P.m);
+            if (diff == 0) return 1;
         }
         s = (s + 1) & mask;
     }
+}
+
+/* block hash of the hashed filter: two 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 are
+ * full-rate, v_mul_lo_u32 is not).  Keep in sync with smh_wm_block_hash in wm_host.c. */
+SMH_LANE uint32_t smh_wm_block_hash(uint32_t key)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    return __umul24(key, 0x9E3779u) + __umul24(key >> 8, 0x85EBCBu);
+#else
+    return (uint32_t)((uint64_t)(key & 0xFFFFFFu) * 0x9E3779u) + (uint32_t)((uint64_t)((key >> 8) & 0xFFFFFFu) * 0x85EBCBu);
+#endif
 }
 
 /* SHIFT stage for one column: returns 1 when the block's filter bit(s) are set */
@@ -68,7 +103,7 @@ SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh
 {
     const uint32_t key = code & P.code_mask;
     if (HASHED) {
-        const uint32_t h = key * SMH_WM_HASH_MUL;
+        const uint32_t h = smh_wm_block_hash(key);
         const int wl = P.filter_log2 - 5;
         const uint32_t word = filter[h >> (32 - wl)];
         const uint32_t b1 = (h >> (32 - wl - 5)) & 31u, b2 = (h >> (32 - wl - 10)) & 31u;
@@ -78,6 +113,40 @@ SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh
     }
 }
 
+/* ---- per-wave survivor queue: columns that passed the SHIFT stage wait here for the HASH/PREFIX
+ * stage, which then runs with all 64 lanes busy (wavefront-level compaction: ballot + prefix
+ * count).  Same scheme as the AC candidate queue (ac_lane.h). */
+#define SMH_WM_QCAP 128u /* END columns per wave, 1 KiB of LDS behind the filter */
+struct smh_wm_queue {
+    uint64_t *slots; /* SMH_WM_QCAP entries, private to this wave (LDS on the GPU) */
+    uint32_t count;  /* wave-uniform */
+    uint32_t matches;
+};
+
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
+{
+    for (uint32_t i = threadIdx.x & 63u; i < Q.count; i += 64u) Q.matches += smh_wm_verify(text, Q.slots[i], P);
+    Q.count = 0;
+}
+/* append without a capacity check: the caller drains first whenever fewer than 64 slots are free */
+SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P, bool cond, uint64_t e)
+{
+    const uint64_t mask = __ballot(cond);
+    if (mask == 0) return;
+    const uint32_t np = (uint32_t)__popcll(mask);
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (cond) Q.slots[Q.count + before] = e; /* LDS, written and read by this wave only */
+    Q.count += np;
+}
+#else
+SMH_LANE void smh_wm_drain(smh_wm_queue &, const uint8_t *, const smh_wm_params &) {}
+SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P, bool cond, uint64_t e)
+{
+    if (cond) Q.matches += smh_wm_verify(text, e, P);
+}
+#endif
+
 /*
  * Fast path: the lane owns the 64 END columns of the segment at byte offset a
  * (a multiple of 64) and reads the 16*HC bytes in front of it to prime the
@@ -85,46 +154,34 @@ SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh
  * 16*HC >= m-1, so every column has a full window.
  */
 template <bool HASHED, bool EXACT, int HC>
-SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32_t *filter,
-                                   const smh_wm_params &P)
+SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[4 * HC + 16],
+                                   const uint32_t *filter, const smh_wm_params &P, smh_wm_queue &Q)
 {
-    uint32_t w[4 * HC + 16];
-#pragma unroll
-    for (int q = 0; q < HC + 4; ++q) {
-        const smh_u32x4 t = smh_load16(text + (a - 16u * HC) + 16u * q);
-        w[4 * q + 0] = t.v[0];
-        w[4 * q + 1] = t.v[1];
-        w[4 * q + 2] = t.v[2];
-        w[4 * q + 3] = t.v[3];
-    }
     uint32_t code = 0, cnt = 0;
 #pragma unroll
     for (int i = 0; i < 16 * HC; ++i) code = (code << P.bits) | smh_byte_of(w[i >> 2], i & 3);
     /* SHIFT stage over the 64 columns; survivors are only recorded (one bit each) so that the
-     * unrolled loop stays branch-free and the rarely taken verify code exists once */
-    uint32_t surv_lo = 0, surv_hi = 0;
+     * unrolled loop stays branch-free */
+    uint32_t surv[2] = {0, 0};
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
         code = (code << P.bits) | smh_byte_of(w[4 * HC + (i >> 2)], i & 3);
         const uint32_t hit = smh_wm_filter<HASHED>(code, filter, P);
         if (EXACT)
             cnt += hit;
-        else if (i < 32)
-            surv_lo |= hit << i;
         else
-            surv_hi |= hit << (i - 32);
+            surv[i >> 5] |= hit << (i & 31);
     }
     if (!EXACT) {
-        /* HASH/PREFIX stage */
-        while (surv_lo) {
-            const int i = __builtin_ctz(surv_lo);
-            surv_lo &= surv_lo - 1;
-            cnt += smh_wm_verify(text, a + (uint64_t)i, P);
-        }
-        while (surv_hi) {
-            const int i = __builtin_ctz(surv_hi);
-            surv_hi &= surv_hi - 1;
-            cnt += smh_wm_verify(text, a + 32u + (uint64_t)i, P);
+        /* compaction: one queue entry per surviving column, as many rounds as the busiest lane has;
+         * the HASH/PREFIX stage (drain) is entered from this one place while the wave scans */
+        uint64_t msk = ((uint64_t)surv[1] << 32) | surv[0];
+        while (SMH_WAVE_ANY(msk != 0)) {
+            if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
+            const bool have = msk != 0;
+            const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
+            smh_wm_emit(Q, text, P, have, a + b);
+            msk &= msk - 1u;
         }
     }
     return cnt;
@@ -202,26 +259,65 @@ SMH_LANE uint32_t smh_wm_lane_table(const uint8_t *text, uint64_t n, uint64_t a,
     return cnt;
 }
 
-/* whole-grid work distribution for one lane; HC == 0: no fast path (m - 1 > 64) */
+/* whole-grid work distribution for one lane; HC == 0: no fast path (m - 1 > 64).  The next chunk's
+ * text is requested before the current chunk is scanned (software prefetch). */
 template <bool HASHED, bool EXACT, int HC>
 SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n,
-                                const uint32_t *filter, const smh_wm_params &P, int block_symbols)
+                                const uint32_t *filter, const smh_wm_params &P, int block_symbols,
+                                uint64_t *queue_base)
 {
     if (n < (uint64_t)P.m) return 0;
+    constexpr int H = HC > 0 ? HC : 1;
     const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
     const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
     const uint32_t lane = (uint32_t)(gthread & 63u);
     const uint64_t wave = gthread >> 6, nwaves = nthreads >> 6;
+    smh_wm_queue Q;
+    Q.slots = queue_base; /* this wave's slice (the kernel passes LDS) */
+    Q.count = 0;
+    Q.matches = 0;
     uint32_t cnt = 0;
-    for (uint64_t k = wave; k < n_chunks; k += nwaves) {
-        const uint64_t base = k * chunk_bytes;
-        const uint64_t a = base + (uint64_t)lane * SMH_SEG;
-        if (HC > 0 && base >= 16u * HC && base + chunk_bytes <= n)
-            cnt += smh_wm_lane_fast<HASHED, EXACT, (HC > 0 ? HC : 1)>(text, a, filter, P);
+    uint32_t cur[4 * H + 16], nxt[4 * H + 16];
+    auto is_fast = [&](uint64_t kk) {
+        return HC > 0 && kk < n_chunks && kk * chunk_bytes >= 16u * H && (kk + 1) * chunk_bytes <= n;
+    };
+    auto load = [&](uint64_t kk, uint32_t (&w)[4 * H + 16]) {
+        const uint8_t *p = text + smh_uniform64(kk * chunk_bytes) + (uint64_t)lane * SMH_SEG - 16u * H;
+#pragma unroll
+        for (int q = 0; q < H + 4; ++q) {
+            const smh_u32x4 t = smh_load16(p + 16u * q);
+            w[4 * q + 0] = t.v[0];
+            w[4 * q + 1] = t.v[1];
+            w[4 * q + 2] = t.v[2];
+            w[4 * q + 3] = t.v[3];
+        }
+    };
+    uint64_t k = wave;
+    bool cur_fast = is_fast(k);
+    if (cur_fast) load(k, cur);
+    while (k < n_chunks) {
+        const uint64_t kn = k + nwaves;
+        const bool nxt_fast = is_fast(kn);
+        constexpr bool PREFETCH = EXACT && H == 1; /* only where registers allow: exact filter, short pre-halo */
+        if (PREFETCH && nxt_fast) load(kn, nxt);
+        const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
+        if (cur_fast)
+            cnt += smh_wm_lane_fast<HASHED, EXACT, H>(text, a, cur, filter, P, Q);
         else
             cnt += smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols);
+        if (nxt_fast) {
+            if (PREFETCH) {
+#pragma unroll
+                for (int q = 0; q < 4 * H + 16; ++q) cur[q] = nxt[q];
+            } else {
+                load(kn, cur);
+            }
+        }
+        cur_fast = nxt_fast;
+        k = kn;
     }
-    return cnt;
+    if (!EXACT) smh_wm_drain(Q, text, P);
+    return cnt + Q.matches;
 }
 
 #define SMH_WM_TABLE_SPAN 256u /* END columns per lane in the table-walking kernel */

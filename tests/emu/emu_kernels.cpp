@@ -15,6 +15,7 @@
 #include <string.h>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <vector>
 #include "smh_internal.h"
 #include "ac_lane.h"
 #include "wm_lane.h"
@@ -130,11 +131,15 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     P.filter_log2 = wm->filter_log2;
     P.verify_log2 = wm->verify_log2;
     P.verify = wm->verify;
-    P.pat_sorted = wm->pat_sorted;
+    /* distinct patterns zero-padded to whole dwords, as smh_runtime.hip uploads them */
+    const size_t row = (size_t)((wm->m + 3) / 4) * 4;
+    std::vector<uint8_t> padded((size_t)wm->distinct * row + 16, 0);
+    for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);
+    P.pat_sorted = padded.data();
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t)
-        total += smh_wm_thread<HASHED, EXACT, HC>(t, nthreads, text, n, wm->filter, P, wm->block_symbols);
+        total += smh_wm_thread<HASHED, EXACT, HC>(t, nthreads, text, n, wm->filter, P, wm->block_symbols, nullptr);
     return total;
 }
 
