@@ -127,6 +127,7 @@ struct smh_wm {
     int filter_log2;      /* bits in the filter = 1 << filter_log2 (>= 5) */
     int filter_exact;
     int filter_hashed;
+    int filter_k;         /* hashed filter: bits per key (2..4), all in one 32-bit word */
     uint32_t *filter;     /* (1 << filter_log2) / 32 words */
     double filter_density; /* fraction of windows expected to pass on uniform text */
     int verify_log2;      /* slots = 1 << verify_log2; 0 slots when exact */

@@ -270,33 +270,53 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
     int use_hashed = !exact && Wh > Wd && direct_density > 1.0 / 64.0;
     if (use_hashed) {
         const int Th = SMH_WM_FILTER_LOG2_MAX;
-        uint32_t *hashed = (uint32_t *)calloc((size_t)1 << (Th - 5), sizeof(uint32_t));
-        if (!hashed) { free(direct); goto oom; }
+        const size_t nwords = (size_t)1 << (Th - 5);
         const int wbits = Wh * bits;
         const uint32_t kmask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
-        for (int j = 0; j < d; ++j) {
-            uint32_t key = block_code(wm->pat_sorted + (size_t)j * m + (m - 1), Wh, bits) & kmask;
-            uint32_t h = smh_wm_block_hash(key);
-            uint32_t w = h >> (32 - (Th - 5));
-            uint32_t b1 = (h >> (32 - (Th - 5) - 5)) & 31u, b2 = (h >> (32 - (Th - 5) - 10)) & 31u;
-            hashed[w] |= (1u << b1) | (1u << b2);
+        uint32_t *best = NULL;
+        double best_density = 2.0;
+        int best_k = 2;
+        /* try 2, 3 and 4 bits per key (all inside one word, so the scan still costs one LDS lookup
+         * per column) and keep the one that lets the fewest random keys through */
+        for (int k = 2; k <= 4; ++k) {
+            uint32_t *hashed = (uint32_t *)calloc(nwords, sizeof(uint32_t));
+            if (!hashed) { free(direct); free(best); goto oom; }
+            for (int j = 0; j < d; ++j) {
+                uint32_t key = block_code(wm->pat_sorted + (size_t)j * m + (m - 1), Wh, bits) & kmask;
+                uint32_t h = smh_wm_block_hash(key);
+                uint32_t w = h >> (32 - (Th - 5));
+                uint32_t bm = (1u << ((h >> (32 - (Th - 5) - 5)) & 31u)) | (1u << ((h >> (32 - (Th - 5) - 10)) & 31u));
+                if (k >= 3) bm |= 1u << ((h >> 2) & 31u);
+                if (k >= 4) bm |= 1u << ((h ^ (h >> 16)) & 31u);
+                hashed[w] |= bm;
+            }
+            /* pass probability of a random key ~ mean over words of (set fraction)^k */
+            double acc = 0;
+            for (size_t w = 0; w < nwords; ++w) {
+                double f = (double)__builtin_popcount(hashed[w]) / 32.0, pk = f;
+                for (int i = 1; i < k; ++i) pk *= f;
+                acc += pk;
+            }
+            const double density = acc / (double)nwords;
+            if (density < best_density) {
+                free(best);
+                best = hashed;
+                best_density = density;
+                best_k = k;
+            } else {
+                free(hashed);
+            }
         }
-        /* pass probability of a random key: mean over words of P(both picked bits set) */
-        double acc = 0;
-        for (size_t w = 0; w < ((size_t)1 << (Th - 5)); ++w) {
-            double f = (double)__builtin_popcount(hashed[w]) / 32.0;
-            acc += f * f;
-        }
-        double hashed_density = acc / (double)((size_t)1 << (Th - 5));
-        if (hashed_density < direct_density) {
+        if (best_density < direct_density) {
             free(direct);
-            wm->filter = hashed;
+            wm->filter = best;
             wm->filter_hashed = 1;
+            wm->filter_k = best_k;
             wm->filter_log2 = Th;
             wm->block_symbols = Wh;
-            wm->filter_density = hashed_density;
+            wm->filter_density = best_density;
         } else {
-            free(hashed);
+            free(best);
             use_hashed = 0;
         }
     }

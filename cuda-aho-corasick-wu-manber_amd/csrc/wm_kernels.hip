@@ -172,6 +172,7 @@ static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
     const int wbits = L.block_symbols * L.bits;
     P.code_mask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
     P.filter_log2 = L.filter_log2;
+    P.filter_k = L.filter_k;
     P.verify_log2 = L.verify_log2;
     P.verify = L.d_verify;
     P.pat_sorted = L.d_pat_sorted;

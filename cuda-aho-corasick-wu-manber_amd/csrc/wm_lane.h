@@ -32,6 +32,7 @@ struct smh_wm_params {
     int bits;            /* bits per symbol */
     uint32_t code_mask;  /* low block_symbols*bits bits of the rolling register */
     int filter_log2;     /* hashed filter: log2 of its bit count */
+    int filter_k;        /* hashed filter: bits per key inside one 32-bit word (2..4) */
     int verify_log2;     /* slots = 1 << verify_log2 */
     const uint32_t *verify;      /* HBM: {tag, pattern + 1} per slot */
     const uint8_t *pat_sorted;   /* HBM: distinct patterns, each zero-padded to ((m+3)/4)*4 bytes */
@@ -107,7 +108,12 @@ SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh
         const int wl = P.filter_log2 - 5;
         const uint32_t word = filter[h >> (32 - wl)];
         const uint32_t b1 = (h >> (32 - wl - 5)) & 31u, b2 = (h >> (32 - wl - 10)) & 31u;
-        return (word >> b1) & (word >> b2) & 1u;
+        uint32_t hit = (word >> b1) & (word >> b2);
+        /* more bits per key when the key set is dense (chosen by the host): fewer survivors for the
+         * HASH/PREFIX stage at the price of two or three more VALU ops per column */
+        if (P.filter_k >= 3) hit &= word >> ((h >> 2) & 31u);
+        if (P.filter_k >= 4) hit &= word >> ((h ^ (h >> 16)) & 31u);
+        return hit & 1u;
     } else {
         return (filter[key >> 5] >> (key & 31u)) & 1u;
     }

@@ -129,6 +129,7 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     const int wbits = wm->block_symbols * wm->bits_per_symbol;
     P.code_mask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
     P.filter_log2 = wm->filter_log2;
+    P.filter_k = wm->filter_k;
     P.verify_log2 = wm->verify_log2;
     P.verify = wm->verify;
     /* distinct patterns zero-padded to whole dwords, as smh_runtime.hip uploads them */
