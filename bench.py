@@ -244,6 +244,34 @@ def main():
                              block_symbols=wi.block_symbols, filter_log2=wi.filter_log2, filter_exact=wi.filter_exact,
                              shift_zero="%d/%d" % (wi.shift_zero, wi.shiftsize))
 
+    # ---- WM on the 256-symbol alphabet (BASELINE configs[4] shape per GPU: 100 000 patterns, lengths 5-20 as
+    #      fixed-length sets; 256 MiB of text per GPU keeps the default run short)
+    if not args.no_wm and world == 1:
+        n5 = min(per_gpu, 256 << 20)
+        text5 = torch.empty(n5 + 64, dtype=torch.uint8, device=dev)
+        S.lib.smh_corpus_text_device(C.c_void_p(text5.data_ptr()), n5, 0, TEXT_SEED, 256, C.c_void_p(stream))
+        c5 = {}
+        cnt5 = torch.zeros(1, dtype=torch.int64, device=dev)
+        for m5 in (5, 12, 20):
+            p5 = S.corpus_patterns(m5, 100000, PAT_SEED + 2, 256, TEXT_SEED, n5, 2)
+            wm5 = S.WmTables.from_patterns(p5, m5, 100000, 256)
+            wm5.scan_device(text5.data_ptr(), n5, cnt5.data_ptr(), S.VARIANT_TUNED, stream)
+            torch.cuda.synchronize()
+            ev5 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+            for a, b in ev5:
+                cnt5.zero_()
+                a.record()
+                wm5.scan_device(text5.data_ptr(), n5, cnt5.data_ptr(), S.VARIANT_TUNED, stream)
+                b.record()
+            torch.cuda.synchronize()
+            ms5 = sorted(a.elapsed_time(b) for a, b in ev5)[2]
+            c5["m%d" % m5] = dict(kernel_ms=round(ms5, 4), GBps=round(n5 / (ms5 * 1e-3) / 1e9, 1),
+                                  hbm_frac=round(n5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), matches=int(cnt5.item()))
+            del wm5
+        out["wm_ascii"] = dict(workload="WM: %d MiB of 256-symbol text, 100000 patterns per set, m=5/12/20 (BASELINE "
+                                        "configs[4] shape on one GPU)" % (n5 >> 20), **c5)
+        del text5
+
     # ---- CPU baseline + bit-exact parity on a bounded prefix (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_cpu:
         sample = min(args.cpu_sample_mib << 20, per_gpu)
