@@ -50,15 +50,15 @@ static inline int has_edge(const int *trans, uint32_t state, int32_t v)
     return state == 0 ? v > 0 : v != -1;
 }
 
-struct ac_table *preproc_ac(unsigned char **pattern, int m, int p_size, int alphabet,
-                            int *state_transition, unsigned int *state_supply,
-                            unsigned int *state_final)
+/* the reference's table construction (ac_init + ac_addstring + ac_maketree) on the caller's flat
+ * arrays; returns the number of states in *idcounter_out */
+static void ac_fill_tables(unsigned char **pattern, int m, int p_size, int alphabet,
+                           int *state_transition, unsigned int *state_supply,
+                           unsigned int *state_final, uint32_t *idcounter_out,
+                           uint32_t *patterncounter_out)
 {
     if (m < 1 || p_size < 0 || alphabet < 1 || alphabet > 256)
         fail("preproc_ac: bad arguments\n");
-    struct smh_ac_table_box *box = (struct smh_ac_table_box *)calloc(1, sizeof *box);
-    if (!box) fail("Could not initialize table\n");
-
     const size_t A = (size_t)alphabet;
     /* ac_init, ac/ac.c:59-62: row 0 of the flat table is all zero */
     for (int c = 0; c < alphabet; ++c) state_transition[c] = 0;
@@ -113,6 +113,20 @@ struct ac_table *preproc_ac(unsigned char **pattern, int m, int p_size, int alph
     }
     free(queue);
     free(failv);
+    *idcounter_out = idcounter;
+    *patterncounter_out = patterncounter;
+}
+
+struct ac_table *preproc_ac(unsigned char **pattern, int m, int p_size, int alphabet,
+                            int *state_transition, unsigned int *state_supply,
+                            unsigned int *state_final)
+{
+    struct smh_ac_table_box *box = (struct smh_ac_table_box *)calloc(1, sizeof *box);
+    if (!box) fail("Could not initialize table\n");
+    uint32_t idcounter, patterncounter;
+    ac_fill_tables(pattern, m, p_size, alphabet, state_transition, state_supply, state_final,
+                   &idcounter, &patterncounter);
+    const size_t A = (size_t)alphabet;
 
     box->pub.idcounter = idcounter;
     box->pub.patterncounter = patterncounter;
@@ -125,8 +139,9 @@ struct ac_table *preproc_ac(unsigned char **pattern, int m, int p_size, int alph
     for (int c = 0; c < alphabet; ++c) box->root.next[c] = &box->root;
     box->pub.zerostate = &box->root;
     box->magic = SMH_MAGIC_AC;
+    /* search_ac only runs the tuned kernel: no reference-layout copy for this handle */
     box->ac = smh_ac_compile_tables_impl(state_transition, state_supply, state_final,
-                                         (uint64_t)idcounter, alphabet, m);
+                                         (uint64_t)idcounter, alphabet, m, SMH_AC_REF_NONE);
     if (!box->ac) {
         fputs(smh_last_error(), stderr);
         fail("\npreproc_ac: could not compile the automaton\n");
@@ -165,7 +180,7 @@ void smh_ac_host_free(struct smh_ac *ac)
 
 struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *supply,
                                           const unsigned int *final, uint64_t rows_in,
-                                          int alphabet, int m)
+                                          int alphabet, int m, int ref_mode)
 {
     if (!trans || !supply || !final || rows_in < 1 || alphabet < 1 || alphabet > 256 || m < 1) {
         smh_set_error("smh_ac_compile_tables: bad arguments");
@@ -273,15 +288,29 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
     ac->fixed_length_ok = fixed_ok;
     ac->entry_bytes = rows <= 32768u ? 2 : 4;
     ac->table_bytes = (uint64_t)rows * A * (uint64_t)ac->entry_bytes;
-    ac->table = malloc((size_t)ac->table_bytes);
-    if (!ac->table) goto oom;
-    for (size_t i = 0; i < (size_t)rows * A; ++i) {
-        uint32_t t = full[i];
-        uint32_t r = newid[canon[t]];
-        if (ac->entry_bytes == 2)
-            ((uint16_t *)ac->table)[i] = (uint16_t)(r | (final[t] ? 0x8000u : 0u));
-        else
-            ((uint32_t *)ac->table)[i] = r | (final[t] ? 0x80000000u : 0u);
+    {
+        /* one lookup per entry (the encoded value of every reference state, computed once), and in
+         * place: `full` becomes the table -- first-touch page faults on another rows*alphabet array
+         * cost more than the arithmetic for alphabet-256 automata */
+        const uint32_t flag = ac->entry_bytes == 2 ? 0x8000u : 0x80000000u;
+        uint32_t *enc = (uint32_t *)malloc((size_t)R * sizeof(uint32_t));
+        if (!enc) goto oom;
+        for (uint32_t k = 0; k < nstates; ++k) {
+            const uint32_t t = order[k];
+            enc[t] = newid[canon[t]] | (final[t] ? flag : 0u);
+        }
+        const size_t total = (size_t)rows * A;
+        if (ac->entry_bytes == 2) {
+            uint16_t *dst = (uint16_t *)full; /* front to back: entry i is read before it is overwritten */
+            for (size_t i = 0; i < total; ++i) dst[i] = (uint16_t)enc[full[i]];
+            ac->table = realloc(full, total ? total * 2 : 2);
+        } else {
+            for (size_t i = 0; i < total; ++i) full[i] = enc[full[i]];
+            ac->table = full;
+        }
+        full = NULL;
+        free(enc);
+        if (!ac->table) goto oom;
     }
 
     /* 5. depth_first[d] = first row whose depth >= d (rows are in BFS order) */
@@ -315,14 +344,24 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
         ac->row_fail[newid[u]] = newid[canon[sup]];
     }
 
-    /* 6. reference-layout copy, truncated to the ids in use, for SMH_VARIANT_TABLE */
-    {
+    /* 6. reference-layout tables, truncated to the ids in use, for SMH_VARIANT_TABLE: copied
+     *    (caller keeps its arrays), adopted (malloc'ed arrays handed over, patched in place -- a
+     *    second states*alphabet array is the most expensive thing in an alphabet-256 compile), or none */
+    if (ref_mode != SMH_AC_REF_NONE) {
         size_t keep = (size_t)max_id + 1;
-        ac->g_transition = (int32_t *)malloc(keep * A * sizeof(int32_t));
-        ac->g_supply = (uint32_t *)malloc(keep * sizeof(uint32_t));
-        ac->g_final = (uint32_t *)malloc(keep * sizeof(uint32_t));
-        if (!ac->g_transition || !ac->g_supply || !ac->g_final) goto oom;
-        memcpy(ac->g_transition, trans, keep * A * sizeof(int32_t));
+        if (ref_mode == SMH_AC_REF_COPY) {
+            ac->g_transition = (int32_t *)malloc(keep * A * sizeof(int32_t));
+            ac->g_supply = (uint32_t *)malloc(keep * sizeof(uint32_t));
+            ac->g_final = (uint32_t *)malloc(keep * sizeof(uint32_t));
+            if (!ac->g_transition || !ac->g_supply || !ac->g_final) goto oom;
+            memcpy(ac->g_transition, trans, keep * A * sizeof(int32_t));
+        } else {
+            /* shrinking in place; a failed shrink leaves the original block valid */
+            void *t = realloc((void *)trans, keep * A * sizeof(int32_t));
+            ac->g_transition = (int32_t *)(t ? t : (void *)trans);
+            ac->g_supply = (uint32_t *)supply;
+            ac->g_final = (uint32_t *)final;
+        }
         for (size_t u = 0; u < keep; ++u) {
             /* depth <= 1 states: the reference never writes their supply entry; the walk needs 0 */
             ac->g_supply[u] = (seen[u] && depth[u] >= 2) ? supply[u] : 0u;
@@ -341,6 +380,8 @@ oom:
     smh_set_error("smh_ac_compile_tables: out of memory");
 bad:
     free(order); free(depth); free(seen); free(leaf); free(canon); free(newid); free(full);
+    if (ac && ref_mode == SMH_AC_REF_ADOPT) /* ownership passes only on success */
+        ac->g_transition = NULL, ac->g_supply = NULL, ac->g_final = NULL;
     smh_ac_host_free(ac);
     return NULL;
 }
@@ -469,7 +510,8 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
 smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *state_supply,
                               const unsigned int *state_final, uint64_t rows, int alphabet, int m)
 {
-    return smh_ac_compile_tables_impl(state_transition, state_supply, state_final, rows, alphabet, m);
+    return smh_ac_compile_tables_impl(state_transition, state_supply, state_final, rows, alphabet, m,
+                                      SMH_AC_REF_COPY);
 }
 
 smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet)
@@ -496,12 +538,12 @@ smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_
     }
     memset(trans, -1, rows * alphabet * sizeof(int));
     for (int j = 0; j < p_size; ++j) ptrs[j] = (unsigned char *)pattern_flat + (size_t)j * m;
-    struct ac_table *t = preproc_ac(ptrs, m, p_size, alphabet, trans, supply, final);
-    struct smh_ac_table_box *box = (struct smh_ac_table_box *)t;
-    smh_ac *ac = box->ac;
-    box->ac = NULL;
-    free_ac(t, alphabet);
-    free(trans); free(supply); free(final); free(ptrs);
+    uint32_t idcounter, patterncounter;
+    ac_fill_tables(ptrs, m, p_size, alphabet, trans, supply, final, &idcounter, &patterncounter);
+    free(ptrs);
+    smh_ac *ac = smh_ac_compile_tables_impl(trans, supply, final, (uint64_t)idcounter, alphabet, m,
+                                            SMH_AC_REF_ADOPT);
+    if (!ac) { free(trans); free(supply); free(final); }
     return ac;
 }
 

@@ -52,7 +52,7 @@ __device__ __forceinline__ void smh_block_add(uint32_t cnt, uint64_t *count, uns
     }
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true>
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true, int SW = 16>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__restrict__ scan_table, uint32_t lds_bytes,
                                                                   smh_ac_verify_ctx V, smh_ac_df df,
                                                                   uint64_t *queue_base, uint64_t *count)
@@ -81,10 +81,10 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__re
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     uint32_t cnt;
     if constexpr (STRIDE == 2) {
-        cnt = smh_ac_thread<smh_fmt_s2, HC, NCH, EXACT, PF>(smh_fmt_s2{}, gthread, nthreads, smh_lds, V, df, queue_base);
+        cnt = smh_ac_thread<smh_fmt_s2, HC, NCH, EXACT, PF, SW>(smh_fmt_s2{}, gthread, nthreads, smh_lds, V, df, queue_base);
     } else {
         const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
-        cnt = smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, NCH, EXACT, PF>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
+        cnt = smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, NCH, EXACT, PF, SW>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
     }
     smh_block_add(cnt, count, smh_lds);
 }
@@ -135,10 +135,10 @@ static int tune_get(const char *key, int dflt)
     return atoi(p + strlen(key) + 1);
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true>
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true, int SW = 16>
 static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
 {
-    auto kern = ac_dfa_kernel<E, SIGMA, STRIDE, HC, EXACT, NCH, PF>;
+    auto kern = ac_dfa_kernel<E, SIGMA, STRIDE, HC, EXACT, NCH, PF, SW>;
     /* the attribute call and the occupancy query cost tens of microseconds of host time, during
      * which the GPU idles between the caller's events: do them once per (kernel, LDS size) */
     static uint32_t cached_lds = 0xFFFFFFFFu;
@@ -158,7 +158,7 @@ static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
     if (per_cu > 2) per_cu = 2;
     if (per_cu > tune_get("bpc", 2)) per_cu = tune_get("bpc", 2);
     /* enough wave-chunks for every wave?  shrink the grid for small texts */
-    const uint64_t chunk = (uint64_t)SMH_SEG * 64u * NCH;
+    const uint64_t chunk = (uint64_t)(4u * SW) * 64u * NCH;
     const uint64_t n_chunks = (L.V.n + chunk - 1) / chunk;
     uint64_t blocks = (uint64_t)L.n_cus * (uint64_t)per_cu;
     const uint64_t want = (n_chunks + (SMH_BLOCK_THREADS / 64) - 1) / (SMH_BLOCK_THREADS / 64);
@@ -176,6 +176,10 @@ static hipError_t launch_exact(const smh_ac_launch &L, hipStream_t stream)
     if constexpr (SIGMA == 4 && HC <= 2 && sizeof(E) == 2) {
         if (getenv("SMH_AC_TUNE")) {
             const int nch = tune_get("nch", SMH_AC_NCH), pf = tune_get("pf", 1);
+            const int sw = tune_get("sw", 16);
+            if (sw == 32 && L.exact) return launch_one<E, SIGMA, STRIDE, HC, true, 1, true, 32>(L, stream);
+            if (sw == 32 && !L.exact && STRIDE == 1) return launch_one<E, SIGMA, 1, HC, false, 1, true, 32>(L, stream);
+            if (sw == 33 && L.exact) return launch_one<E, SIGMA, STRIDE, HC, true, 1, false, 32>(L, stream);
             if (L.exact) {
                 if (nch == 1 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, true, 1, false>(L, stream);
                 if (nch == 2 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, true, 2, false>(L, stream);

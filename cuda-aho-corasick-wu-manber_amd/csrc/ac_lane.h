@@ -204,7 +204,7 @@ struct smh_fmt_s2 { /* stride 2, alphabet 4: entry = row | F1 << 14 | F2 << 15, 
     SMH_MEMBER uint32_t any(uint32_t e) const { return e >> 14; }
 };
 
-template <typename FMT, int HC, int NCH, bool EXACT> struct smh_ac_scan_ctx {
+template <typename FMT, int HC, int NCH, bool EXACT, int SW = 16> struct smh_ac_scan_ctx {
     FMT fmt;
     const void *tab; /* LDS: depth-K automaton */
     int halo;        /* K - 1 */
@@ -218,8 +218,8 @@ template <typename FMT, int HC, int NCH, bool EXACT> struct smh_ac_scan_ctx {
 };
 
 /* queue the candidates flagged by entry `e` (reached from `prev`) for the byte (pair) at `pos` */
-template <typename FMT, int HC, int NCH, bool EXACT>
-SMH_LANE void smh_ac_emit_flags(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, uint32_t f, uint32_t prev, uint32_t e,
+template <typename FMT, int HC, int NCH, bool EXACT, int SW>
+SMH_LANE void smh_ac_emit_flags(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c, uint32_t f, uint32_t prev, uint32_t e,
                                 uint64_t pos)
 {
     if (FMT::STRIDE == 1) {
@@ -232,8 +232,8 @@ SMH_LANE void smh_ac_emit_flags(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, u
 }
 
 /* one step of all chains with full flag handling: the halo steps and the replay of a flagged piece */
-template <typename FMT, int HC, int NCH, bool EXACT>
-SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, const uint32_t (&x)[NCH], int k,
+template <typename FMT, int HC, int NCH, bool EXACT, int SW>
+SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c, const uint32_t (&x)[NCH], int k,
                                const uint64_t (&pos)[NCH], bool second_valid, uint32_t (&e)[NCH], uint32_t &cnt,
                                int hbit = 0)
 {
@@ -272,8 +272,8 @@ SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, co
  * are past that point keep stepping with the rest of the wave (it is harmless: they cannot reach
  * depth K inside the halo), which keeps the step free of divergence.
  */
-template <int H, typename FMT, int HC, int NCH, bool EXACT>
-SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, const uint32_t (&w)[NCH][16],
+template <int H, typename FMT, int HC, int NCH, bool EXACT, int SW>
+SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c, const uint32_t (&w)[NCH][SW],
                                uint32_t (&hx)[NCH], uint32_t (&e)[NCH], uint32_t &cnt)
 {
     if (H % FMT::STRIDE != 0) return true; /* stride 2 consumes bytes H and H+1 at even H */
@@ -289,18 +289,18 @@ SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, co
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const uint32_t edge = j + 1 < NCH ? smh_first_lane(w[j + 1 < NCH ? j + 1 : j][H >> 2]) : c.tail[H >> 2];
-            hx[j] = c.fmt.prep(smh_next_lane_word(w[j][H >> 2], edge, c.text, c.a[j] + SMH_SEG + (uint64_t)H));
+            hx[j] = c.fmt.prep(smh_next_lane_word(w[j][H >> 2], edge, c.text, c.a[j] + 4u * SW + (uint64_t)H));
         }
     }
     uint64_t pos[NCH];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) pos[j] = c.a[j] + SMH_SEG + (uint64_t)H;
+    for (int j = 0; j < NCH; ++j) pos[j] = c.a[j] + 4u * SW + (uint64_t)H;
     smh_ac_step_full(c, hx, (H & 3) / FMT::STRIDE, pos, H + 1 < c.halo, e, cnt, H);
     return true;
 }
 
-template <typename FMT, int HC, int NCH, bool EXACT, int... Hs>
-SMH_LANE void smh_ac_halo_all(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT> &c, const uint32_t (&w)[NCH][16],
+template <typename FMT, int HC, int NCH, bool EXACT, int SW, int... Hs>
+SMH_LANE void smh_ac_halo_all(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c, const uint32_t (&w)[NCH][SW],
                               uint32_t (&e)[NCH], uint32_t &cnt, std::integer_sequence<int, Hs...>)
 {
     uint32_t hx[NCH];
@@ -324,13 +324,13 @@ SMH_LANE void smh_ac_load_tail(const uint8_t *p, uint32_t (&t)[4 * HC])
     }
 }
 
-template <int NCH>
-SMH_LANE void smh_ac_load_segments(const uint8_t *text, const uint64_t (&a)[NCH], uint32_t (&w)[NCH][16])
+template <int NCH, int SW>
+SMH_LANE void smh_ac_load_segments(const uint8_t *text, const uint64_t (&a)[NCH], uint32_t (&w)[NCH][SW])
 {
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < SW / 4; ++q) {
             const smh_u32x4 t = smh_load16(text + a[j] + 16u * q);
             w[j][4 * q + 0] = t.v[0];
             w[j][4 * q + 1] = t.v[1];
@@ -351,9 +351,9 @@ SMH_LANE void smh_ac_load_segments(const uint8_t *text, const uint64_t (&a)[NCH]
  * wave-wide vote, and a piece that holds a candidate anywhere in the wave is walked again from a
  * snapshot of the states, this time queueing the candidates.
  */
-template <typename FMT, int HC, int NCH, bool EXACT>
+template <typename FMT, int HC, int NCH, bool EXACT, int SW>
 SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const uint64_t (&a)[NCH],
-                                   const uint32_t (&w)[NCH][16], const uint32_t (&tail)[4 * HC], const void *tab,
+                                   const uint32_t (&w)[NCH][SW], const uint32_t (&tail)[4 * HC], const void *tab,
                                    int K, const smh_ac_df &df, const smh_ac_verify_ctx &V, smh_ac_queue &Q)
 {
     uint32_t e[NCH], snap[NCH], cnt = 0, anyf = 0;
@@ -363,15 +363,16 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
      * wave holds 2048 positions); every lookup instead drops its two flag bits into a per-lane bit
      * mask (one bit per text byte) and the set bits are queued after the segment, position only --
      * the verify stage then walks the pattern from the root (SMH_CAND_ROOT). */
-    constexpr bool BITS = !EXACT && FMT::STRIDE == 2 && HC == 1;
+    constexpr bool BITS = !EXACT && FMT::STRIDE == 2 && HC == 1 && SW == 16;
+    static_assert(EXACT || FMT::STRIDE == 1 || SW == 16, "stride-2 candidate recording assumes 64-byte segments");
     uint32_t mlo[NCH], mhi[NCH], mhalo[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) mlo[j] = mhi[j] = mhalo[j] = 0;
-    smh_ac_scan_ctx<FMT, HC, NCH, EXACT> ctx{fmt, tab, K - 1, &df, text, a, tail, &V, &Q, BITS ? mhalo : nullptr};
+    smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> ctx{fmt, tab, K - 1, &df, text, a, tail, &V, &Q, BITS ? mhalo : nullptr};
     constexpr int SPD = 4 / FMT::STRIDE; /* steps per text dword */
 
 #pragma unroll
-    for (int piece = 0; piece < 4; ++piece) {
+    for (int piece = 0; piece < SW / 4; ++piece) {
 #pragma unroll
         for (int q = 4 * piece; q < 4 * piece + 4; ++q) {
             uint32_t x[NCH];
@@ -444,10 +445,10 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
 /* Slow path: any segment, byte loads with bounds checks, stride-1 depth-K table from HBM,
  * candidates verified on the spot.  Used for the last wave-chunk(s) of a text and for texts
  * shorter than one wave-chunk. */
-SMH_LANE uint32_t smh_ac_lane_slow(const smh_ac_verify_ctx &V, uint64_t n_starts, uint64_t a)
+SMH_LANE uint32_t smh_ac_lane_slow(const smh_ac_verify_ctx &V, uint64_t n_starts, uint64_t a, uint32_t seg_bytes = SMH_SEG)
 {
     if (a >= n_starts) return 0;
-    uint64_t own_end = a + SMH_SEG;
+    uint64_t own_end = a + seg_bytes;
     if (own_end > n_starts) own_end = n_starts;
     /* K-symbol prefixes that START in [a, own_end) END before own_end + K - 1 */
     uint64_t stop = own_end + (uint64_t)(V.K - 1);
@@ -496,13 +497,14 @@ SMH_LANE uint32_t smh_ac_lane_table(const uint8_t *text, uint64_t n, uint64_t n_
  * 64 lanes per wave): wave-chunks of NCH*4 KiB are dealt round-robin to waves,
  * so at any moment the resident waves stream one contiguous window of text.
  */
-template <typename FMT, int HC, int NCH, bool EXACT, bool PREFETCH = true>
+template <typename FMT, int HC, int NCH, bool EXACT, bool PREFETCH = true, int SW = 16>
 SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthreads, const void *tab,
                                 const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base)
 {
     if (V.n < (uint64_t)V.m) return 0;
     const uint64_t n_starts = V.n - (uint64_t)V.m + 1;
-    const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u * NCH;
+    constexpr uint32_t SEGB = 4u * SW; /* bytes per lane segment */
+    const uint64_t chunk_bytes = (uint64_t)SEGB * 64u * NCH;
     const uint64_t n_chunks = (n_starts + chunk_bytes - 1) / chunk_bytes;
     const uint32_t lane = (uint32_t)(gthread & 63u);
     const uint64_t wave = gthread >> 6, nwaves = nthreads >> 6;
@@ -513,7 +515,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthre
     uint32_t cnt = 0;
     /* software pipeline: the segments of the wave's NEXT chunk are requested before the current
      * chunk is scanned, so the HBM latency of a chunk hides behind a whole chunk of lookups */
-    uint32_t cur[NCH][16], nxt[NCH][16], cur_tail[4 * HC], nxt_tail[4 * HC];
+    uint32_t cur[NCH][SW], nxt[NCH][SW], cur_tail[4 * HC], nxt_tail[4 * HC];
     uint64_t k = wave;
     bool cur_fast = false;
     if (k < n_chunks) {
@@ -522,8 +524,8 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthre
         if (cur_fast) {
             uint64_t a[NCH];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SMH_SEG;
-            smh_ac_load_segments<NCH>(V.text, a, cur);
+            for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SEGB;
+            smh_ac_load_segments<NCH, SW>(V.text, a, cur);
             smh_ac_load_tail<HC>(V.text + base + chunk_bytes, cur_tail);
         }
     }
@@ -535,32 +537,32 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthre
         if (PREFETCH && nxt_fast) {
             uint64_t an[NCH];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) an[j] = base_n + ((uint64_t)j * 64u + lane) * SMH_SEG;
-            smh_ac_load_segments<NCH>(V.text, an, nxt);
+            for (int j = 0; j < NCH; ++j) an[j] = base_n + ((uint64_t)j * 64u + lane) * SEGB;
+            smh_ac_load_segments<NCH, SW>(V.text, an, nxt);
             smh_ac_load_tail<HC>(V.text + base_n + chunk_bytes, nxt_tail);
         }
         if (cur_fast) {
             uint64_t a[NCH];
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SMH_SEG;
-            cnt += smh_ac_lane_fast<FMT, HC, NCH, EXACT>(fmt, V.text, a, cur, cur_tail, tab, V.K, df, V, Q);
+            for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SEGB;
+            cnt += smh_ac_lane_fast<FMT, HC, NCH, EXACT, SW>(fmt, V.text, a, cur, cur_tail, tab, V.K, df, V, Q);
         } else {
             for (int j = 0; j < NCH; ++j)
-                cnt += smh_ac_lane_slow(V, n_starts, base + ((uint64_t)j * 64u + lane) * SMH_SEG);
+                cnt += smh_ac_lane_slow(V, n_starts, base + ((uint64_t)j * 64u + lane) * SEGB, SEGB);
         }
         if (nxt_fast) {
             if (PREFETCH) {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) cur[j][q] = nxt[j][q];
+                    for (int q = 0; q < SW; ++q) cur[j][q] = nxt[j][q];
 #pragma unroll
                 for (int q = 0; q < 4 * HC; ++q) cur_tail[q] = nxt_tail[q];
             } else {
                 uint64_t an[NCH];
 #pragma unroll
-                for (int j = 0; j < NCH; ++j) an[j] = base_n + ((uint64_t)j * 64u + lane) * SMH_SEG;
-                smh_ac_load_segments<NCH>(V.text, an, cur);
+                for (int j = 0; j < NCH; ++j) an[j] = base_n + ((uint64_t)j * 64u + lane) * SEGB;
+                smh_ac_load_segments<NCH, SW>(V.text, an, cur);
                 smh_ac_load_tail<HC>(V.text + base_n + chunk_bytes, cur_tail);
             }
         }

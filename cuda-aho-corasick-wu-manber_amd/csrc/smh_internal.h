@@ -90,9 +90,10 @@ struct smh_ac_table_box {
 };
 
 /* host-side builders (ac_host.c) */
+enum { SMH_AC_REF_NONE = 0, SMH_AC_REF_COPY = 1, SMH_AC_REF_ADOPT = 2 };
 struct smh_ac *smh_ac_compile_tables_impl(const int *state_transition, const unsigned int *state_supply,
                                           const unsigned int *state_final, uint64_t rows,
-                                          int alphabet, int m);
+                                          int alphabet, int m, int ref_mode);
 void smh_ac_host_free(struct smh_ac *ac);
 /* choose K / stride for an LDS budget and build scan_table (+ trunc1_table); force_stride 0 = auto */
 int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth);

@@ -199,6 +199,22 @@ static int ac_ensure_device(struct smh_ac *ac)
     std::vector<uint32_t> df(dflen, ac->rows);
     for (int i = 0; i <= ac->max_depth + 1 && (size_t)i < dflen; ++i) df[i] = ac->depth_first[i];
     if ((rc = upload((void **)&d->d_depth_first, df.data(), df.size() * 4, 0)) != SMH_OK) return rc;
+    return SMH_OK;
+}
+
+/* the reference-layout tables go up on the first SMH_VARIANT_TABLE scan only: for an alphabet-256
+ * automaton they are the largest object the handle owns and the tuned kernel never reads them */
+static int ac_ensure_reference_tables(struct smh_ac *ac)
+{
+    smh_ac_dev *d = ac->dev;
+    if (d->d_transition) return SMH_OK;
+    if (!ac->g_transition) {
+        smh_set_error("smh_ac_scan: this handle carries no reference-layout tables (it came from preproc_ac, "
+                      "whose search_ac runs the tuned kernel only); build it with smh_ac_compile_tables or "
+                      "smh_ac_compile_patterns for SMH_VARIANT_TABLE");
+        return SMH_EUNSUP;
+    }
+    int rc;
     const size_t A = (size_t)ac->alphabet;
     if ((rc = upload((void **)&d->d_transition, ac->g_transition, (size_t)ac->states * A * 4, 0)) != SMH_OK) return rc;
     if ((rc = upload((void **)&d->d_supply, ac->g_supply, (size_t)ac->states * 4, 0)) != SMH_OK) return rc;
@@ -229,6 +245,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     if (variant == SMH_VARIANT_TABLE) {
+        if ((rc = ac_ensure_reference_tables(ac)) != SMH_OK) return rc;
         smh_ac_table_launch L;
         L.d_text = d_text; L.n = n; L.m = ac->m; L.alphabet = ac->alphabet;
         L.d_transition = ac->dev->d_transition; L.d_supply = ac->dev->d_supply; L.d_final = ac->dev->d_final;

@@ -237,3 +237,26 @@ def test_text_longer_than_4gib():
     host_tail = S.corpus_text(n - tail_off, 42, sigma, offset=tail_off)
     want_tail, _ = O.oracle_ac(pat, m, p, sigma, host_tail)
     assert run(ac, tail_off, n - tail_off) == want_tail
+
+
+@pytest.mark.parametrize("m", [5, 12, 20])
+def test_ascii_100k_patterns_against_bruteforce(m):
+    """BASELINE configs[4] shape (256-symbol alphabet, 100 000 patterns, lengths 5-20) at a size the
+    definition-level brute force finishes in seconds: WM hashed filter + survivor queue + verify, WM table
+    walk, and AC with the automaton cut at a shallow depth (alphabet 256 rows are 512 B: K = 1)."""
+    sigma, p, n = 256, 100000, 6 * 1024 * 1024 + 77
+    text = S.corpus_text(n, 42, sigma)
+    pat = S.corpus_patterns(m, p, 9, sigma, 42, n, 2)
+    want = O.count_bruteforce(pat, m, p, text)
+    assert want > p // 3  # about half the patterns are cut from the text
+    wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    info = wm.info()
+    assert info.filter_hashed and not info.filter_exact and info.distinct <= p
+    assert wm.count_host(text, S.VARIANT_TUNED)[0] == want
+    assert wm.count_host(text[:1 << 20], S.VARIANT_TABLE)[0] == O.count_bruteforce(pat, m, p, text[:1 << 20])
+    if m <= 12:
+        # the automaton over the first 30 000 patterns (a 0.3-3 GB host compile stays in seconds)
+        pa = 30000
+        ac = S.AcAutomaton.from_patterns(pat[:pa * m], m, pa, sigma)
+        assert not ac.info().scan_exact
+        assert ac.count_host(text[:1 << 20], S.VARIANT_TUNED)[0] == O.count_bruteforce(pat[:pa * m], m, pa, text[:1 << 20])
