@@ -21,6 +21,8 @@ LIB_PATH = os.path.join(HERE, "libsmatcher_hip.so")
 SMH_OK = 0
 VARIANT_TUNED = 0
 VARIANT_TABLE = 1
+ALGO_AC = 0
+ALGO_WM = 1
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int)
@@ -49,6 +51,12 @@ class WmInfo(C.Structure):
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32)]
 
 
+class PsetInfo(C.Structure):
+    _fields_ = [("alphabet", C.c_uint32), ("algorithm", C.c_uint32), ("classes", C.c_uint32),
+                ("patterns", C.c_uint32), ("min_length", C.c_uint32), ("max_length", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
+
+
 class AcTable(C.Structure):
     """struct ac_table (include/smatcher.h)"""
     _fields_ = [("idcounter", C.c_uint), ("patterncounter", C.c_uint), ("zerostate", C.c_void_p)]
@@ -66,7 +74,9 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
                "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
                "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info",
-               "smh_wm_scan", "smh_wm_count_host", "smh_wm_free"]
+               "smh_wm_scan", "smh_wm_count_host", "smh_wm_free", "smh_pset_compile", "smh_pset_get_info",
+               "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
+               "smh_pset_free"]
 
 
 def _load():
@@ -115,6 +125,15 @@ def _load():
     lib.smh_wm_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, u64p, dblp]
     lib.smh_wm_free.restype = None
     lib.smh_wm_free.argtypes = [C.c_void_p]
+    lib.smh_pset_compile.restype = C.c_void_p
+    lib.smh_pset_compile.argtypes = [u8p, u32p, C.c_int, C.c_int, C.c_int]
+    lib.smh_pset_get_info.argtypes = [C.c_void_p, C.POINTER(PsetInfo)]
+    lib.smh_pset_get_class.argtypes = [C.c_void_p, C.c_uint32, u32p, u32p]
+    lib.smh_pset_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.smh_pset_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.smh_pset_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, u64p, dblp]
+    lib.smh_pset_free.restype = None
+    lib.smh_pset_free.argtypes = [C.c_void_p]
     # legacy names, with the reference's argument lists (smatcher.h)
     lib.preproc_ac.restype = C.POINTER(AcTable)
     lib.preproc_ac.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p, u32p, u32p]
@@ -286,6 +305,58 @@ class WmTables:
     def close(self):
         if self.h:
             lib.smh_wm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PatternSet:
+    """smh_pset handle: patterns of mixed lengths, one compiled class per distinct length."""
+
+    def __init__(self, patterns, lengths, alphabet, algorithm=ALGO_AC):
+        a, ptr = _u8(patterns)
+        ln = np.ascontiguousarray(lengths, dtype=np.uint32)
+        if int(ln.sum()) != len(a):
+            raise SmhError("PatternSet: lengths sum to %d, %d pattern bytes given" % (int(ln.sum()), len(a)))
+        h = lib.smh_pset_compile(ptr, ln.ctypes.data_as(u32p), len(ln), alphabet, algorithm)
+        if not h:
+            raise SmhError("pattern set compile failed: %s" % lib.smh_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def info(self):
+        out = PsetInfo()
+        _check(lib.smh_pset_get_info(self.h, C.byref(out)), "smh_pset_get_info")
+        return out
+
+    def classes(self):
+        out = []
+        for i in range(self.info().classes):
+            ln, cnt = C.c_uint32(), C.c_uint32()
+            _check(lib.smh_pset_get_class(self.h, i, C.byref(ln), C.byref(cnt)), "smh_pset_get_class")
+            out.append((ln.value, cnt.value))
+        return out
+
+    def scan_device(self, d_text_ptr, n, d_count_ptr, stream=None):
+        _check(lib.smh_pset_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr),
+                                 C.c_void_p(stream or 0)), "smh_pset_scan")
+
+    def positions_device(self, d_text_ptr, n, d_positions_ptr, capacity, d_cursor_ptr, stream=None):
+        _check(lib.smh_pset_positions(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_positions_ptr), capacity,
+                                      C.c_void_p(d_cursor_ptr), C.c_void_p(stream or 0)), "smh_pset_positions")
+
+    def count_host(self, text):
+        t, ptr = _u8(text)
+        cnt, secs = C.c_uint64(), C.c_double()
+        _check(lib.smh_pset_count_host(self.h, ptr, len(t), C.byref(cnt), C.byref(secs)), "smh_pset_count_host")
+        return cnt.value, secs.value
+
+    def close(self):
+        if self.h:
+            lib.smh_pset_free(self.h)
             self.h = None
 
     def __del__(self):

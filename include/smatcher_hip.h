@@ -153,6 +153,44 @@ int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int var
                       uint64_t *count, double *kernel_seconds);
 void smh_wm_free(smh_wm *wm);
 
+/* ---- pattern sets with mixed lengths ----
+ * The reference API carries ONE pattern length per run (preproc_ac / preproc_wu take a single m;
+ * feeding ac_addstring mixed lengths marks wrong states final, ac/ac.c:136-143,183-186), so the
+ * bit-exact meaning of a mixed set is the length-class decomposition: group the patterns by
+ * length, run the reference once per length, sum the counts -- the number of (end column, distinct
+ * pattern) occurrences.  A set handle does exactly that on the device: one compiled automaton
+ * (SMH_ALGO_AC) or Wu-Manber table set (SMH_ALGO_WM) per distinct length, all scanning the same
+ * resident text on the caller's stream and adding into the same counter.  Wu-Manber needs m >= 3
+ * (wu/wu.c:119-125): classes of length 1 and 2 of a SMH_ALGO_WM set are compiled as automata. */
+#define SMH_ALGO_AC 0
+#define SMH_ALGO_WM 1
+typedef struct smh_pset smh_pset;
+
+typedef struct smh_pset_info {
+    uint32_t alphabet;
+    uint32_t algorithm;
+    uint32_t classes;      /* distinct pattern lengths */
+    uint32_t patterns;     /* as given */
+    uint32_t min_length;
+    uint32_t max_length;
+    uint32_t reserved[2];
+} smh_pset_info;
+
+/* patterns: the p_size patterns back to back (pattern j has lengths[j] symbols, each < alphabet) */
+smh_pset *smh_pset_compile(const unsigned char *patterns, const uint32_t *lengths, int p_size, int alphabet,
+                         int algorithm);
+int smh_pset_get_info(const smh_pset *set, smh_pset_info *out);
+/* class i in ascending length order: its length and its number of patterns */
+int smh_pset_get_class(const smh_pset *set, uint32_t i, uint32_t *length, uint32_t *patterns);
+/* asynchronous, same contract as smh_ac_scan: adds sum over classes of the class's match count */
+int smh_pset_scan(smh_pset *set, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream);
+/* END columns of all (column, pattern) occurrences; a column appears once per class that matches there */
+int smh_pset_positions(smh_pset *set, const unsigned char *d_text, uint64_t n, uint64_t *d_positions,
+                      uint64_t capacity, uint64_t *d_cursor, void *stream);
+int smh_pset_count_host(smh_pset *set, const unsigned char *text, uint64_t n, uint64_t *count,
+                       double *kernel_seconds);
+void smh_pset_free(smh_pset *set);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,3 +106,55 @@ def build(case):
     else:
         raise ValueError(kind)
     return text, np.ascontiguousarray(pat, dtype=np.uint8)
+
+
+# ------------------------------------------------------------------ mixed-length pattern sets
+def mixed_cases():
+    """Pattern sets with several lengths.  The reference takes one m per run, so the
+    expected value is the length-class decomposition: the reference run once per distinct length, summed."""
+    return [
+        dict(name="mixed_dna_8_32", n=200003, sigma=4, classes=[[8, 200], [12, 200], [16, 200], [24, 200], [32, 200]],
+             kind="classes", text_seed=61, pat_seed=62),
+        dict(name="mixed_ascii_5_20", n=200017, sigma=256, classes=[[L, 150] for L in range(5, 21)],
+             kind="classes", text_seed=63, pat_seed=64),
+        dict(name="mixed_protein", n=150001, sigma=20, classes=[[3, 40], [7, 300], [9, 300]],
+             kind="classes", text_seed=65, pat_seed=66),
+        dict(name="mixed_len_1_2", n=90001, sigma=8, classes=[[1, 3], [2, 10], [3, 30], [5, 100]],
+             kind="classes", text_seed=67, pat_seed=68),
+        # short patterns that are prefixes of longer ones -- what ac_addstring cannot take in one trie
+        # (ac/ac.c:136-143) -- plus duplicates inside a class
+        dict(name="mixed_prefix_hazard", n=120007, sigma=4, classes=[[4, 50], [6, 100], [10, 100]],
+             kind="prefixes", text_seed=69, pat_seed=70),
+    ]
+
+
+def build_mixed(case):
+    """-> (text uint8[n], patterns uint8[sum lengths] back to back, lengths uint32[p])"""
+    n, sigma = case["n"], case["sigma"]
+    text = O.gen_text(n, case["text_seed"], sigma)
+    per_class = {}
+    for L, p in case["classes"]:
+        per_class[L] = O.gen_patterns_mixed(L, p, case["pat_seed"] + L, sigma, case["text_seed"], n, 2).reshape(p, L)
+    if case["kind"] == "prefixes":
+        long = per_class[10]
+        per_class[4] = np.ascontiguousarray(long[:50, :4])
+        six = np.ascontiguousarray(long[:100, :6])
+        six[50:] = six[:50]  # duplicates
+        per_class[6] = six
+    items = [(L, j) for L, p in case["classes"] for j in range(p)]
+    order = np.random.RandomState(case["pat_seed"]).permutation(len(items))
+    pats, lengths = [], []
+    for k in order:
+        L, j = items[k]
+        pats.append(per_class[L][j])
+        lengths.append(L)
+    return text, np.ascontiguousarray(np.concatenate(pats), dtype=np.uint8), np.asarray(lengths, dtype=np.uint32)
+
+
+def split_classes(patterns, lengths):
+    """length -> flat uint8 array of that class's patterns, in the order given"""
+    out, off = {}, 0
+    for L in lengths:
+        out.setdefault(int(L), []).append(patterns[off:off + int(L)])
+        off += int(L)
+    return {L: np.ascontiguousarray(np.concatenate(v), dtype=np.uint8) for L, v in out.items()}

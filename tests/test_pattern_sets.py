@@ -1,0 +1,128 @@
+"""Pattern sets with mixed lengths (include/smatcher_hip.h smh_pset_*).
+
+The reference takes one pattern length per run, so the expected value of a mixed set is the
+length-class decomposition -- tests/golden/ref_mixed_vectors.json holds, per class, the counts the
+reference's own search_ac / search_wu2 produced (tests/golden/make_golden_mixed.py), and their sum.
+CPU: the oracle and the emulated lane code reproduce every class count (including the length-1 and
+length-2 classes Wu-Manber cannot take); the set handle groups classes correctly and rejects bad
+input.  GPU: smh_pset_count_host / smh_pset_scan / smh_pset_positions on the device equal the totals,
+for both algorithms."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import emu_lib as E
+import oracle_lib as O
+from emu_lib import S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(ROOT, "tests", "golden", "ref_mixed_vectors.json")) as f:
+    MIXED = json.load(f)
+IDS = [v["name"] for v in MIXED]
+
+
+@pytest.mark.parametrize("vec", MIXED, ids=IDS)
+def test_oracle_and_lane_code_reproduce_every_class(vec):
+    text, patterns, lengths = cases.build_mixed(vec)
+    classes = cases.split_classes(patterns, lengths)
+    assert sorted(classes) == [c["length"] for c in vec["per_class"]]
+    total = 0
+    for c in vec["per_class"]:
+        L, p, sigma = c["length"], c["patterns"], vec["sigma"]
+        flat = classes[L]
+        assert len(flat) == L * p
+        got, t = O.oracle_ac(flat, L, p, sigma, text)
+        assert got == c["count_ac"] and t.patterncounter == c["distinct"]
+        assert got == O.count_bruteforce(flat, L, p, text)  # the definition
+        assert E.ac_scan(S.AcAutomaton.from_patterns(flat, L, p, sigma), text, blocks=2) == got
+        if L >= 3:
+            assert O.oracle_wu(flat, L, p, sigma, text)[0] == c["count_wu2"] == got
+            assert E.wm_scan(S.WmTables.from_patterns(flat, L, p, sigma), text, blocks=3) == got
+        total += got
+    assert total == vec["total"]
+
+
+@pytest.mark.parametrize("algo", [S.ALGO_AC, S.ALGO_WM])
+def test_set_handle_groups_by_length(algo):
+    vec = MIXED[0]
+    _, patterns, lengths = cases.build_mixed(vec)
+    ps = S.PatternSet(patterns, lengths, vec["sigma"], algo)
+    info = ps.info()
+    assert ps.classes() == [tuple(c) for c in vec["classes"]]
+    assert (info.classes, info.patterns, info.min_length, info.max_length, info.algorithm) == \
+           (len(vec["classes"]), len(lengths), vec["classes"][0][0], vec["classes"][-1][0], algo)
+    ps.close()
+
+
+def test_set_compile_rejects_bad_input():
+    with pytest.raises(S.SmhError, match="length 0"):
+        S.PatternSet(np.array([1, 2], dtype=np.uint8), [2, 0], 4)
+    with pytest.raises(S.SmhError, match="alphabet"):
+        S.PatternSet(np.array([1, 2, 9], dtype=np.uint8), [1, 2], 4)
+    with pytest.raises(S.SmhError, match="lengths sum"):
+        S.PatternSet(np.array([1, 2, 3], dtype=np.uint8), [1, 1], 4)
+    with pytest.raises(S.SmhError, match="bad arguments"):
+        S.PatternSet(np.array([1, 2, 3], dtype=np.uint8), [1, 2], 4, algorithm=7)
+    if S.device_count() == 0:  # no GPU: the scan fails loudly, nothing is computed on the host
+        ps = S.PatternSet(np.array([0, 1, 2, 3, 1, 2], dtype=np.uint8), [4, 2], 4)
+        with pytest.raises(S.SmhError):
+            ps.count_host(np.zeros(100, dtype=np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vec", MIXED, ids=IDS)
+def test_gpu_set_counts_match_reference_decomposition(vec):
+    import torch
+    text, patterns, lengths = cases.build_mixed(vec)
+    n, sigma = len(text), vec["sigma"]
+    dev = torch.device("cuda", 0)
+    d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    d_text[:n] = torch.from_numpy(text).to(dev)
+    classes = cases.split_classes(patterns, lengths)
+    want_pos = np.sort(np.concatenate([O.positions_bruteforce(classes[L], L, len(classes[L]) // L, text)
+                                       for L in sorted(classes)]))
+    assert len(want_pos) == vec["total"]
+    for algo in (S.ALGO_AC, S.ALGO_WM):
+        ps = S.PatternSet(patterns, lengths, sigma, algo)
+        assert ps.count_host(text)[0] == vec["total"]
+        cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        ps.scan_device(d_text.data_ptr(), n, cnt.data_ptr(), stream)
+        ps.scan_device(d_text.data_ptr(), n, cnt.data_ptr(), stream)  # accumulates
+        cap = vec["total"] + 3
+        pos = torch.zeros(cap, dtype=torch.int64, device=dev)
+        ps.positions_device(d_text.data_ptr(), n, pos.data_ptr(), cap, cnt.data_ptr() + 8, stream)
+        torch.cuda.synchronize()
+        assert cnt.tolist() == [2 * vec["total"], vec["total"]]
+        assert np.array_equal(np.sort(pos[:vec["total"]].cpu().numpy()), want_pos)
+        ps.close()
+
+
+@pytest.mark.gpu
+def test_gpu_set_at_baseline_shape():
+    """BASELINE configs[1] read as ONE set: 1000 DNA patterns with lengths drawn from 8..32, 64 MiB of text;
+    the set count equals the sum of fixed-length counts of its classes (each checked against the oracle on a
+    prefix) and AC == WM."""
+    sigma, n = 4, 64 << 20
+    text = S.corpus_text(n, 42, sigma)
+    rng = np.random.RandomState(5)
+    lengths = rng.randint(8, 33, size=1000).astype(np.uint32)
+    pats = []
+    for j, L in enumerate(lengths):
+        if j % 2 == 0:
+            off = int(rng.randint(0, n - L))
+            pats.append(text[off:off + L])
+        else:
+            pats.append(rng.randint(0, sigma, size=L).astype(np.uint8))
+    patterns = np.concatenate(pats)
+    ac = S.PatternSet(patterns, lengths, sigma, S.ALGO_AC)
+    wm = S.PatternSet(patterns, lengths, sigma, S.ALGO_WM)
+    got = ac.count_host(text)[0]
+    assert got == wm.count_host(text)[0] and got >= 500
+    sample = text[:4 << 20]
+    want = sum(O.oracle_ac(flat, L, len(flat) // L, sigma, sample)[0]
+               for L, flat in cases.split_classes(patterns, lengths).items())
+    assert ac.count_host(sample)[0] == want == wm.count_host(sample)[0]
