@@ -397,7 +397,8 @@ bad:
  * stride 2 with K < m has to verify every candidate from the root and only pays when candidates are
  * very rare (it measured 2.0 TB/s at one candidate per 260 bytes).  Relative cost per text byte:
  *     stride 1:  1 + 0.08 [K < m] + 3 * P(a 16-byte piece of a wave holds a candidate)
- *     stride 2:  0.72 + 300 * r [K < m]                       r = candidates per text byte      */
+ *     stride 2:  0.72 + 300 * r [K < m]                       r = candidates per text byte
+ *     hybrid  :  0.72 + 2.55 * P(a wave holds a lane deeper than D) + (0.13 + 300 * r) [K < m]   */
 
 static uint32_t entry_get(const void *t, int eb, size_t i)
 {
@@ -428,18 +429,182 @@ static double candidate_rate(const struct smh_ac *ac, int K)
     return r > 1.0 ? 1.0 : r;
 }
 
-int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth)
+
+/* ------------------------------------------------------------------ hybrid stride-2 table (alphabet 4)
+ * A full stride-2 row costs 32 bytes, so only ~5000 rows fit LDS, while 1000 patterns of length 16
+ * make ~11000.  But on random-looking text a lane is almost always in a SHALLOW state (the chance
+ * of being deeper than d is (rows at depth d) / 4^d), and a deep state of a set of distinct
+ * patterns is almost always a link of a chain: one child, one grandchild.  So:
+ *   rows of depth <= D ("full")   16 entries of 16 bits: the row after the two symbols (no flags:
+ *                                 D <= K-3, so two symbols from a full row never complete a prefix)
+ *   deeper rows ("compact")       a list of 4-byte items, each "if the pair (or its first symbol)
+ *                                 equals X then {flag F1/F2 | go to row N}", ending in the row's
+ *                                 supply (fail) link.  Exact because for a pair x that is not a
+ *                                 goto path out of s:  delta2(s, x) = delta2(fail(s), x), and when
+ *                                 a goto path ends in an accepting (depth-K) leaf the automaton
+ *                                 continues from that leaf's supply state, which again is
+ *                                 delta2(fail(s), x)  (ac/ac.c:209-211 applied twice).
+ * Item (32 bits): [0..15] link = where to continue when the item does not end the step (next item of
+ * the same row, finally the supply row), [16..19] pair code c1*4+c2, [20..23] compare mask (15, or 12
+ * to compare c1 only), [24..25] flags to raise on a hit (1: prefix ends at the first symbol, 2: at
+ * the second), [26] hit => the step ends in row (this id + 1), [27] hit => the step ends in the row
+ * whose id is in the next 4-byte slot.  Compact rows are numbered along their chains so that [26]
+ * covers all but the branching states.  Row ids are 16 bits; ids >= scan_full_rows are compact. */
+struct hyb_item { uint8_t code, c1only, flags; uint32_t target; /* old row id, or UINT32_MAX */ };
+
+static uint32_t hyb_step(const struct smh_ac *ac, int K, uint32_t r, int c, int *flag)
+{
+    uint32_t t = trunc_step(ac, K, r, c, flag);
+    if (K < ac->m && *flag) t = ac->row_fail[t]; /* depth-K rows are leaves of the cut automaton */
+    return t;
+}
+
+static int hyb_items(const struct smh_ac *ac, int K, uint32_t s, struct hyb_item *it)
+{
+    int n = 0;
+    const int d = ac->row_depth[s];
+    for (int c1 = 0; c1 < 4; ++c1) {
+        int f1;
+        const uint32_t t1 = hyb_step(ac, K, s, c1, &f1);
+        if (f1) {
+            it[n++] = (struct hyb_item){(uint8_t)(c1 * 4), 1, 1, UINT32_MAX};
+            continue;
+        }
+        if (ac->row_depth[t1] != d + 1) continue; /* not a goto edge */
+        for (int c2 = 0; c2 < 4; ++c2) {
+            int f2;
+            const uint32_t t2 = hyb_step(ac, K, t1, c2, &f2);
+            if (f2)
+                it[n++] = (struct hyb_item){(uint8_t)(c1 * 4 + c2), 0, 2, UINT32_MAX};
+            else if (ac->row_depth[t2] == d + 2)
+                it[n++] = (struct hyb_item){(uint8_t)(c1 * 4 + c2), 0, 0, t2};
+        }
+    }
+    /* a chain item first: it is the one that can use the implicit "next id" link */
+    for (int i = 1; i < n; ++i)
+        if (it[i].target != UINT32_MAX && it[0].target == UINT32_MAX) {
+            struct hyb_item t = it[0]; it[0] = it[i]; it[i] = t;
+            break;
+        }
+    return n;
+}
+
+/* returns SMH_OK and the image, SMH_EUNSUP when (K, D) does not fit or is not representable */
+static int hyb_build(const struct smh_ac *ac, int K, int D, uint32_t budget, void **image, uint32_t *bytes, uint32_t *nf_out)
+{
+    if (ac->alphabet != 4 || K > ac->m || D < 1 || D > K - 3) return SMH_EUNSUP;
+    const uint32_t rk = ac->depth_first[K], nf = ac->depth_first[D + 1];
+    if (nf >= rk || (uint64_t)nf * 32u > budget) return SMH_EUNSUP;
+    const uint32_t nc = rk - nf;
+    uint32_t *hid = (uint32_t *)malloc((size_t)nc * sizeof(uint32_t));   /* new id of compact row nf + i */
+    uint32_t *extra = (uint32_t *)malloc((size_t)nc * sizeof(uint32_t)); /* first pseudo slot of the row */
+    uint32_t *order = (uint32_t *)malloc((size_t)nc * sizeof(uint32_t));
+    int rc = SMH_EUNSUP;
+    void *img = NULL;
+    if (!hid || !extra || !order) { rc = SMH_ENOMEM; goto out; }
+    memset(hid, 0xFF, (size_t)nc * sizeof(uint32_t));
+    struct hyb_item it[16];
+    uint32_t cursor = nf, n_order = 0;
+    for (uint32_t s0 = nf; s0 < rk; ++s0) {
+        if (hid[s0 - nf] != UINT32_MAX) continue;
+        /* number the chain that starts here, then the extra items of its rows */
+        const uint32_t first = n_order;
+        for (uint32_t cur = s0;;) {
+            hid[cur - nf] = cursor++;
+            order[n_order++] = cur;
+            const int n = hyb_items(ac, K, cur, it);
+            if (n == 0 || it[0].target == UINT32_MAX || hid[it[0].target - nf] != UINT32_MAX) break;
+            cur = it[0].target;
+        }
+        for (uint32_t k = first; k < n_order; ++k) {
+            const uint32_t cur = order[k];
+            const int n = hyb_items(ac, K, cur, it);
+            extra[cur - nf] = cursor;
+            /* item 0 sits in the row's own slot when it is a flag item or the implicit chain link */
+            const int own = n > 0 && (it[0].target == UINT32_MAX || hid[it[0].target - nf] == hid[cur - nf] + 1u);
+            for (int i = own ? 1 : 0; i < n; ++i) cursor += it[i].target == UINT32_MAX ? 1u : 2u;
+        }
+        if (cursor > 65535u) goto out;
+    }
+    {
+        const uint64_t total = (uint64_t)nf * 32u + (uint64_t)(cursor - nf) * 4u;
+        if (total > budget) goto out;
+        *bytes = (uint32_t)((total + 15u) & ~(uint64_t)15u);
+    }
+    img = calloc(*bytes + 16u, 1);
+    if (!img) { rc = SMH_ENOMEM; goto out; }
+#define HYB_ID(r) ((r) < nf ? (r) : hid[(r) - nf])
+    uint16_t *t16 = (uint16_t *)img;
+    for (uint32_t r = 0; r < nf; ++r)
+        for (int c1 = 0; c1 < 4; ++c1)
+            for (int c2 = 0; c2 < 4; ++c2) {
+                int f1, f2;
+                const uint32_t r1 = hyb_step(ac, K, r, c1, &f1);
+                const uint32_t r2 = hyb_step(ac, K, r1, c2, &f2);
+                if (f1 || f2) goto out; /* cannot happen with D <= K-3 */
+                t16[(size_t)r * 16 + c1 * 4 + c2] = (uint16_t)HYB_ID(r2);
+            }
+    uint32_t *rec = (uint32_t *)((uint8_t *)img + (size_t)nf * 32u); /* slot of id i: rec[i - nf] */
+    for (uint32_t s = nf; s < rk; ++s) {
+        const int n = hyb_items(ac, K, s, it);
+        const uint32_t id = hid[s - nf], fail = HYB_ID(ac->row_fail[s]);
+        const int own = n > 0 && (it[0].target == UINT32_MAX || hid[it[0].target - nf] == id + 1u);
+        uint32_t item_slot[16], pos = extra[s - nf];
+        for (int i = 0; i < n; ++i) {
+            if (i == 0 && own) { item_slot[0] = id; continue; }
+            item_slot[i] = pos;
+            pos += it[i].target == UINT32_MAX ? 1u : 2u;
+        }
+        /* own slot without an item: a pass-through (mask 0 always "hits", but with no flags and no
+         * end-of-step bits a hit just follows the link) */
+        if (!own) rec[id - nf] = n > 0 ? item_slot[0] : fail;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t link = i == n - 1 ? fail : item_slot[i + 1];
+            uint32_t v = link | ((uint32_t)it[i].code << 16) | ((it[i].c1only ? 12u : 15u) << 20) |
+                         ((uint32_t)it[i].flags << 24);
+            if (it[i].target != UINT32_MAX) {
+                if (i == 0 && own) {
+                    v |= 1u << 26;
+                } else {
+                    v |= 1u << 27;
+                    rec[item_slot[i] + 1u - nf] = hid[it[i].target - nf];
+                }
+            }
+            rec[item_slot[i] - nf] = v;
+        }
+    }
+#undef HYB_ID
+    *image = img;
+    img = NULL;
+    *nf_out = nf;
+    rc = SMH_OK;
+out:
+    free(hid); free(extra); free(order); free(img);
+    return rc;
+}
+
+/* fraction of uniform-text positions at which the automaton is deeper than D */
+static double deep_rate(const struct smh_ac *ac, int D)
+{
+    if (D + 1 > ac->max_depth) return 0.0;
+    double r = (double)(ac->depth_first[D + 2] - ac->depth_first[D + 1]);
+    for (int i = 0; i <= D; ++i) r /= 4.0;
+    return r > 1.0 ? 1.0 : r;
+}
+
+static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth, int allow_hybrid)
 {
     const int A = ac->alphabet;
     const int kmax = ac->m < SMH_AC_MAX_SCAN_DEPTH ? ac->m : SMH_AC_MAX_SCAN_DEPTH;
-    int best_k[3] = {0, 0, 0};
+    const int force_k = force_depth & 0xFF, force_d = (force_depth >> 8) & 0xFF;
+    int best_k[4] = {0, 0, 0, 0}, best_d = 0;
     double best_cost = 1e30;
     int best_s = 0;
     for (int s = 1; s <= 2; ++s) {
         if (s == 2 && A != 4) continue;
         if (force_stride && s != force_stride) continue;
         for (int K = kmax; K >= 1; --K) {
-            if (force_depth && K != force_depth) continue;
+            if (force_k && K != force_k) continue;
             uint64_t rk = ac->depth_first[K + 1 <= ac->max_depth + 1 ? K + 1 : ac->max_depth + 1];
             if (K >= ac->m) rk = ac->rows;
             uint64_t per_row = s == 1 ? (uint64_t)A * (rk <= 32768 ? 2u : 4u) : (uint64_t)A * A * 2u;
@@ -452,12 +617,50 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
             else
                 cost = 0.72 + 300.0 * r;
             if (cost < best_cost) { best_cost = cost; best_s = s; best_k[s] = K; }
-            if (!force_depth) break; /* the deepest K that fits is the best for this stride */
+            if (!force_k) break; /* the deepest K that fits is the best for this stride */
+        }
+    }
+    /* hybrid stride 2 (see hyb_build): for every K the deepest D whose estimated image fits.  Measured
+     * (1000 patterns, m = 16 / 32, 1 GiB): the common step costs what a plain stride-2 step costs
+     * (0.21 ms/GiB), a step in which ANY lane of the wave sits in a compact row 3.5 x that (two more
+     * dependent LDS round trips and the item arithmetic), recording candidates as bits 0.04 ms/GiB */
+    if (allow_hybrid && A == 4 && (!force_stride || force_stride == 3)) {
+        for (int K = kmax; K >= 4; --K) {
+            if (force_k && K != force_k) continue;
+            if (K < ac->m && K - 1 > 32) continue; /* the candidate-bit recording covers a 32-byte halo */
+            for (int D = K - 3; D >= 1; --D) {
+                if (force_d && D != force_d) continue;
+                const uint64_t nf = ac->depth_first[D + 1], rk = ac->depth_first[K];
+                if (nf >= rk) continue;
+                const uint64_t nc = rk - nf;
+                if (nf * 32u + nc * 4u + nc / 4u + 64u > lds_budget || rk + nc / 8u > 65000u) continue;
+                const double r = candidate_rate(ac, K), q = deep_rate(ac, D);
+                const double cost = 0.72 + 2.55 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.13 + 300.0 * r : 0.0);
+                if (cost < best_cost) { best_cost = cost; best_s = 3; best_k[3] = K; best_d = D; }
+                break;
+            }
         }
     }
     if (!best_s) {
         smh_set_error("smh_ac_plan_scan: no depth-K automaton fits %u bytes of LDS (alphabet %d)", lds_budget, A);
         return SMH_EUNSUP;
+    }
+    void *hyb_image = NULL;
+    uint32_t hyb_bytes = 0, hyb_nf = 0;
+    if (best_s == 3) {
+        int rc = SMH_EUNSUP;
+        for (int D = best_d; D >= 1 && rc != SMH_OK; --D) {
+            rc = hyb_build(ac, best_k[3], D, lds_budget, &hyb_image, &hyb_bytes, &hyb_nf);
+            if (rc == SMH_ENOMEM) { smh_set_error("smh_ac_plan_scan: out of memory"); return rc; }
+            if (force_d) break;
+        }
+        if (rc != SMH_OK) {
+            if (force_stride == 3) {
+                smh_set_error("smh_ac_plan_scan: the hybrid stride-2 table does not fit %u bytes of LDS", lds_budget);
+                return SMH_EUNSUP;
+            }
+            return plan_scan(ac, lds_budget, force_stride, force_depth, 0);
+        }
     }
     const int K = best_k[best_s];
     const uint32_t rk = K >= ac->m ? ac->rows : ac->depth_first[K + 1];
@@ -465,7 +668,8 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
     free(ac->scan_table);
     ac->scan_table = ac->trunc1_table = NULL;
     ac->scan_depth = K;
-    ac->scan_stride = best_s;
+    ac->scan_stride = best_s == 3 ? 2 : best_s;
+    ac->scan_full_rows = hyb_nf;
     ac->scan_exact = K >= ac->m;
     ac->scan_rows = rk;
     ac->scan_candidate_rate = candidate_rate(ac, K);
@@ -473,7 +677,7 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
     const int eb1 = rk <= 32768 ? 2 : 4;
     const size_t n1 = (size_t)rk * A;
     void *t1 = calloc(n1 * eb1 + 16, 1);
-    if (!t1) { smh_set_error("smh_ac_plan_scan: out of memory"); return SMH_ENOMEM; }
+    if (!t1) { free(hyb_image); smh_set_error("smh_ac_plan_scan: out of memory"); return SMH_ENOMEM; }
     for (uint32_t r = 0; r < rk; ++r)
         for (int c = 0; c < A; ++c) {
             int flag;
@@ -488,6 +692,10 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
         ac->scan_table = t1;
         ac->scan_entry_bytes = eb1;
         ac->scan_bytes = (uint32_t)((n1 * eb1 + 15) & ~(size_t)15);
+    } else if (best_s == 3) {
+        ac->scan_table = hyb_image;
+        ac->scan_entry_bytes = 2;
+        ac->scan_bytes = hyb_bytes;
     } else {
         const size_t n2 = (size_t)rk * 16;
         uint16_t *t2 = (uint16_t *)calloc(n2 * 2 + 16, 1);
@@ -505,6 +713,11 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
         ac->scan_bytes = (uint32_t)((n2 * 2 + 15) & ~(size_t)15);
     }
     return SMH_OK;
+}
+
+int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth)
+{
+    return plan_scan(ac, lds_budget, force_stride, force_depth, 1);
 }
 
 smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *state_supply,
@@ -566,12 +779,13 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_depth = (uint32_t)ac->scan_depth;
     out->scan_stride = (uint32_t)ac->scan_stride;
     out->scan_exact = (uint32_t)ac->scan_exact;
+    out->scan_full_rows = ac->scan_full_rows;
     return SMH_OK;
 }
 
 int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
 {
-    if (!ac || ac->magic != SMH_MAGIC_AC || stride < 0 || stride > 2 || depth < 0) {
+    if (!ac || ac->magic != SMH_MAGIC_AC || stride < 0 || stride > 3 || depth < 0) {
         smh_set_error("smh_ac_set_scan_plan: bad arguments");
         return SMH_EINVAL;
     }

@@ -55,7 +55,8 @@ __device__ __forceinline__ void smh_block_add(uint32_t cnt, uint64_t *count, uns
 template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true, int SW = 16>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__restrict__ scan_table, uint32_t lds_bytes,
                                                                   smh_ac_verify_ctx V, smh_ac_df df,
-                                                                  uint64_t *queue_base, uint64_t *count)
+                                                                  uint64_t *queue_base, uint64_t *count,
+                                                                  uint32_t full_rows)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smh_lds[];
     /* stage the depth-K automaton: 16 bytes per lane per step, coalesced; four loads in flight per
@@ -80,7 +81,10 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__re
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     uint32_t cnt;
-    if constexpr (STRIDE == 2) {
+    if constexpr (STRIDE == 3) { /* hybrid stride 2: full rows + compact item lists */
+        const smh_fmt_s2h fmt{full_rows, full_rows * 28u};
+        cnt = smh_ac_thread<smh_fmt_s2h, HC, NCH, EXACT, PF, SW>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
+    } else if constexpr (STRIDE == 2) {
         cnt = smh_ac_thread<smh_fmt_s2, HC, NCH, EXACT, PF, SW>(smh_fmt_s2{}, gthread, nthreads, smh_lds, V, df, queue_base);
     } else {
         const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
@@ -125,7 +129,9 @@ hipError_t smh_launch_ac_positions(const smh_ac_verify_ctx &V, uint64_t *d_posit
 /* ------------------------------------------------------------------ launch */
 uint32_t smh_ac_max_blocks(int n_cus) { return (uint32_t)n_cus * 2u; }
 
-/* development knobs (not part of the API): SMH_AC_TUNE="nch=1|2|4,pf=0|1,bpc=1|2" */
+/* development knob (not part of the API): SMH_AC_TUNE="bpc=1|2" caps the workgroups per CU.  Other
+ * variants that were measured and dropped (two or four segments per lane, no software prefetch,
+ * 128-byte segments) remain available as template parameters: profiles/README.md */
 static int tune_get(const char *key, int dflt)
 {
     const char *t = getenv("SMH_AC_TUNE");
@@ -166,32 +172,21 @@ static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
     if (blocks < 1) blocks = 1;
     if (blocks > smh_ac_max_blocks(L.n_cus)) blocks = smh_ac_max_blocks(L.n_cus); /* the queue workspace is sized for this */
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), L.lds_bytes, stream,
-                       reinterpret_cast<const E *>(L.d_scan_table), L.lds_bytes, L.V, L.df, L.d_queue, L.d_count);
+                       reinterpret_cast<const E *>(L.d_scan_table), L.lds_bytes, L.V, L.df, L.d_queue, L.d_count,
+                       L.full_rows);
     return hipGetLastError();
 }
 
 template <typename E, int SIGMA, int STRIDE, int HC>
 static hipError_t launch_exact(const smh_ac_launch &L, hipStream_t stream)
 {
-    if constexpr (SIGMA == 4 && HC <= 2 && sizeof(E) == 2) {
-        if (getenv("SMH_AC_TUNE")) {
-            const int nch = tune_get("nch", SMH_AC_NCH), pf = tune_get("pf", 1);
-            const int sw = tune_get("sw", 16);
-            if (sw == 32 && L.exact) return launch_one<E, SIGMA, STRIDE, HC, true, 1, true, 32>(L, stream);
-            if (sw == 32 && !L.exact && STRIDE == 1) return launch_one<E, SIGMA, 1, HC, false, 1, true, 32>(L, stream);
-            if (sw == 33 && L.exact) return launch_one<E, SIGMA, STRIDE, HC, true, 1, false, 32>(L, stream);
-            if (L.exact) {
-                if (nch == 1 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, true, 1, false>(L, stream);
-                if (nch == 2 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, true, 2, false>(L, stream);
-                if (nch == 2 && pf == 1) return launch_one<E, SIGMA, STRIDE, HC, true, 2, true>(L, stream);
-            } else {
-                if (nch == 1 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, false, 1, false>(L, stream);
-                if (nch == 2 && pf == 0) return launch_one<E, SIGMA, STRIDE, HC, false, 2, false>(L, stream);
-                if (nch == 2 && pf == 1) return launch_one<E, SIGMA, STRIDE, HC, false, 2, true>(L, stream);
-            }
-        }
-    }
+    if constexpr (STRIDE == 3) {
+        if (L.exact) return launch_one<E, SIGMA, 3, HC, true>(L, stream);
+        if constexpr (HC <= 2) return launch_one<E, SIGMA, 3, HC, false>(L, stream);
+        return hipErrorInvalidValue; /* the plan keeps K - 1 <= 32 for a depth-cut hybrid image */
+    } else {
     return L.exact ? launch_one<E, SIGMA, STRIDE, HC, true>(L, stream) : launch_one<E, SIGMA, STRIDE, HC, false>(L, stream);
+    }
 }
 
 template <typename E, int SIGMA, int STRIDE>
@@ -208,6 +203,7 @@ hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream)
     if (L.V.K - 1 > 64) return hipErrorInvalidValue;
     if (L.stride == 2) {
         if (L.V.sigma != 4 || L.scan_entry_bytes != 2) return hipErrorInvalidValue;
+        if (L.full_rows) return launch_halo<uint16_t, 4, 3>(L, stream);
         return launch_halo<uint16_t, 4, 2>(L, stream);
     }
     if (L.scan_entry_bytes == 2)

@@ -165,6 +165,7 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
  */
 template <typename E, int SIGMA> struct smh_fmt_s1 { /* stride 1: entry = row | FLAG (top bit) */
     static constexpr int STRIDE = 1;
+    static constexpr bool SPARSE = false;
     static constexpr uint32_t FSHIFT = smh_ac_entry<E>::FLAG_SHIFT, MASK = smh_ac_entry<E>::MASK;
     int sigma_rt;
     SMH_MEMBER uint32_t prep(uint32_t w) const { return SIGMA == 4 ? w << (sizeof(E) == 2 ? 1 : 2) : w; }
@@ -192,6 +193,7 @@ template <typename E, int SIGMA> struct smh_fmt_s1 { /* stride 1: entry = row | 
 
 struct smh_fmt_s2 { /* stride 2, alphabet 4: entry = row | F1 << 14 | F2 << 15, 16 entries per row */
     static constexpr int STRIDE = 2;
+    static constexpr bool SPARSE = false;
     /* pair codes * 2 land at bits 1..4 (bytes 0,1) and 17..20 (bytes 2,3) */
     SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 3) | (w >> 7); }
     SMH_MEMBER uint32_t next(uint32_t e, uint32_t x, int k, const void *tab) const
@@ -202,6 +204,71 @@ struct smh_fmt_s2 { /* stride 2, alphabet 4: entry = row | F1 << 14 | F2 << 15, 
     SMH_MEMBER uint32_t flags(uint32_t e) const { return e >> 14; }
     SMH_MEMBER uint32_t row(uint32_t e) const { return e & 0x3FFFu; }
     SMH_MEMBER uint32_t any(uint32_t e) const { return e >> 14; }
+};
+
+/*
+ * Hybrid stride 2, alphabet 4 (image built by hyb_build in ac_host.c, which documents the layout):
+ * rows below `nf` are full -- 16 two-symbol entries holding the plain next row, never a flag --
+ * and the others are lists of 4-byte items.  A step first resolves the lanes that sit in a compact
+ * row (rare: the wave votes), walking the row's items until one ends the step or the supply link
+ * leads into a full row, and then does the ordinary two-symbol lookup for the lanes still open.
+ * Flags are raised only inside that resolution, so the common path carries no flag arithmetic:
+ * next_f hands them to a callback.  The lane state is the row id (16 bits).
+ */
+struct smh_fmt_s2h {
+    static constexpr int STRIDE = 2;
+    static constexpr bool SPARSE = true;
+    uint32_t nf;    /* ids >= nf are compact */
+    uint32_t cbase; /* nf * 28: byte address of item slot i is i * 4 + cbase */
+    SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 3) | (w >> 7); }
+    template <typename F>
+    SMH_MEMBER uint32_t next_f(uint32_t row, uint32_t x, int k, const void *tab, F &&on_flags) const
+    {
+        const uint32_t c = k == 0 ? (x & 0x1Eu) : smh_bfe(x, 16, 5); /* pair code * 2 */
+        /* the full-row lookup is issued for every lane before the vote (a compact row id is clamped
+         * to a harmless full row), so the common path is as short as the plain stride-2 one:
+         * min, shift-or, read */
+        const uint32_t rc = row < nf ? row : nf - 1u;
+        uint32_t t = smh_lds_u16(tab, (rc << 5) | c);
+        bool deep = row >= nf;
+        if (SMH_WAVE_ANY(deep)) {
+            const uint32_t code = c >> 1;
+            uint32_t r = row, acc = 0;
+            bool done = false, moved = false;
+            do {
+                if (deep) {
+                    const uint32_t addr = r * 4u + cbase;
+                    const uint32_t rec = smh_lds_u32(tab, addr);
+                    const bool hit = ((code ^ smh_bfe(rec, 16, 4)) & smh_bfe(rec, 20, 4)) == 0;
+                    uint32_t nr = rec & 0xFFFFu;
+                    if (hit) {
+                        acc |= smh_bfe(rec, 24, 2);
+                        if (rec & (1u << 26)) nr = r + 1u;
+                        if (rec & (1u << 27)) nr = smh_lds_u32(tab, addr + 4u) & 0xFFFFu;
+                        done = (rec & (3u << 26)) != 0;
+                    }
+                    r = nr;
+                    moved = true;
+                }
+                deep = !done && r >= nf;
+            } while (SMH_WAVE_ANY(deep));
+            on_flags(acc);
+            /* lanes that left their compact row through a supply link now stand in a full row */
+            if (moved && !done) t = smh_lds_u16(tab, (r << 5) | c);
+            if (done) t = r;
+        }
+        return t;
+    }
+    /* generic form for the halo steps: row | flags << 16 */
+    SMH_MEMBER uint32_t next(uint32_t e, uint32_t x, int k, const void *tab) const
+    {
+        uint32_t f = 0;
+        const uint32_t r = next_f(e & 0xFFFFu, x, k, tab, [&](uint32_t a) { f = a; });
+        return r | (f << 16);
+    }
+    SMH_MEMBER uint32_t flags(uint32_t e) const { return e >> 16; }
+    SMH_MEMBER uint32_t row(uint32_t e) const { return e & 0xFFFFu; }
+    SMH_MEMBER uint32_t any(uint32_t e) const { return e >> 16; }
 };
 
 template <typename FMT, int HC, int NCH, bool EXACT, int SW = 16> struct smh_ac_scan_ctx {
@@ -363,7 +430,7 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
      * wave holds 2048 positions); every lookup instead drops its two flag bits into a per-lane bit
      * mask (one bit per text byte) and the set bits are queued after the segment, position only --
      * the verify stage then walks the pattern from the root (SMH_CAND_ROOT). */
-    constexpr bool BITS = !EXACT && FMT::STRIDE == 2 && HC == 1 && SW == 16;
+    constexpr bool BITS = !EXACT && FMT::STRIDE == 2 && (HC == 1 || (FMT::SPARSE && HC == 2)) && SW == 16;
     static_assert(EXACT || FMT::STRIDE == 1 || SW == 16, "stride-2 candidate recording assumes 64-byte segments");
     uint32_t mlo[NCH], mhi[NCH], mhalo[NCH];
 #pragma unroll
@@ -382,6 +449,20 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
             for (int k = 0; k < SPD; ++k)
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
+                    if constexpr (FMT::SPARSE) {
+                        /* flags arrive through the callback, from the rare compact-row resolution only */
+                        static_assert(EXACT || BITS, "the hybrid image records candidates as bits");
+                        const int bit = 4 * q + 2 * k;
+                        e[j] = fmt.next_f(e[j], x[j], k, tab, [&](uint32_t f) {
+                            if (EXACT)
+                                cnt += (uint32_t)__builtin_popcount(f);
+                            else if (bit < 32)
+                                mlo[j] |= f << bit;
+                            else
+                                mhi[j] |= f << (bit - 32);
+                        });
+                        continue;
+                    }
                     e[j] = fmt.next(e[j], x[j], k, tab);
                     if (EXACT) {
                         cnt += (uint32_t)__builtin_popcount(fmt.flags(e[j]));

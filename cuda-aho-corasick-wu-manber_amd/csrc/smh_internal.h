@@ -64,6 +64,8 @@ struct smh_ac {
     int scan_stride;      /* 1 or 2 symbols per lookup */
     int scan_exact;       /* K == m */
     uint32_t scan_rows;   /* rows with depth <= K */
+    uint32_t scan_full_rows; /* hybrid stride-2 image: rows below this id have 16 entries, the others are
+                              * compact item lists (ac_host.c hyb_build); 0 = not a hybrid image */
     int scan_entry_bytes; /* 2 or 4 (stride 2: always 2) */
     void *scan_table;     /* scan_rows * alphabet^stride entries */
     uint32_t scan_bytes;  /* padded to 16 */

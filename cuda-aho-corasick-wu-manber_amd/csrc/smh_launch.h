@@ -19,6 +19,7 @@ struct smh_ac_launch {
     smh_ac_verify_ctx V;        /* text, n, m, K, sigma, full DFA, depth_first, trunc1 (device pointers) */
     smh_ac_df df;               /* depth_first[0..71] by value (kernel argument) */
     int stride;                 /* 1 or 2 */
+    uint32_t full_rows;         /* stride 2: 0 = plain image, else the hybrid image's full-row count */
     int exact;                  /* K == m: flags are matches, no queue */
     int scan_entry_bytes;
     const void *d_scan_table;   /* LDS image */

@@ -259,6 +259,11 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
         L.d_scan_table = ac->dev->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = ac->dev->d_queue;
         for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+        L.full_rows = ac->scan_full_rows;
+        if (L.full_rows) /* hybrid image: compact rows are not numbered by depth; the halo's "deep enough"
+                          * test treats every compact row as deep (conservative, see ac_lane.h) */
+            for (int i = 0; i < SMH_AC_DF_LEN; ++i)
+                if (L.df.v[i] > L.full_rows) L.df.v[i] = L.full_rows;
         L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_ac_dfa(L, (hipStream_t)stream));
     } else {

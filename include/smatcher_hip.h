@@ -88,7 +88,8 @@ typedef struct smh_ac_info {
     uint32_t scan_depth;   /* K: the LDS automaton is the Aho-Corasick machine of the K-symbol prefixes */
     uint32_t scan_stride;  /* text symbols consumed per LDS lookup (1 or 2) */
     uint32_t scan_exact;   /* 1: K == m, a flagged transition is a match; 0: candidates are verified in HBM */
-    uint32_t reserved;
+    uint32_t scan_full_rows; /* hybrid stride-2 image: rows below this id hold 16 two-symbol entries, deeper
+                              * rows are 4-byte item lists; 0 for the plain stride-1 / stride-2 images */
 } smh_ac_info;
 
 /* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
@@ -97,8 +98,9 @@ smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *s
 /* from patterns: builds the reference tables internally, then compiles them */
 smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
 int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out);
-/* tuning / test knob: rebuild the LDS scan automaton with a forced stride (1 or 2; 0 = choose) and
- * a forced depth K (1..min(m,65); 0 = the deepest that fits).  SMH_EUNSUP when it does not fit LDS. */
+/* tuning / test knob: rebuild the LDS scan automaton with a forced stride (1 or 2, 3 = hybrid stride 2;
+ * 0 = choose) and a forced depth K (1..min(m,65); 0 = the deepest that fits; for the hybrid image
+ * bits 8..15 may force the depth D of its full rows).  SMH_EUNSUP when it does not fit LDS. */
 int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth);
 /* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).
  * d_text must be 16-byte aligned; n may exceed 2^32.  A handle owns one candidate-queue workspace

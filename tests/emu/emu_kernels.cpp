@@ -54,10 +54,17 @@ static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t b
 {
     smh_ac_df df;
     for (int i = 0; i < SMH_AC_DF_LEN; ++i) df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+    if (STRIDE == 3) /* as smh_runtime.hip: compact rows of the hybrid image count as "deep enough" */
+        for (int i = 0; i < SMH_AC_DF_LEN; ++i)
+            if (df.v[i] > ac->scan_full_rows) df.v[i] = ac->scan_full_rows;
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t) {
-        if constexpr (STRIDE == 2) {
+        if constexpr (STRIDE == 3) {
+            const smh_fmt_s2h fmt{ac->scan_full_rows, ac->scan_full_rows * 28u};
+            if constexpr (EXACT || HC <= 2)
+                total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
+        } else if constexpr (STRIDE == 2) {
             total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT>(smh_fmt_s2{}, t, nthreads, ac->scan_table, V, df, nullptr);
         } else {
             const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
@@ -105,7 +112,9 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
             V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
             V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
             V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
-            if (ac->scan_stride == 2)
+            if (ac->scan_stride == 2 && ac->scan_full_rows)
+                total = ac_halo<uint16_t, 4, 3>(ac, V, blocks);
+            else if (ac->scan_stride == 2)
                 total = ac_halo<uint16_t, 4, 2>(ac, V, blocks);
             else if (ac->scan_entry_bytes == 2)
                 total = ac->alphabet == 4 ? ac_halo<uint16_t, 4, 1>(ac, V, blocks) : ac_halo<uint16_t, 0, 1>(ac, V, blocks);

@@ -30,6 +30,17 @@ def scan_plans(ac, m, sigma):
             except S.SmhError:
                 continue  # does not fit LDS at this depth / stride
             plans.append((stride, depth))
+    if sigma == 4:
+        # hybrid stride-2 image (stride code 3): full rows down to depth D, compact item lists below
+        for depth in sorted({m, max(4, m - 1), max(4, m // 2)}):
+            for full in sorted({1, max(1, depth - 3), max(1, (depth - 3) // 2)}):
+                if depth > min(m, 65) or full > depth - 3:
+                    continue
+                try:
+                    ac.set_scan_plan(3, depth | (full << 8))
+                except S.SmhError:
+                    continue
+                plans.append((3, depth | (full << 8)))
     ac.set_scan_plan(0, 0)
     return plans
 
@@ -45,7 +56,12 @@ def test_emulated_kernels_match_reference_counts(vec):
     for stride, depth in scan_plans(ac, m, sigma):
         ac.set_scan_plan(stride, depth)
         info = ac.info()
-        assert info.scan_stride == stride and info.scan_depth == depth and info.scan_exact == (depth == m)
+        if stride == 3:
+            assert info.scan_stride == 2 and info.scan_depth == (depth & 0xFF) and info.scan_full_rows > 0
+            assert info.scan_exact == ((depth & 0xFF) == m)
+        else:
+            assert info.scan_stride == stride and info.scan_depth == depth and info.scan_exact == (depth == m)
+            assert info.scan_full_rows == 0
         assert E.ac_scan(ac, text, S.VARIANT_TUNED, 1) == want, (stride, depth)
     wm = S.WmTables.from_patterns(pat, m, p, sigma)
     assert E.wm_scan(wm, text, S.VARIANT_TUNED, 3) == want == vec["count_wu2"]
@@ -66,7 +82,8 @@ def test_every_boundary_offset():
         text = np.zeros(n, dtype=np.uint8)
         text[off:off + m] = pat
         got = [E.ac_scan(ac, text, 1, 1), E.wm_scan(wm, text, 0, 1), E.wm_scan(wm, text, 1, 1)]
-        for stride, depth in ((1, 8), (2, 8), (1, 5), (2, 5), (2, 4), (1, 1)):
+        for stride, depth in ((1, 8), (2, 8), (1, 5), (2, 5), (2, 4), (1, 1), (3, 8 | (2 << 8)), (3, 7 | (4 << 8)),
+                              (3, 5 | (1 << 8))):
             ac.set_scan_plan(stride, depth)
             got.append(E.ac_scan(ac, text, 0, 1))
         assert got == [1] * len(got), (off, got)
@@ -85,7 +102,11 @@ def test_long_patterns_straddling_segments(m):
         text[off:off + m] = pat
         want = O.count_bruteforce(pat, m, 1, text)
         assert want >= 1
-        for stride, depth in ((0, 0), (1, min(m, 65)), (2, min(m, 65)), (1, 7), (2, 7), (2, 6), (1, 3)):
+        for stride, depth in ((0, 0), (1, min(m, 65)), (2, min(m, 65)), (1, 7), (2, 7), (2, 6), (1, 3),
+                              (3, min(m, 65) | (1 << 8)), (3, min(m, 65) | (5 << 8)), (3, min(m, 33) | (4 << 8)),
+                              (3, 9 | (3 << 8)), (3, 6 | (2 << 8))):
+            if stride == 3 and (depth & 0xFF) < m and (depth & 0xFF) > 33:
+                continue  # a depth-cut hybrid image records candidates as bits: halo K - 1 <= 32
             ac.set_scan_plan(stride, depth)
             assert E.ac_scan(ac, text, 0, 1) == want, (stride, depth)
         assert E.wm_scan(wm, text, 0, 1) == want

@@ -146,8 +146,8 @@ def test_dfa_larger_than_lds(name):
 @pytest.mark.parametrize("name", ["dense_dna", "kat_1m_100x8", "mx_s4_m16_p1000", "mx_s4_m32_p100", "edge_m65",
                                   "overlap_zeros", "mx_s20_m8_p1000", "big_dfa"])
 def test_every_scan_plan_gives_the_same_count(name):
-    """Stride 1 / 2, exact (K = m) and depth-cut (K < m) automata, down to K = 1 where nearly every
-    position is a candidate and the per-wave queue overflows and drains constantly."""
+    """Stride 1 / 2 / hybrid, exact (K = m) and depth-cut (K < m) automata, down to K = 1 where nearly
+    every position is a candidate and the per-wave queue overflows and drains constantly."""
     vec = BY_NAME[name]
     text, pat = cases.build(vec)
     m, sigma = vec["m"], vec["sigma"]
@@ -163,6 +163,17 @@ def test_every_scan_plan_gives_the_same_count(name):
                 continue
             tried += 1
             assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"], (stride, depth)
+    if sigma == 4:  # hybrid stride-2 images: (K, D) = scan depth, depth of the full rows
+        for K in sorted({min(m, 65), max(4, m - 1), max(4, m // 2), 5}):
+            for D in sorted({1, 2, max(1, K - 3)}):
+                if K > min(m, 65) or D > K - 3:
+                    continue
+                try:
+                    ac.set_scan_plan(3, K | (D << 8))
+                except S.SmhError:
+                    continue
+                assert ac.info().scan_full_rows > 0
+                assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"], ("hybrid", K, D)
     assert tried >= 3
 
 
