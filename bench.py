@@ -52,10 +52,12 @@ def measured_traffic(info):
     halo = info.scan_depth - 1
     hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
     entry = "unsigned short" if (info.scan_stride == 2 or info.lds_rows <= 32768) else "unsigned int"
-    name = "ac_dfa_kernel<%s, 4, %d, %d, %s, 1, true>" % (entry, info.scan_stride, hc,
-                                                          "true" if info.scan_exact else "false")
-    rec = kernels.get(name)
-    return rec["hbm_bytes"] if rec else None
+    stride = 3 if info.scan_full_rows else info.scan_stride  # template value of the hybrid image
+    prefix = "ac_dfa_kernel<%s, 4, %d, %d, %s," % (entry, stride, hc, "true" if info.scan_exact else "false")
+    for name, rec in kernels.items():
+        if name.startswith(prefix):
+            return rec["hbm_bytes"]
+    return None
 
 
 def cpu_baseline(text_prefix, pats):
@@ -80,6 +82,30 @@ def cpu_baseline(text_prefix, pats):
     return dict(value=bits / secs / 1e9, unit="Gbit/s", cores=1, kind=kind,
                 sample="search_ac (ac/ac.c:198-222) over the first %d MiB of the same text, m=%s, %d patterns each, "
                        "1 thread, %.1f s" % (len(text_prefix) >> 20, "/".join(str(m) for m in pats), AC_PATTERNS, secs)), counts
+
+
+def cpu_baseline_all_cores(text_prefix, pats, want_counts):
+    """The same reference search fanned out over the host's cores by byte range with an m-1 halo -- the
+    reference's own MPI decomposition (main.c:467-477) with threads for ranks; ctypes releases the GIL
+    during the C call.  Counts must add up to the single-thread counts."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
+    if not O.have_ref():
+        return None
+    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    n = len(text_prefix)
+    ok, secs, wall0 = True, 0.0, time.perf_counter()
+    with ThreadPoolExecutor(cores) as pool:
+        for m, pat in pats.items():
+            ranges = [O.shard_range(n, cores, r, m) for r in range(cores)]
+            parts = list(pool.map(lambda be: O.ref_ac(pat, m, AC_PATTERNS, SIGMA, text_prefix[be[0]:be[1]]), ranges))
+            ok = ok and sum(p[0] for p in parts) == want_counts[m]
+            secs += max(p[3] for p in parts)  # the slowest shard's search_ac time (table build excluded, as on the GPU)
+    return dict(value=8.0 * n * len(pats) / secs / 1e9, unit="Gbit/s", cores=cores, kind="reference", counts_match=ok,
+                sample="same sample as byte-range shards (main.c:467-477) on %d threads; time = slowest shard's search_ac "
+                       "per set, summed (%.2f s; %.1f s wall with preproc_ac repeated per shard as every MPI rank of the "
+                       "reference does)" % (cores, secs, time.perf_counter() - wall0))
 
 
 def main():
@@ -193,7 +219,7 @@ def main():
                                         Gbit_s=round(8 * gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                                         dfa_rows=info.rows, lds_rows=info.lds_rows, lds_bytes=info.lds_bytes,
                                         scan_stride=info.scan_stride, scan_depth=info.scan_depth,
-                                        scan_exact=info.scan_exact,
+                                        scan_exact=info.scan_exact, scan_full_rows=info.scan_full_rows,
                                         matches=total_counts[AC_LENGTHS.index(m)])
         dom = max(AC_LENGTHS, key=lambda m: mean(kern_ms[m]))
         dom_ms = mean(kern_ms[dom])
@@ -215,6 +241,21 @@ def main():
                        "sharding": "byte-range x%d, m-1 halo, RCCL sum of counts" % world},
             "roofline": roofline, "ac": ac_detail, "device": S.device_name(),
         }
+
+    # ---- what a pure streaming read of the same 1 GiB reaches on this device, same run
+    if rank == 0:
+        probe = torch.zeros(1, dtype=torch.int64, device=dev)
+        pev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+        for a, b in pev:
+            a.record()
+            S.lib.smh_stream_read_probe(C.c_void_p(text.data_ptr()), per_gpu, C.c_void_p(probe.data_ptr()), C.c_void_p(stream))
+            b.record()
+        torch.cuda.synchronize()
+        pms = sorted(a.elapsed_time(b) for a, b in pev[1:])[2]
+        sgbs = per_gpu / (pms * 1e-3) / 1e9
+        out["stream_read"] = dict(kernel="smh_stream_read_kernel (16-byte loads, XOR, no table work)", ms=round(pms, 4),
+                                  GBps=round(sgbs, 1), hbm_frac=round(sgbs / HBM_PEAK_GBS, 4))
+        out["roofline"]["of_stream_read"] = round(out["roofline"]["achieved"] / sgbs, 4)
 
     # ---- WM side measurement (BASELINE configs[2]: same text, 10 000 patterns of length 8)
     if not args.no_wm:
@@ -286,6 +327,9 @@ def main():
             torch.cuda.synchronize()
             gpu_counts[m] = int(c1.item())
         out["cpu_baseline"] = base
+        allc = cpu_baseline_all_cores(prefix, pats, cpu_counts)
+        if allc:
+            out["cpu_baseline_all_cores"] = allc
         out["parity"] = dict(bit_exact=all(gpu_counts[m] == cpu_counts[m] for m in AC_LENGTHS),
                              gpu_counts=gpu_counts, cpu_counts=cpu_counts, sample_bytes=sample)
         if not out["parity"]["bit_exact"]:

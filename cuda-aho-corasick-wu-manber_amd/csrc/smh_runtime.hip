@@ -134,6 +134,50 @@ extern "C" int smh_stream_synchronize(void *stream)
     return SMH_OK;
 }
 
+/* ---- measurement aid: what a pure streaming read of the same buffer reaches on this device.
+ * SURVEY 8(d) asks for a read-only streaming kernel bandwidth from the same run beside the
+ * roofline fraction; this is that kernel: 16-byte loads, four in flight per lane, grid-stride,
+ * one XOR per load, one atomic per workgroup.  Not used by any scan path. */
+__global__ __launch_bounds__(1024) void smh_stream_read_kernel(const uint4 *__restrict__ p, uint64_t n16,
+                                                               unsigned long long *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 3u * stride < n16; i += 4u * stride) {
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2u * stride], d = p[i + 3u * stride];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n16; i += stride) {
+        const uint4 a = p[i];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_down(acc, off, 64);
+    __shared__ uint32_t part[16];
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t v = 0;
+        for (unsigned w = 0; w < (blockDim.x >> 6); ++w) v ^= part[w];
+        atomicXor(out, (unsigned long long)v);
+    }
+}
+
+extern "C" int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t *d_out, void *stream)
+{
+    if (!d_buf || !d_out || ((uintptr_t)d_buf & 15u) != 0) {
+        smh_set_error("smh_stream_read_probe: bad arguments");
+        return SMH_EINVAL;
+    }
+    int n_cus = 0, rc;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    hipLaunchKernelGGL(smh_stream_read_kernel, dim3((unsigned)n_cus * 2u), dim3(1024), 0, (hipStream_t)stream,
+                       (const uint4 *)d_buf, bytes / 16u, (unsigned long long *)d_out);
+    HIP_TRY(hipGetLastError());
+    return SMH_OK;
+}
+
 extern "C" int smh_corpus_text_device(unsigned char *d_out, uint64_t n, uint64_t offset, uint64_t seed,
                                       int alphabet, void *stream)
 {

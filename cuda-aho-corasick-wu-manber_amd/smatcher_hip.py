@@ -69,7 +69,7 @@ LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_s
                   + ["cuda_ac%d" % k for k in range(1, 6)] + ["cuda_wm%d" % k for k in range(1, 6)])
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
                "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
-               "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize",
+               "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
                "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
@@ -95,6 +95,7 @@ def _load():
     lib.smh_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.smh_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.smh_stream_synchronize.argtypes = [C.c_void_p]
+    lib.smh_stream_read_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.smh_splitmix64_at.restype = C.c_uint64
     lib.smh_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
     lib.smh_corpus_text_host.restype = None

@@ -55,6 +55,10 @@ int smh_device_memset(void *dptr, int value, uint64_t bytes, void *stream);
 int smh_copy_to_device(void *dst, const void *src, uint64_t bytes, void *stream);
 int smh_copy_to_host(void *dst, const void *src, uint64_t bytes, void *stream);
 int smh_stream_synchronize(void *stream);
+/* measurement aid: a pure streaming read of d_buf[0, bytes) -- 16-byte loads, XOR of all
+ * words into *d_out (device uint64) -- so that a bench can report what a read-only kernel reaches on
+ * the same buffer in the same run.  d_buf must be 16-byte aligned. */
+int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t *d_out, void *stream);
 
 /* ---- synthetic corpus (clean-room stand-in for the reference's missing helper.c:
  *      load_files / create_multiple_pattern_with_hits, main.c:49,453) ----
