@@ -131,6 +131,9 @@ struct smh_wm {
     int filter_exact;
     int filter_hashed;
     int filter_k;         /* hashed filter: bits per key (2..4), all in one 32-bit word */
+    int filter_le4;       /* hashed filter keyed by the block's last four BYTES read as a little-endian dword
+                           * (8-bit symbols, 4-symbol block): the scan takes it from its registers with one
+                           * v_alignbyte instead of rolling a code */
     uint32_t *filter;     /* (1 << filter_log2) / 32 words */
     double filter_density; /* fraction of windows expected to pass on uniform text */
     int verify_log2;      /* slots = 1 << verify_log2; 0 slots when exact */

@@ -55,6 +55,7 @@ struct smh_wm_launch {
     int filter_log2;
     int filter_hashed;
     int filter_k;
+    int filter_le4;
     int filter_exact;
     const uint32_t *d_filter;
     const uint32_t *d_pair; /* pair filter (alphabet 4, m <= 8, exact), else NULL */

@@ -470,7 +470,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
     } else if (variant == SMH_VARIANT_TUNED) {
         smh_wm_launch L;
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
-        L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_exact = wm->filter_exact;
+        L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
         L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
         L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_queue = wm->dev->d_queue; L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));

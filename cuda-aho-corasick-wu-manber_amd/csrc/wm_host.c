@@ -276,6 +276,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         uint32_t *best = NULL;
         double best_density = 2.0;
         int best_k = 2;
+        const int le4 = bits == 8 && Wh == 4;
         /* try 2, 3 and 4 bits per key (all inside one word, so the scan still costs one LDS lookup
          * per column) and keep the one that lets the fewest random keys through */
         for (int k = 2; k <= 4; ++k) {
@@ -283,21 +284,24 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
             if (!hashed) { free(direct); free(best); goto oom; }
             for (int j = 0; j < d; ++j) {
                 uint32_t key = block_code(wm->pat_sorted + (size_t)j * m + (m - 1), Wh, bits) & kmask;
+                if (le4) key = __builtin_bswap32(key); /* rolling code = big-endian; the scan reads the dword */
                 uint32_t h = smh_wm_block_hash(key);
-                uint32_t w = h >> (32 - (Th - 5));
-                uint32_t bm = (1u << ((h >> (32 - (Th - 5) - 5)) & 31u)) | (1u << ((h >> (32 - (Th - 5) - 10)) & 31u));
-                if (k >= 3) bm |= 1u << ((h >> 2) & 31u);
-                if (k >= 4) bm |= 1u << ((h ^ (h >> 16)) & 31u);
-                hashed[w] |= bm;
+                /* 64-bit blocks, bit positions: smh_wm_filter_key in wm_lane.h */
+                uint32_t blk = h >> (32 - (Th - 6));
+                hashed[2u * blk] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+                if (k >= 3) hashed[2u * blk + 1u] |= 1u << ((h >> 10) & 31u);
+                if (k >= 4) hashed[2u * blk + 1u] |= 1u << ((h >> 13) & 31u);
             }
-            /* pass probability of a random key ~ mean over words of (set fraction)^k */
+            /* pass probability of a random key ~ mean over blocks of f_lo^2 * f_hi^(k-2) */
             double acc = 0;
-            for (size_t w = 0; w < nwords; ++w) {
-                double f = (double)__builtin_popcount(hashed[w]) / 32.0, pk = f;
-                for (int i = 1; i < k; ++i) pk *= f;
+            for (size_t b = 0; b < nwords / 2; ++b) {
+                const double fl = (double)__builtin_popcount(hashed[2 * b]) / 32.0;
+                const double fh = (double)__builtin_popcount(hashed[2 * b + 1]) / 32.0;
+                double pk = fl * fl;
+                for (int i = 2; i < k; ++i) pk *= fh;
                 acc += pk;
             }
-            const double density = acc / (double)nwords;
+            const double density = acc / (double)(nwords / 2);
             if (density < best_density) {
                 free(best);
                 best = hashed;
@@ -312,6 +316,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
             wm->filter = best;
             wm->filter_hashed = 1;
             wm->filter_k = best_k;
+            wm->filter_le4 = le4;
             wm->filter_log2 = Th;
             wm->block_symbols = Wh;
             wm->filter_density = best_density;

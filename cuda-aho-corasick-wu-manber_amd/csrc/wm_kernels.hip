@@ -40,7 +40,7 @@ __device__ __forceinline__ void smh_block_add_wm(uint32_t cnt, uint64_t *count, 
     }
 }
 
-template <bool HASHED, bool EXACT, int HC>
+template <bool HASHED, bool EXACT, int HC, int FK = 0>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ filter_g, uint32_t lds_bytes,
     smh_wm_params P, int block_symbols, uint64_t *count)
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     /* survivor queues: 1 KiB per wave right behind the filter */
     uint64_t *queue = EXACT ? nullptr
                             : reinterpret_cast<uint64_t *>(smh_lds + lds_bytes) + (threadIdx.x >> 6) * SMH_WM_QCAP;
-    const uint32_t cnt = smh_wm_thread<HASHED, EXACT, HC>(gthread, nthreads, text, n, filter, P, block_symbols, queue);
+    const uint32_t cnt = smh_wm_thread<HASHED, EXACT, HC, FK>(gthread, nthreads, text, n, filter, P, block_symbols, queue);
     smh_block_add_wm(cnt, count, smh_lds);
 }
 
@@ -139,10 +139,10 @@ hipError_t smh_launch_wm_positions(const smh_wm_table_launch &L, uint64_t *d_pos
 /* ------------------------------------------------------------------ launch */
 uint32_t smh_wm_max_blocks(int n_cus) { return (uint32_t)n_cus * 2u; }
 
-template <bool HASHED, bool EXACT, int HC>
+template <bool HASHED, bool EXACT, int HC, int FK = 0>
 static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
 {
-    auto kern = wm_block_kernel<HASHED, EXACT, HC>;
+    auto kern = wm_block_kernel<HASHED, EXACT, HC, FK>;
     uint32_t lds_bytes = (uint32_t)(((uint64_t)1 << L.filter_log2) / 8u);
     if (lds_bytes < 16u) lds_bytes = 16u;
     const uint32_t lds_total = lds_bytes + (EXACT ? 0u : (SMH_BLOCK_THREADS / 64) * SMH_WM_QCAP * 8u);
@@ -173,6 +173,7 @@ static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
     P.code_mask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
     P.filter_log2 = L.filter_log2;
     P.filter_k = L.filter_k;
+    P.filter_le4 = L.filter_le4;
     P.verify_log2 = L.verify_log2;
     P.verify = L.d_verify;
     P.pat_sorted = L.d_pat_sorted;
@@ -185,6 +186,19 @@ template <bool HASHED, bool EXACT>
 static hipError_t launch_halo(const smh_wm_launch &L, hipStream_t stream)
 {
     const int halo = L.m - 1;
+    if constexpr (HASHED && !EXACT) {
+        /* byte symbols, 4-byte block: the specialised scan (compile-time bits per key) */
+        if (L.filter_le4 && halo <= 32) {
+            if (halo <= 16) {
+                if (L.filter_k == 2) return launch_one<true, false, 1, 2>(L, stream);
+                if (L.filter_k == 3) return launch_one<true, false, 1, 3>(L, stream);
+                return launch_one<true, false, 1, 4>(L, stream);
+            }
+            if (L.filter_k == 2) return launch_one<true, false, 2, 2>(L, stream);
+            if (L.filter_k == 3) return launch_one<true, false, 2, 3>(L, stream);
+            return launch_one<true, false, 2, 4>(L, stream);
+        }
+    }
     if (halo <= 16) return launch_one<HASHED, EXACT, 1>(L, stream);
     if (halo <= 32) return launch_one<HASHED, EXACT, 2>(L, stream);
     if (halo <= 64) return launch_one<HASHED, EXACT, 4>(L, stream);

@@ -33,6 +33,7 @@ struct smh_wm_params {
     uint32_t code_mask;  /* low block_symbols*bits bits of the rolling register */
     int filter_log2;     /* hashed filter: log2 of its bit count */
     int filter_k;        /* hashed filter: bits per key inside one 32-bit word (2..4) */
+    int filter_le4;      /* hashed filter keyed by the block's 4 bytes as a little-endian dword (8-bit symbols) */
     int verify_log2;     /* slots = 1 << verify_log2 */
     const uint32_t *verify;      /* HBM: {tag, pattern + 1} per slot */
     const uint8_t *pat_sorted;   /* HBM: distinct patterns, each zero-padded to ((m+3)/4)*4 bytes */
@@ -98,22 +99,54 @@ SMH_LANE uint32_t smh_wm_block_hash(uint32_t key)
 #endif
 }
 
+/* bit `pos & 31` of word (v_bfe_u32 takes the low five bits of its offset operand by itself) */
+SMH_LANE uint32_t smh_bit_at(uint32_t word, uint32_t pos)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    return __builtin_amdgcn_ubfe(word, pos, 1u);
+#else
+    return (word >> (pos & 31u)) & 1u;
+#endif
+}
+
+SMH_LANE uint32_t smh_bswap32(uint32_t v) { return __builtin_bswap32(v); }
+
+/* hashed SHIFT stage for one key: a blocked Bloom filter with 64-bit blocks.  The block comes from
+ * the top bits of the block hash (one ds_read_b64), the K bit positions from its low bits: the first
+ * two index the block's low dword, the others its high dword (5 bits each; the fourth overlaps the
+ * third by two bits).  32-bit blocks let 2.6 % of random keys through at 100 000 keys in 2^20 bits
+ * (the load per block varies too much), 64-bit blocks 1.8 %, for the same VALU work.  K is a
+ * compile-time constant on the tuned path (0 = read it from P).  Mirrored by wm_host.c. */
+struct smh_u32x2 { uint32_t lo, hi; };
+SMH_LANE smh_u32x2 smh_filter_block(const uint32_t *filter, uint32_t block)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    const uint2 v = *reinterpret_cast<const uint2 *>(filter + 2u * block);
+    return smh_u32x2{v.x, v.y};
+#else
+    return smh_u32x2{filter[2u * block], filter[2u * block + 1u]};
+#endif
+}
+
+template <int K>
+SMH_LANE uint32_t smh_wm_filter_key(uint32_t key, const uint32_t *filter, const smh_wm_params &P)
+{
+    const uint32_t h = smh_wm_block_hash(key);
+    const smh_u32x2 w = smh_filter_block(filter, h >> (38 - P.filter_log2));
+    const int k = K ? K : P.filter_k;
+    uint32_t hit = smh_bit_at(w.lo, h) & smh_bit_at(w.lo, h >> 5);
+    if (k >= 3) hit &= smh_bit_at(w.hi, h >> 10);
+    if (k >= 4) hit &= smh_bit_at(w.hi, h >> 13);
+    return hit;
+}
+
 /* SHIFT stage for one column: returns 1 when the block's filter bit(s) are set */
 template <bool HASHED>
 SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh_wm_params &P)
 {
     const uint32_t key = code & P.code_mask;
     if (HASHED) {
-        const uint32_t h = smh_wm_block_hash(key);
-        const int wl = P.filter_log2 - 5;
-        const uint32_t word = filter[h >> (32 - wl)];
-        const uint32_t b1 = (h >> (32 - wl - 5)) & 31u, b2 = (h >> (32 - wl - 10)) & 31u;
-        uint32_t hit = (word >> b1) & (word >> b2);
-        /* more bits per key when the key set is dense (chosen by the host): fewer survivors for the
-         * HASH/PREFIX stage at the price of two or three more VALU ops per column */
-        if (P.filter_k >= 3) hit &= word >> ((h >> 2) & 31u);
-        if (P.filter_k >= 4) hit &= word >> ((h ^ (h >> 16)) & 31u);
-        return hit & 1u;
+        return smh_wm_filter_key<0>(P.filter_le4 ? smh_bswap32(key) : key, filter, P);
     } else {
         return (filter[key >> 5] >> (key & 31u)) & 1u;
     }
@@ -122,6 +155,61 @@ SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh
 /* ---- per-wave survivor queue: columns that passed the SHIFT stage wait here for the HASH/PREFIX
  * stage, which then runs with all 64 lanes busy (wavefront-level compaction: ballot + prefix
  * count).  Same scheme as the AC candidate queue (ac_lane.h). */
+/* Two windows at once: the stage is three DEPENDENT memory round trips (window dwords, table slot,
+ * pattern dwords) and a wave has nothing else to do while it waits, so a second independent chain
+ * per lane hides about half of that latency.  Same result as two smh_wm_verify calls. */
+SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, const smh_wm_params &P, uint32_t &r1)
+{
+    const uint64_t b0 = e0 + 1 - (uint64_t)P.m, b1 = e1 + 1 - (uint64_t)P.m;
+    const uint32_t *al0 = reinterpret_cast<const uint32_t *>(text + (b0 & ~(uint64_t)3));
+    const uint32_t *al1 = reinterpret_cast<const uint32_t *>(text + (b1 & ~(uint64_t)3));
+    const uint32_t sh0 = (uint32_t)(b0 & 3u) * 8u, sh1 = (uint32_t)(b1 & 3u) * 8u;
+    const int nd = (P.m + 3) >> 2;
+    const uint32_t mask = (1u << P.verify_log2) - 1u;
+    uint32_t tag0 = 0x811C9DC5u, tag1 = 0x811C9DC5u;
+    for (int j = 0; j < nd; ++j) {
+        const uint32_t v0 = smh_window_dword(al0, sh0, j, P.m), v1 = smh_window_dword(al1, sh1, j, P.m);
+        tag0 = smh_wm_mix(tag0, v0);
+        tag1 = smh_wm_mix(tag1, v1);
+    }
+    uint32_t s0 = (tag0 * SMH_WM_HASH_MUL) >> (32 - P.verify_log2), s1 = (tag1 * SMH_WM_HASH_MUL) >> (32 - P.verify_log2);
+    uint32_t r0 = 0;
+    bool a0 = true, a1 = true;
+    r1 = 0;
+    for (;;) {
+        const uint32_t stag0 = P.verify[2 * s0], sidx0 = P.verify[2 * s0 + 1];
+        const uint32_t stag1 = P.verify[2 * s1], sidx1 = P.verify[2 * s1 + 1];
+        if (a0) {
+            if (sidx0 == 0) {
+                a0 = false;
+            } else {
+                if (stag0 == tag0) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx0 - 1) * (uint32_t)nd;
+                    uint32_t diff = 0;
+                    for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(al0, sh0, j, P.m);
+                    if (diff == 0) { r0 = 1; a0 = false; }
+                }
+                s0 = (s0 + 1) & mask;
+            }
+        }
+        if (a1) {
+            if (sidx1 == 0) {
+                a1 = false;
+            } else {
+                if (stag1 == tag1) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx1 - 1) * (uint32_t)nd;
+                    uint32_t diff = 0;
+                    for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(al1, sh1, j, P.m);
+                    if (diff == 0) { r1 = 1; a1 = false; }
+                }
+                s1 = (s1 + 1) & mask;
+            }
+        }
+        if (!(a0 || a1)) break;
+    }
+    return r0;
+}
+
 #define SMH_WM_QCAP 128u /* END columns per wave, 1 KiB of LDS behind the filter */
 struct smh_wm_queue {
     uint64_t *slots; /* SMH_WM_QCAP entries, private to this wave (LDS on the GPU) */
@@ -132,7 +220,17 @@ struct smh_wm_queue {
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
 {
-    for (uint32_t i = threadIdx.x & 63u; i < Q.count; i += 64u) Q.matches += smh_wm_verify(text, Q.slots[i], P);
+    /* at most SMH_WM_QCAP = 128 entries: lane l takes entries l and l + 64, both chains in flight
+     * together; a lane with one or no entry re-verifies a column it knows to be valid and drops the
+     * answer */
+    if (Q.count == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool h0 = lane < Q.count, h1 = lane + 64u < Q.count;
+    const uint64_t e0 = h0 ? Q.slots[lane] : Q.slots[0];
+    const uint64_t e1 = h1 ? Q.slots[lane + 64u] : e0;
+    uint32_t r1;
+    const uint32_t r0 = smh_wm_verify2(text, e0, e1, P, r1);
+    Q.matches += (h0 ? r0 : 0u) + (h1 ? r1 : 0u);
     Q.count = 0;
 }
 /* append without a capacity check: the caller drains first whenever fewer than 64 slots are free */
@@ -159,16 +257,38 @@ SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_par
  * rolling block code; the caller guarantees a >= 16*HC, a + 64 <= n and
  * 16*HC >= m-1, so every column has a full window.
  */
-template <bool HASHED, bool EXACT, int HC>
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+SMH_LANE uint32_t smh_alignbyte(uint32_t hi, uint32_t lo, uint32_t r) { return __builtin_amdgcn_alignbyte(hi, lo, r); }
+#else
+SMH_LANE uint32_t smh_alignbyte(uint32_t hi, uint32_t lo, uint32_t r)
+{
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * r));
+}
+#endif
+
+/* FK > 0: the byte-symbol tuned path -- the block is the column's last four bytes, read as one
+ * unaligned little-endian dword out of the lane's registers (v_alignbyte), hashed filter with FK
+ * bits per key.  FK == 0: any symbol width, rolling code. */
+template <bool HASHED, bool EXACT, int HC, int FK = 0>
 SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[4 * HC + 16],
                                    const uint32_t *filter, const smh_wm_params &P, smh_wm_queue &Q)
 {
     uint32_t code = 0, cnt = 0;
+    uint32_t surv[2] = {0, 0};
+    if constexpr (FK > 0) {
+        static_assert(HASHED && !EXACT, "the byte-block path is the hashed, verified one");
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int first = 16 * HC + i - 3; /* register byte index of the block's first byte */
+            const int d = first >> 2, r = first & 3;
+            const uint32_t key = r == 0 ? w[d] : smh_alignbyte(w[d + 1], w[d], (uint32_t)r);
+            surv[i >> 5] |= smh_wm_filter_key<FK>(key, filter, P) << (i & 31);
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 16 * HC; ++i) code = (code << P.bits) | smh_byte_of(w[i >> 2], i & 3);
     /* SHIFT stage over the 64 columns; survivors are only recorded (one bit each) so that the
      * unrolled loop stays branch-free */
-    uint32_t surv[2] = {0, 0};
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
         code = (code << P.bits) | smh_byte_of(w[4 * HC + (i >> 2)], i & 3);
@@ -177,6 +297,7 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
             cnt += hit;
         else
             surv[i >> 5] |= hit << (i & 31);
+    }
     }
     if (!EXACT) {
         /* compaction: one queue entry per surviving column, as many rounds as the busiest lane has;
@@ -267,7 +388,7 @@ SMH_LANE uint32_t smh_wm_lane_table(const uint8_t *text, uint64_t n, uint64_t a,
 
 /* whole-grid work distribution for one lane; HC == 0: no fast path (m - 1 > 64).  The next chunk's
  * text is requested before the current chunk is scanned (software prefetch). */
-template <bool HASHED, bool EXACT, int HC>
+template <bool HASHED, bool EXACT, int HC, int FK = 0>
 SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n,
                                 const uint32_t *filter, const smh_wm_params &P, int block_symbols,
                                 uint64_t *queue_base)
@@ -308,7 +429,8 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8
         if (PREFETCH && nxt_fast) load(kn, nxt);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast)
-            cnt += smh_wm_lane_fast<HASHED, EXACT, H>(text, a, cur, filter, P, Q);
+            cnt += smh_wm_lane_fast<HASHED, EXACT, H, FK>(text, a, cur, filter, P, Q);
+
         else
             cnt += smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols);
         if (nxt_fast) {

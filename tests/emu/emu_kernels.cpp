@@ -129,7 +129,7 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
 }
 
 /* ------------------------------------------------------------------ WM */
-template <bool HASHED, bool EXACT, int HC>
+template <bool HASHED, bool EXACT, int HC, int FK = 0>
 static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks)
 {
     smh_wm_params P;
@@ -139,6 +139,7 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     P.code_mask = wbits >= 32 ? 0xFFFFFFFFu : ((1u << wbits) - 1u);
     P.filter_log2 = wm->filter_log2;
     P.filter_k = wm->filter_k;
+    P.filter_le4 = wm->filter_le4;
     P.verify_log2 = wm->verify_log2;
     P.verify = wm->verify;
     /* distinct patterns zero-padded to whole dwords, as smh_runtime.hip uploads them */
@@ -149,7 +150,7 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t)
-        total += smh_wm_thread<HASHED, EXACT, HC>(t, nthreads, text, n, wm->filter, P, wm->block_symbols, nullptr);
+        total += smh_wm_thread<HASHED, EXACT, HC, FK>(t, nthreads, text, n, wm->filter, P, wm->block_symbols, nullptr);
     return total;
 }
 
@@ -157,6 +158,17 @@ template <bool HASHED, bool EXACT>
 static uint64_t wm_halo(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks)
 {
     const int halo = wm->m - 1;
+    if constexpr (HASHED && !EXACT) {
+        if (wm->filter_le4 && halo <= 32) { /* as launch_halo in wm_kernels.hip */
+            if (halo <= 16)
+                return wm->filter_k == 2 ? wm_grid<true, false, 1, 2>(wm, text, n, blocks)
+                     : wm->filter_k == 3 ? wm_grid<true, false, 1, 3>(wm, text, n, blocks)
+                                         : wm_grid<true, false, 1, 4>(wm, text, n, blocks);
+            return wm->filter_k == 2 ? wm_grid<true, false, 2, 2>(wm, text, n, blocks)
+                 : wm->filter_k == 3 ? wm_grid<true, false, 2, 3>(wm, text, n, blocks)
+                                     : wm_grid<true, false, 2, 4>(wm, text, n, blocks);
+        }
+    }
     if (halo <= 16) return wm_grid<HASHED, EXACT, 1>(wm, text, n, blocks);
     if (halo <= 32) return wm_grid<HASHED, EXACT, 2>(wm, text, n, blocks);
     if (halo <= 64) return wm_grid<HASHED, EXACT, 4>(wm, text, n, blocks);
