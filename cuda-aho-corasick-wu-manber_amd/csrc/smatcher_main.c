@@ -10,7 +10,8 @@
  *                                               on device rank % device_count; counts summed as
  *                                               MPI_Reduce does, main.c:656)
  *   multiac / multiwm2        main.c:125-157 / 268-298   ("search_ac matches \t%i\t time \t%f\n")
- *   cuda_ac1..5 / cuda_wm1..5 main.c:582-648
+ *   multish                   main.c:158-196             (preBmBc, preproc_sh, search_sh)
+ *   cuda_ac1..5 / cuda_wm1..5 main.c:582-648, cuda_sh1..5 main.c:595-605
  *   report                    main.c:662-670   ("Total results: %d." ...)
  *
  * Data formats (upstream's load_files / create_multiple_pattern_with_hits live in the missing
@@ -45,7 +46,7 @@ static double now_seconds(void)
 static void usage(void)
 {
     printf("smatcher - multiple pattern matching (Aho-Corasick, Wu-Manber) on MI355X\n");
-    printf("Usage: smatcher <ac|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet> [options]\n");
+    printf("Usage: smatcher <ac|sh|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet> [options]\n");
     printf("-h,--help\t\t print this help message\n");
     printf("-c\t\t\t create the data files that are missing\n");
     printf("-data <dir>\t\t data directory (default ./data-cuda-multi)\n");
@@ -194,7 +195,8 @@ int main(int argc, char **argv)
     const char *algo = argc > 1 ? argv[1] : "";
     const int run_ac = strcmp(algo, "ac") == 0 || strcmp(algo, "all") == 0;
     const int run_wm = strcmp(algo, "wm") == 0 || strcmp(algo, "all") == 0;
-    if (m == 0 || nFull == 0 || p_size == 0 || alphabet == 0 || (!run_ac && !run_wm)) usage();
+    const int run_sh = strcmp(algo, "sh") == 0 || strcmp(algo, "all") == 0;
+    if (m == 0 || nFull == 0 || p_size == 0 || alphabet == 0 || (!run_ac && !run_wm && !run_sh)) usage();
     if (p_size > 100000) fail("Only up to 100.000 patterns are supported\n"); /* main.c:370-371 */
     if (m < 3) fail("The pattern length must be at least 3 (Wu-Manber block size)\n");
     if (ranks < 1 || ranks > 4096) fail("-ranks must be between 1 and 4096\n");
@@ -273,6 +275,16 @@ int main(int argc, char **argv)
         if (!state_transition || !state_supply || !state_final) fail("Failed to allocate array\n");
         memset(state_transition, -1, rows * alphabet * sizeof(int));
     }
+    int *sh_transition = NULL, *bmBc = NULL;
+    unsigned int *sh_final = NULL;
+    if (run_sh) { /* main.c:410-427: the Set-Horspool trie uses the same table shapes */
+        size_t rows = (size_t)m * p_size + 1;
+        sh_transition = (int *)malloc(rows * alphabet * sizeof(int));
+        sh_final = (unsigned int *)calloc(rows, sizeof(unsigned int));
+        bmBc = (int *)malloc(alphabet * sizeof(int));
+        if (!sh_transition || !sh_final || !bmBc) fail("Failed to allocate array\n");
+        memset(sh_transition, -1, rows * alphabet * sizeof(int));
+    }
     int *SHIFT = NULL, *PREFIX_value = NULL, *PREFIX_index = NULL, *PREFIX_size = NULL;
     if (run_wm) {
         wu_determine_shiftsize(alphabet);
@@ -296,6 +308,13 @@ int main(int argc, char **argv)
         printf("preproc_ac states \t%u\t patterns \t%u\t time \t%f\n", table->idcounter, table->patterncounter, now_seconds() - t0);
     }
     t0 = now_seconds();
+    struct ac_table *sh_table = NULL;
+    if (run_sh) {
+        preBmBc(pattern, m, p_size, alphabet, bmBc);
+        sh_table = preproc_sh(pattern, m, p_size, alphabet, sh_transition, sh_final);
+        printf("preproc_sh states \t%u\t patterns \t%u\t time \t%f\n", sh_table->idcounter, sh_table->patterncounter, now_seconds() - t0);
+    }
+    t0 = now_seconds();
     if (run_wm) {
         preproc_wu2(pattern2, m, p_size, alphabet, B, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
         int zero = 0;
@@ -305,6 +324,7 @@ int main(int argc, char **argv)
     fflush(stdout);
     if (dry) {
         if (table) free_ac(table, alphabet);
+        if (sh_table) free_sh(sh_table, alphabet);
         printf("dry run: no search\n");
         fflush(stdout);
         return 0;
@@ -312,7 +332,7 @@ int main(int argc, char **argv)
 
     /* main.c:464-489: rank r scans [r*c, min((r+1)*c + m-1, nFull)), c = ceil(nFull / R) */
     const int devices = smh_device_count();
-    long long ac_sum = 0, wm_sum = 0, wm_gpu_sum[5] = {0};
+    long long ac_sum = 0, sh_sum = 0, wm_sum = 0, wm_gpu_sum[5] = {0};
     double timeExecuteCPU = 0, gpuTime_sum[5] = {0};
     for (int r = 0; r < ranks; ++r) {
         uint64_t begin, end;
@@ -334,6 +354,21 @@ int main(int argc, char **argv)
             cuda_ac3(m, text, n, p_size, alphabet, state_transition, state_supply, state_final);
             cuda_ac4(m, text, n, p_size, alphabet, state_transition, state_supply, state_final);
             cuda_ac5(m, text, n, p_size, alphabet, state_transition, state_supply, state_final);
+        }
+        if (run_sh) {
+            /* multish, main.c:158-196 */
+            double t2 = now_seconds();
+            int matches = (int)search_sh(m, text, n, sh_table, bmBc);
+            double t3 = now_seconds();
+            timeExecuteCPU += t3 - t2;
+            printf("search_sh matches \t%i\t time \t%f\n", matches, t3 - t2);
+            fflush(stdout);
+            sh_sum += matches;
+            cuda_sh1(m, text, n, p_size, alphabet, sh_transition, sh_final, bmBc);
+            cuda_sh2(m, text, n, p_size, alphabet, sh_transition, sh_final, bmBc);
+            cuda_sh3(m, text, n, p_size, alphabet, sh_transition, sh_final, bmBc);
+            cuda_sh4(m, text, n, p_size, alphabet, sh_transition, sh_final, bmBc);
+            cuda_sh5(m, text, n, p_size, alphabet, sh_transition, sh_final, bmBc);
         }
         if (run_wm) {
             /* multiwm2, main.c:268-298 */
@@ -357,6 +392,15 @@ int main(int argc, char **argv)
 
     /* main.c:662-670 */
     if (run_ac) printf("Total results (ac): %lld.\n", ac_sum);
+    if (run_sh) printf("Total results (sh): %lld.\n", sh_sum);
+    if (run_sh && run_ac && sh_sum != ac_sum) {
+        fprintf(stderr, "Set-Horspool counted %lld, Aho-Corasick %lld\n", sh_sum, ac_sum);
+        exit(1);
+    }
+    if (run_sh && run_wm && sh_sum != wm_sum) {
+        fprintf(stderr, "Set-Horspool counted %lld, Wu-Manber %lld\n", sh_sum, wm_sum);
+        exit(1);
+    }
     if (run_wm) {
         printf("Total results: %lld.\n", wm_sum);
         for (i = 0; i < 5; i++)
@@ -375,6 +419,8 @@ int main(int argc, char **argv)
         for (i = 0; i < 5; i++) printf("gpuTime[%d]: %f.\n", (i + 1), gpuTime_sum[i] / ranks);
 
     if (table) free_ac(table, alphabet);
+    if (sh_table) free_sh(sh_table, alphabet);
+    free(sh_transition); free(sh_final); free(bmBc);
     for (j = 0; j < p_size; j++) free(pattern[j]);
     free(pattern); free(pattern2); free(textFull);
     free(state_transition); free(state_supply); free(state_final);

@@ -16,6 +16,7 @@ extern "C" {
 
 #define SMH_MAGIC_AC 0x41434446u /* "ACDF" */
 #define SMH_MAGIC_WM 0x574d424cu /* "WMBL" */
+#define SMH_MAGIC_SH 0x53485452u /* "SHTR" */
 
 void smh_set_error(const char *fmt, ...);
 
@@ -102,6 +103,34 @@ int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
 #define SMH_AC_LDS_BUDGET (160u * 1024u - 512u)
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
+
+/* ------------------------------------------------------------------ SH (Set-Horspool, sh_host.c)
+ * The reversed trie as the reference lays it out (for the table-walking kernel), the patterns read
+ * back from it, the valid bad-character table, and the tuned engine that scans them. */
+struct smh_sh_dev; /* opaque to C: device buffers, owned by smh_runtime.hip */
+struct smh_sh {
+    uint32_t magic;
+    int alphabet;
+    int m;
+    uint32_t states;        /* ids in use (== struct ac_table.idcounter of preproc_sh) */
+    uint32_t finals;        /* == patterncounter */
+    uint32_t n_patterns;    /* distinct patterns read back from the trie */
+    int32_t *g_transition;  /* states * alphabet: row 0 uses 0, the other rows -1, for "no edge" */
+    uint32_t *g_final;
+    unsigned char *patterns; /* n_patterns * m */
+    int32_t *valid_bmbc;    /* [alphabet] */
+    struct smh_wm *wm;      /* tuned engine: exactly one of wm / ac */
+    struct smh_ac *ac;
+    struct smh_sh_dev *dev;
+};
+struct smh_sh_table_box { /* handed out by preproc_sh: the public struct first */
+    struct ac_table pub;
+    uint32_t magic;
+    struct smh_sh *sh;
+};
+void smh_sh_host_free(struct smh_sh *sh);
+void smh_sh_dev_free(struct smh_sh_dev *dev); /* smh_runtime.hip */
+int smh_sh_check_bmbc(const struct smh_sh *sh, const int *bmBc);
 
 /* ------------------------------------------------------------------ WM
  * Device tables (DESIGN.md "WM layout"):

@@ -46,6 +46,19 @@ hipError_t smh_launch_ac_table(const smh_ac_table_launch &L, hipStream_t stream)
 hipError_t smh_launch_ac_positions(const smh_ac_verify_ctx &V, uint64_t *d_positions, uint64_t capacity,
                                    uint64_t *d_cursor, int n_cus, hipStream_t stream);
 
+struct smh_sh_table_launch {
+    const uint8_t *d_text;
+    uint64_t n;
+    int m;
+    int alphabet;
+    const int32_t *d_transition; /* reversed trie, reference layout */
+    const uint32_t *d_final;
+    const int32_t *d_bmbc;       /* alphabet entries */
+    uint64_t *d_count;
+    int n_cus;
+};
+hipError_t smh_launch_sh_table(const smh_sh_table_launch &L, hipStream_t stream);
+
 struct smh_wm_launch {
     const uint8_t *d_text;
     uint64_t n;

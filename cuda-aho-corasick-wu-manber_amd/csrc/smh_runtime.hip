@@ -509,6 +509,83 @@ extern "C" int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t
     });
 }
 
+/* ------------------------------------------------------------------ SH */
+struct smh_sh_dev {
+    int device;
+    int32_t *d_transition;
+    uint32_t *d_final;
+    int32_t *d_bmbc; /* the table of the last scan (alphabet entries) */
+};
+
+extern "C" void smh_sh_dev_free(struct smh_sh_dev *dev)
+{
+    if (!dev) return;
+    (void)hipFree(dev->d_transition);
+    (void)hipFree(dev->d_final);
+    (void)hipFree(dev->d_bmbc);
+    delete dev;
+}
+
+static int sh_ensure_device(struct smh_sh *sh)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (sh->dev && sh->dev->device == dev) return SMH_OK;
+    if (sh->dev) { smh_sh_dev_free(sh->dev); sh->dev = NULL; }
+    smh_sh_dev *d = new smh_sh_dev();
+    memset(d, 0, sizeof *d);
+    d->device = dev;
+    sh->dev = d;
+    int rc;
+    const size_t A = (size_t)sh->alphabet;
+    if ((rc = upload((void **)&d->d_transition, sh->g_transition, (size_t)sh->states * A * 4, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_final, sh->g_final, (size_t)sh->states * 4, 0)) != SMH_OK) return rc;
+    HIP_TRY(hipMalloc((void **)&d->d_bmbc, 256 * sizeof(int32_t)));
+    return SMH_OK;
+}
+
+extern "C" int smh_sh_scan(smh_sh *sh, const unsigned char *d_text, uint64_t n, const int *bmBc, uint64_t *d_count,
+                           int variant, void *stream)
+{
+    if (!sh || sh->magic != SMH_MAGIC_SH || !d_count || (n && !d_text)) {
+        smh_set_error("smh_sh_scan: bad arguments");
+        return SMH_EINVAL;
+    }
+    int rc = smh_sh_check_bmbc(sh, bmBc);
+    if (rc != SMH_OK) return rc;
+    if (n < (uint64_t)sh->m) return SMH_OK;
+    if (variant == SMH_VARIANT_TUNED) {
+        /* every column is tested: the shifts of a valid table only skip columns that end no match */
+        return sh->wm ? smh_wm_scan(sh->wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream)
+                      : smh_ac_scan(sh->ac, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
+    }
+    if (variant != SMH_VARIANT_TABLE) {
+        smh_set_error("smh_sh_scan: unknown variant %d", variant);
+        return SMH_EINVAL;
+    }
+    if ((rc = sh_ensure_device(sh)) != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    /* the table travels with the launch (stream-ordered copy from a pageable host buffer: the call
+     * returns after the copy has been staged) */
+    HIP_TRY(hipMemcpyAsync(sh->dev->d_bmbc, bmBc ? bmBc : sh->valid_bmbc, (size_t)sh->alphabet * sizeof(int32_t),
+                           hipMemcpyHostToDevice, (hipStream_t)stream));
+    smh_sh_table_launch L;
+    L.d_text = d_text; L.n = n; L.m = sh->m; L.alphabet = sh->alphabet;
+    L.d_transition = sh->dev->d_transition; L.d_final = sh->dev->d_final; L.d_bmbc = sh->dev->d_bmbc;
+    L.d_count = d_count; L.n_cus = n_cus;
+    HIP_TRY(smh_launch_sh_table(L, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_sh_count_host(smh_sh *sh, const unsigned char *text, uint64_t n, const int *bmBc, int variant,
+                                 uint64_t *count, double *kernel_seconds)
+{
+    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
+        return smh_sh_scan(sh, d_text, n, bmBc, d_count, variant, NULL);
+    });
+}
+
 /* ------------------------------------------------------------------ legacy names (smatcher.h) */
 static void die_with_error(const char *where)
 {
@@ -614,3 +691,42 @@ SMH_CUDA_WM(2, SMH_VARIANT_TABLE)
 SMH_CUDA_WM(3, SMH_VARIANT_TUNED)
 SMH_CUDA_WM(4, SMH_VARIANT_TUNED)
 SMH_CUDA_WM(5, SMH_VARIANT_TUNED)
+
+/* smatcher.h:94 / sh/sh.c:151-176 -- same count, computed by the tuned kernels */
+extern "C" unsigned search_sh(int m, unsigned char *text, int n, struct ac_table *table, int *bmBc)
+{
+    struct smh_sh_table_box *box = (struct smh_sh_table_box *)table;
+    if (!box || box->magic != SMH_MAGIC_SH) fail("search_sh: not a table from preproc_sh\n");
+    if (m != box->sh->m) fail("search_sh: m differs from the m given to preproc_sh\n");
+    uint64_t count = 0;
+    if (smh_sh_count_host(box->sh, text, n < 0 ? 0 : (uint64_t)n, bmBc, SMH_VARIANT_TUNED, &count, NULL) != SMH_OK)
+        die_with_error("search_sh");
+    return (unsigned)count;
+}
+
+static void cuda_sh_any(int k, int variant, int m, unsigned char *text, int n, int p_size, int alphabet,
+                        int *state_transition, unsigned int *state_final, int *bmBc)
+{
+    smh_sh *sh = smh_sh_compile_tables(state_transition, state_final, (uint64_t)m * p_size + 1, alphabet, m);
+    if (!sh) die_with_error("cuda_sh");
+    uint64_t count = 0;
+    double secs = 0.0;
+    if (smh_sh_count_host(sh, text, n < 0 ? 0 : (uint64_t)n, bmBc, variant, &count, &secs) != SMH_OK)
+        die_with_error("cuda_sh");
+    /* cuda/cuda_sh.cu:191 */
+    printf("Kernel %d matches \t%i\t time \t%f\n", k, (int)count, secs);
+    fflush(stdout);
+    smh_sh_free(sh);
+}
+
+#define SMH_CUDA_SH(K, VARIANT)                                                                        \
+    extern "C" void cuda_sh##K(int m, unsigned char *text, int n, int p_size, int alphabet,            \
+                               int *state_transition, unsigned int *state_final, int *bmBc)            \
+    {                                                                                                  \
+        cuda_sh_any(K, VARIANT, m, text, n, p_size, alphabet, state_transition, state_final, bmBc);    \
+    }
+SMH_CUDA_SH(1, SMH_VARIANT_TABLE)
+SMH_CUDA_SH(2, SMH_VARIANT_TABLE)
+SMH_CUDA_SH(3, SMH_VARIANT_TUNED)
+SMH_CUDA_SH(4, SMH_VARIANT_TUNED)
+SMH_CUDA_SH(5, SMH_VARIANT_TUNED)

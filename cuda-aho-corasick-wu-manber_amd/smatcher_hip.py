@@ -57,6 +57,11 @@ class PsetInfo(C.Structure):
                 ("reserved", C.c_uint32 * 2)]
 
 
+class ShInfo(C.Structure):
+    _fields_ = [("alphabet", C.c_uint32), ("m", C.c_uint32), ("states", C.c_uint32), ("finals", C.c_uint32),
+                ("tuned_engine", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
 class AcTable(C.Structure):
     """struct ac_table (include/smatcher.h)"""
     _fields_ = [("idcounter", C.c_uint), ("patterncounter", C.c_uint), ("zerostate", C.c_void_p)]
@@ -66,7 +71,8 @@ class AcTable(C.Structure):
 LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_shiftsize",
                    "preproc_wu", "preproc_wu2", "search_wu", "search_wu2", "m_nBitsInShift",
                    "shiftsize"]
-                  + ["cuda_ac%d" % k for k in range(1, 6)] + ["cuda_wm%d" % k for k in range(1, 6)])
+                  + ["cuda_ac%d" % k for k in range(1, 6)] + ["cuda_wm%d" % k for k in range(1, 6)]
+                  + ["preBmBc", "preproc_sh", "search_sh", "free_sh"] + ["cuda_sh%d" % k for k in range(1, 6)])
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
                "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
@@ -76,7 +82,8 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info",
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free", "smh_pset_compile", "smh_pset_get_info",
                "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
-               "smh_pset_free"]
+               "smh_pset_free", "smh_sh_compile_tables", "smh_sh_compile_patterns", "smh_sh_get_info",
+               "smh_sh_valid_bmbc", "smh_sh_scan", "smh_sh_count_host", "smh_sh_free"]
 
 
 def _load():
@@ -135,6 +142,28 @@ def _load():
     lib.smh_pset_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, u64p, dblp]
     lib.smh_pset_free.restype = None
     lib.smh_pset_free.argtypes = [C.c_void_p]
+    lib.smh_sh_compile_tables.restype = C.c_void_p
+    lib.smh_sh_compile_tables.argtypes = [i32p, u32p, C.c_uint64, C.c_int, C.c_int]
+    lib.smh_sh_compile_patterns.restype = C.c_void_p
+    lib.smh_sh_compile_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
+    lib.smh_sh_get_info.argtypes = [C.c_void_p, C.POINTER(ShInfo)]
+    lib.smh_sh_valid_bmbc.argtypes = [C.c_void_p, i32p]
+    lib.smh_sh_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, i32p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.smh_sh_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, i32p, C.c_int, u64p, dblp]
+    lib.smh_sh_free.restype = None
+    lib.smh_sh_free.argtypes = [C.c_void_p]
+    lib.preBmBc.restype = None
+    lib.preBmBc.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p]
+    lib.preproc_sh.restype = C.POINTER(AcTable)
+    lib.preproc_sh.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p, u32p]
+    lib.search_sh.restype = C.c_uint
+    lib.search_sh.argtypes = [C.c_int, u8p, C.c_int, C.POINTER(AcTable), i32p]
+    lib.free_sh.restype = None
+    lib.free_sh.argtypes = [C.POINTER(AcTable), C.c_int]
+    for k in range(1, 6):
+        f = getattr(lib, "cuda_sh%d" % k)
+        f.restype = None
+        f.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_int, i32p, u32p, i32p]
     # legacy names, with the reference's argument lists (smatcher.h)
     lib.preproc_ac.restype = C.POINTER(AcTable)
     lib.preproc_ac.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p, u32p, u32p]
@@ -358,6 +387,65 @@ class PatternSet:
     def close(self):
         if self.h:
             lib.smh_pset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShTrie:
+    """smh_sh handle: Set-Horspool reversed trie + tuned engine."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise SmhError("SH compile failed: %s" % lib.smh_last_error().decode())
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def from_patterns(cls, pat_flat, m, p, alphabet):
+        a, ptr = _u8(pat_flat)
+        return cls(lib.smh_sh_compile_patterns(ptr, m, p, alphabet))
+
+    @classmethod
+    def from_tables(cls, state_transition, state_final, rows, alphabet, m):
+        return cls(lib.smh_sh_compile_tables(state_transition.ctypes.data_as(i32p), state_final.ctypes.data_as(u32p),
+                                             rows, alphabet, m))
+
+    def info(self):
+        out = ShInfo()
+        _check(lib.smh_sh_get_info(self.h, C.byref(out)), "smh_sh_get_info")
+        return out
+
+    def valid_bmbc(self):
+        out = np.zeros(self.info().alphabet, dtype=np.int32)
+        _check(lib.smh_sh_valid_bmbc(self.h, out.ctypes.data_as(i32p)), "smh_sh_valid_bmbc")
+        return out
+
+    @staticmethod
+    def _bm(bmbc):
+        if bmbc is None:
+            return None, None
+        b = np.ascontiguousarray(bmbc, dtype=np.int32)
+        return b, b.ctypes.data_as(i32p)
+
+    def scan_device(self, d_text_ptr, n, d_count_ptr, bmbc=None, variant=VARIANT_TUNED, stream=None):
+        keep, b = self._bm(bmbc)
+        _check(lib.smh_sh_scan(self.h, C.c_void_p(d_text_ptr), n, b, C.c_void_p(d_count_ptr), variant,
+                               C.c_void_p(stream or 0)), "smh_sh_scan")
+
+    def count_host(self, text, bmbc=None, variant=VARIANT_TUNED):
+        t, ptr = _u8(text)
+        keep, b = self._bm(bmbc)
+        cnt, secs = C.c_uint64(), C.c_double()
+        _check(lib.smh_sh_count_host(self.h, ptr, len(t), b, variant, C.byref(cnt), C.byref(secs)), "smh_sh_count_host")
+        return cnt.value, secs.value
+
+    def close(self):
+        if self.h:
+            lib.smh_sh_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -123,6 +123,29 @@ int cuda_wm5(unsigned char *pattern_flat, int m, unsigned char *text, int n, int
              int alphabet, int B, int *SHIFT, int *PREFIX_value, int *PREFIX_index,
              int *PREFIX_size, double *gpuTime);
 
+/* ---- Set-Horspool (smatcher.h:93-95, sh/sh.c) ----
+ * preproc_sh fills the caller's state_transition / state_final (pre-initialised like the AC tables:
+ * -1 / 0, main.c:410-420) with the REVERSED trie of the patterns, numbered as sh/sh.c:82-149 does.
+ * preBmBc is the bad-character table main.c:173 obtains from the reference's missing helper.
+ * search_sh / cuda_sh1..5 (cuda/cuda_sh.cu:110,289,429,558,687) count on the GPU; cuda_shK print
+ * "Kernel K matches \t%i\t time \t%f\n" (cuda/cuda_sh.cu:191).  K = 1,2 walk the reversed trie as
+ * given with the bmBc skip loop, K = 3,4,5 and search_sh run the tuned kernels. */
+void preBmBc(unsigned char **pattern, int m, int p_size, int alphabet, int *bmBc);
+struct ac_table *preproc_sh(unsigned char **pattern, int m, int p_size, int alphabet,
+                            int *state_transition, unsigned int *state_final);
+unsigned search_sh(int m, unsigned char *text, int n, struct ac_table *table, int *bmBc);
+void free_sh(struct ac_table *table, int alphabet);
+void cuda_sh1(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_final, int *bmBc);
+void cuda_sh2(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_final, int *bmBc);
+void cuda_sh3(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_final, int *bmBc);
+void cuda_sh4(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_final, int *bmBc);
+void cuda_sh5(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
+              unsigned int *state_final, int *bmBc);
+
 #ifdef __cplusplus
 }
 #endif

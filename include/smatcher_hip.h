@@ -159,6 +159,37 @@ int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int var
                       uint64_t *count, double *kernel_seconds);
 void smh_wm_free(smh_wm *wm);
 
+/* ---- Set-Horspool (sh/sh.c, cuda/cuda_sh.cu) ----
+ * The reversed trie of the patterns plus a bad-character table.  SMH_VARIANT_TABLE walks the
+ * reference-layout trie as given with the caller's bmBc driving a per-lane skip loop;
+ * SMH_VARIANT_TUNED scans the patterns read back from the trie with the tuned Wu-Manber kernels (the
+ * first levels of a reversed trie are a suffix-block filter, the rest its verify stage) or, for sets
+ * Wu-Manber cannot take (m < 3, other alphabets), the automaton kernels.  Both return the number of
+ * end columns of pattern occurrences, which is what search_sh counts for a valid bmBc. */
+typedef struct smh_sh smh_sh;
+typedef struct smh_sh_info {
+    uint32_t alphabet;
+    uint32_t m;
+    uint32_t states;        /* == struct ac_table.idcounter of preproc_sh */
+    uint32_t finals;        /* == patterncounter */
+    uint32_t tuned_engine;  /* SMH_ALGO_WM or SMH_ALGO_AC */
+    uint32_t reserved[3];
+} smh_sh_info;
+/* from the reference-layout tables preproc_sh filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
+smh_sh *smh_sh_compile_tables(const int *state_transition, const unsigned int *state_final, uint64_t rows,
+                              int alphabet, int m);
+smh_sh *smh_sh_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
+int smh_sh_get_info(const smh_sh *sh, smh_sh_info *out);
+/* the valid set-Horspool table of the handle's patterns: bmBc[alphabet] */
+int smh_sh_valid_bmbc(const smh_sh *sh, int *bmBc);
+/* asynchronous, same contract as smh_ac_scan.  bmBc (host, alphabet ints) may be NULL = the valid table;
+ * an entry outside 1..valid is refused (SMH_EINVAL): the reference would skip matches with it */
+int smh_sh_scan(smh_sh *sh, const unsigned char *d_text, uint64_t n, const int *bmBc, uint64_t *d_count,
+                int variant, void *stream);
+int smh_sh_count_host(smh_sh *sh, const unsigned char *text, uint64_t n, const int *bmBc, int variant,
+                      uint64_t *count, double *kernel_seconds);
+void smh_sh_free(smh_sh *sh);
+
 /* ---- pattern sets with mixed lengths ----
  * The reference API carries ONE pattern length per run (preproc_ac / preproc_wu take a single m;
  * feeding ac_addstring mixed lengths marks wrong states final, ac/ac.c:136-143,183-186), so the

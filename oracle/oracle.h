@@ -57,6 +57,16 @@ uint64_t ora_search_ac_tables(const uint8_t *text, int64_t n, int alphabet,
                               const uint32_t *state_final);
 void ora_free_ac(ora_ac_table *t);
 
+/* ---- Set-Horspool (sh/sh.c) ---- */
+/* tables caller-owned and pre-initialised as for AC: state_transition <- -1, state_final <- 0 */
+void ora_preproc_sh(const uint8_t *const *pattern, int m, int p_size, int alphabet,
+                    int32_t *state_transition, uint32_t *state_final,
+                    uint32_t *idcounter_out, uint32_t *patterncounter_out);
+/* the bad-character table main.c:173 gets from the (missing) helper's preBmBc */
+void ora_pre_bmbc(const uint8_t *const *pattern, int m, int p_size, int alphabet, int32_t *bmBc);
+uint64_t ora_search_sh(int m, const uint8_t *text, int64_t n, int alphabet,
+                       const int32_t *state_transition, const uint32_t *state_final, const int32_t *bmBc);
+
 /* ---- Wu-Manber (wu/wu.c) ---- */
 /* returns the table length for an alphabet, 0 if unsupported (reference calls fail()) */
 uint32_t ora_wu_determine_shiftsize(int alphabet);

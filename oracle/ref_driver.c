@@ -103,3 +103,34 @@ unsigned long long ref_run_wu(const unsigned char *pat_flat, int m, int p_size, 
     if (t_search) *t_search = t2 - t1;
     return matches;
 }
+
+/* Set-Horspool, main.c:158-196 (multish): preproc_sh then search_sh with the caller's bmBc (the
+ * reference gets it from preBmBc in its missing helper; the tests pass the oracle's ora_pre_bmbc) */
+unsigned long long ref_run_sh(const unsigned char *pat_flat, int m, int p_size, int alphabet,
+                              const unsigned char *text, int n, int *state_transition,
+                              unsigned int *state_final, int *bmBc,
+                              unsigned int *idcounter, unsigned int *patterncounter,
+                              double *t_preproc, double *t_search)
+{
+    size_t rows = (size_t)m * p_size + 1;
+    memset(state_transition, -1, rows * alphabet * sizeof(int));
+    memset(state_final, 0, rows * sizeof(unsigned int));
+    unsigned char **pattern = (unsigned char **)malloc((size_t)p_size * sizeof(unsigned char *));
+    for (int j = 0; j < p_size; j++) {
+        pattern[j] = (unsigned char *)calloc((size_t)m + 1, 1);
+        memcpy(pattern[j], pat_flat + (size_t)j * m, (size_t)m);
+    }
+    double t0 = now_s();
+    struct ac_table *table = preproc_sh(pattern, m, p_size, alphabet, state_transition, state_final);
+    double t1 = now_s();
+    unsigned int matches = text ? search_sh(m, (unsigned char *)text, n, table, bmBc) : 0;
+    double t2 = now_s();
+    if (idcounter) *idcounter = table->idcounter;
+    if (patterncounter) *patterncounter = table->patterncounter;
+    if (t_preproc) *t_preproc = t1 - t0;
+    if (t_search) *t_search = t2 - t1;
+    free_sh(table, alphabet);
+    for (int j = 0; j < p_size; j++) free(pattern[j]);
+    free(pattern);
+    return matches;
+}

@@ -242,3 +242,30 @@ extern "C" uint64_t emu_wm_positions(const smh_wm *wm, const uint8_t *text, uint
     free(sh);
     return cursor;
 }
+
+/* ------------------------------------------------------------------ SH */
+#include "sh_lane.h"
+
+/* variant TABLE: the reversed-trie walk with the bmBc skip loop (sh_lane.h); TUNED: the engine the
+ * handle compiled (the Wu-Manber or the automaton lane code above).  bmbc NULL = the valid table. */
+extern "C" uint64_t emu_sh_scan(const smh_sh *sh, const uint8_t *text_in, uint64_t n, const int32_t *bmbc, int variant,
+                                uint32_t blocks)
+{
+    if (n < (uint64_t)sh->m) return 0;
+    if (variant == SMH_VARIANT_TUNED)
+        return sh->wm ? emu_wm_scan(sh->wm, text_in, n, SMH_VARIANT_TUNED, blocks)
+                      : emu_ac_scan(sh->ac, text_in, n, SMH_VARIANT_TUNED, blocks);
+    if (!blocks) blocks = 3;
+    uint64_t result[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        const uint64_t nthreads = (uint64_t)blocks * 256;
+        uint64_t total = 0;
+        for (uint64_t t = 0; t < nthreads; ++t)
+            total += smh_sh_table_thread<int32_t>(t, nthreads, g.text, n, sh->g_transition, sh->g_final,
+                                                  bmbc ? bmbc : sh->valid_bmbc, sh->m, sh->alphabet);
+        guard_free(g);
+        result[mode] = total;
+    }
+    return result[0] == result[1] ? result[0] : ~0ull;
+}

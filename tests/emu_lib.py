@@ -52,3 +52,16 @@ def ac_positions(ac, text, capacity, blocks=0):
 
 def wm_positions(wm, text, capacity, blocks=0):
     return _positions(_emu.emu_wm_positions, wm.h, text, capacity, blocks)
+
+
+_emu.emu_sh_scan.restype = C.c_uint64
+_emu.emu_sh_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, S.i32p, C.c_int, C.c_uint32]
+
+
+def sh_scan(sh, text, bmbc=None, variant=S.VARIANT_TUNED, blocks=0):
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    b = None
+    if bmbc is not None:
+        bmbc = np.ascontiguousarray(bmbc, dtype=np.int32)
+        b = bmbc.ctypes.data_as(S.i32p)
+    return int(_emu.emu_sh_scan(sh.h, text.ctypes.data_as(S.u8p), len(text), b, variant, blocks))

@@ -52,6 +52,12 @@ def _load():
     lib.ora_search_ac_tables.restype = C.c_uint64
     lib.ora_search_ac_tables.argtypes = [u8p, C.c_int64, C.c_int, i32p, u32p, u32p]
     lib.ora_free_ac.argtypes = [C.c_void_p]
+    lib.ora_preproc_sh.restype = None
+    lib.ora_preproc_sh.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p, u32p, u32p, u32p]
+    lib.ora_pre_bmbc.restype = None
+    lib.ora_pre_bmbc.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p]
+    lib.ora_search_sh.restype = C.c_uint64
+    lib.ora_search_sh.argtypes = [C.c_int, u8p, C.c_int64, C.c_int, i32p, u32p, i32p]
     lib.ora_wu_determine_shiftsize.restype = C.c_uint32
     lib.ora_wu_determine_shiftsize.argtypes = [C.c_int]
     wu_tabs = [i32p, i32p, i32p, i32p]
@@ -229,6 +235,63 @@ def positions_bruteforce(pat_flat, m, p, text):
 
 
 # ------------------------------------------------------------------ compiled reference
+# ------------------------------------------------------------------ Set-Horspool
+class SHTables:
+    """Flat tables as main.c:410-420,427 allocates them for multish: the reversed trie and bmBc."""
+
+    def __init__(self, m, p, sigma):
+        rows = m * p + 1
+        self.m, self.p, self.sigma, self.rows = m, p, sigma, rows
+        self.state_transition = np.full(rows * sigma, -1, dtype=np.int32)
+        self.state_final = np.zeros(rows, dtype=np.uint32)
+        self.bmBc = np.zeros(sigma, dtype=np.int32)
+        self.idcounter = 0
+        self.patterncounter = 0
+
+
+def pre_bmbc(pat_flat, m, p, sigma):
+    """The set-Horspool bad-character table the reference's missing helper computes (oracle/ora_sh.c)."""
+    out = np.zeros(sigma, dtype=np.int32)
+    arr, keep = _pattern_ptrs(pat_flat, m, p)
+    lib.ora_pre_bmbc(arr, m, p, sigma, _ptr(out, i32p))
+    del keep
+    return out
+
+
+def oracle_sh(pat_flat, m, p, sigma, text=None):
+    """-> (count or None, SHTables) from the restatement (oracle/ora_sh.c)."""
+    t = SHTables(m, p, sigma)
+    arr, keep = _pattern_ptrs(pat_flat, m, p)
+    idc, pc = C.c_uint32(), C.c_uint32()
+    lib.ora_preproc_sh(arr, m, p, sigma, _ptr(t.state_transition, i32p), _ptr(t.state_final, u32p),
+                       C.byref(idc), C.byref(pc))
+    lib.ora_pre_bmbc(arr, m, p, sigma, _ptr(t.bmBc, i32p))
+    t.idcounter, t.patterncounter = idc.value, pc.value
+    count = None
+    if text is not None:
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        count = int(lib.ora_search_sh(m, _ptr(text, u8p), len(text), sigma, _ptr(t.state_transition, i32p),
+                                      _ptr(t.state_final, u32p), _ptr(t.bmBc, i32p)))
+    del keep
+    return count, t
+
+
+def ref_sh(pat_flat, m, p, sigma, text=None, bmBc=None):
+    """-> (count, SHTables) from the reference's own sh/sh.c; bmBc defaults to the oracle's table."""
+    t = SHTables(m, p, sigma)
+    pat_flat = np.ascontiguousarray(pat_flat, dtype=np.uint8)
+    t.bmBc = np.ascontiguousarray(bmBc if bmBc is not None else pre_bmbc(pat_flat, m, p, sigma), dtype=np.int32)
+    idc, pc = C.c_uint32(), C.c_uint32()
+    tp, ts = C.c_double(), C.c_double()
+    tptr = _ptr(np.ascontiguousarray(text, dtype=np.uint8), u8p) if text is not None else None
+    n = len(text) if text is not None else 0
+    cnt = ref().ref_run_sh(_ptr(pat_flat, u8p), m, p, sigma, tptr, n, _ptr(t.state_transition, i32p),
+                           _ptr(t.state_final, u32p), _ptr(t.bmBc, i32p), C.byref(idc), C.byref(pc),
+                           C.byref(tp), C.byref(ts))
+    t.idcounter, t.patterncounter = idc.value, pc.value
+    return (int(cnt) if text is not None else None), t
+
+
 def have_ref():
     return os.path.exists(_REF)
 
@@ -244,6 +307,9 @@ def ref():
         r.ref_shiftsize.argtypes = [C.c_int]
         r.ref_run_ac.restype = C.c_ulonglong
         r.ref_run_ac.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, i32p, u32p, u32p,
+                                 u32p, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        r.ref_run_sh.restype = C.c_ulonglong
+        r.ref_run_sh.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, i32p, u32p, i32p,
                                  u32p, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         r.ref_run_wu.restype = C.c_ulonglong
         r.ref_run_wu.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, i32p, i32p, i32p,

@@ -51,7 +51,7 @@ def run(args, cwd):
 @no_spawn
 def test_help_and_argument_errors(tmp_path):
     r = run(["--help"], tmp_path)
-    assert r.returncode == 0 and "Usage: smatcher <ac|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet>" in r.stdout
+    assert r.returncode == 0 and "Usage: smatcher <ac|sh|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet>" in r.stdout
     assert run(["ac", "-m", "8"], tmp_path).stdout.startswith("smatcher - ")  # main.c:364-365: missing arguments -> usage
     r = run(["wm", "-m", "8", "-p_size", "100001", "-n", "1000", "-alphabet", "4"], tmp_path)
     assert r.returncode == 1 and "Only up to 100.000 patterns are supported" in r.stderr  # main.c:370-371
@@ -77,6 +77,8 @@ def test_create_then_dry_run_builds_the_reference_tables(tmp_path):
     assert hits == p // 2  # create_multiple_pattern_with_hits' role: every even pattern occurs in the text
     _, t = O.oracle_ac(pat, m, p, sigma)
     assert "preproc_ac states \t%d\t patterns \t%d\t" % (t.idcounter, t.patterncounter) in r.stdout
+    ts = O.oracle_sh(pat, m, p, sigma)[1]
+    assert "preproc_sh states \t%d\t patterns \t%d\t" % (ts.idcounter, ts.patterncounter) in r.stdout
     assert "text symbols \t%d\t fnv1a64 \t%016x\n" % (n, fnv1a64(text)) in r.stdout
     # second run: files exist, nothing is created, same tables
     r2 = run(args + ["-dry"], tmp_path)
@@ -130,8 +132,9 @@ def test_driver_totals_match_oracle_on_a_fasta_text(tmp_path, capfd, ranks):
     want, _ = O.oracle_ac(pat, m, p, sigma, sym)
     assert want >= p // 2
     assert "Total results (ac): %d.\n" % want in out and "Total results: %d.\n" % want in out
+    assert "Total results (sh): %d.\n" % want in out and out.count("search_sh matches") == ranks
     assert out.count("search_ac matches") == ranks and out.count("search_wm2 matches") == ranks
-    assert out.count("Kernel 5 matches") == ranks and "gpuTime[5]:" in out
+    assert out.count("Kernel 5 matches") == 2 * ranks and "gpuTime[5]:" in out  # cuda_ac5 and cuda_sh5
     per_rank = [int(ln.split("\t")[1]) for ln in out.splitlines() if ln.startswith("search_ac matches")]
     shard = []
     for r in range(ranks):
