@@ -11,7 +11,8 @@
  *                                               MPI_Reduce does, main.c:656)
  *   multiac / multiwm2        main.c:125-157 / 268-298   ("search_ac matches \t%i\t time \t%f\n")
  *   multish                   main.c:158-196             (preBmBc, preproc_sh, search_sh)
- *   cuda_ac1..5 / cuda_wm1..5 main.c:582-648, cuda_sh1..5 main.c:595-605
+ *   multisbom                 main.c:197-231             (preproc_sbom, search_sbom)
+ *   cuda_ac1..5 / cuda_wm1..5 main.c:582-648, cuda_sh1..5 / cuda_sbom1..5 main.c:595-618
  *   report                    main.c:662-670   ("Total results: %d." ...)
  *
  * Data formats (upstream's load_files / create_multiple_pattern_with_hits live in the missing
@@ -46,7 +47,7 @@ static double now_seconds(void)
 static void usage(void)
 {
     printf("smatcher - multiple pattern matching (Aho-Corasick, Wu-Manber) on MI355X\n");
-    printf("Usage: smatcher <ac|sh|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet> [options]\n");
+    printf("Usage: smatcher <ac|sh|sbom|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet> [options]\n");
     printf("-h,--help\t\t print this help message\n");
     printf("-c\t\t\t create the data files that are missing\n");
     printf("-data <dir>\t\t data directory (default ./data-cuda-multi)\n");
@@ -196,7 +197,8 @@ int main(int argc, char **argv)
     const int run_ac = strcmp(algo, "ac") == 0 || strcmp(algo, "all") == 0;
     const int run_wm = strcmp(algo, "wm") == 0 || strcmp(algo, "all") == 0;
     const int run_sh = strcmp(algo, "sh") == 0 || strcmp(algo, "all") == 0;
-    if (m == 0 || nFull == 0 || p_size == 0 || alphabet == 0 || (!run_ac && !run_wm && !run_sh)) usage();
+    const int run_sbom = strcmp(algo, "sbom") == 0 || strcmp(algo, "all") == 0;
+    if (m == 0 || nFull == 0 || p_size == 0 || alphabet == 0 || (!run_ac && !run_wm && !run_sh && !run_sbom)) usage();
     if (p_size > 100000) fail("Only up to 100.000 patterns are supported\n"); /* main.c:370-371 */
     if (m < 3) fail("The pattern length must be at least 3 (Wu-Manber block size)\n");
     if (ranks < 1 || ranks > 4096) fail("-ranks must be between 1 and 4096\n");
@@ -285,6 +287,15 @@ int main(int argc, char **argv)
         if (!sh_transition || !sh_final || !bmBc) fail("Failed to allocate array\n");
         memset(sh_transition, -1, rows * alphabet * sizeof(int));
     }
+    int *sbom_transition = NULL;
+    unsigned int *state_final_multi = NULL;
+    if (run_sbom) { /* main.c:410-412,422-425 */
+        size_t rows = (size_t)m * p_size + 1;
+        sbom_transition = (int *)malloc(rows * alphabet * sizeof(int));
+        state_final_multi = (unsigned int *)calloc(rows * 200, sizeof(unsigned int));
+        if (!sbom_transition || !state_final_multi) fail("Failed to allocate array\n");
+        memset(sbom_transition, -1, rows * alphabet * sizeof(int));
+    }
     int *SHIFT = NULL, *PREFIX_value = NULL, *PREFIX_index = NULL, *PREFIX_size = NULL;
     if (run_wm) {
         wu_determine_shiftsize(alphabet);
@@ -315,6 +326,12 @@ int main(int argc, char **argv)
         printf("preproc_sh states \t%u\t patterns \t%u\t time \t%f\n", sh_table->idcounter, sh_table->patterncounter, now_seconds() - t0);
     }
     t0 = now_seconds();
+    struct sbom_table *sbom_table = NULL;
+    if (run_sbom) {
+        sbom_table = preproc_sbom(pattern, m, p_size, alphabet, sbom_transition, state_final_multi);
+        printf("preproc_sbom states \t%u\t patterns \t%u\t time \t%f\n", sbom_table->idcounter, sbom_table->patterncounter, now_seconds() - t0);
+    }
+    t0 = now_seconds();
     if (run_wm) {
         preproc_wu2(pattern2, m, p_size, alphabet, B, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
         int zero = 0;
@@ -325,6 +342,7 @@ int main(int argc, char **argv)
     if (dry) {
         if (table) free_ac(table, alphabet);
         if (sh_table) free_sh(sh_table, alphabet);
+        if (sbom_table) free_sbom(sbom_table, m);
         printf("dry run: no search\n");
         fflush(stdout);
         return 0;
@@ -332,7 +350,7 @@ int main(int argc, char **argv)
 
     /* main.c:464-489: rank r scans [r*c, min((r+1)*c + m-1, nFull)), c = ceil(nFull / R) */
     const int devices = smh_device_count();
-    long long ac_sum = 0, sh_sum = 0, wm_sum = 0, wm_gpu_sum[5] = {0};
+    long long ac_sum = 0, sh_sum = 0, sbom_sum = 0, wm_sum = 0, wm_gpu_sum[5] = {0};
     double timeExecuteCPU = 0, gpuTime_sum[5] = {0};
     for (int r = 0; r < ranks; ++r) {
         uint64_t begin, end;
@@ -370,6 +388,21 @@ int main(int argc, char **argv)
             cuda_sh4(m, text, n, p_size, alphabet, sh_transition, sh_final, bmBc);
             cuda_sh5(m, text, n, p_size, alphabet, sh_transition, sh_final, bmBc);
         }
+        if (run_sbom) {
+            /* multisbom, main.c:197-231 */
+            double t2 = now_seconds();
+            int matches = (int)search_sbom(pattern, m, text, n, sbom_table);
+            double t3 = now_seconds();
+            timeExecuteCPU += t3 - t2;
+            printf("search_sbom matches \t%i\t time \t%f\n", matches, t3 - t2);
+            fflush(stdout);
+            sbom_sum += matches;
+            cuda_sbom1(pattern2, m, text, n, p_size, alphabet, sbom_transition, state_final_multi);
+            cuda_sbom2(pattern2, m, text, n, p_size, alphabet, sbom_transition, state_final_multi);
+            cuda_sbom3(pattern2, m, text, n, p_size, alphabet, sbom_transition, state_final_multi);
+            cuda_sbom4(pattern2, m, text, n, p_size, alphabet, sbom_transition, state_final_multi);
+            cuda_sbom5(pattern2, m, text, n, p_size, alphabet, sbom_transition, state_final_multi);
+        }
         if (run_wm) {
             /* multiwm2, main.c:268-298 */
             double t2 = now_seconds();
@@ -393,6 +426,11 @@ int main(int argc, char **argv)
     /* main.c:662-670 */
     if (run_ac) printf("Total results (ac): %lld.\n", ac_sum);
     if (run_sh) printf("Total results (sh): %lld.\n", sh_sum);
+    if (run_sbom) printf("Total results (sbom): %lld.\n", sbom_sum);
+    if (run_sbom && ((run_ac && sbom_sum != ac_sum) || (run_sh && sbom_sum != sh_sum) || (run_wm && sbom_sum != wm_sum))) {
+        fprintf(stderr, "SBOM counted %lld; the other algorithms disagree\n", sbom_sum);
+        exit(1);
+    }
     if (run_sh && run_ac && sh_sum != ac_sum) {
         fprintf(stderr, "Set-Horspool counted %lld, Aho-Corasick %lld\n", sh_sum, ac_sum);
         exit(1);
@@ -421,6 +459,8 @@ int main(int argc, char **argv)
     if (table) free_ac(table, alphabet);
     if (sh_table) free_sh(sh_table, alphabet);
     free(sh_transition); free(sh_final); free(bmBc);
+    if (sbom_table) free_sbom(sbom_table, m);
+    free(sbom_transition); free(state_final_multi);
     for (j = 0; j < p_size; j++) free(pattern[j]);
     free(pattern); free(pattern2); free(textFull);
     free(state_transition); free(state_supply); free(state_final);

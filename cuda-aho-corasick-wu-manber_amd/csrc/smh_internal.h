@@ -17,6 +17,7 @@ extern "C" {
 #define SMH_MAGIC_AC 0x41434446u /* "ACDF" */
 #define SMH_MAGIC_WM 0x574d424cu /* "WMBL" */
 #define SMH_MAGIC_SH 0x53485452u /* "SHTR" */
+#define SMH_MAGIC_SBOM 0x53424f4du /* "SBOM" */
 
 void smh_set_error(const char *fmt, ...);
 
@@ -131,6 +132,33 @@ struct smh_sh_table_box { /* handed out by preproc_sh: the public struct first *
 void smh_sh_host_free(struct smh_sh *sh);
 void smh_sh_dev_free(struct smh_sh_dev *dev); /* smh_runtime.hip */
 int smh_sh_check_bmbc(const struct smh_sh *sh, const int *bmBc);
+
+/* ------------------------------------------------------------------ SBOM (sbom_host.c)
+ * The factor oracle as the reference lays it out, its per-state pattern lists packed from the
+ * 200-entry rows into offsets + ids, the patterns, and the tuned engine that scans them. */
+struct smh_sbom_dev;
+struct smh_sbom {
+    uint32_t magic;
+    int alphabet;
+    int m;
+    uint32_t states;
+    uint32_t n_patterns;   /* as given, duplicates included (== patterncounter) */
+    uint32_t listed;       /* entries over all per-state lists */
+    int32_t *g_transition; /* states * alphabet: trie edges and external transitions */
+    uint32_t *g_final_off; /* [states + 1] */
+    uint32_t *g_final_ids; /* pattern ids, in list order */
+    unsigned char *patterns; /* n_patterns * m */
+    struct smh_wm *wm;     /* tuned engine: exactly one of wm / ac */
+    struct smh_ac *ac;
+    struct smh_sbom_dev *dev;
+};
+struct smh_sbom_table_box { /* handed out by preproc_sbom: the public struct first */
+    struct sbom_table pub;
+    uint32_t magic;
+    struct smh_sbom *sb;
+};
+void smh_sbom_host_free(struct smh_sbom *sb);
+void smh_sbom_dev_free(struct smh_sbom_dev *dev); /* smh_runtime.hip */
 
 /* ------------------------------------------------------------------ WM
  * Device tables (DESIGN.md "WM layout"):

@@ -59,6 +59,20 @@ struct smh_sh_table_launch {
 };
 hipError_t smh_launch_sh_table(const smh_sh_table_launch &L, hipStream_t stream);
 
+struct smh_sbom_table_launch {
+    const uint8_t *d_text;
+    uint64_t n;
+    int m;
+    int alphabet;
+    const int32_t *d_transition;  /* factor oracle, reference layout */
+    const uint32_t *d_final_off;  /* [states + 1] */
+    const uint32_t *d_final_ids;
+    const uint8_t *d_patterns;    /* n_patterns * m */
+    uint64_t *d_count;
+    int n_cus;
+};
+hipError_t smh_launch_sbom_table(const smh_sbom_table_launch &L, hipStream_t stream);
+
 struct smh_wm_launch {
     const uint8_t *d_text;
     uint64_t n;

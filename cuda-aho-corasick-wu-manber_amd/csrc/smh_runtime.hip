@@ -586,6 +586,79 @@ extern "C" int smh_sh_count_host(smh_sh *sh, const unsigned char *text, uint64_t
     });
 }
 
+/* ------------------------------------------------------------------ SBOM */
+struct smh_sbom_dev {
+    int device;
+    int32_t *d_transition;
+    uint32_t *d_final_off;
+    uint32_t *d_final_ids;
+    uint8_t *d_patterns;
+};
+
+extern "C" void smh_sbom_dev_free(struct smh_sbom_dev *dev)
+{
+    if (!dev) return;
+    (void)hipFree(dev->d_transition);
+    (void)hipFree(dev->d_final_off);
+    (void)hipFree(dev->d_final_ids);
+    (void)hipFree(dev->d_patterns);
+    delete dev;
+}
+
+static int sbom_ensure_device(struct smh_sbom *sb)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (sb->dev && sb->dev->device == dev) return SMH_OK;
+    if (sb->dev) { smh_sbom_dev_free(sb->dev); sb->dev = NULL; }
+    smh_sbom_dev *d = new smh_sbom_dev();
+    memset(d, 0, sizeof *d);
+    d->device = dev;
+    sb->dev = d;
+    int rc;
+    const size_t A = (size_t)sb->alphabet;
+    if ((rc = upload((void **)&d->d_transition, sb->g_transition, (size_t)sb->states * A * 4, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_final_off, sb->g_final_off, ((size_t)sb->states + 1) * 4, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_final_ids, sb->g_final_ids, (size_t)sb->listed * 4, 0)) != SMH_OK) return rc;
+    if ((rc = upload((void **)&d->d_patterns, sb->patterns, (size_t)sb->n_patterns * sb->m, 0)) != SMH_OK) return rc;
+    return SMH_OK;
+}
+
+extern "C" int smh_sbom_scan(smh_sbom *sb, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
+                             void *stream)
+{
+    if (!sb || sb->magic != SMH_MAGIC_SBOM || !d_count || (n && !d_text)) {
+        smh_set_error("smh_sbom_scan: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (n < (uint64_t)sb->m) return SMH_OK;
+    if (variant == SMH_VARIANT_TUNED)
+        return sb->wm ? smh_wm_scan(sb->wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream)
+                      : smh_ac_scan(sb->ac, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
+    if (variant != SMH_VARIANT_TABLE) {
+        smh_set_error("smh_sbom_scan: unknown variant %d", variant);
+        return SMH_EINVAL;
+    }
+    int rc = sbom_ensure_device(sb);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_sbom_table_launch L;
+    L.d_text = d_text; L.n = n; L.m = sb->m; L.alphabet = sb->alphabet;
+    L.d_transition = sb->dev->d_transition; L.d_final_off = sb->dev->d_final_off; L.d_final_ids = sb->dev->d_final_ids;
+    L.d_patterns = sb->dev->d_patterns; L.d_count = d_count; L.n_cus = n_cus;
+    HIP_TRY(smh_launch_sbom_table(L, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_sbom_count_host(smh_sbom *sb, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
+                                   double *kernel_seconds)
+{
+    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
+        return smh_sbom_scan(sb, d_text, n, d_count, variant, NULL);
+    });
+}
+
 /* ------------------------------------------------------------------ legacy names (smatcher.h) */
 static void die_with_error(const char *where)
 {
@@ -730,3 +803,45 @@ SMH_CUDA_SH(2, SMH_VARIANT_TABLE)
 SMH_CUDA_SH(3, SMH_VARIANT_TUNED)
 SMH_CUDA_SH(4, SMH_VARIANT_TUNED)
 SMH_CUDA_SH(5, SMH_VARIANT_TUNED)
+
+/* smatcher.h:98 / sbom/sbom.c:128-172 -- same count, computed by the tuned kernels.  `pattern` is the
+ * array preproc_sbom was given (the reference compares against it; the handle holds its own copy). */
+extern "C" unsigned search_sbom(unsigned char **pattern, int m, unsigned char *text, int n, struct sbom_table *table)
+{
+    (void)pattern;
+    struct smh_sbom_table_box *box = (struct smh_sbom_table_box *)table;
+    if (!box || box->magic != SMH_MAGIC_SBOM) fail("search_sbom: not a table from preproc_sbom\n");
+    if (m != box->sb->m) fail("search_sbom: m differs from the m given to preproc_sbom\n");
+    uint64_t count = 0;
+    if (smh_sbom_count_host(box->sb, text, n < 0 ? 0 : (uint64_t)n, SMH_VARIANT_TUNED, &count, NULL) != SMH_OK)
+        die_with_error("search_sbom");
+    return (unsigned)count;
+}
+
+static void cuda_sbom_any(int k, int variant, unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size,
+                          int alphabet, int *state_transition, unsigned int *state_final_multi)
+{
+    smh_sbom *sb = smh_sbom_compile_tables(pattern_flat, m, p_size, alphabet, state_transition, state_final_multi,
+                                           (uint64_t)m * p_size + 1);
+    if (!sb) die_with_error("cuda_sbom");
+    uint64_t count = 0;
+    double secs = 0.0;
+    if (smh_sbom_count_host(sb, text, n < 0 ? 0 : (uint64_t)n, variant, &count, &secs) != SMH_OK)
+        die_with_error("cuda_sbom");
+    /* cuda/cuda_sbom.cu:212 */
+    printf("Kernel %d matches \t%i\t time \t%f\n", k, (int)count, secs);
+    fflush(stdout);
+    smh_sbom_free(sb);
+}
+
+#define SMH_CUDA_SBOM(K, VARIANT)                                                                              \
+    extern "C" void cuda_sbom##K(unsigned char *pattern, int m, unsigned char *text, int n, int p_size,        \
+                                 int alphabet, int *state_transition, unsigned int *state_final_multi)         \
+    {                                                                                                          \
+        cuda_sbom_any(K, VARIANT, pattern, m, text, n, p_size, alphabet, state_transition, state_final_multi); \
+    }
+SMH_CUDA_SBOM(1, SMH_VARIANT_TABLE)
+SMH_CUDA_SBOM(2, SMH_VARIANT_TABLE)
+SMH_CUDA_SBOM(3, SMH_VARIANT_TUNED)
+SMH_CUDA_SBOM(4, SMH_VARIANT_TUNED)
+SMH_CUDA_SBOM(5, SMH_VARIANT_TUNED)

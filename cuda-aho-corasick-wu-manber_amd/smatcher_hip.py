@@ -62,6 +62,16 @@ class ShInfo(C.Structure):
                 ("tuned_engine", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
+class SbomInfo(C.Structure):
+    _fields_ = [("alphabet", C.c_uint32), ("m", C.c_uint32), ("states", C.c_uint32), ("patterns", C.c_uint32),
+                ("listed", C.c_uint32), ("tuned_engine", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+
+class SbomTable(C.Structure):
+    """struct sbom_table (include/smatcher.h)"""
+    _fields_ = [("idcounter", C.c_uint), ("patterncounter", C.c_uint), ("zerostate", C.c_void_p)]
+
+
 class AcTable(C.Structure):
     """struct ac_table (include/smatcher.h)"""
     _fields_ = [("idcounter", C.c_uint), ("patterncounter", C.c_uint), ("zerostate", C.c_void_p)]
@@ -72,7 +82,8 @@ LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_s
                    "preproc_wu", "preproc_wu2", "search_wu", "search_wu2", "m_nBitsInShift",
                    "shiftsize"]
                   + ["cuda_ac%d" % k for k in range(1, 6)] + ["cuda_wm%d" % k for k in range(1, 6)]
-                  + ["preBmBc", "preproc_sh", "search_sh", "free_sh"] + ["cuda_sh%d" % k for k in range(1, 6)])
+                  + ["preBmBc", "preproc_sh", "search_sh", "free_sh"] + ["cuda_sh%d" % k for k in range(1, 6)]
+                  + ["preproc_sbom", "search_sbom", "free_sbom", "pointer_array"] + ["cuda_sbom%d" % k for k in range(1, 6)])
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
                "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
@@ -83,7 +94,8 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free", "smh_pset_compile", "smh_pset_get_info",
                "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
                "smh_pset_free", "smh_sh_compile_tables", "smh_sh_compile_patterns", "smh_sh_get_info",
-               "smh_sh_valid_bmbc", "smh_sh_scan", "smh_sh_count_host", "smh_sh_free"]
+               "smh_sh_valid_bmbc", "smh_sh_scan", "smh_sh_count_host", "smh_sh_free", "smh_sbom_compile_tables",
+               "smh_sbom_compile_patterns", "smh_sbom_get_info", "smh_sbom_scan", "smh_sbom_count_host", "smh_sbom_free"]
 
 
 def _load():
@@ -152,6 +164,25 @@ def _load():
     lib.smh_sh_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, i32p, C.c_int, u64p, dblp]
     lib.smh_sh_free.restype = None
     lib.smh_sh_free.argtypes = [C.c_void_p]
+    lib.smh_sbom_compile_tables.restype = C.c_void_p
+    lib.smh_sbom_compile_tables.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p, u32p, C.c_uint64]
+    lib.smh_sbom_compile_patterns.restype = C.c_void_p
+    lib.smh_sbom_compile_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
+    lib.smh_sbom_get_info.argtypes = [C.c_void_p, C.POINTER(SbomInfo)]
+    lib.smh_sbom_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+    lib.smh_sbom_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, u64p, dblp]
+    lib.smh_sbom_free.restype = None
+    lib.smh_sbom_free.argtypes = [C.c_void_p]
+    lib.preproc_sbom.restype = C.POINTER(SbomTable)
+    lib.preproc_sbom.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p, u32p]
+    lib.search_sbom.restype = C.c_uint
+    lib.search_sbom.argtypes = [C.POINTER(u8p), C.c_int, u8p, C.c_int, C.POINTER(SbomTable)]
+    lib.free_sbom.restype = None
+    lib.free_sbom.argtypes = [C.POINTER(SbomTable), C.c_int]
+    for k in range(1, 6):
+        f = getattr(lib, "cuda_sbom%d" % k)
+        f.restype = None
+        f.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, i32p, u32p]
     lib.preBmBc.restype = None
     lib.preBmBc.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p]
     lib.preproc_sh.restype = C.POINTER(AcTable)
@@ -446,6 +477,52 @@ class ShTrie:
     def close(self):
         if self.h:
             lib.smh_sh_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SbomOracle:
+    """smh_sbom handle: Set Backward Oracle Matching tables + tuned engine."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise SmhError("SBOM compile failed: %s" % lib.smh_last_error().decode())
+        self.h = C.c_void_p(handle)
+
+    @classmethod
+    def from_patterns(cls, pat_flat, m, p, alphabet):
+        a, ptr = _u8(pat_flat)
+        return cls(lib.smh_sbom_compile_patterns(ptr, m, p, alphabet))
+
+    @classmethod
+    def from_tables(cls, pat_flat, m, p, alphabet, state_transition, state_final_multi, rows):
+        a, ptr = _u8(pat_flat)
+        return cls(lib.smh_sbom_compile_tables(ptr, m, p, alphabet, state_transition.ctypes.data_as(i32p),
+                                               state_final_multi.ctypes.data_as(u32p), rows))
+
+    def info(self):
+        out = SbomInfo()
+        _check(lib.smh_sbom_get_info(self.h, C.byref(out)), "smh_sbom_get_info")
+        return out
+
+    def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
+        _check(lib.smh_sbom_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,
+                                 C.c_void_p(stream or 0)), "smh_sbom_scan")
+
+    def count_host(self, text, variant=VARIANT_TUNED):
+        t, ptr = _u8(text)
+        cnt, secs = C.c_uint64(), C.c_double()
+        _check(lib.smh_sbom_count_host(self.h, ptr, len(t), variant, C.byref(cnt), C.byref(secs)), "smh_sbom_count_host")
+        return cnt.value, secs.value
+
+    def close(self):
+        if self.h:
+            lib.smh_sbom_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -146,6 +146,42 @@ void cuda_sh4(int m, unsigned char *text, int n, int p_size, int alphabet, int *
 void cuda_sh5(int m, unsigned char *text, int n, int p_size, int alphabet, int *state_transition,
               unsigned int *state_final, int *bmBc);
 
+/* ---- Set Backward Oracle Matching (smatcher.h:55-69,97-99, sbom/sbom.c) ----
+ * preproc_sbom fills the caller's state_transition (pre-initialised to -1) with the factor oracle of
+ * the reversed patterns -- trie edges and external transitions -- and state_final_multi (zeroed,
+ * (m*p_size+1) rows of 200 entries, main.c:422-425) with {count, pattern ids...} per state, as
+ * sbom/sbom.c:52-126 does.  pointer_array is the reference's header global; its driver allocates and
+ * frees it around preproc_sbom / free_sbom (main.c:208,229); this library does not use it.
+ * cuda_sbomK print "Kernel K matches \t%i\t time \t%f\n" (cuda/cuda_sbom.cu:212); K = 1,2 walk the
+ * oracle and the lists as given, K = 3,4,5 and search_sbom run the tuned kernels. */
+struct sbom_state {
+    unsigned int id;
+    unsigned int *F;
+    unsigned int num;
+    struct sbom_state *fail;
+    struct sbom_state **next;
+};
+struct sbom_table {
+    unsigned int idcounter;
+    unsigned int patterncounter;
+    struct sbom_state *zerostate; /* NULL here: the pointer graph is not materialised */
+};
+extern struct sbom_state **pointer_array;
+struct sbom_table *preproc_sbom(unsigned char **pattern, int m, int p_size, int alphabet,
+                                int *state_transition, unsigned int *state_final_multi);
+unsigned search_sbom(unsigned char **pattern, int m, unsigned char *text, int n, struct sbom_table *table);
+void free_sbom(struct sbom_table *table, int m);
+void cuda_sbom1(unsigned char *pattern, int m, unsigned char *text, int n, int p_size, int alphabet,
+                int *state_transition, unsigned int *state_final_multi);
+void cuda_sbom2(unsigned char *pattern, int m, unsigned char *text, int n, int p_size, int alphabet,
+                int *state_transition, unsigned int *state_final_multi);
+void cuda_sbom3(unsigned char *pattern, int m, unsigned char *text, int n, int p_size, int alphabet,
+                int *state_transition, unsigned int *state_final_multi);
+void cuda_sbom4(unsigned char *pattern, int m, unsigned char *text, int n, int p_size, int alphabet,
+                int *state_transition, unsigned int *state_final_multi);
+void cuda_sbom5(unsigned char *pattern, int m, unsigned char *text, int n, int p_size, int alphabet,
+                int *state_transition, unsigned int *state_final_multi);
+
 #ifdef __cplusplus
 }
 #endif

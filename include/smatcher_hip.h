@@ -190,6 +190,32 @@ int smh_sh_count_host(smh_sh *sh, const unsigned char *text, uint64_t n, const i
                       uint64_t *count, double *kernel_seconds);
 void smh_sh_free(smh_sh *sh);
 
+/* ---- Set Backward Oracle Matching (sbom/sbom.c, cuda/cuda_sbom.cu) ----
+ * The factor oracle of the reversed patterns with its per-state pattern lists.  SMH_VARIANT_TABLE runs
+ * the reference's loop per lane over the tables as given (walk, compare the listed patterns, skip
+ * max(m - j, 1)); SMH_VARIANT_TUNED scans the patterns with the tuned Wu-Manber kernels (the oracle is
+ * a suffix-first filter followed by a compare, which is what those kernels do) or the automaton
+ * kernels for sets Wu-Manber cannot take.  Both return the number of end columns of occurrences. */
+typedef struct smh_sbom smh_sbom;
+typedef struct smh_sbom_info {
+    uint32_t alphabet;
+    uint32_t m;
+    uint32_t states;        /* == struct sbom_table.idcounter */
+    uint32_t patterns;      /* == patterncounter (duplicates included) */
+    uint32_t listed;        /* entries over all per-state lists */
+    uint32_t tuned_engine;  /* SMH_ALGO_WM or SMH_ALGO_AC */
+    uint32_t reserved[2];
+} smh_sbom_info;
+/* from the tables preproc_sbom filled (rows = m*p_size+1; state_final_multi has rows*200 entries) */
+smh_sbom *smh_sbom_compile_tables(const unsigned char *pattern_flat, int m, int p_size, int alphabet,
+                                  const int *state_transition, const unsigned int *state_final_multi, uint64_t rows);
+smh_sbom *smh_sbom_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
+int smh_sbom_get_info(const smh_sbom *sb, smh_sbom_info *out);
+int smh_sbom_scan(smh_sbom *sb, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant, void *stream);
+int smh_sbom_count_host(smh_sbom *sb, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
+                        double *kernel_seconds);
+void smh_sbom_free(smh_sbom *sb);
+
 /* ---- pattern sets with mixed lengths ----
  * The reference API carries ONE pattern length per run (preproc_ac / preproc_wu take a single m;
  * feeding ac_addstring mixed lengths marks wrong states final, ac/ac.c:136-143,183-186), so the

@@ -67,6 +67,14 @@ void ora_pre_bmbc(const uint8_t *const *pattern, int m, int p_size, int alphabet
 uint64_t ora_search_sh(int m, const uint8_t *text, int64_t n, int alphabet,
                        const int32_t *state_transition, const uint32_t *state_final, const int32_t *bmBc);
 
+/* ---- Set Backward Oracle Matching (sbom/sbom.c) ---- */
+/* state_transition <- -1 as for AC; state_final_multi: (m*p+1) rows of 200 entries, zeroed (main.c:422-425) */
+void ora_preproc_sbom(const uint8_t *const *pattern, int m, int p_size, int alphabet,
+                      int32_t *state_transition, uint32_t *state_final_multi,
+                      uint32_t *idcounter_out, uint32_t *patterncounter_out);
+uint64_t ora_search_sbom(const uint8_t *pattern_flat, int m, const uint8_t *text, int64_t n, int alphabet,
+                         const int32_t *state_transition, const uint32_t *state_final_multi);
+
 /* ---- Wu-Manber (wu/wu.c) ---- */
 /* returns the table length for an alphabet, 0 if unsupported (reference calls fail()) */
 uint32_t ora_wu_determine_shiftsize(int alphabet);

@@ -134,3 +134,37 @@ unsigned long long ref_run_sh(const unsigned char *pat_flat, int m, int p_size, 
     free(pattern);
     return matches;
 }
+
+/* Set Backward Oracle Matching, main.c:197-231 (multisbom): pointer_array (a global of the reference's
+ * header, smatcher.h:55) is allocated by the caller, main.c:208; state_final_multi holds up to 199
+ * pattern ids per state (main.c:422-425), zeroed by the caller */
+unsigned long long ref_run_sbom(const unsigned char *pat_flat, int m, int p_size, int alphabet,
+                                const unsigned char *text, int n, int *state_transition,
+                                unsigned int *state_final_multi, unsigned int *idcounter,
+                                unsigned int *patterncounter, double *t_preproc, double *t_search)
+{
+    size_t rows = (size_t)m * p_size + 1;
+    memset(state_transition, -1, rows * alphabet * sizeof(int));
+    memset(state_final_multi, 0, rows * 200 * sizeof(unsigned int));
+    unsigned char **pattern = (unsigned char **)malloc((size_t)p_size * sizeof(unsigned char *));
+    for (int j = 0; j < p_size; j++) {
+        pattern[j] = (unsigned char *)calloc((size_t)m + 1, 1);
+        memcpy(pattern[j], pat_flat + (size_t)j * m, (size_t)m);
+    }
+    pointer_array = calloc((size_t)p_size * m, sizeof(struct sbom_state *));
+    double t0 = now_s();
+    struct sbom_table *table = preproc_sbom(pattern, m, p_size, alphabet, state_transition, state_final_multi);
+    double t1 = now_s();
+    unsigned int matches = text ? search_sbom(pattern, m, (unsigned char *)text, n, table) : 0;
+    double t2 = now_s();
+    if (idcounter) *idcounter = table->idcounter;
+    if (patterncounter) *patterncounter = table->patterncounter;
+    if (t_preproc) *t_preproc = t1 - t0;
+    if (t_search) *t_search = t2 - t1;
+    free_sbom(table, m);
+    free(pointer_array);
+    pointer_array = NULL;
+    for (int j = 0; j < p_size; j++) free(pattern[j]);
+    free(pattern);
+    return matches;
+}

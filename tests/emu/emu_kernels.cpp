@@ -269,3 +269,27 @@ extern "C" uint64_t emu_sh_scan(const smh_sh *sh, const uint8_t *text_in, uint64
     }
     return result[0] == result[1] ? result[0] : ~0ull;
 }
+
+/* ------------------------------------------------------------------ SBOM */
+#include "sbom_lane.h"
+
+extern "C" uint64_t emu_sbom_scan(const smh_sbom *sb, const uint8_t *text_in, uint64_t n, int variant, uint32_t blocks)
+{
+    if (n < (uint64_t)sb->m) return 0;
+    if (variant == SMH_VARIANT_TUNED)
+        return sb->wm ? emu_wm_scan(sb->wm, text_in, n, SMH_VARIANT_TUNED, blocks)
+                      : emu_ac_scan(sb->ac, text_in, n, SMH_VARIANT_TUNED, blocks);
+    if (!blocks) blocks = 3;
+    uint64_t result[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        const uint64_t nthreads = (uint64_t)blocks * 256;
+        uint64_t total = 0;
+        for (uint64_t t = 0; t < nthreads; ++t)
+            total += smh_sbom_table_thread(t, nthreads, g.text, n, sb->g_transition, sb->g_final_off, sb->g_final_ids,
+                                           sb->patterns, sb->m, sb->alphabet);
+        guard_free(g);
+        result[mode] = total;
+    }
+    return result[0] == result[1] ? result[0] : ~0ull;
+}

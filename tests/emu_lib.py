@@ -65,3 +65,12 @@ def sh_scan(sh, text, bmbc=None, variant=S.VARIANT_TUNED, blocks=0):
         bmbc = np.ascontiguousarray(bmbc, dtype=np.int32)
         b = bmbc.ctypes.data_as(S.i32p)
     return int(_emu.emu_sh_scan(sh.h, text.ctypes.data_as(S.u8p), len(text), b, variant, blocks))
+
+
+_emu.emu_sbom_scan.restype = C.c_uint64
+_emu.emu_sbom_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_int, C.c_uint32]
+
+
+def sbom_scan(sb, text, variant=S.VARIANT_TUNED, blocks=0):
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    return int(_emu.emu_sbom_scan(sb.h, text.ctypes.data_as(S.u8p), len(text), variant, blocks))

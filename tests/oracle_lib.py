@@ -58,6 +58,10 @@ def _load():
     lib.ora_pre_bmbc.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p]
     lib.ora_search_sh.restype = C.c_uint64
     lib.ora_search_sh.argtypes = [C.c_int, u8p, C.c_int64, C.c_int, i32p, u32p, i32p]
+    lib.ora_preproc_sbom.restype = None
+    lib.ora_preproc_sbom.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, C.c_int, i32p, u32p, u32p, u32p]
+    lib.ora_search_sbom.restype = C.c_uint64
+    lib.ora_search_sbom.argtypes = [u8p, C.c_int, u8p, C.c_int64, C.c_int, i32p, u32p]
     lib.ora_wu_determine_shiftsize.restype = C.c_uint32
     lib.ora_wu_determine_shiftsize.argtypes = [C.c_int]
     wu_tabs = [i32p, i32p, i32p, i32p]
@@ -292,6 +296,51 @@ def ref_sh(pat_flat, m, p, sigma, text=None, bmBc=None):
     return (int(cnt) if text is not None else None), t
 
 
+# ------------------------------------------------------------------ SBOM
+class SBOMTables:
+    """Flat tables as main.c:410-425 allocates them for multisbom: the factor oracle and, per state,
+    {count, pattern ids...} in rows of 200 entries."""
+
+    def __init__(self, m, p, sigma):
+        rows = m * p + 1
+        self.m, self.p, self.sigma, self.rows = m, p, sigma, rows
+        self.state_transition = np.full(rows * sigma, -1, dtype=np.int32)
+        self.state_final_multi = np.zeros(rows * 200, dtype=np.uint32)
+        self.idcounter = 0
+        self.patterncounter = 0
+
+
+def oracle_sbom(pat_flat, m, p, sigma, text=None):
+    """-> (count or None, SBOMTables) from the restatement (oracle/ora_sbom.c)."""
+    t = SBOMTables(m, p, sigma)
+    pat_flat = np.ascontiguousarray(pat_flat, dtype=np.uint8)
+    arr, keep = _pattern_ptrs(pat_flat, m, p)
+    idc, pc = C.c_uint32(), C.c_uint32()
+    lib.ora_preproc_sbom(arr, m, p, sigma, _ptr(t.state_transition, i32p), _ptr(t.state_final_multi, u32p),
+                         C.byref(idc), C.byref(pc))
+    t.idcounter, t.patterncounter = idc.value, pc.value
+    count = None
+    if text is not None:
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        count = int(lib.ora_search_sbom(_ptr(pat_flat, u8p), m, _ptr(text, u8p), len(text), sigma,
+                                        _ptr(t.state_transition, i32p), _ptr(t.state_final_multi, u32p)))
+    del keep
+    return count, t
+
+
+def ref_sbom(pat_flat, m, p, sigma, text=None):
+    """-> (count, SBOMTables) from the reference's own sbom/sbom.c."""
+    t = SBOMTables(m, p, sigma)
+    pat_flat = np.ascontiguousarray(pat_flat, dtype=np.uint8)
+    idc, pc = C.c_uint32(), C.c_uint32()
+    tptr = _ptr(np.ascontiguousarray(text, dtype=np.uint8), u8p) if text is not None else None
+    n = len(text) if text is not None else 0
+    cnt = ref().ref_run_sbom(_ptr(pat_flat, u8p), m, p, sigma, tptr, n, _ptr(t.state_transition, i32p),
+                             _ptr(t.state_final_multi, u32p), C.byref(idc), C.byref(pc), None, None)
+    t.idcounter, t.patterncounter = idc.value, pc.value
+    return (int(cnt) if text is not None else None), t
+
+
 def have_ref():
     return os.path.exists(_REF)
 
@@ -311,6 +360,9 @@ def ref():
         r.ref_run_sh.restype = C.c_ulonglong
         r.ref_run_sh.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, i32p, u32p, i32p,
                                  u32p, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        r.ref_run_sbom.restype = C.c_ulonglong
+        r.ref_run_sbom.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, i32p, u32p,
+                                   u32p, u32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         r.ref_run_wu.restype = C.c_ulonglong
         r.ref_run_wu.argtypes = [u8p, C.c_int, C.c_int, C.c_int, u8p, C.c_int, i32p, i32p, i32p,
                                  i32p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -51,7 +51,7 @@ def run(args, cwd):
 @no_spawn
 def test_help_and_argument_errors(tmp_path):
     r = run(["--help"], tmp_path)
-    assert r.returncode == 0 and "Usage: smatcher <ac|sh|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet>" in r.stdout
+    assert r.returncode == 0 and "Usage: smatcher <ac|sh|sbom|wm|all> -m <m> -p_size <p_size> -n <n> -alphabet <alphabet>" in r.stdout
     assert run(["ac", "-m", "8"], tmp_path).stdout.startswith("smatcher - ")  # main.c:364-365: missing arguments -> usage
     r = run(["wm", "-m", "8", "-p_size", "100001", "-n", "1000", "-alphabet", "4"], tmp_path)
     assert r.returncode == 1 and "Only up to 100.000 patterns are supported" in r.stderr  # main.c:370-371
@@ -133,8 +133,9 @@ def test_driver_totals_match_oracle_on_a_fasta_text(tmp_path, capfd, ranks):
     assert want >= p // 2
     assert "Total results (ac): %d.\n" % want in out and "Total results: %d.\n" % want in out
     assert "Total results (sh): %d.\n" % want in out and out.count("search_sh matches") == ranks
+    assert "Total results (sbom): %d.\n" % want in out and out.count("search_sbom matches") == ranks
     assert out.count("search_ac matches") == ranks and out.count("search_wm2 matches") == ranks
-    assert out.count("Kernel 5 matches") == 2 * ranks and "gpuTime[5]:" in out  # cuda_ac5 and cuda_sh5
+    assert out.count("Kernel 5 matches") == 3 * ranks and "gpuTime[5]:" in out  # cuda_ac5, cuda_sh5, cuda_sbom5
     per_rank = [int(ln.split("\t")[1]) for ln in out.splitlines() if ln.startswith("search_ac matches")]
     shard = []
     for r in range(ranks):
