@@ -398,7 +398,7 @@ bad:
  * very rare (it measured 2.0 TB/s at one candidate per 260 bytes).  Relative cost per text byte:
  *     stride 1:  1 + 0.08 [K < m] + 3 * P(a 16-byte piece of a wave holds a candidate)
  *     stride 2:  0.72 + 300 * r [K < m]                       r = candidates per text byte
- *     hybrid  :  0.72 + 2.55 * P(a wave holds a lane deeper than D) + (0.13 + 300 * r) [K < m]   */
+ *     hybrid  :  0.72 + 2.3 * P(a wave holds a lane deeper than D) + (0.13 + 300 * r) [K < m]   */
 
 static uint32_t entry_get(const void *t, int eb, size_t i)
 {
@@ -622,7 +622,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
     }
     /* hybrid stride 2 (see hyb_build): for every K the deepest D whose estimated image fits.  Measured
      * (1000 patterns, m = 16 / 32, 1 GiB): the common step costs what a plain stride-2 step costs
-     * (0.21 ms/GiB), a step in which ANY lane of the wave sits in a compact row 3.5 x that (two more
+     * (0.21 ms/GiB), a step in which ANY lane of the wave sits in a compact row 3.2-3.5 x that (two more
      * dependent LDS round trips and the item arithmetic), recording candidates as bits 0.04 ms/GiB */
     if (allow_hybrid && A == 4 && (!force_stride || force_stride == 3)) {
         for (int K = kmax; K >= 4; --K) {
@@ -635,7 +635,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 const uint64_t nc = rk - nf;
                 if (nf * 32u + nc * 4u + nc / 4u + 64u > lds_budget || rk + nc / 8u > 65000u) continue;
                 const double r = candidate_rate(ac, K), q = deep_rate(ac, D);
-                const double cost = 0.72 + 2.55 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.13 + 300.0 * r : 0.0);
+                const double cost = 0.72 + 2.3 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.13 + 300.0 * r : 0.0);
                 if (cost < best_cost) { best_cost = cost; best_s = 3; best_k[3] = K; best_d = D; }
                 break;
             }

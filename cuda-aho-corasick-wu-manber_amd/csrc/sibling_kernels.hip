@@ -1,5 +1,5 @@
 /*
- * csrc/sh_kernels.hip -- table-walking kernels of the sibling algorithms (Set-Horspool, SBOM) for gfx950.
+ * csrc/sibling_kernels.hip -- table-walking kernels of the sibling algorithms (Set-Horspool, SBOM) for gfx950.
  *
  * sh_table_kernel  the reference-layout reversed trie (state_transition / state_final as
  *                  preproc_sh fills them) walked from HBM/L2 as given, the caller's bmBc staged in
