@@ -52,7 +52,7 @@ __device__ __forceinline__ void smh_block_add(uint32_t cnt, uint64_t *count, uns
     }
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true, int SW = 16>
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true, int SW = 16, bool POS = false>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__restrict__ scan_table, uint32_t lds_bytes,
                                                                   smh_ac_verify_ctx V, smh_ac_df df,
                                                                   uint64_t *queue_base, uint64_t *count,
@@ -83,14 +83,14 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void ac_dfa_kernel(const E *__re
     uint32_t cnt;
     if constexpr (STRIDE == 3) { /* hybrid stride 2: full rows + compact item lists */
         const smh_fmt_s2h fmt{full_rows, full_rows * 28u};
-        cnt = smh_ac_thread<smh_fmt_s2h, HC, NCH, EXACT, PF, SW>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
+        cnt = smh_ac_thread<smh_fmt_s2h, HC, NCH, EXACT, PF, SW, POS>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
     } else if constexpr (STRIDE == 2) {
-        cnt = smh_ac_thread<smh_fmt_s2, HC, NCH, EXACT, PF, SW>(smh_fmt_s2{}, gthread, nthreads, smh_lds, V, df, queue_base);
+        cnt = smh_ac_thread<smh_fmt_s2, HC, NCH, EXACT, PF, SW, POS>(smh_fmt_s2{}, gthread, nthreads, smh_lds, V, df, queue_base);
     } else {
         const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
-        cnt = smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, NCH, EXACT, PF, SW>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
+        cnt = smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, NCH, EXACT, PF, SW, POS>(fmt, gthread, nthreads, smh_lds, V, df, queue_base);
     }
-    smh_block_add(cnt, count, smh_lds);
+    if constexpr (!POS) smh_block_add(cnt, count, smh_lds); /* positions mode: the cursor is the count */
 }
 
 __global__ __launch_bounds__(256) void ac_table_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,
@@ -141,10 +141,11 @@ static int tune_get(const char *key, int dflt)
     return atoi(p + strlen(key) + 1);
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, int NCH = SMH_AC_NCH, bool PF = true, int SW = 16>
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, bool POS = false>
 static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
 {
-    auto kern = ac_dfa_kernel<E, SIGMA, STRIDE, HC, EXACT, NCH, PF, SW>;
+    constexpr int NCH = SMH_AC_NCH, SW = 16;
+    auto kern = ac_dfa_kernel<E, SIGMA, STRIDE, HC, EXACT, NCH, true, SW, POS>;
     /* the attribute call and the occupancy query cost tens of microseconds of host time, during
      * which the GPU idles between the caller's events: do them once per (kernel, LDS size) */
     static uint32_t cached_lds = 0xFFFFFFFFu;
@@ -177,39 +178,49 @@ static hipError_t launch_one(const smh_ac_launch &L, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC>
+template <typename E, int SIGMA, int STRIDE, int HC, bool POS>
 static hipError_t launch_exact(const smh_ac_launch &L, hipStream_t stream)
 {
-    if constexpr (STRIDE == 3) {
-        if (L.exact) return launch_one<E, SIGMA, 3, HC, true>(L, stream);
-        if constexpr (HC <= 2) return launch_one<E, SIGMA, 3, HC, false>(L, stream);
+    if constexpr (POS && HC > 2) {
+        return hipErrorNotSupported; /* match recording covers a 32-byte halo: the caller falls back */
+    } else if constexpr (STRIDE == 3) {
+        if (L.exact) return launch_one<E, SIGMA, 3, HC, true, POS>(L, stream);
+        if constexpr (HC <= 2) return launch_one<E, SIGMA, 3, HC, false, POS>(L, stream);
         return hipErrorInvalidValue; /* the plan keeps K - 1 <= 32 for a depth-cut hybrid image */
     } else {
-    return L.exact ? launch_one<E, SIGMA, STRIDE, HC, true>(L, stream) : launch_one<E, SIGMA, STRIDE, HC, false>(L, stream);
+        return L.exact ? launch_one<E, SIGMA, STRIDE, HC, true, POS>(L, stream)
+                       : launch_one<E, SIGMA, STRIDE, HC, false, POS>(L, stream);
     }
 }
 
-template <typename E, int SIGMA, int STRIDE>
+template <typename E, int SIGMA, int STRIDE, bool POS>
 static hipError_t launch_halo(const smh_ac_launch &L, hipStream_t stream)
 {
     const int halo = L.V.K - 1;
-    if (halo <= 16) return launch_exact<E, SIGMA, STRIDE, 1>(L, stream);
-    if (halo <= 32) return launch_exact<E, SIGMA, STRIDE, 2>(L, stream);
-    return launch_exact<E, SIGMA, STRIDE, 4>(L, stream);
+    if (halo <= 16) return launch_exact<E, SIGMA, STRIDE, 1, POS>(L, stream);
+    if (halo <= 32) return launch_exact<E, SIGMA, STRIDE, 2, POS>(L, stream);
+    return launch_exact<E, SIGMA, STRIDE, 4, POS>(L, stream);
 }
 
-hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream)
+template <bool POS>
+static hipError_t launch_dfa(const smh_ac_launch &L, hipStream_t stream)
 {
     if (L.V.K - 1 > 64) return hipErrorInvalidValue;
     if (L.stride == 2) {
         if (L.V.sigma != 4 || L.scan_entry_bytes != 2) return hipErrorInvalidValue;
-        if (L.full_rows) return launch_halo<uint16_t, 4, 3>(L, stream);
-        return launch_halo<uint16_t, 4, 2>(L, stream);
+        if (L.full_rows) return launch_halo<uint16_t, 4, 3, POS>(L, stream);
+        return launch_halo<uint16_t, 4, 2, POS>(L, stream);
     }
     if (L.scan_entry_bytes == 2)
-        return L.V.sigma == 4 ? launch_halo<uint16_t, 4, 1>(L, stream) : launch_halo<uint16_t, 0, 1>(L, stream);
-    return L.V.sigma == 4 ? launch_halo<uint32_t, 4, 1>(L, stream) : launch_halo<uint32_t, 0, 1>(L, stream);
+        return L.V.sigma == 4 ? launch_halo<uint16_t, 4, 1, POS>(L, stream) : launch_halo<uint16_t, 0, 1, POS>(L, stream);
+    return L.V.sigma == 4 ? launch_halo<uint32_t, 4, 1, POS>(L, stream) : launch_halo<uint32_t, 0, 1, POS>(L, stream);
 }
+
+hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream) { return launch_dfa<false>(L, stream); }
+
+/* positions mode of the same kernels (L.po set); hipErrorNotSupported when the plan's halo exceeds 32
+ * bytes -- the caller then runs ac_positions_kernel */
+hipError_t smh_launch_ac_dfa_positions(const smh_ac_launch &L, hipStream_t stream) { return launch_dfa<true>(L, stream); }
 
 hipError_t smh_launch_ac_table(const smh_ac_table_launch &L, hipStream_t stream)
 {

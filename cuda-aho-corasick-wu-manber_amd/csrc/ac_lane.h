@@ -49,6 +49,7 @@ struct smh_ac_verify_ctx {
     const uint32_t *depth_first; /* [d] = first row with depth >= d; padded with `rows` */
     const void *trunc1;          /* stride-1 depth-K table in HBM */
     int trunc1_entry_bytes;
+    smh_pos_out pos;             /* positions mode: where match END columns go (cursor == NULL: counting) */
 };
 
 /* depth_first[0..71] BY VALUE: as a kernel argument it is read with scalar loads from the kernarg
@@ -123,6 +124,23 @@ SMH_LANE void smh_ac_drain(smh_ac_queue &Q, const smh_ac_verify_ctx &V)
      * on the m = 32 set -- the call's register save/restore lands in the scan loop.) */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t lane = threadIdx.x & 63u;
+    if (V.pos.cursor) {
+        /* positions mode: same walk, and the verified candidates append their match END column
+         * (the K-symbol prefix ends at the queued position, the pattern m - K symbols later) */
+        for (uint32_t base = 0; base < Q.count; base += 64u) {
+            const uint32_t i = base + lane;
+            uint64_t hit = 0, q = 0;
+            if (i < Q.count) {
+                const uint64_t ent = __hip_atomic_load(Q.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t rl = (uint32_t)(ent >> 40);
+                q = ent & 0xFFFFFFFFFFull;
+                hit = smh_ac_deep_walk(V, q, rl & 0x3FFFFFu, rl >> 22);
+            }
+            Q.matches += smh_append_bits(hit, q + (uint64_t)(V.m - V.K), V.pos);
+        }
+        Q.count = 0;
+        return;
+    }
     for (uint32_t i = lane; i < Q.count; i += 64u) {
         const uint64_t ent = __hip_atomic_load(Q.slots + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t rl = (uint32_t)(ent >> 40);
@@ -150,7 +168,10 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
 SMH_LANE void smh_ac_drain(smh_ac_queue &, const smh_ac_verify_ctx &) {}
 SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, uint32_t kind)
 {
-    if (cond) Q.matches += smh_ac_deep_walk(V, pos, row, kind);
+    if (!cond) return;
+    const uint32_t hit = smh_ac_deep_walk(V, pos, row, kind);
+    Q.matches += hit;
+    if (hit && V.pos.cursor) smh_append_bits(1u, pos + (uint64_t)(V.m - V.K), V.pos);
 }
 #endif
 
@@ -281,7 +302,8 @@ template <typename FMT, int HC, int NCH, bool EXACT, int SW = 16> struct smh_ac_
     const uint32_t *tail; /* 4*HC words, same in every lane: the bytes that follow the wave-chunk */
     const smh_ac_verify_ctx *V;
     smh_ac_queue *Q;
-    uint32_t *hmask; /* stride-2 bit-recording mode: halo flags are OR-ed in here (NCH words), else NULL */
+    uint32_t *hmask; /* bit-recording modes (stride-2 candidates, positions): halo flags are OR-ed in here
+                      * (NCH words, bit = halo byte index), else NULL */
 };
 
 /* queue the candidates flagged by entry `e` (reached from `prev`) for the byte (pair) at `pos` */
@@ -314,12 +336,12 @@ SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c
         if (FMT::STRIDE == 2 && !second_valid) f[j] &= 1u;
         anyf |= f[j];
     }
-    if (EXACT) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) cnt += (uint32_t)__builtin_popcount(f[j]);
-    } else if (c.hmask) {
+    if (c.hmask) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) c.hmask[j] |= f[j] << hbit;
+    } else if (EXACT) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) cnt += (uint32_t)__builtin_popcount(f[j]);
     } else if (SMH_WAVE_ANY(anyf != 0)) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) smh_ac_emit_flags(c, f[j], prev[j], e[j], pos[j]);
@@ -418,7 +440,7 @@ SMH_LANE void smh_ac_load_segments(const uint8_t *text, const uint64_t (&a)[NCH]
  * wave-wide vote, and a piece that holds a candidate anywhere in the wave is walked again from a
  * snapshot of the states, this time queueing the candidates.
  */
-template <typename FMT, int HC, int NCH, bool EXACT, int SW>
+template <typename FMT, int HC, int NCH, bool EXACT, int SW, bool POS = false>
 SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const uint64_t (&a)[NCH],
                                    const uint32_t (&w)[NCH][SW], const uint32_t (&tail)[4 * HC], const void *tab,
                                    int K, const smh_ac_df &df, const smh_ac_verify_ctx &V, smh_ac_queue &Q)
@@ -432,10 +454,14 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
      * the verify stage then walks the pattern from the root (SMH_CAND_ROOT). */
     constexpr bool BITS = !EXACT && FMT::STRIDE == 2 && (HC == 1 || (FMT::SPARSE && HC == 2)) && SW == 16;
     static_assert(EXACT || FMT::STRIDE == 1 || SW == 16, "stride-2 candidate recording assumes 64-byte segments");
+    /* positions mode with K == m: every flag is a match; they are recorded the same way (one bit per
+     * END column, halo bits separately) and appended to the output after the segment */
+    constexpr bool REC = POS && EXACT;
+    static_assert(!REC || (HC <= 2 && SW == 16), "match recording covers a 32-byte halo");
     uint32_t mlo[NCH], mhi[NCH], mhalo[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) mlo[j] = mhi[j] = mhalo[j] = 0;
-    smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> ctx{fmt, tab, K - 1, &df, text, a, tail, &V, &Q, BITS ? mhalo : nullptr};
+    smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> ctx{fmt, tab, K - 1, &df, text, a, tail, &V, &Q, (BITS || REC) ? mhalo : nullptr};
     constexpr int SPD = 4 / FMT::STRIDE; /* steps per text dword */
 
 #pragma unroll
@@ -454,7 +480,7 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
                         static_assert(EXACT || BITS, "the hybrid image records candidates as bits");
                         const int bit = 4 * q + 2 * k;
                         e[j] = fmt.next_f(e[j], x[j], k, tab, [&](uint32_t f) {
-                            if (EXACT)
+                            if (EXACT && !REC)
                                 cnt += (uint32_t)__builtin_popcount(f);
                             else if (bit < 32)
                                 mlo[j] |= f << bit;
@@ -464,10 +490,10 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
                         continue;
                     }
                     e[j] = fmt.next(e[j], x[j], k, tab);
-                    if (EXACT) {
+                    if (EXACT && !REC) {
                         cnt += (uint32_t)__builtin_popcount(fmt.flags(e[j]));
-                    } else if (BITS) {
-                        const int bit = 4 * q + 2 * k;
+                    } else if (BITS || REC) {
+                        const int bit = 4 * q + k * FMT::STRIDE;
                         if (bit < 32)
                             mlo[j] |= fmt.flags(e[j]) << bit;
                         else
@@ -503,6 +529,12 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
         }
     }
     smh_ac_halo_all(ctx, w, e, cnt, std::make_integer_sequence<int, 16 * HC>{});
+    if (REC) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            cnt += smh_append_bits2(((uint64_t)mhi[j] << 32) | mlo[j], a[j], mhalo[j], a[j] + SMH_SEG, V.pos);
+        }
+    }
     if (BITS) {
         /* compaction: one queue entry per set bit, as many rounds as the busiest lane has bits */
 #pragma unroll
@@ -578,7 +610,11 @@ SMH_LANE uint32_t smh_ac_lane_table(const uint8_t *text, uint64_t n, uint64_t n_
  * 64 lanes per wave): wave-chunks of NCH*4 KiB are dealt round-robin to waves,
  * so at any moment the resident waves stream one contiguous window of text.
  */
-template <typename FMT, int HC, int NCH, bool EXACT, bool PREFETCH = true, int SW = 16>
+SMH_LANE uint64_t smh_ac_segment_match_mask(const smh_ac_verify_ctx &V, uint64_t n_starts, uint64_t a);
+
+/* POS: positions mode -- instead of counting, every match appends its END column to V.pos (the return
+ * value is then the number of matches this lane appended; the kernels ignore it). */
+template <typename FMT, int HC, int NCH, bool EXACT, bool PREFETCH = true, int SW = 16, bool POS = false>
 SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthreads, const void *tab,
                                 const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base)
 {
@@ -626,7 +662,14 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthre
             uint64_t a[NCH];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SEGB;
-            cnt += smh_ac_lane_fast<FMT, HC, NCH, EXACT, SW>(fmt, V.text, a, cur, cur_tail, tab, V.K, df, V, Q);
+            cnt += smh_ac_lane_fast<FMT, HC, NCH, EXACT, SW, POS>(fmt, V.text, a, cur, cur_tail, tab, V.K, df, V, Q);
+        } else if (POS) {
+            /* the text's last chunk(s): per-lane mask of matching STARTS, then the wave-level append */
+            static_assert(!POS || SW == 16, "positions mode uses 64-byte segments");
+            for (int j = 0; j < NCH; ++j) {
+                const uint64_t as = base + ((uint64_t)j * 64u + lane) * SEGB;
+                cnt += smh_append_bits(smh_ac_segment_match_mask(V, n_starts, as), as + (uint64_t)(V.m - 1), V.pos);
+            }
         } else {
             for (int j = 0; j < NCH; ++j)
                 cnt += smh_ac_lane_slow(V, n_starts, base + ((uint64_t)j * 64u + lane) * SEGB, SEGB);

@@ -152,6 +152,52 @@ SMH_LANE uint64_t smh_wave_reserve(uint64_t *cursor, uint32_t mine)
 }
 #endif
 
+/* where match END columns go in positions mode (smh_ac_positions): a device array, its capacity and
+ * the device cursor that counts every match (entries past the capacity are dropped but counted) */
+struct smh_pos_out {
+    uint64_t *out;
+    uint64_t capacity;
+    uint64_t *cursor;
+};
+
+/* wave-level append of the END columns base + (bit index) of the set bits of `mask`: one vote, one
+ * prefix sum, one atomic on the cursor per wave (smh_wave_reserve).  All 64 lanes must call it. */
+SMH_LANE uint32_t smh_append_bits(uint64_t mask, uint64_t base, const smh_pos_out &po)
+{
+    if (!SMH_WAVE_ANY(mask != 0)) return 0;
+    const uint32_t mine = (uint32_t)__builtin_popcountll(mask);
+    uint64_t slot = smh_wave_reserve(po.cursor, mine);
+    while (mask) {
+        const int b = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (slot < po.capacity) po.out[slot] = base + (uint64_t)b;
+        ++slot;
+    }
+    return mine;
+}
+
+/* two masks, two bases, ONE reservation (a segment's own columns and its halo): the cursor atomic is
+ * what bounds dense outputs, so it is spent once per wave and segment */
+SMH_LANE uint32_t smh_append_bits2(uint64_t mask_a, uint64_t base_a, uint64_t mask_b, uint64_t base_b, const smh_pos_out &po)
+{
+    if (!SMH_WAVE_ANY((mask_a | mask_b) != 0)) return 0;
+    const uint32_t mine = (uint32_t)(__builtin_popcountll(mask_a) + __builtin_popcountll(mask_b));
+    uint64_t slot = smh_wave_reserve(po.cursor, mine);
+    while (mask_a) {
+        const int b = __builtin_ctzll(mask_a);
+        mask_a &= mask_a - 1;
+        if (slot < po.capacity) po.out[slot] = base_a + (uint64_t)b;
+        ++slot;
+    }
+    while (mask_b) {
+        const int b = __builtin_ctzll(mask_b);
+        mask_b &= mask_b - 1;
+        if (slot < po.capacity) po.out[slot] = base_b + (uint64_t)b;
+        ++slot;
+    }
+    return mine;
+}
+
 SMH_LANE uint32_t smh_byte_of(uint32_t word, int k) { return (word >> (8 * k)) & 0xFFu; }
 
 #endif

@@ -30,6 +30,7 @@ struct smh_ac_launch {
 };
 uint32_t smh_ac_max_blocks(int n_cus);
 hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream);
+hipError_t smh_launch_ac_dfa_positions(const smh_ac_launch &L, hipStream_t stream);
 
 struct smh_ac_table_launch {
     const uint8_t *d_text;
@@ -92,9 +93,11 @@ struct smh_wm_launch {
     uint64_t *d_queue; /* smh_wm_max_blocks * 16 waves * SMH_WM_QCAP columns (NULL when exact) */
     uint64_t *d_count;
     int n_cus;
+    smh_pos_out po;       /* positions mode only */
 };
 uint32_t smh_wm_max_blocks(int n_cus);
 hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream);
+hipError_t smh_launch_wm_block_positions(const smh_wm_launch &L, hipStream_t stream);
 
 struct smh_wm_table_launch {
     const uint8_t *d_text;

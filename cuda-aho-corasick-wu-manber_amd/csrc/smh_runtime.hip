@@ -296,7 +296,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_ac_table(L, (hipStream_t)stream));
     } else if (variant == SMH_VARIANT_TUNED) {
-        smh_ac_launch L;
+        smh_ac_launch L = {};
         L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
         L.V.full = ac->dev->d_table; L.V.full_entry_bytes = ac->entry_bytes; L.V.depth_first = ac->dev->d_depth_first;
         L.V.trunc1 = ac->dev->d_trunc1; L.V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
@@ -309,6 +309,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
             for (int i = 0; i < SMH_AC_DF_LEN; ++i)
                 if (L.df.v[i] > L.full_rows) L.df.v[i] = L.full_rows;
         L.d_count = d_count; L.n_cus = n_cus;
+        L.V.pos.out = NULL; L.V.pos.capacity = 0; L.V.pos.cursor = NULL;
         HIP_TRY(smh_launch_ac_dfa(L, (hipStream_t)stream));
     } else {
         smh_set_error("smh_ac_scan: unknown variant %d", variant);
@@ -333,10 +334,28 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
-    smh_ac_verify_ctx V;
+    smh_ac_verify_ctx V = {};
     V.text = d_text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
     V.full = ac->dev->d_table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = ac->dev->d_depth_first;
     V.trunc1 = ac->dev->d_trunc1; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    /* the tuned scan kernels in positions mode: matches are recorded as bits and appended per wave */
+    smh_ac_launch L = {};
+    L.V = V;
+    L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
+    L.d_scan_table = ac->dev->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = ac->dev->d_queue;
+    for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+    L.full_rows = ac->scan_full_rows;
+    if (L.full_rows)
+        for (int i = 0; i < SMH_AC_DF_LEN; ++i)
+            if (L.df.v[i] > L.full_rows) L.df.v[i] = L.full_rows;
+    L.d_count = NULL; L.n_cus = n_cus;
+    L.V.pos.out = d_positions; L.V.pos.capacity = capacity; L.V.pos.cursor = d_cursor;
+    if (((uintptr_t)d_text & 15u) == 0) {
+        const hipError_t e = smh_launch_ac_dfa_positions(L, (hipStream_t)stream);
+        if (e == hipSuccess) return SMH_OK;
+        if (e != hipErrorNotSupported) HIP_TRY(e);
+    }
+    /* plans with a halo beyond 32 bytes, unaligned text: one lane per segment over the stride-1 table in HBM */
     HIP_TRY(smh_launch_ac_positions(V, d_positions, capacity, d_cursor, n_cus, (hipStream_t)stream));
     return SMH_OK;
 }
@@ -473,6 +492,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
         L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
         L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_queue = wm->dev->d_queue; L.d_count = d_count; L.n_cus = n_cus;
+        L.po.out = NULL; L.po.capacity = 0; L.po.cursor = NULL;
         HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
     } else {
         smh_set_error("smh_wm_scan: unknown variant %d", variant);
@@ -493,6 +513,19 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    if (((uintptr_t)d_text & 15u) == 0) {
+        /* the tuned scan kernels in positions mode: matching columns are recorded as bits (exact
+         * filters) or verified through the survivor queue, and appended per wave */
+        smh_wm_launch L;
+        L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
+        L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
+        L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
+        L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_queue = wm->dev->d_queue; L.d_count = NULL; L.n_cus = n_cus;
+        L.po.out = d_positions; L.po.capacity = capacity; L.po.cursor = d_cursor;
+        HIP_TRY(smh_launch_wm_block_positions(L, (hipStream_t)stream));
+        return SMH_OK;
+    }
+    /* unaligned text: the reference tables walked as given, one lane per 256 columns */
     smh_wm_table_launch L;
     L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = wm->dev->d_shift;
     L.d_bucket_off = wm->dev->d_bucket_off; L.d_bucket = wm->dev->d_bucket; L.d_pat_orig = wm->dev->d_pat_orig;

@@ -40,10 +40,10 @@ __device__ __forceinline__ void smh_block_add_wm(uint32_t cnt, uint64_t *count, 
     }
 }
 
-template <bool HASHED, bool EXACT, int HC, int FK = 0>
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     const uint8_t *__restrict__ text, uint64_t n, const uint32_t *__restrict__ filter_g, uint32_t lds_bytes,
-    smh_wm_params P, int block_symbols, uint64_t *count)
+    smh_wm_params P, int block_symbols, uint64_t *count, smh_pos_out po)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smh_lds[];
     {
@@ -58,15 +58,16 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_block_kernel(
     /* survivor queues: 1 KiB per wave right behind the filter */
     uint64_t *queue = EXACT ? nullptr
                             : reinterpret_cast<uint64_t *>(smh_lds + lds_bytes) + (threadIdx.x >> 6) * SMH_WM_QCAP;
-    const uint32_t cnt = smh_wm_thread<HASHED, EXACT, HC, FK>(gthread, nthreads, text, n, filter, P, block_symbols, queue);
-    smh_block_add_wm(cnt, count, smh_lds);
+    const uint32_t cnt = smh_wm_thread<HASHED, EXACT, HC, FK, POS>(gthread, nthreads, text, n, filter, P, block_symbols, queue, &po);
+    if constexpr (!POS) smh_block_add_wm(cnt, count, smh_lds); /* positions mode: the cursor is the count */
 }
 
 /* alphabet 4, m <= 8: pair filter (two end columns per LDS lookup), 64 KiB of LDS */
+template <bool POS>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_pair_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,
                                                                    const uint32_t *__restrict__ pair_g,
                                                                    const uint32_t *__restrict__ filter_g,
-                                                                   uint64_t *count)
+                                                                   uint64_t *count, smh_pos_out po)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smh_lds[];
     {
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void wm_pair_kernel(const uint8_
     __syncthreads();
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t cnt = smh_wm_pair_thread<true>(gthread, nthreads, text, n, m, smh_lds, filter_g);
-    smh_block_add_wm(cnt, count, smh_lds);
+    const uint32_t cnt = smh_wm_pair_thread<true, POS>(gthread, nthreads, text, n, m, smh_lds, filter_g, &po);
+    if constexpr (!POS) smh_block_add_wm(cnt, count, smh_lds);
 }
 
 __global__ __launch_bounds__(256) void wm_table_kernel(const uint8_t *__restrict__ text, uint64_t n, int m,
@@ -139,10 +140,10 @@ hipError_t smh_launch_wm_positions(const smh_wm_table_launch &L, uint64_t *d_pos
 /* ------------------------------------------------------------------ launch */
 uint32_t smh_wm_max_blocks(int n_cus) { return (uint32_t)n_cus * 2u; }
 
-template <bool HASHED, bool EXACT, int HC, int FK = 0>
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
 static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
 {
-    auto kern = wm_block_kernel<HASHED, EXACT, HC, FK>;
+    auto kern = wm_block_kernel<HASHED, EXACT, HC, FK, POS>;
     uint32_t lds_bytes = (uint32_t)(((uint64_t)1 << L.filter_log2) / 8u);
     if (lds_bytes < 16u) lds_bytes = 16u;
     const uint32_t lds_total = lds_bytes + (EXACT ? 0u : (SMH_BLOCK_THREADS / 64) * SMH_WM_QCAP * 8u);
@@ -178,11 +179,11 @@ static hipError_t launch_one(const smh_wm_launch &L, hipStream_t stream)
     P.verify = L.d_verify;
     P.pat_sorted = L.d_pat_sorted;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), lds_total, stream, L.d_text, L.n,
-                       L.d_filter, lds_bytes, P, L.block_symbols, L.d_count);
+                       L.d_filter, lds_bytes, P, L.block_symbols, L.d_count, L.po);
     return hipGetLastError();
 }
 
-template <bool HASHED, bool EXACT>
+template <bool HASHED, bool EXACT, bool POS>
 static hipError_t launch_halo(const smh_wm_launch &L, hipStream_t stream)
 {
     const int halo = L.m - 1;
@@ -190,23 +191,25 @@ static hipError_t launch_halo(const smh_wm_launch &L, hipStream_t stream)
         /* byte symbols, 4-byte block: the specialised scan (compile-time bits per key) */
         if (L.filter_le4 && halo <= 32) {
             if (halo <= 16) {
-                if (L.filter_k == 2) return launch_one<true, false, 1, 2>(L, stream);
-                if (L.filter_k == 3) return launch_one<true, false, 1, 3>(L, stream);
-                return launch_one<true, false, 1, 4>(L, stream);
+                if (L.filter_k == 2) return launch_one<true, false, 1, 2, POS>(L, stream);
+                if (L.filter_k == 3) return launch_one<true, false, 1, 3, POS>(L, stream);
+                return launch_one<true, false, 1, 4, POS>(L, stream);
             }
-            if (L.filter_k == 2) return launch_one<true, false, 2, 2>(L, stream);
-            if (L.filter_k == 3) return launch_one<true, false, 2, 3>(L, stream);
-            return launch_one<true, false, 2, 4>(L, stream);
+            if (L.filter_k == 2) return launch_one<true, false, 2, 2, POS>(L, stream);
+            if (L.filter_k == 3) return launch_one<true, false, 2, 3, POS>(L, stream);
+            return launch_one<true, false, 2, 4, POS>(L, stream);
         }
     }
-    if (halo <= 16) return launch_one<HASHED, EXACT, 1>(L, stream);
-    if (halo <= 32) return launch_one<HASHED, EXACT, 2>(L, stream);
-    if (halo <= 64) return launch_one<HASHED, EXACT, 4>(L, stream);
-    return launch_one<HASHED, EXACT, 0>(L, stream);
+    if (halo <= 16) return launch_one<HASHED, EXACT, 1, 0, POS>(L, stream);
+    if (halo <= 32) return launch_one<HASHED, EXACT, 2, 0, POS>(L, stream);
+    if (halo <= 64) return launch_one<HASHED, EXACT, 4, 0, POS>(L, stream);
+    return launch_one<HASHED, EXACT, 0, 0, POS>(L, stream);
 }
 
+template <bool POS>
 static hipError_t launch_pair(const smh_wm_launch &L, hipStream_t stream)
 {
+    auto wm_pair_kernel = ::wm_pair_kernel<POS>;
     const uint32_t lds_bytes = 65536u;
     static int cached_per_cu = 0;
     if (!cached_per_cu) {
@@ -225,17 +228,22 @@ static hipError_t launch_pair(const smh_wm_launch &L, hipStream_t stream)
     if (blocks > want) blocks = want;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(wm_pair_kernel, dim3((unsigned)blocks), dim3(SMH_BLOCK_THREADS), lds_bytes, stream, L.d_text,
-                       L.n, L.m, L.d_pair, L.d_filter, L.d_count);
+                       L.n, L.m, L.d_pair, L.d_filter, L.d_count, L.po);
     return hipGetLastError();
 }
 
-hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream)
+template <bool POS>
+static hipError_t launch_block(const smh_wm_launch &L, hipStream_t stream)
 {
-    if (L.d_pair) return launch_pair(L, stream);
-    if (L.filter_hashed) return launch_halo<true, false>(L, stream);
-    if (L.filter_exact) return launch_halo<false, true>(L, stream);
-    return launch_halo<false, false>(L, stream);
+    if (L.d_pair) return launch_pair<POS>(L, stream);
+    if (L.filter_hashed) return launch_halo<true, false, POS>(L, stream);
+    if (L.filter_exact) return launch_halo<false, true, POS>(L, stream);
+    return launch_halo<false, false, POS>(L, stream);
 }
+
+hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream) { return launch_block<false>(L, stream); }
+/* positions mode of the same kernels (L.po set): END columns of all matches appended per wave */
+hipError_t smh_launch_wm_block_positions(const smh_wm_launch &L, hipStream_t stream) { return launch_block<true>(L, stream); }
 
 hipError_t smh_launch_wm_table(const smh_wm_table_launch &L, hipStream_t stream)
 {

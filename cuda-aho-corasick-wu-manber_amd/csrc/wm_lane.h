@@ -215,6 +215,7 @@ struct smh_wm_queue {
     uint64_t *slots; /* SMH_WM_QCAP entries, private to this wave (LDS on the GPU) */
     uint32_t count;  /* wave-uniform */
     uint32_t matches;
+    const smh_pos_out *po; /* positions mode: verified columns are appended here; else NULL */
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -231,6 +232,10 @@ SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_pa
     uint32_t r1;
     const uint32_t r0 = smh_wm_verify2(text, e0, e1, P, r1);
     Q.matches += (h0 ? r0 : 0u) + (h1 ? r1 : 0u);
+    if (Q.po) { /* positions mode: the verified END columns */
+        smh_append_bits(h0 ? r0 : 0u, e0, *Q.po);
+        smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
+    }
     Q.count = 0;
 }
 /* append without a capacity check: the caller drains first whenever fewer than 64 slots are free */
@@ -247,7 +252,10 @@ SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_par
 SMH_LANE void smh_wm_drain(smh_wm_queue &, const uint8_t *, const smh_wm_params &) {}
 SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P, bool cond, uint64_t e)
 {
-    if (cond) Q.matches += smh_wm_verify(text, e, P);
+    if (!cond) return;
+    const uint32_t hit = smh_wm_verify(text, e, P);
+    Q.matches += hit;
+    if (hit && Q.po) smh_append_bits(1u, e, *Q.po);
 }
 #endif
 
@@ -269,7 +277,7 @@ SMH_LANE uint32_t smh_alignbyte(uint32_t hi, uint32_t lo, uint32_t r)
 /* FK > 0: the byte-symbol tuned path -- the block is the column's last four bytes, read as one
  * unaligned little-endian dword out of the lane's registers (v_alignbyte), hashed filter with FK
  * bits per key.  FK == 0: any symbol width, rolling code. */
-template <bool HASHED, bool EXACT, int HC, int FK = 0>
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
 SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[4 * HC + 16],
                                    const uint32_t *filter, const smh_wm_params &P, smh_wm_queue &Q)
 {
@@ -293,12 +301,14 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
     for (int i = 0; i < 64; ++i) {
         code = (code << P.bits) | smh_byte_of(w[4 * HC + (i >> 2)], i & 3);
         const uint32_t hit = smh_wm_filter<HASHED>(code, filter, P);
-        if (EXACT)
+        if (EXACT && !POS)
             cnt += hit;
         else
             surv[i >> 5] |= hit << (i & 31);
     }
     }
+    if (EXACT && POS) /* a set filter bit IS a match: append the END columns */
+        cnt += smh_append_bits(((uint64_t)surv[1] << 32) | surv[0], a, *Q.po);
     if (!EXACT) {
         /* compaction: one queue entry per surviving column, as many rounds as the busiest lane has;
          * the HASH/PREFIX stage (drain) is entered from this one place while the wave scans */
@@ -317,8 +327,9 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
 /* Slow path: any segment of END columns, bounds checked, no pre-halo requirement. */
 template <bool HASHED, bool EXACT>
 SMH_LANE uint32_t smh_wm_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const uint32_t *filter,
-                                   const smh_wm_params &P, int block_symbols)
+                                   const smh_wm_params &P, int block_symbols, uint64_t *match_mask = nullptr)
 {
+    if (match_mask) *match_mask = 0;
     if (a >= n) return 0;
     uint64_t end = a + SMH_SEG;
     if (end > n) end = n;
@@ -330,11 +341,10 @@ SMH_LANE uint32_t smh_wm_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, 
     for (uint64_t i = e0 - (uint64_t)(block_symbols - 1); i < e0; ++i) code = (code << P.bits) | text[i];
     for (uint64_t e = e0; e < end; ++e) {
         code = (code << P.bits) | text[e];
-        const uint32_t hit = smh_wm_filter<HASHED>(code, filter, P);
-        if (EXACT)
-            cnt += hit;
-        else if (hit)
-            cnt += smh_wm_verify(text, e, P);
+        uint32_t hit = smh_wm_filter<HASHED>(code, filter, P);
+        if (!EXACT && hit) hit = smh_wm_verify(text, e, P);
+        cnt += hit;
+        if (match_mask && hit) *match_mask |= 1ull << (e - a); /* positions mode: bit = END column - a */
     }
     return cnt;
 }
@@ -388,10 +398,10 @@ SMH_LANE uint32_t smh_wm_lane_table(const uint8_t *text, uint64_t n, uint64_t a,
 
 /* whole-grid work distribution for one lane; HC == 0: no fast path (m - 1 > 64).  The next chunk's
  * text is requested before the current chunk is scanned (software prefetch). */
-template <bool HASHED, bool EXACT, int HC, int FK = 0>
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
 SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n,
                                 const uint32_t *filter, const smh_wm_params &P, int block_symbols,
-                                uint64_t *queue_base)
+                                uint64_t *queue_base, const smh_pos_out *po = nullptr)
 {
     if (n < (uint64_t)P.m) return 0;
     constexpr int H = HC > 0 ? HC : 1;
@@ -403,6 +413,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8
     Q.slots = queue_base; /* this wave's slice (the kernel passes LDS) */
     Q.count = 0;
     Q.matches = 0;
+    Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
     uint32_t cur[4 * H + 16], nxt[4 * H + 16];
     auto is_fast = [&](uint64_t kk) {
@@ -428,11 +439,16 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8
         constexpr bool PREFETCH = EXACT && H == 1; /* only where registers allow: exact filter, short pre-halo */
         if (PREFETCH && nxt_fast) load(kn, nxt);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
-        if (cur_fast)
-            cnt += smh_wm_lane_fast<HASHED, EXACT, H, FK>(text, a, cur, filter, P, Q);
-
-        else
+        if (cur_fast) {
+            cnt += smh_wm_lane_fast<HASHED, EXACT, H, FK, POS>(text, a, cur, filter, P, Q);
+        } else if (POS) {
+            /* first / last chunks: per-lane mask of matching END columns, then the wave-level append */
+            uint64_t mm;
+            smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols, &mm);
+            cnt += smh_append_bits(mm, a, *po);
+        } else {
             cnt += smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols);
+        }
         if (nxt_fast) {
             if (PREFETCH) {
 #pragma unroll
@@ -506,10 +522,19 @@ SMH_LANE uint32_t smh_wm_pair_step(uint32_t &code, uint32_t x, int k, const void
     smh_lds_u32x2(tab, (code >> 2) & 0xFFF8u, lo, hi); /* ((code & 0x3FFFF) >> 5) * 8 */
     return smh_bfe(lo, code & 31u, 1) + smh_bfe(hi, code & 31u, 1);
 }
+/* positions mode: the two answers as two bits (bit 0 = the pair's first column, bit 1 = its second) */
+SMH_LANE uint32_t smh_wm_pair_step_bits(uint32_t &code, uint32_t x, int k, const void *tab)
+{
+    code = (code << 4) | smh_bfe(x, k == 0 ? 1 : 17, 4);
+    uint32_t lo, hi;
+    smh_lds_u32x2(tab, (code >> 2) & 0xFFF8u, lo, hi);
+    return smh_bfe(lo, code & 31u, 1) | (smh_bfe(hi, code & 31u, 1) << 1);
+}
 
 /* fast path: the 64 END columns of the segment at a (a >= 8, a + 64 <= n, first column >= m-1) */
+template <bool POS = false>
 SMH_LANE uint32_t smh_wm_pair_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16],
-                                        const uint32_t (&edge)[2], const void *tab)
+                                        const uint32_t (&edge)[2], const void *tab, const smh_pos_out *po = nullptr)
 {
     /* prime the rolling code with the 8 symbols in front of the segment */
     uint32_t code = 0, cnt = 0;
@@ -521,6 +546,20 @@ SMH_LANE uint32_t smh_wm_pair_lane_fast(const uint8_t *text, uint64_t a, const u
         code = (code << 4) | smh_bfe(x, 17, 4);
     }
     /* `code` now holds symbols a-8 .. a-1; the lookup after the pair (a+2i, a+2i+1) sees a+2i-7 .. a+2i+1 */
+    if constexpr (POS) {
+        uint32_t mlo = 0, mhi = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = smh_wm_pairs_prep(w[q]);
+            const uint32_t b0 = smh_wm_pair_step_bits(code, x, 0, tab), b1 = smh_wm_pair_step_bits(code, x, 1, tab);
+            const uint32_t four = b0 | (b1 << 2);
+            if (q < 8)
+                mlo |= four << (4 * q);
+            else
+                mhi |= four << (4 * (q - 8));
+        }
+        return smh_append_bits(((uint64_t)mhi << 32) | mlo, a, *po);
+    } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const uint32_t x = smh_wm_pairs_prep(w[q]);
@@ -528,11 +567,14 @@ SMH_LANE uint32_t smh_wm_pair_lane_fast(const uint8_t *text, uint64_t a, const u
         cnt += smh_wm_pair_step(code, x, 1, tab);
     }
     return cnt;
+    }
 }
 
 /* slow path of the pair kernel: per-column test against the exact m-symbol filter held in HBM */
-SMH_LANE uint32_t smh_wm_pair_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const uint32_t *filter_g, int m)
+SMH_LANE uint32_t smh_wm_pair_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const uint32_t *filter_g, int m,
+                                        uint64_t *match_mask = nullptr)
 {
+    if (match_mask) *match_mask = 0;
     if (a >= n) return 0;
     uint64_t end = a + SMH_SEG;
     if (end > n) end = n;
@@ -545,14 +587,16 @@ SMH_LANE uint32_t smh_wm_pair_lane_slow(const uint8_t *text, uint64_t n, uint64_
     for (uint64_t e = e0; e < end; ++e) {
         code = (code << 2) | (text[e] & 3u);
         const uint32_t key = code & mask;
-        cnt += (filter_g[key >> 5] >> (key & 31u)) & 1u;
+        const uint32_t hit = (filter_g[key >> 5] >> (key & 31u)) & 1u;
+        cnt += hit;
+        if (match_mask && hit) *match_mask |= 1ull << (e - a);
     }
     return cnt;
 }
 
-template <bool PREFETCH>
+template <bool PREFETCH, bool POS = false>
 SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n, int m,
-                                     const void *tab, const uint32_t *filter_g)
+                                     const void *tab, const uint32_t *filter_g, const smh_pos_out *po = nullptr)
 {
     if (n < (uint64_t)m) return 0;
     const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
@@ -587,10 +631,15 @@ SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, uint64_t nthreads, const 
         const bool nxt_fast = is_fast(kn);
         if (PREFETCH && nxt_fast) load(kn, nxt, nxt_edge);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
-        if (cur_fast)
-            cnt += smh_wm_pair_lane_fast(text, a, cur, cur_edge, tab);
-        else
+        if (cur_fast) {
+            cnt += smh_wm_pair_lane_fast<POS>(text, a, cur, cur_edge, tab, po);
+        } else if (POS) {
+            uint64_t mm;
+            smh_wm_pair_lane_slow(text, n, a, filter_g, m, &mm);
+            cnt += smh_append_bits(mm, a, *po);
+        } else {
             cnt += smh_wm_pair_lane_slow(text, n, a, filter_g, m);
+        }
         if (nxt_fast) {
             if (PREFETCH) {
 #pragma unroll

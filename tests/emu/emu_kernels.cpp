@@ -49,9 +49,11 @@ static guarded guard_copy(const uint8_t *src, uint64_t n, int mode)
 static void guard_free(guarded &g) { munmap(g.map, g.map_len); }
 
 /* ------------------------------------------------------------------ AC */
-template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT>
+template <typename E, int SIGMA, int STRIDE, int HC, bool EXACT, bool POS = false>
 static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t blocks)
 {
+    if constexpr (POS && HC > 2) return ~0ull; /* as the launcher: positions mode covers a 32-byte halo */
+    else {
     smh_ac_df df;
     for (int i = 0; i < SMH_AC_DF_LEN; ++i) df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
     if (STRIDE == 3) /* as smh_runtime.hip: compact rows of the hybrid image count as "deep enough" */
@@ -63,30 +65,63 @@ static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t b
         if constexpr (STRIDE == 3) {
             const smh_fmt_s2h fmt{ac->scan_full_rows, ac->scan_full_rows * 28u};
             if constexpr (EXACT || HC <= 2)
-                total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
+                total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT, true, 16, POS>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
         } else if constexpr (STRIDE == 2) {
-            total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT>(smh_fmt_s2{}, t, nthreads, ac->scan_table, V, df, nullptr);
+            total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT, true, 16, POS>(smh_fmt_s2{}, t, nthreads, ac->scan_table, V, df, nullptr);
         } else {
             const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
-            total += smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, EMU_AC_NCH, EXACT>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
+            total += smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, EMU_AC_NCH, EXACT, true, 16, POS>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
         }
     }
     return total;
+    }
 }
 
-template <typename E, int SIGMA, int STRIDE, int HC>
+template <typename E, int SIGMA, int STRIDE, int HC, bool POS = false>
 static uint64_t ac_exact(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t blocks)
 {
-    return ac->scan_exact ? ac_grid<E, SIGMA, STRIDE, HC, true>(ac, V, blocks) : ac_grid<E, SIGMA, STRIDE, HC, false>(ac, V, blocks);
+    return ac->scan_exact ? ac_grid<E, SIGMA, STRIDE, HC, true, POS>(ac, V, blocks)
+                          : ac_grid<E, SIGMA, STRIDE, HC, false, POS>(ac, V, blocks);
 }
 
-template <typename E, int SIGMA, int STRIDE>
+template <typename E, int SIGMA, int STRIDE, bool POS = false>
 static uint64_t ac_halo(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t blocks)
 {
     const int halo = ac->scan_depth - 1;
-    if (halo <= 16) return ac_exact<E, SIGMA, STRIDE, 1>(ac, V, blocks);
-    if (halo <= 32) return ac_exact<E, SIGMA, STRIDE, 2>(ac, V, blocks);
-    return ac_exact<E, SIGMA, STRIDE, 4>(ac, V, blocks);
+    if (halo <= 16) return ac_exact<E, SIGMA, STRIDE, 1, POS>(ac, V, blocks);
+    if (halo <= 32) return ac_exact<E, SIGMA, STRIDE, 2, POS>(ac, V, blocks);
+    return ac_exact<E, SIGMA, STRIDE, 4, POS>(ac, V, blocks);
+}
+
+/* the tuned kernels in positions mode, whatever scan plan the handle holds; ~0 = the plan's halo is
+ * beyond the 32 bytes the mode covers (smh_ac_positions then runs the per-segment kernel) */
+extern "C" uint64_t emu_ac_positions_tuned(const smh_ac *ac, const uint8_t *text, uint64_t n, uint64_t *out,
+                                           uint64_t capacity, uint32_t blocks)
+{
+    if (n < (uint64_t)ac->m) return 0;
+    if (!blocks) blocks = 2;
+    size_t dflen = (size_t)ac->m + 2 < 72 ? 72 : (size_t)ac->m + 2;
+    std::vector<uint32_t> df(dflen);
+    for (size_t i = 0; i < dflen; ++i) df[i] = (int)i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+    /* the fast path reads 16-byte pieces: give the text the padding the runtime gives device text */
+    std::vector<uint8_t> padded(((n + 15) / 16) * 16 + 64, 0);
+    memcpy(padded.data(), text, n);
+    smh_ac_verify_ctx V = {};
+    V.text = padded.data(); V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
+    V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df.data();
+    V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    uint64_t cursor = 0;
+    V.pos = smh_pos_out{out, capacity, &cursor};
+    uint64_t r;
+    if (ac->scan_stride == 2 && ac->scan_full_rows)
+        r = ac_halo<uint16_t, 4, 3, true>(ac, V, blocks);
+    else if (ac->scan_stride == 2)
+        r = ac_halo<uint16_t, 4, 2, true>(ac, V, blocks);
+    else if (ac->scan_entry_bytes == 2)
+        r = ac->alphabet == 4 ? ac_halo<uint16_t, 4, 1, true>(ac, V, blocks) : ac_halo<uint16_t, 0, 1, true>(ac, V, blocks);
+    else
+        r = ac->alphabet == 4 ? ac_halo<uint32_t, 4, 1, true>(ac, V, blocks) : ac_halo<uint32_t, 0, 1, true>(ac, V, blocks);
+    return r == ~0ull ? ~0ull : cursor;
 }
 
 /* blocks: grid size (0 = 4); the scan plan (stride, depth K) is whatever the handle holds */
@@ -108,7 +143,7 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
                 total += smh_ac_table_thread(t, nthreads, text, n, ac->m, ac->g_transition, ac->g_supply,
                                              ac->g_final, ac->alphabet);
         } else {
-            smh_ac_verify_ctx V;
+            smh_ac_verify_ctx V = {};
             V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
             V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
             V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
@@ -129,8 +164,8 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
 }
 
 /* ------------------------------------------------------------------ WM */
-template <bool HASHED, bool EXACT, int HC, int FK = 0>
-static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks)
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
+static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po = nullptr)
 {
     smh_wm_params P;
     P.m = wm->m;
@@ -150,29 +185,29 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t)
-        total += smh_wm_thread<HASHED, EXACT, HC, FK>(t, nthreads, text, n, wm->filter, P, wm->block_symbols, nullptr);
+        total += smh_wm_thread<HASHED, EXACT, HC, FK, POS>(t, nthreads, text, n, wm->filter, P, wm->block_symbols, nullptr, po);
     return total;
 }
 
-template <bool HASHED, bool EXACT>
-static uint64_t wm_halo(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks)
+template <bool HASHED, bool EXACT, bool POS = false>
+static uint64_t wm_halo(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po = nullptr)
 {
     const int halo = wm->m - 1;
     if constexpr (HASHED && !EXACT) {
         if (wm->filter_le4 && halo <= 32) { /* as launch_halo in wm_kernels.hip */
             if (halo <= 16)
-                return wm->filter_k == 2 ? wm_grid<true, false, 1, 2>(wm, text, n, blocks)
-                     : wm->filter_k == 3 ? wm_grid<true, false, 1, 3>(wm, text, n, blocks)
-                                         : wm_grid<true, false, 1, 4>(wm, text, n, blocks);
-            return wm->filter_k == 2 ? wm_grid<true, false, 2, 2>(wm, text, n, blocks)
-                 : wm->filter_k == 3 ? wm_grid<true, false, 2, 3>(wm, text, n, blocks)
-                                     : wm_grid<true, false, 2, 4>(wm, text, n, blocks);
+                return wm->filter_k == 2 ? wm_grid<true, false, 1, 2, POS>(wm, text, n, blocks, po)
+                     : wm->filter_k == 3 ? wm_grid<true, false, 1, 3, POS>(wm, text, n, blocks, po)
+                                         : wm_grid<true, false, 1, 4, POS>(wm, text, n, blocks, po);
+            return wm->filter_k == 2 ? wm_grid<true, false, 2, 2, POS>(wm, text, n, blocks, po)
+                 : wm->filter_k == 3 ? wm_grid<true, false, 2, 3, POS>(wm, text, n, blocks, po)
+                                     : wm_grid<true, false, 2, 4, POS>(wm, text, n, blocks, po);
         }
     }
-    if (halo <= 16) return wm_grid<HASHED, EXACT, 1>(wm, text, n, blocks);
-    if (halo <= 32) return wm_grid<HASHED, EXACT, 2>(wm, text, n, blocks);
-    if (halo <= 64) return wm_grid<HASHED, EXACT, 4>(wm, text, n, blocks);
-    return wm_grid<HASHED, EXACT, 0>(wm, text, n, blocks);
+    if (halo <= 16) return wm_grid<HASHED, EXACT, 1, 0, POS>(wm, text, n, blocks, po);
+    if (halo <= 32) return wm_grid<HASHED, EXACT, 2, 0, POS>(wm, text, n, blocks, po);
+    if (halo <= 64) return wm_grid<HASHED, EXACT, 4, 0, POS>(wm, text, n, blocks, po);
+    return wm_grid<HASHED, EXACT, 0, 0, POS>(wm, text, n, blocks, po);
 }
 
 extern "C" uint64_t emu_wm_scan(const smh_wm *wm, const uint8_t *text_in, uint64_t n, int variant, uint32_t blocks)
@@ -217,7 +252,7 @@ extern "C" uint64_t emu_ac_positions(const smh_ac *ac, const uint8_t *text, uint
     size_t dflen = (size_t)ac->m + 2 < 72 ? 72 : (size_t)ac->m + 2;
     uint32_t *df = (uint32_t *)malloc(dflen * 4);
     for (size_t i = 0; i < dflen; ++i) df[i] = (int)i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
-    smh_ac_verify_ctx V;
+    smh_ac_verify_ctx V = {};
     V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
     V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
     V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
@@ -292,4 +327,29 @@ extern "C" uint64_t emu_sbom_scan(const smh_sbom *sb, const uint8_t *text_in, ui
         result[mode] = total;
     }
     return result[0] == result[1] ? result[0] : ~0ull;
+}
+
+/* the tuned WM kernels in positions mode (pair filter, exact / hashed / direct block filters) */
+extern "C" uint64_t emu_wm_positions_tuned(const smh_wm *wm, const uint8_t *text_in, uint64_t n, uint64_t *out,
+                                           uint64_t capacity, uint32_t blocks)
+{
+    if (n < (uint64_t)wm->m) return 0;
+    if (!blocks) blocks = 2;
+    std::vector<uint8_t> padded(((n + 15) / 16) * 16 + 64 + 64, 0);
+    uint8_t *text = padded.data() + 64; /* the pair kernel reads the 16 bytes in front of a chunk (never of chunk 0) */
+    memcpy(text, text_in, n);
+    uint64_t cursor = 0;
+    smh_pos_out po{out, capacity, &cursor};
+    if (wm->pair_table) {
+        const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
+        for (uint64_t t = 0; t < nthreads; ++t)
+            smh_wm_pair_thread<false, true>(t, nthreads, text, n, wm->m, wm->pair_table, wm->filter, &po);
+    } else if (wm->filter_hashed) {
+        wm_halo<true, false, true>(wm, text, n, blocks, &po);
+    } else if (wm->filter_exact) {
+        wm_halo<false, true, true>(wm, text, n, blocks, &po);
+    } else {
+        wm_halo<false, false, true>(wm, text, n, blocks, &po);
+    }
+    return cursor;
 }

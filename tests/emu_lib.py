@@ -74,3 +74,27 @@ _emu.emu_sbom_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_int, C.c_uint3
 def sbom_scan(sb, text, variant=S.VARIANT_TUNED, blocks=0):
     text = np.ascontiguousarray(text, dtype=np.uint8)
     return int(_emu.emu_sbom_scan(sb.h, text.ctypes.data_as(S.u8p), len(text), variant, blocks))
+
+
+_emu.emu_ac_positions_tuned.restype = C.c_uint64
+_emu.emu_ac_positions_tuned.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32]
+
+
+def ac_positions_tuned(ac, text, capacity, blocks=0):
+    """Positions mode of the tuned scan kernels under the handle's current plan; total is None when the
+    plan's halo exceeds what the mode covers (the runtime then uses the per-segment kernel)."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    out = np.zeros(max(capacity, 1), dtype=np.uint64)
+    total = int(_emu.emu_ac_positions_tuned(ac.h, text.ctypes.data_as(S.u8p), len(text),
+                                            out.ctypes.data_as(C.POINTER(C.c_uint64)), capacity, blocks))
+    if total == 0xFFFFFFFFFFFFFFFF:
+        return None, out[:0]
+    return total, out[:min(total, capacity)]
+
+
+_emu.emu_wm_positions_tuned.restype = C.c_uint64
+_emu.emu_wm_positions_tuned.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32]
+
+
+def wm_positions_tuned(wm, text, capacity, blocks=0):
+    return _positions(_emu.emu_wm_positions_tuned, wm.h, text, capacity, blocks)

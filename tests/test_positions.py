@@ -1,5 +1,8 @@
 """Match-position output: END columns of all matches, compacted with a wave-level
-prefix sum into a device buffer.  The reference only has commented-out printf's for positions
+prefix sum into a device buffer.  Two implementations behind smh_ac_positions / smh_wm_positions: the
+tuned scan kernels in positions mode (matches recorded as bits / verified through the candidate queues,
+appended per wave) and the per-segment kernels over the HBM tables (unaligned text, halos beyond 32
+bytes); both are checked.  The reference only has commented-out printf's for positions
 (ac/ac.c:217, wu/wu.c:93), so parity is the sorted list against the oracle's definition-level
 brute force; the count of positions must also equal the reference's golden match count."""
 import ctypes as C
@@ -41,6 +44,24 @@ def test_emulated_positions_match_bruteforce(name):
         # too small a buffer: the cursor still reports the full count, nothing is written past the end
         total, got = E.ac_positions(ac, text, 3, 1)
         assert total == len(want) and len(got) == 3 and set(got.astype(np.int64)) <= set(want.tolist())
+    # the tuned kernels in positions mode: every scan-table format, K = m and K < m
+    total, got = E.wm_positions_tuned(wm, text, cap, 2)
+    assert total == len(want) and np.array_equal(np.sort(got).astype(np.int64), want)
+    plans = [(0, 0), (1, min(m, 33)), (1, max(1, m // 2)), (1, 2)]
+    if sigma == 4:
+        plans += [(2, min(m, 33)), (2, max(1, m // 2)), (3, min(m, 33) | (1 << 8)), (3, max(4, m // 2) | (2 << 8))]
+    tried = 0
+    for stride, depth in plans:
+        try:
+            ac.set_scan_plan(stride, depth)
+        except S.SmhError:
+            continue
+        total, got = E.ac_positions_tuned(ac, text, cap, 2)
+        if total is None:
+            continue  # halo beyond 32 bytes: the runtime uses the per-segment kernel
+        tried += 1
+        assert total == len(want) and np.array_equal(np.sort(got).astype(np.int64), want), (stride, depth)
+    assert tried >= 1 or m > 33
 
 
 @pytest.mark.gpu
@@ -67,6 +88,28 @@ def test_gpu_positions_match_bruteforce(name):
         assert total == len(want) == vec["count_ac"]
         got = np.sort(out[:total].cpu().numpy())
         assert np.array_equal(got, want)
+    # the per-segment kernels (what unaligned text gets): same positions, shifted by the 4-byte offset
+    d_un = torch.zeros(n + 68, dtype=torch.uint8, device=dev)
+    d_un[4:4 + n] = torch.from_numpy(text).to(dev)
+    for obj in (ac, wm):
+        out = torch.zeros(cap, dtype=torch.int64, device=dev)
+        cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        obj.positions_device(d_un.data_ptr() + 4, n, out.data_ptr(), cap, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(cur.item()) == len(want) and np.array_equal(np.sort(out[:len(want)].cpu().numpy()), want)
+    # other scan plans of the automaton in positions mode
+    if sigma == 4 and m >= 6:
+        for stride, depth in ((1, min(m, 33)), (2, min(m, 33)), (3, min(m, 33) | (1 << 8)), (1, max(2, m // 2)), (2, max(2, m // 2))):
+            try:
+                ac.set_scan_plan(stride, depth)
+            except S.SmhError:
+                continue
+            out = torch.zeros(cap, dtype=torch.int64, device=dev)
+            cur = torch.zeros(1, dtype=torch.int64, device=dev)
+            ac.positions_device(d_text.data_ptr(), n, out.data_ptr(), cap, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert int(cur.item()) == len(want) and np.array_equal(np.sort(out[:len(want)].cpu().numpy()), want), (stride, depth)
+        ac.set_scan_plan(0, 0)
     if len(want) > 3:
         out = torch.full((8,), -1, dtype=torch.int64, device=dev)
         cur = torch.zeros(1, dtype=torch.int64, device=dev)
