@@ -55,7 +55,7 @@ def measured_traffic(info):
     stride = 3 if info.scan_full_rows else info.scan_stride  # template value of the hybrid image
     prefix = "ac_dfa_kernel<%s, 4, %d, %d, %s," % (entry, stride, hc, "true" if info.scan_exact else "false")
     for name, rec in kernels.items():
-        if name.startswith(prefix):
+        if name.startswith(prefix) and not name.endswith("true>"):  # "..., true>" = the positions-mode instance
             return rec["hbm_bytes"]
     return None
 
@@ -256,6 +256,24 @@ def main():
         out["stream_read"] = dict(kernel="smh_stream_read_kernel (16-byte loads, XOR, no table work)", ms=round(pms, 4),
                                   GBps=round(sgbs, 1), hbm_frac=round(sgbs / HBM_PEAK_GBS, 4))
         out["roofline"]["of_stream_read"] = round(out["roofline"]["achieved"] / sgbs, 4)
+
+    # ---- match positions: the m=16 set's END columns into a device buffer, same text
+    if rank == 0:
+        m_pos = 16
+        cap = max(1024, 2 * int(total_counts[AC_LENGTHS.index(m_pos)]))
+        pbuf = torch.zeros(cap, dtype=torch.int64, device=dev)
+        pcur = torch.zeros(1, dtype=torch.int64, device=dev)
+        pe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(6)]
+        for a, b in pe:
+            pcur.zero_()
+            a.record()
+            acs[m_pos].positions_device(text.data_ptr(), shard_len(m_pos), pbuf.data_ptr(), cap, pcur.data_ptr(), stream)
+            b.record()
+        torch.cuda.synchronize()
+        pms = sorted(a.elapsed_time(b) for a, b in pe[1:])[2]
+        out["positions"] = dict(workload="smh_ac_positions, m=%d set, same text: END columns of all matches" % m_pos,
+                                kernel_ms=round(pms, 4), GBps=round(shard_len(m_pos) / (pms * 1e-3) / 1e9, 1),
+                                matches=int(pcur.item()))
 
     # ---- WM side measurement (BASELINE configs[2]: same text, 10 000 patterns of length 8)
     if not args.no_wm:
