@@ -174,8 +174,56 @@ void smh_ac_host_free(struct smh_ac *ac)
     free(ac->g_transition);
     free(ac->g_supply);
     free(ac->g_final);
+    smh_wm_free(ac->alt_wm);
     ac->magic = 0;
     free(ac);
+}
+
+/* the patterns of a fixed-length goto trie, depth-first: `count` strings of m symbols (NULL on a
+ * malformed trie or when memory runs out -- the caller then keeps the automaton engine) */
+static unsigned char *ac_extract_patterns(const int *trans, const unsigned int *final, uint32_t R, int alphabet, int m,
+                                          uint32_t count)
+{
+    const size_t A = (size_t)alphabet;
+    unsigned char *out = (unsigned char *)malloc((size_t)(count ? count : 1) * (size_t)m);
+    uint32_t *stack = (uint32_t *)malloc(((size_t)m + 2) * sizeof(uint32_t));
+    int *sym = (int *)malloc(((size_t)m + 2) * sizeof(int));
+    unsigned char *path = (unsigned char *)malloc((size_t)m + 1);
+    size_t np = 0;
+    int ok = out && stack && sym && path;
+    if (ok) {
+        int depth = 0;
+        stack[0] = 0;
+        sym[0] = 0;
+        while (depth >= 0 && ok) {
+            const uint32_t r = stack[depth];
+            if (depth == m) {
+                if (final[r]) {
+                    if (np >= count) { ok = 0; break; }
+                    memcpy(out + np * (size_t)m, path, (size_t)m);
+                    ++np;
+                }
+                --depth;
+                continue;
+            }
+            int c = sym[depth];
+            int32_t s = -1;
+            for (; c < alphabet; ++c) {
+                s = trans[r * A + (size_t)c];
+                if (has_edge(trans, r, s)) break;
+            }
+            if (c >= alphabet) { --depth; continue; }
+            sym[depth] = c + 1;
+            if ((uint32_t)s >= R) { ok = 0; break; }
+            path[depth] = (unsigned char)c;
+            ++depth;
+            stack[depth] = (uint32_t)s;
+            sym[depth] = 0;
+        }
+    }
+    free(stack); free(sym); free(path);
+    if (!ok || np != count) { free(out); return NULL; }
+    return out;
 }
 
 struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *supply,
@@ -374,6 +422,21 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
     order = depth = canon = newid = full = NULL;
     seen = leaf = NULL;
     if (ac->fixed_length_ok && smh_ac_plan_scan(ac, SMH_AC_LDS_BUDGET, 0, 0) != SMH_OK) goto bad;
+    /* Scan-engine choice.  When even the best LDS automaton lets so many candidates through that the
+     * verify stage dominates (alphabet-256 sets: K = 1; thousands of long DNA patterns: K = 8, one
+     * position in nine) the same count is obtained much faster by the suffix-filter kernels, which
+     * hash W symbols instead of walking K levels.  The patterns are read back from the goto trie and
+     * compiled for that engine; smh_ac_scan / smh_ac_positions use it unless a plan is forced. */
+    if (ac->fixed_length_ok && ac->scan_cost > SMH_AC_ALT_ENGINE_COST && m >= 3 && smh_wu_shiftsize_for(alphabet)) {
+        /* the caller's arrays may have been adopted (and shrunk in place) in step 6: read the handle's copy */
+        const int *tsrc = ac->g_transition ? ac->g_transition : trans;
+        const unsigned int *fsrc = ac->g_final ? ac->g_final : final;
+        unsigned char *pats = ac_extract_patterns(tsrc, fsrc, ac->g_transition ? ac->states : R, alphabet, m, ac->finals);
+        if (pats) {
+            ac->alt_wm = smh_wm_compile(pats, m, (int)ac->finals, alphabet); /* NULL: stay with the automaton */
+            free(pats);
+        }
+    }
     return ac;
 
 oom:
@@ -673,6 +736,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
     ac->scan_exact = K >= ac->m;
     ac->scan_rows = rk;
     ac->scan_candidate_rate = candidate_rate(ac, K);
+    ac->scan_cost = best_cost;
     /* stride-1 depth-K table */
     const int eb1 = rk <= 32768 ? 2 : 4;
     const size_t n1 = (size_t)rk * A;
@@ -780,6 +844,7 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_stride = (uint32_t)ac->scan_stride;
     out->scan_exact = (uint32_t)ac->scan_exact;
     out->scan_full_rows = ac->scan_full_rows;
+    out->scan_engine = ac->alt_wm && !ac->alt_off ? SMH_ALGO_WM : SMH_ALGO_AC;
     return SMH_OK;
 }
 
@@ -795,6 +860,7 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
     }
     if (ac->dev) smh_ac_dev_free(ac->dev); /* device copies are rebuilt on the next scan */
     ac->dev = NULL;
+    ac->alt_off = stride != 0 || depth != 0; /* a forced plan means "run the automaton kernels" */
     return smh_ac_plan_scan(ac, SMH_AC_LDS_BUDGET, stride, depth);
 }
 

@@ -72,6 +72,9 @@ struct smh_ac {
     void *scan_table;     /* scan_rows * alphabet^stride entries */
     uint32_t scan_bytes;  /* padded to 16 */
     double scan_candidate_rate; /* expected candidates per text byte on uniform text (0 when exact) */
+    double scan_cost;     /* plan cost model's estimate, 1.0 = an exact stride-1 scan (ac_host.c) */
+    struct smh_wm *alt_wm; /* suffix-filter engine for sets whose best automaton plan is verify-bound, else NULL */
+    int alt_off;          /* a scan plan was forced: scans use the automaton kernels regardless */
     /* stride-1 depth-K table in HBM: the slow path and the resolution of stride-2 "first symbol"
      * candidates read it; identical to scan_table when scan_stride == 1 */
     void *trunc1_table;
@@ -102,6 +105,7 @@ void smh_ac_host_free(struct smh_ac *ac);
 /* choose K / stride for an LDS budget and build scan_table (+ trunc1_table); force_stride 0 = auto */
 int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth);
 #define SMH_AC_LDS_BUDGET (160u * 1024u - 512u)
+#define SMH_AC_ALT_ENGINE_COST 2.5 /* above this plan cost (< ~1.4 TB/s) the suffix-filter engine scans the set */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
 

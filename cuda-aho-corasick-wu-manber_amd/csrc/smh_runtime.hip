@@ -284,6 +284,8 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         return SMH_EUNSUP;
     }
     if (n < (uint64_t)ac->m) return SMH_OK;
+    if (variant == SMH_VARIANT_TUNED && ac->alt_wm && !ac->alt_off) /* engine choice: ac_host.c, end of the compile */
+        return smh_wm_scan(ac->alt_wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
     int rc = ac_ensure_device(ac);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
@@ -330,6 +332,7 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
         return SMH_EUNSUP;
     }
     if (n < (uint64_t)ac->m) return SMH_OK;
+    if (ac->alt_wm && !ac->alt_off) return smh_wm_positions(ac->alt_wm, d_text, n, d_positions, capacity, d_cursor, stream);
     int rc = ac_ensure_device(ac);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;

@@ -76,6 +76,9 @@ void smh_corpus_patterns(unsigned char *out, int m, int p_size, uint64_t seed, i
 /* ---- byte-range shards: main.c:375-378,464-477 with the true length of the last shard ---- */
 void smh_shard_range(uint64_t n, int n_shards, int shard, int m, uint64_t *begin, uint64_t *end);
 
+#define SMH_ALGO_AC 0
+#define SMH_ALGO_WM 1
+
 /* ---- Aho-Corasick ---- */
 typedef struct smh_ac smh_ac;
 
@@ -94,6 +97,12 @@ typedef struct smh_ac_info {
     uint32_t scan_exact;   /* 1: K == m, a flagged transition is a match; 0: candidates are verified in HBM */
     uint32_t scan_full_rows; /* hybrid stride-2 image: rows below this id hold 16 two-symbol entries, deeper
                               * rows are 4-byte item lists; 0 for the plain stride-1 / stride-2 images */
+    uint32_t scan_engine;    /* SMH_ALGO_AC: the automaton kernels scan; SMH_ALGO_WM: even the best LDS automaton
+                              * would be verify-bound (alphabet-256 sets, thousands of long DNA patterns), so
+                              * smh_ac_scan / smh_ac_positions run the suffix-filter kernels on the same patterns
+                              * -- same count, several times faster.  smh_ac_set_scan_plan with a forced stride or
+                              * depth switches back to the automaton kernels; (0, 0) restores the choice. */
+    uint32_t reserved;
 } smh_ac_info;
 
 /* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
@@ -225,8 +234,6 @@ void smh_sbom_free(smh_sbom *sb);
  * (SMH_ALGO_AC) or Wu-Manber table set (SMH_ALGO_WM) per distinct length, all scanning the same
  * resident text on the caller's stream and adding into the same counter.  Wu-Manber needs m >= 3
  * (wu/wu.c:119-125): classes of length 1 and 2 of a SMH_ALGO_WM set are compiled as automata. */
-#define SMH_ALGO_AC 0
-#define SMH_ALGO_WM 1
 typedef struct smh_pset smh_pset;
 
 typedef struct smh_pset_info {

@@ -140,11 +140,50 @@ def test_dfa_larger_than_lds(name):
     ac = S.AcAutomaton.from_patterns(pat, vec["m"], vec["p"], vec["sigma"])
     info = ac.info()
     assert info.lds_rows < info.rows and not info.scan_exact and info.scan_depth < vec["m"]
+    assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"]  # whichever engine the handle chose
+    ac.set_scan_plan(info.scan_stride, info.scan_depth)               # the automaton kernels, same plan
+    assert ac.info().scan_engine == S.ALGO_AC
     assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"]
 
 
+@pytest.mark.parametrize("name,engine", [("ascii_5_20", 1), ("ascii_m5", 1), ("mx_s256_m16_p1000", 1), ("dense_dna", 0),
+                                         ("big_dfa", 0), ("kat_1m_100x8", 0)])
+def test_scan_engine_choice(name, engine):
+    """Sets whose best LDS automaton would be verify-bound (alphabet 256: K = 1) are scanned by the
+    suffix-filter kernels behind the same AC entry points -- counts and positions identical; forcing a
+    plan switches back to the automaton kernels, (0, 0) restores the choice."""
+    import torch
+    vec = BY_NAME[name]
+    text, pat = cases.build(vec)
+    m, p, sigma, want = vec["m"], vec["p"], vec["sigma"], vec["count_ac"]
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    assert ac.info().scan_engine == (S.ALGO_WM if engine else S.ALGO_AC)
+    assert ac.count_host(text, S.VARIANT_TUNED)[0] == want
+    dev = torch.device("cuda", 0)
+    d_text = torch.zeros(len(text) + 64, dtype=torch.uint8, device=dev)
+    d_text[:len(text)] = torch.from_numpy(text).to(dev)
+    wantpos = O.positions_bruteforce(pat, m, p, text)
+    for forced in (False, True):
+        if forced:
+            ac.set_scan_plan(1, ac.info().scan_depth)
+            assert ac.info().scan_engine == S.ALGO_AC and ac.count_host(text, S.VARIANT_TUNED)[0] == want
+        out = torch.zeros(want + 4, dtype=torch.int64, device=dev)
+        cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        ac.positions_device(d_text.data_ptr(), len(text), out.data_ptr(), want + 4, cur.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(cur.item()) == want and np.array_equal(np.sort(out[:want].cpu().numpy()), wantpos)
+    ac.set_scan_plan(0, 0)
+    assert ac.info().scan_engine == (S.ALGO_WM if engine else S.ALGO_AC)
+    # a handle built from the reference tables reads the patterns back from the goto trie
+    t = O.oracle_ac(pat, m, p, sigma)[1]
+    ac2 = S.AcAutomaton.from_tables(t.state_transition, t.state_supply, t.state_final, m * p + 1, sigma, m)
+    assert ac2.info().scan_engine == ac.info().scan_engine and ac2.count_host(text, S.VARIANT_TUNED)[0] == want
+
+
 @pytest.mark.parametrize("name", ["dense_dna", "kat_1m_100x8", "mx_s4_m16_p1000", "mx_s4_m32_p100", "edge_m65",
-                                  "overlap_zeros", "mx_s20_m8_p1000", "big_dfa"])
+                                  "overlap_zeros", "mx_s20_m8_p1000", "big_dfa", "mx_s256_m8_p1000", "ascii_m5",
+                                  "mx_s128_m16_p100"])
 def test_every_scan_plan_gives_the_same_count(name):
     """Stride 1 / 2 / hybrid, exact (K = m) and depth-cut (K < m) automata, down to K = 1 where nearly
     every position is a candidate and the per-wave queue overflows and drains constantly."""
@@ -174,7 +213,7 @@ def test_every_scan_plan_gives_the_same_count(name):
                     continue
                 assert ac.info().scan_full_rows > 0
                 assert ac.count_host(text, S.VARIANT_TUNED)[0] == vec["count_ac"], ("hybrid", K, D)
-    assert tried >= 3
+    assert tried >= (3 if sigma <= 20 else 1)  # alphabet 128 / 256: only K = 1 fits LDS
 
 
 def test_baseline_size_properties():

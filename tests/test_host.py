@@ -174,3 +174,24 @@ def test_search_without_gpu_fails_loudly():
             "print('survived')\n")
     r = _run_snippet(code)
     assert r.returncode == 1 and "survived" not in r.stdout
+
+
+def test_scan_engine_choice_is_made_on_the_host():
+    """alphabet-256 sets and thousands of long DNA patterns get the suffix-filter engine behind the AC
+    handle (the patterns are read back from the goto trie when the handle comes from tables)."""
+    import cases
+    v = next(x for x in VECTORS if x["name"] == "ascii_m5")
+    _, pat = cases.build(v)
+    ac = S.AcAutomaton.from_patterns(pat, v["m"], v["p"], v["sigma"])
+    assert ac.info().scan_engine == S.ALGO_WM
+    ac.set_scan_plan(1, 1)
+    assert ac.info().scan_engine == S.ALGO_AC
+    ac.set_scan_plan(0, 0)
+    assert ac.info().scan_engine == S.ALGO_WM
+    t = O.oracle_ac(pat, v["m"], v["p"], v["sigma"])[1]
+    assert S.AcAutomaton.from_tables(t.state_transition, t.state_supply, t.state_final, v["m"] * v["p"] + 1,
+                                     v["sigma"], v["m"]).info().scan_engine == S.ALGO_WM
+    dna = S.corpus_patterns(16, 8000, 7, 4, 42, 1 << 24, 2)
+    assert S.AcAutomaton.from_patterns(dna, 16, 8000, 4).info().scan_engine == S.ALGO_WM
+    small = S.corpus_patterns(16, 1000, 7, 4, 42, 1 << 24, 2)
+    assert S.AcAutomaton.from_patterns(small, 16, 1000, 4).info().scan_engine == S.ALGO_AC
