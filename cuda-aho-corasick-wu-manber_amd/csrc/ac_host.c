@@ -34,6 +34,7 @@ void smh_set_error(const char *fmt, ...)
 }
 
 const char *smh_last_error(void) { return g_err; }
+_Thread_local int smh_alt_engine_depth = 0;
 const char *smh_version(void) { return "mi355x-smatcher 0.1 (gfx950)"; }
 
 /* reference: fail() from the absent ../helper2.h -- message, then exit */
@@ -427,7 +428,9 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
      * position in nine) the same count is obtained much faster by the suffix-filter kernels, which
      * hash W symbols instead of walking K levels.  The patterns are read back from the goto trie and
      * compiled for that engine; smh_ac_scan / smh_ac_positions use it unless a plan is forced. */
-    if (ac->fixed_length_ok && ac->scan_cost > SMH_AC_ALT_ENGINE_COST && m >= 3 && smh_wu_shiftsize_for(alphabet)) {
+    if (ac->fixed_length_ok && ac->scan_cost > SMH_AC_ALT_ENGINE_COST && m >= 3 && smh_wu_shiftsize_for(alphabet) &&
+        smh_alt_engine_depth == 0) {
+        ++smh_alt_engine_depth;
         /* the caller's arrays may have been adopted (and shrunk in place) in step 6: read the handle's copy */
         const int *tsrc = ac->g_transition ? ac->g_transition : trans;
         const unsigned int *fsrc = ac->g_final ? ac->g_final : final;
@@ -436,6 +439,7 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
             ac->alt_wm = smh_wm_compile(pats, m, (int)ac->finals, alphabet); /* NULL: stay with the automaton */
             free(pats);
         }
+        --smh_alt_engine_depth;
     }
     return ac;
 

@@ -105,6 +105,14 @@ void smh_ac_host_free(struct smh_ac *ac);
 /* choose K / stride for an LDS budget and build scan_table (+ trunc1_table); force_stride 0 = auto */
 int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth);
 #define SMH_AC_LDS_BUDGET (160u * 1024u - 512u)
+/* engine choices compile a handle of the OTHER kind; while one is being built no further one is (an
+ * automaton handle built as a Wu-Manber handle's engine must not build a Wu-Manber engine of its own) */
+#ifdef __cplusplus
+extern thread_local int smh_alt_engine_depth;
+#else
+extern _Thread_local int smh_alt_engine_depth;
+#endif
+#define SMH_WM_ALT_ENGINE_COST 1.15 /* automaton plan cost (1.0 = 3.5 TB/s) below which it beats the non-exact direct filter */
 #define SMH_AC_ALT_ENGINE_COST 2.5 /* above this plan cost (< ~1.4 TB/s) the suffix-filter engine scans the set */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
@@ -214,6 +222,8 @@ struct smh_wm {
     int32_t *l_bucket;      /* 2 ints per entry: PREFIX_value, PREFIX_index */
     unsigned char *pat_orig; /* patterns * m, original order (PREFIX_index refers to it) */
     struct smh_wm_dev *dev;
+    struct smh_ac *alt_ac; /* automaton engine for small-alphabet sets of long patterns when it is the faster one, else NULL */
+    int alt_off;           /* smh_wm_set_scan_engine(SMH_ALGO_WM): scans use this path's own kernels regardless */
 };
 
 struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int p_size, int alphabet,

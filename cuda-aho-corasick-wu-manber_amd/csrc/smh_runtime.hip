@@ -479,6 +479,8 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         return SMH_EINVAL;
     }
     if (n < (uint64_t)wm->m) return SMH_OK;
+    if (variant == SMH_VARIANT_TUNED && wm->alt_ac && !wm->alt_off) /* engine choice: wm_host.c, end of the compile */
+        return smh_ac_scan(wm->alt_ac, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
     int rc = wm_ensure_device(wm);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
@@ -512,6 +514,7 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         return SMH_EINVAL;
     }
     if (n < (uint64_t)wm->m) return SMH_OK;
+    if (wm->alt_ac && !wm->alt_off) return smh_ac_positions(wm->alt_ac, d_text, n, d_positions, capacity, d_cursor, stream);
     int rc = wm_ensure_device(wm);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;

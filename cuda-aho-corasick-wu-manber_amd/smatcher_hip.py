@@ -48,7 +48,8 @@ class WmInfo(C.Structure):
                 ("distinct", C.c_uint32), ("shiftsize", C.c_uint32), ("shift_zero", C.c_uint32),
                 ("block_symbols", C.c_uint32), ("filter_log2", C.c_uint32),
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
-                ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32)]
+                ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class PsetInfo(C.Structure):
@@ -90,7 +91,7 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
                "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
-               "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info",
+               "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info", "smh_wm_set_scan_engine",
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free", "smh_pset_compile", "smh_pset_get_info",
                "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
                "smh_pset_free", "smh_sh_compile_tables", "smh_sh_compile_patterns", "smh_sh_get_info",
@@ -141,6 +142,7 @@ def _load():
     lib.smh_wm_compile_tables.restype = C.c_void_p
     lib.smh_wm_compile_tables.argtypes = [u8p, C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, i32p]
     lib.smh_wm_get_info.argtypes = [C.c_void_p, C.POINTER(WmInfo)]
+    lib.smh_wm_set_scan_engine.argtypes = [C.c_void_p, C.c_int]
     lib.smh_wm_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
     lib.smh_wm_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, u64p, dblp]
     lib.smh_wm_free.restype = None
@@ -347,6 +349,9 @@ class WmTables:
         out = WmInfo()
         _check(lib.smh_wm_get_info(self.h, C.byref(out)), "smh_wm_get_info")
         return out
+
+    def set_scan_engine(self, engine):
+        _check(lib.smh_wm_set_scan_engine(self.h, engine), "smh_wm_set_scan_engine")
 
     def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
         _check(lib.smh_wm_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,

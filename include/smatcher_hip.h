@@ -149,6 +149,10 @@ typedef struct smh_wm_info {
     uint32_t filter_hashed;   /* 1: block code is hashed into the filter, 0: indexes it directly */
     uint32_t verify_slots;    /* open-addressing slots of the HBM verify table (0 when exact) */
     uint32_t lds_bytes;
+    uint32_t scan_engine;     /* SMH_ALGO_WM: this path's kernels scan; SMH_ALGO_AC: a small-alphabet set of long
+                               * patterns whose automaton fits LDS is scanned by the automaton kernels (faster
+                               * than a non-exact direct filter; same count) -- see smh_wm_set_scan_engine */
+    uint32_t reserved;
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */
@@ -158,6 +162,9 @@ smh_wm *smh_wm_compile_tables(const unsigned char *pattern_flat, int m, int p_si
                               const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
                               const int *PREFIX_size);
 int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out);
+/* test / tuning knob: SMH_ALGO_WM forces this path's own kernels, SMH_ALGO_AC the automaton engine
+ * (SMH_EUNSUP when the set has none), -1 restores the choice made at compile time */
+int smh_wm_set_scan_engine(smh_wm *wm, int engine);
 int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count,
                 int variant, void *stream);
 /* END columns of all matches (wu/wu.c:93 printed them from commented-out code); same contract as

@@ -40,6 +40,10 @@ def test_kernels_match_reference_vectors(vec):
     assert ac.count_host(text, S.VARIANT_TABLE)[0] == want
     assert wm.count_host(text, S.VARIANT_TUNED)[0] == want == vec["count_wu2"]
     assert wm.count_host(text, S.VARIANT_TABLE)[0] == want
+    if wm.info().scan_engine == S.ALGO_AC:
+        # a small-alphabet set of long patterns: the handle chose the automaton kernels; its own too
+        wm.set_scan_engine(S.ALGO_WM)
+        assert wm.info().scan_engine == S.ALGO_WM and wm.count_host(text, S.VARIANT_TUNED)[0] == want
 
 
 @pytest.mark.parametrize("seed", range(10))

@@ -195,3 +195,21 @@ def test_scan_engine_choice_is_made_on_the_host():
     assert S.AcAutomaton.from_patterns(dna, 16, 8000, 4).info().scan_engine == S.ALGO_WM
     small = S.corpus_patterns(16, 1000, 7, 4, 42, 1 << 24, 2)
     assert S.AcAutomaton.from_patterns(small, 16, 1000, 4).info().scan_engine == S.ALGO_AC
+
+
+def test_wm_scan_engine_choice_and_knob():
+    long_dna = S.corpus_patterns(16, 1000, 7, 4, 42, 1 << 24, 2)
+    wm = S.WmTables.from_patterns(long_dna, 16, 1000, 4)
+    assert wm.info().scan_engine == S.ALGO_AC          # its automaton fits LDS with next to no candidates
+    wm.set_scan_engine(S.ALGO_WM)
+    assert wm.info().scan_engine == S.ALGO_WM
+    wm.set_scan_engine(-1)
+    assert wm.info().scan_engine == S.ALGO_AC
+    short = S.WmTables.from_patterns(S.corpus_patterns(8, 10000, 7, 4, 42, 1 << 24, 2), 8, 10000, 4)
+    assert short.info().scan_engine == S.ALGO_WM        # exact pair filter: nothing to gain
+    with pytest.raises(S.SmhError):
+        short.set_scan_engine(S.ALGO_AC)
+    dense = S.WmTables.from_patterns(S.corpus_patterns(16, 8000, 7, 4, 42, 1 << 24, 2), 16, 8000, 4)
+    assert dense.info().scan_engine == S.ALGO_WM        # the automaton would be verify-bound
+    ascii_ = S.WmTables.from_patterns(S.corpus_patterns(12, 1000, 7, 256, 42, 1 << 24, 2), 12, 1000, 256)
+    assert ascii_.info().scan_engine == S.ALGO_WM

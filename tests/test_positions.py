@@ -88,6 +88,14 @@ def test_gpu_positions_match_bruteforce(name):
         assert total == len(want) == vec["count_ac"]
         got = np.sort(out[:total].cpu().numpy())
         assert np.array_equal(got, want)
+    if wm.info().scan_engine == S.ALGO_AC:  # the Wu-Manber path's own kernels in positions mode
+        wm.set_scan_engine(S.ALGO_WM)
+        out = torch.zeros(cap, dtype=torch.int64, device=dev)
+        cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        wm.positions_device(d_text.data_ptr(), n, out.data_ptr(), cap, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(cur.item()) == len(want) and np.array_equal(np.sort(out[:len(want)].cpu().numpy()), want)
+        wm.set_scan_engine(-1)
     # the per-segment kernels (what unaligned text gets): same positions, shifted by the 4-byte offset
     d_un = torch.zeros(n + 68, dtype=torch.uint8, device=dev)
     d_un[4:4 + n] = torch.from_numpy(text).to(dev)
