@@ -197,6 +197,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_counts = [int(x) for x in counts.tolist()]
+    # per-GPU counts for the report: one untimed pass without the reduce, then one small all-gather
+    counts.zero_()
+    for i, m in enumerate(AC_LENGTHS):
+        acs[m].scan_device(text.data_ptr(), shard_len(m), counts.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
+    torch.cuda.synchronize()
+    per_gpu_counts = sharded.gather_counts(counts).tolist()
 
     # per-launch durations (ms) from the events on the launch stream
     kern_ms = {m: [evs[k][i][0].elapsed_time(evs[k][i][1]) for k in range(args.steps)] for i, m in enumerate(AC_LENGTHS)}
@@ -215,7 +221,8 @@ def main():
             info = acs[m].info()
             ms = mean(kern_ms[m])
             gbs = shard_len(m) / (ms * 1e-3) / 1e9
-            ac_detail["m%d" % m] = dict(kernel_ms=round(ms, 4), min_ms=round(min(kern_ms[m]), 4), GBps=round(gbs, 1),
+            ac_detail["m%d" % m] = dict(kernel_ms=round(ms, 4), median_ms=round(sorted(kern_ms[m])[len(kern_ms[m]) // 2], 4),
+                                        min_ms=round(min(kern_ms[m]), 4), GBps=round(gbs, 1),
                                         Gbit_s=round(8 * gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4),
                                         dfa_rows=info.rows, lds_rows=info.lds_rows, lds_bytes=info.lds_bytes,
                                         scan_stride=info.scan_stride, scan_depth=info.scan_depth,
@@ -240,6 +247,7 @@ def main():
                        "pattern_lengths": list(AC_LENGTHS), "text_seed": TEXT_SEED, "pattern_seed": PAT_SEED,
                        "sharding": "byte-range x%d, m-1 halo, RCCL sum of counts" % world},
             "roofline": roofline, "ac": ac_detail, "device": S.device_name(),
+            "per_gpu_matches": {"m%d" % m: [int(r[i]) for r in per_gpu_counts] for i, m in enumerate(AC_LENGTHS)},
         }
 
     # ---- what a pure streaming read of the same 1 GiB reaches on this device, same run
@@ -345,6 +353,14 @@ def main():
             torch.cuda.synchronize()
             gpu_counts[m] = int(c1.item())
         out["cpu_baseline"] = base
+        # the legacy host-pointer path (search_ac): device allocation + H2D copy + kernel, PCIe-bound; never `value`
+        t0 = time.perf_counter()
+        legacy_cnt, _ = acs[AC_LENGTHS[0]].count_host(prefix, S.VARIANT_TUNED)
+        secs = time.perf_counter() - t0
+        out["host_pointer_path"] = dict(what="smh_ac_count_host (what search_ac runs) on the same %d MiB sample: hipMalloc + "
+                                             "pageable H2D copy + kernel + D2H of the count" % (sample >> 20),
+                                        GBps=round(sample / secs / 1e9, 2), seconds=round(secs, 4),
+                                        count_matches=legacy_cnt == cpu_counts[AC_LENGTHS[0]])
         allc = cpu_baseline_all_cores(prefix, pats, cpu_counts)
         if allc:
             out["cpu_baseline_all_cores"] = allc

@@ -26,3 +26,14 @@ def reduce_count(local_count):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(local_count, op=dist.ReduceOp.SUM)
     return local_count
+
+
+def gather_counts(local_counts):
+    """Every rank's per-shard counts, for the report (and as a parity check against per-shard CPU counts):
+    `local_counts` is an int64 tensor of the same shape on every rank; returns a [world, ...] int64 CPU
+    tensor on every rank.  One all-gather of a few bytes; not on the timed path."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.zeros_like(local_counts) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, local_counts)
+        return torch.stack([p.cpu() for p in parts])
+    return local_counts.cpu().unsqueeze(0)

@@ -46,7 +46,10 @@ def _worker(rank, world, port, name, out_dir):
     wm = S.WmTables.from_patterns(pat, m, p, sigma)
     local = torch.tensor([E.ac_scan(ac, text[b:e], 0, 1), E.wm_scan(wm, text[b:e], 0, 1)], dtype=torch.int64)
     mine = local.clone()
+    everyone = sharded.gather_counts(local)  # [world, 2]: what bench.py reports as per-GPU counts
+    assert everyone.shape == (world, 2) and torch.equal(everyone[rank], mine)
     sharded.reduce_count(local)
+    assert torch.equal(everyone.sum(dim=0), local)
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([mine[0], mine[1], local[0], local[1], b, e]))
     dist.destroy_process_group()
 
