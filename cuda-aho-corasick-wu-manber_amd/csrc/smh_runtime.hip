@@ -446,7 +446,7 @@ static int wm_ensure_device(struct smh_wm *wm)
     if ((rc = upload((void **)&d->d_filter, wm->filter, fbytes, 0)) != SMH_OK) return rc;
     if (wm->pair_table && (rc = upload((void **)&d->d_pair, wm->pair_table, 65536, 0)) != SMH_OK) return rc;
     if (!wm->filter_exact) {
-        if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 8, 0)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 4, 0)) != SMH_OK) return rc;
     }
     {
         /* distinct patterns, each zero-padded to whole dwords (the verify stage compares dwords) */

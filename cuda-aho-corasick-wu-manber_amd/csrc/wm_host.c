@@ -348,20 +348,25 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         }
     }
 
-    /* ---- verify table (device HASH/PREFIX stage): FNV-1a(window) -> {tag, pattern + 1} ---- */
+    /* ---- verify table (device HASH/PREFIX stage): hash(window) -> one 32-bit slot, 12 tag bits above
+     *      (pattern + 1) in 20 bits, 0 = empty.  Four bytes a slot keep the table of 100 000 patterns at
+     *      1 MiB, so the random probes of the verify stage mostly hit L2 beside the streaming text ---- */
     if (!wm->filter_exact) {
+        if (d >= (1 << 20) - 1) {
+            smh_set_error("smh_wm_compile: more than 2^20 - 2 distinct patterns");
+            goto bad;
+        }
         int lg = ceil_log2_u32((uint32_t)d * 2u);
         if (lg < 4) lg = 4;
         wm->verify_log2 = lg;
         size_t slots = (size_t)1 << lg;
-        wm->verify = (uint32_t *)calloc(slots * 2, sizeof(uint32_t));
+        wm->verify = (uint32_t *)calloc(slots, sizeof(uint32_t));
         if (!wm->verify) goto oom;
         for (int j = 0; j < d; ++j) {
             uint32_t tag = smh_wm_tag(wm->pat_sorted + (size_t)j * m, m);
             size_t s = (size_t)((tag * SMH_HASH_MUL) >> (32 - lg));
-            while (wm->verify[2 * s + 1]) s = (s + 1) & (slots - 1);
-            wm->verify[2 * s] = tag;
-            wm->verify[2 * s + 1] = (uint32_t)j + 1u;
+            while (wm->verify[s]) s = (s + 1) & (slots - 1);
+            wm->verify[s] = ((tag & 0xFFFu) << 20) | ((uint32_t)j + 1u);
         }
     }
 

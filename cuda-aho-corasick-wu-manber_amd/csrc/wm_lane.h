@@ -35,7 +35,7 @@ struct smh_wm_params {
     int filter_k;        /* hashed filter: bits per key inside one 32-bit word (2..4) */
     int filter_le4;      /* hashed filter keyed by the block's 4 bytes as a little-endian dword (8-bit symbols) */
     int verify_log2;     /* slots = 1 << verify_log2 */
-    const uint32_t *verify;      /* HBM: {tag, pattern + 1} per slot */
+    const uint32_t *verify;      /* HBM: one word per slot, tag (12 bits) << 20 | pattern + 1; 0 = empty */
     const uint8_t *pat_sorted;   /* HBM: distinct patterns, each zero-padded to ((m+3)/4)*4 bytes */
 };
 
@@ -75,10 +75,10 @@ SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_pa
     for (int j = 0; j < nd; ++j) tag = smh_wm_mix(tag, smh_window_dword(aligned, shift_bits, j, P.m));
     uint32_t s = (tag * SMH_WM_HASH_MUL) >> (32 - P.verify_log2);
     for (;;) {
-        const uint32_t stag = P.verify[2 * s];
-        const uint32_t sidx = P.verify[2 * s + 1];
-        if (sidx == 0) return 0;
-        if (stag == tag) {
+        const uint32_t slot = P.verify[s]; /* 12 tag bits | pattern + 1 (20 bits); 0 = empty */
+        const uint32_t sidx = slot & 0xFFFFFu;
+        if (slot == 0) return 0;
+        if ((slot >> 20) == (tag & 0xFFFu)) {
             const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx - 1) * (uint32_t)nd;
             uint32_t diff = 0;
             for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(aligned, shift_bits, j, P.m);
@@ -177,13 +177,14 @@ SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, 
     bool a0 = true, a1 = true;
     r1 = 0;
     for (;;) {
-        const uint32_t stag0 = P.verify[2 * s0], sidx0 = P.verify[2 * s0 + 1];
-        const uint32_t stag1 = P.verify[2 * s1], sidx1 = P.verify[2 * s1 + 1];
+        const uint32_t slot0 = P.verify[s0], slot1 = P.verify[s1];
+        const uint32_t stag0 = slot0 >> 20, sidx0 = slot0 & 0xFFFFFu;
+        const uint32_t stag1 = slot1 >> 20, sidx1 = slot1 & 0xFFFFFu;
         if (a0) {
             if (sidx0 == 0) {
                 a0 = false;
             } else {
-                if (stag0 == tag0) {
+                if (stag0 == (tag0 & 0xFFFu)) {
                     const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx0 - 1) * (uint32_t)nd;
                     uint32_t diff = 0;
                     for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(al0, sh0, j, P.m);
@@ -196,7 +197,7 @@ SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, 
             if (sidx1 == 0) {
                 a1 = false;
             } else {
-                if (stag1 == tag1) {
+                if (stag1 == (tag1 & 0xFFFu)) {
                     const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx1 - 1) * (uint32_t)nd;
                     uint32_t diff = 0;
                     for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(al1, sh1, j, P.m);
