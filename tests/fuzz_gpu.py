@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Differential fuzzing on the GPU (development aid, not part of the test suite): random pattern sets
+"""Differential fuzzing on the GPU (run by tests/test_fuzz_gpu.py, or by hand for more cases): random pattern sets
 with long shared prefixes / suffixes, duplicates and text-cut patterns over random alphabets and sizes;
 every engine and forced plan must give the oracle's count, positions must equal the brute force.
-usage: fuzz_gpu.py [cases] [seed]"""
+usage: python tests/fuzz_gpu.py [cases] [seed]"""
 import os
 import sys
 
@@ -11,7 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402,F401  (before the library: one HIP runtime per process)
-import oracle_lib as O  # noqa: E402
+import oracle_lib as O  # noqa: E402  (the checker)
 sys.path.insert(0, os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd"))
 import smatcher_hip as S  # noqa: E402
 
@@ -45,9 +45,7 @@ def make_case(rng):
     return sigma, m, p, text, np.ascontiguousarray(pats.reshape(-1))
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+def run(cases, seed, verbose=True):
     rng = np.random.RandomState(seed)
     dev = torch.device("cuda", 0)
     checks = 0
@@ -107,9 +105,12 @@ def main():
                 assert sb.count_host(text)[0] == want, (tag, "sbom tuned")
                 assert sb.count_host(text[:200000], S.VARIANT_TABLE)[0] == O.count_bruteforce(pat, m, p, text[:200000]), (tag, "sbom table")
         checks += 8
-        print(tag, "ok", flush=True)
-    print("fuzz: %d cases, %d checks, all equal" % (cases, checks))
+        if verbose:
+            print(tag, "ok", flush=True)
+    if verbose:
+        print("fuzz: %d cases, %d checks, all equal" % (cases, checks))
+    return checks
 
 
 if __name__ == "__main__":
-    main()
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
