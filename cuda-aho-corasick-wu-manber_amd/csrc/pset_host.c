@@ -37,6 +37,12 @@ struct smh_pset {
     uint32_t patterns;
     uint32_t n_classes;
     struct smh_pset_class *cls;
+    /* SMH_ALGO_WM sets with 2..32 lengths, all >= 3: ONE pass.  `suffix` is a handle over the patterns'
+     * last min-length symbols: its block filter proposes END columns for every length at once, and a
+     * surviving column is verified against each class's table (wm_lane.h smh_wm_verify_class).  The
+     * count is the same sum over classes; the text is read once instead of once per length. */
+    smh_wm *suffix;
+    smh_wm **class_wm;
 };
 
 static int cmp_u32(const void *a, const void *b)
@@ -52,6 +58,8 @@ void smh_pset_free(smh_pset *set)
         smh_ac_free(set->cls[i].ac);
         smh_wm_free(set->cls[i].wm);
     }
+    smh_wm_free(set->suffix);
+    free(set->class_wm);
     free(set->cls);
     set->magic = 0;
     free(set);
@@ -116,6 +124,25 @@ smh_pset *smh_pset_compile(const unsigned char *patterns, const uint32_t *length
             return NULL;
         }
     }
+    /* one-pass form */
+    if (algorithm == SMH_ALGO_WM && n_classes >= 2 && n_classes <= SMH_PSET_MAX_ONE_PASS_CLASSES && set->cls[0].length >= 3) {
+        const uint32_t Lmin = set->cls[0].length;
+        uint64_t off = 0;
+        for (int j = 0; j < p_size; ++j) { /* every pattern's last Lmin symbols */
+            memcpy(flat + (size_t)j * Lmin, patterns + off + lengths[j] - Lmin, Lmin);
+            off += lengths[j];
+        }
+        set->suffix = smh_wm_compile(flat, (int)Lmin, p_size, alphabet);
+        set->class_wm = (smh_wm **)malloc(n_classes * sizeof(smh_wm *));
+        /* worth it only while survivors are rare: each one costs a verify per class (~20 ps each), a scan
+         * per class ~0.25 ms/GiB -- break-even near 1 % of the columns surviving the filter */
+        if (set->suffix && set->class_wm && set->suffix->filter_density < SMH_PSET_ONE_PASS_DENSITY) {
+            for (uint32_t c = 0; c < n_classes; ++c) set->class_wm[c] = set->cls[c].wm;
+        } else { /* stay with one scan per class */
+            smh_wm_free(set->suffix);
+            set->suffix = NULL;
+        }
+    }
     free(sorted);
     free(flat);
     return set;
@@ -143,6 +170,7 @@ int smh_pset_get_info(const smh_pset *set, smh_pset_info *out)
     out->patterns = set->patterns;
     out->min_length = set->cls[0].length;
     out->max_length = set->cls[set->n_classes - 1].length;
+    out->one_pass = set->suffix != NULL;
     return SMH_OK;
 }
 
@@ -161,6 +189,8 @@ int smh_pset_get_class(const smh_pset *set, uint32_t i, uint32_t *length, uint32
 int smh_pset_scan(smh_pset *set, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream)
 {
     if (!pset_ok(set, "smh_pset_scan")) return SMH_EINVAL;
+    if (set->suffix && ((uintptr_t)d_text & 15u) == 0)
+        return smh_wm_scan_multi(set->suffix, set->class_wm, (int)set->n_classes, d_text, n, d_count, stream);
     for (uint32_t c = 0; c < set->n_classes; ++c) {
         struct smh_pset_class *k = &set->cls[c];
         const int rc = k->wm ? smh_wm_scan(k->wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream)
@@ -174,6 +204,9 @@ int smh_pset_positions(smh_pset *set, const unsigned char *d_text, uint64_t n, u
                        uint64_t capacity, uint64_t *d_cursor, void *stream)
 {
     if (!pset_ok(set, "smh_pset_positions")) return SMH_EINVAL;
+    if (set->suffix && ((uintptr_t)d_text & 15u) == 0)
+        return smh_wm_positions_multi(set->suffix, set->class_wm, (int)set->n_classes, d_text, n, d_positions, capacity,
+                                      d_cursor, stream);
     for (uint32_t c = 0; c < set->n_classes; ++c) {
         struct smh_pset_class *k = &set->cls[c];
         const int rc = k->wm ? smh_wm_positions(k->wm, d_text, n, d_positions, capacity, d_cursor, stream)

@@ -141,6 +141,14 @@ struct smh_sh_table_box { /* handed out by preproc_sh: the public struct first *
     uint32_t magic;
     struct smh_sh *sh;
 };
+/* mixed-length sets in one pass (smh_runtime.hip) */
+int smh_wm_scan_multi(struct smh_wm *suffix, struct smh_wm *const *classes, int n_classes, const unsigned char *d_text,
+                      uint64_t n, uint64_t *d_count, void *stream);
+int smh_wm_positions_multi(struct smh_wm *suffix, struct smh_wm *const *classes, int n_classes,
+                           const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                           uint64_t *d_cursor, void *stream);
+#define SMH_PSET_MAX_ONE_PASS_CLASSES 32
+#define SMH_PSET_ONE_PASS_DENSITY 0.004 /* fraction of columns the suffix filter lets through, above which one scan per class is faster */
 void smh_sh_host_free(struct smh_sh *sh);
 void smh_sh_dev_free(struct smh_sh_dev *dev); /* smh_runtime.hip */
 int smh_sh_check_bmbc(const struct smh_sh *sh, const int *bmBc);

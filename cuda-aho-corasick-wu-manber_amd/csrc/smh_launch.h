@@ -95,6 +95,8 @@ struct smh_wm_launch {
     uint64_t *d_count;
     int n_cus;
     smh_pos_out po;       /* positions mode only */
+    int n_classes;        /* > 0: mixed-length set in one pass, d_classes[n_classes] on the device */
+    const smh_wm_class *d_classes;
 };
 uint32_t smh_wm_max_blocks(int n_cus);
 hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream);

@@ -51,6 +51,7 @@ struct smh_wm_dev {
     uint32_t *d_bucket_off;
     int32_t *d_bucket;
     uint8_t *d_pat_orig;
+    smh_wm_class *d_classes; /* SMH_WM_MAX_CLASSES entries, when the handle is the suffix filter of a mixed-length set */
 };
 
 static int g_n_cus = 0;
@@ -428,6 +429,7 @@ extern "C" void smh_wm_dev_free(struct smh_wm_dev *dev)
     (void)hipFree(dev->d_bucket_off);
     (void)hipFree(dev->d_bucket);
     (void)hipFree(dev->d_pat_orig);
+    (void)hipFree(dev->d_classes);
     delete dev;
 }
 
@@ -445,7 +447,7 @@ static int wm_ensure_device(struct smh_wm *wm)
     const size_t fbytes = ((size_t)1 << wm->filter_log2) / 8;
     if ((rc = upload((void **)&d->d_filter, wm->filter, fbytes, 0)) != SMH_OK) return rc;
     if (wm->pair_table && (rc = upload((void **)&d->d_pair, wm->pair_table, 65536, 0)) != SMH_OK) return rc;
-    if (!wm->filter_exact) {
+    if (wm->verify) {
         if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 4, 0)) != SMH_OK) return rc;
     }
     {
@@ -492,7 +494,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_wm_table(L, (hipStream_t)stream));
     } else if (variant == SMH_VARIANT_TUNED) {
-        smh_wm_launch L;
+        smh_wm_launch L = {};
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
         L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
@@ -522,7 +524,7 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
     if (((uintptr_t)d_text & 15u) == 0) {
         /* the tuned scan kernels in positions mode: matching columns are recorded as bits (exact
          * filters) or verified through the survivor queue, and appended per wave */
-        smh_wm_launch L;
+        smh_wm_launch L = {};
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
         L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
@@ -538,6 +540,80 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
     L.d_count = NULL; L.n_cus = n_cus;
     HIP_TRY(smh_launch_wm_positions(L, d_positions, capacity, d_cursor, (hipStream_t)stream));
     return SMH_OK;
+}
+
+/* ---- mixed-length sets in one pass (pset_host.c): `suffix` is a handle compiled over the patterns'
+ * last min-length symbols -- its block filter proposes END columns -- and `classes` are the per-length
+ * handles whose verify tables decide them.  d_count / positions exactly as in the single-length calls. */
+static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes, const unsigned char *d_text, uint64_t n,
+                           uint64_t *d_count, const smh_pos_out *po, void *stream)
+{
+    if (!suffix || suffix->magic != SMH_MAGIC_WM || !classes || n_classes < 1 || n_classes > SMH_WM_MAX_CLASSES ||
+        (n && !d_text)) {
+        smh_set_error("smh_wm_scan_multi: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (((uintptr_t)d_text & 15u) != 0) {
+        smh_set_error("smh_wm_scan_multi: d_text must be 16-byte aligned");
+        return SMH_EINVAL;
+    }
+    if (n < (uint64_t)suffix->m) return SMH_OK;
+    int rc = wm_ensure_device(suffix);
+    if (rc != SMH_OK) return rc;
+    smh_wm_class host[SMH_WM_MAX_CLASSES];
+    for (int c = 0; c < n_classes; ++c) {
+        smh_wm *k = classes[c];
+        if (!k || k->magic != SMH_MAGIC_WM || k->m < suffix->m) {
+            smh_set_error("smh_wm_scan_multi: class %d is not a Wu-Manber handle of length >= %d", c, suffix->m);
+            return SMH_EINVAL;
+        }
+        if ((rc = wm_ensure_device(k)) != SMH_OK) return rc;
+        if (!k->dev->d_verify) {
+            /* an exact class has no verify table of its own: build it now (host table exists only when the
+             * filter is not exact) -- pset_host.c compiles the classes so that this cannot happen */
+            smh_set_error("smh_wm_scan_multi: class %d has no verify table", c);
+            return SMH_EUNSUP;
+        }
+        host[c].m = k->m;
+        host[c].verify_log2 = k->verify_log2;
+        host[c].verify = k->dev->d_verify;
+        host[c].pat_sorted = k->dev->d_pat_sorted;
+    }
+    if (!suffix->dev->d_classes) HIP_TRY(hipMalloc((void **)&suffix->dev->d_classes, sizeof host));
+    HIP_TRY(hipMemcpyAsync(suffix->dev->d_classes, host, sizeof(smh_wm_class) * (size_t)n_classes, hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_wm *wm = suffix;
+    smh_wm_launch L = {};
+    L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
+    L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4;
+    L.filter_exact = 0;
+    L.d_filter = wm->dev->d_filter; L.d_pair = NULL; L.verify_log2 = 4; L.d_verify = NULL; L.d_pat_sorted = NULL;
+    L.d_queue = wm->dev->d_queue; L.d_count = d_count; L.n_cus = n_cus;
+    L.n_classes = n_classes; L.d_classes = suffix->dev->d_classes;
+    if (po) {
+        L.po = *po;
+        HIP_TRY(smh_launch_wm_block_positions(L, (hipStream_t)stream));
+    } else {
+        HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
+    }
+    return SMH_OK;
+}
+
+extern "C" int smh_wm_scan_multi(smh_wm *suffix, smh_wm *const *classes, int n_classes, const unsigned char *d_text,
+                                 uint64_t n, uint64_t *d_count, void *stream)
+{
+    if (!d_count) { smh_set_error("smh_wm_scan_multi: bad arguments"); return SMH_EINVAL; }
+    return wm_multi_launch(suffix, classes, n_classes, d_text, n, d_count, NULL, stream);
+}
+
+extern "C" int smh_wm_positions_multi(smh_wm *suffix, smh_wm *const *classes, int n_classes, const unsigned char *d_text,
+                                      uint64_t n, uint64_t *d_positions, uint64_t capacity, uint64_t *d_cursor, void *stream)
+{
+    if (!d_cursor || (capacity && !d_positions)) { smh_set_error("smh_wm_positions_multi: bad arguments"); return SMH_EINVAL; }
+    const smh_pos_out po = {d_positions, capacity, d_cursor};
+    return wm_multi_launch(suffix, classes, n_classes, d_text, n, NULL, &po, stream);
 }
 
 extern "C" int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int variant, uint64_t *count,

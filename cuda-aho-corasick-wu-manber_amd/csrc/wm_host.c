@@ -351,7 +351,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
     /* ---- verify table (device HASH/PREFIX stage): hash(window) -> one 32-bit slot, 12 tag bits above
      *      (pattern + 1) in 20 bits, 0 = empty.  Four bytes a slot keep the table of 100 000 patterns at
      *      1 MiB, so the random probes of the verify stage mostly hit L2 beside the streaming text ---- */
-    if (!wm->filter_exact) {
+    {   /* built for exact filters too: a handle may serve as one length class of a mixed-length set */
         if (d >= (1 << 20) - 1) {
             smh_set_error("smh_wm_compile: more than 2^20 - 2 distinct patterns");
             goto bad;

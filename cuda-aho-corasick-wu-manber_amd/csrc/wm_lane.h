@@ -37,6 +37,18 @@ struct smh_wm_params {
     int verify_log2;     /* slots = 1 << verify_log2 */
     const uint32_t *verify;      /* HBM: one word per slot, tag (12 bits) << 20 | pattern + 1; 0 = empty */
     const uint8_t *pat_sorted;   /* HBM: distinct patterns, each zero-padded to ((m+3)/4)*4 bytes */
+    /* mixed-length sets scanned in ONE pass (smh_pset, SMH_ALGO_WM): the filter is built over the
+     * patterns' last min-length symbols, and a surviving column is verified once per length class */
+    int n_classes;                       /* 0 = a single-length set: verify / pat_sorted above */
+    const struct smh_wm_class *classes;  /* HBM */
+};
+
+#define SMH_WM_MAX_CLASSES 32 /* distinct lengths of a mixed-length set scanned in one pass */
+struct smh_wm_class {
+    int m;
+    int verify_log2;
+    const uint32_t *verify;
+    const uint8_t *pat_sorted;
 };
 
 /* window dword j of the m-byte window that starts at byte offset s: built from ALIGNED dword loads
@@ -86,6 +98,27 @@ SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_pa
         }
         s = (s + 1) & mask;
     }
+}
+
+/* one length class of a mixed-length set: is text[e-m_c+1 .. e] one of the class's patterns? */
+SMH_LANE uint32_t smh_wm_verify_class(const uint8_t *text, uint64_t e, const smh_wm_params &P, int c)
+{
+    const smh_wm_class k = P.classes[c];
+    if (e + 1 < (uint64_t)k.m) return 0; /* no full window of this length ends here */
+    smh_wm_params Pc = P;
+    Pc.m = k.m;
+    Pc.verify_log2 = k.verify_log2;
+    Pc.verify = k.verify;
+    Pc.pat_sorted = k.pat_sorted;
+    return smh_wm_verify(text, e, Pc);
+}
+/* number of length classes with a pattern ending at e (== the column's count in the decomposition) */
+SMH_LANE uint32_t smh_wm_verify_any(const uint8_t *text, uint64_t e, const smh_wm_params &P)
+{
+    if (P.n_classes == 0) return smh_wm_verify(text, e, P);
+    uint32_t cnt = 0;
+    for (int c = 0; c < P.n_classes; ++c) cnt += smh_wm_verify_class(text, e, P, c);
+    return cnt;
 }
 
 /* block hash of the hashed filter: two 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 are
@@ -227,6 +260,20 @@ SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_pa
      * answer */
     if (Q.count == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
+    if (P.n_classes) {
+        /* mixed-length set: every surviving column is tried against each length class */
+        for (uint32_t base = 0; base < Q.count; base += 64u) {
+            const bool valid = base + lane < Q.count;
+            const uint64_t e = valid ? Q.slots[base + lane] : Q.slots[0];
+            for (int c = 0; c < P.n_classes; ++c) {
+                const uint32_t hit = valid ? smh_wm_verify_class(text, e, P, c) : 0u;
+                Q.matches += hit;
+                if (Q.po) smh_append_bits(hit, e, *Q.po);
+            }
+        }
+        Q.count = 0;
+        return;
+    }
     const bool h0 = lane < Q.count, h1 = lane + 64u < Q.count;
     const uint64_t e0 = h0 ? Q.slots[lane] : Q.slots[0];
     const uint64_t e1 = h1 ? Q.slots[lane + 64u] : e0;
@@ -254,6 +301,14 @@ SMH_LANE void smh_wm_drain(smh_wm_queue &, const uint8_t *, const smh_wm_params 
 SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P, bool cond, uint64_t e)
 {
     if (!cond) return;
+    if (P.n_classes) {
+        for (int c = 0; c < P.n_classes; ++c) {
+            const uint32_t hit = smh_wm_verify_class(text, e, P, c);
+            Q.matches += hit;
+            if (hit && Q.po) smh_append_bits(1u, e, *Q.po);
+        }
+        return;
+    }
     const uint32_t hit = smh_wm_verify(text, e, P);
     Q.matches += hit;
     if (hit && Q.po) smh_append_bits(1u, e, *Q.po);
@@ -328,7 +383,8 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
 /* Slow path: any segment of END columns, bounds checked, no pre-halo requirement. */
 template <bool HASHED, bool EXACT>
 SMH_LANE uint32_t smh_wm_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const uint32_t *filter,
-                                   const smh_wm_params &P, int block_symbols, uint64_t *match_mask = nullptr)
+                                   const smh_wm_params &P, int block_symbols, uint64_t *match_mask = nullptr,
+                                   int only_class = -1)
 {
     if (match_mask) *match_mask = 0;
     if (a >= n) return 0;
@@ -343,7 +399,7 @@ SMH_LANE uint32_t smh_wm_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, 
     for (uint64_t e = e0; e < end; ++e) {
         code = (code << P.bits) | text[e];
         uint32_t hit = smh_wm_filter<HASHED>(code, filter, P);
-        if (!EXACT && hit) hit = smh_wm_verify(text, e, P);
+        if (!EXACT && hit) hit = only_class >= 0 ? smh_wm_verify_class(text, e, P, only_class) : smh_wm_verify_any(text, e, P);
         cnt += hit;
         if (match_mask && hit) *match_mask |= 1ull << (e - a); /* positions mode: bit = END column - a */
     }
@@ -445,8 +501,15 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8
         } else if (POS) {
             /* first / last chunks: per-lane mask of matching END columns, then the wave-level append */
             uint64_t mm;
-            smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols, &mm);
-            cnt += smh_append_bits(mm, a, *po);
+            if (P.n_classes) { /* a column is appended once per length class that matches there */
+                for (int c = 0; c < P.n_classes; ++c) {
+                    smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols, &mm, c);
+                    cnt += smh_append_bits(mm, a, *po);
+                }
+            } else {
+                smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols, &mm);
+                cnt += smh_append_bits(mm, a, *po);
+            }
         } else {
             cnt += smh_wm_lane_slow<HASHED, EXACT>(text, n, a, filter, P, block_symbols);
         }

@@ -250,7 +250,10 @@ typedef struct smh_pset_info {
     uint32_t patterns;     /* as given */
     uint32_t min_length;
     uint32_t max_length;
-    uint32_t reserved[2];
+    uint32_t one_pass;     /* 1: SMH_ALGO_WM set with 2..32 lengths, all >= 3 -- the text is read ONCE: a block filter
+                            * over the patterns' last min-length symbols proposes END columns, each survivor is
+                            * verified per length class.  0: one scan per class. */
+    uint32_t reserved;
 } smh_pset_info;
 
 /* patterns: the p_size patterns back to back (pattern j has lengths[j] symbols, each < alphabet) */

@@ -164,6 +164,10 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
 }
 
 /* ------------------------------------------------------------------ WM */
+/* mixed-length one-pass emulation: when set, wm_grid verifies against these classes (host pointers) */
+static const smh_wm_class *g_emu_classes = nullptr;
+static int g_emu_n_classes = 0;
+
 template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
 static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po = nullptr)
 {
@@ -175,6 +179,8 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     P.filter_log2 = wm->filter_log2;
     P.filter_k = wm->filter_k;
     P.filter_le4 = wm->filter_le4;
+    P.n_classes = g_emu_n_classes;
+    P.classes = g_emu_classes;
     P.verify_log2 = wm->verify_log2;
     P.verify = wm->verify;
     /* distinct patterns zero-padded to whole dwords, as smh_runtime.hip uploads them */
@@ -352,4 +358,44 @@ extern "C" uint64_t emu_wm_positions_tuned(const smh_wm *wm, const uint8_t *text
         wm_halo<false, false, true>(wm, text, n, blocks, &po);
     }
     return cursor;
+}
+
+/* a mixed-length set in one pass, as smh_wm_scan_multi / smh_wm_positions_multi run it: `suffix` is the
+ * handle over the patterns' last min-length symbols, `classes` the per-length handles.  out == NULL:
+ * count; else positions mode (returns the cursor). */
+extern "C" uint64_t emu_wm_scan_multi(const smh_wm *suffix, const smh_wm *const *classes, int n_classes,
+                                      const uint8_t *text_in, uint64_t n, uint64_t *out, uint64_t capacity, uint32_t blocks)
+{
+    if (n < (uint64_t)suffix->m) return 0;
+    if (!blocks) blocks = 2;
+    std::vector<uint8_t> padded(((n + 15) / 16) * 16 + 64 + 64, 0);
+    uint8_t *text = padded.data() + 64;
+    memcpy(text, text_in, n);
+    std::vector<std::vector<uint8_t>> rows(n_classes);
+    std::vector<smh_wm_class> cls(n_classes);
+    for (int c = 0; c < n_classes; ++c) {
+        const smh_wm *k = classes[c];
+        const size_t row = (size_t)((k->m + 3) / 4) * 4;
+        rows[c].assign((size_t)k->distinct * row + 16, 0);
+        for (int j = 0; j < k->distinct; ++j) memcpy(rows[c].data() + (size_t)j * row, k->pat_sorted + (size_t)j * k->m, (size_t)k->m);
+        cls[c].m = k->m;
+        cls[c].verify_log2 = k->verify_log2;
+        cls[c].verify = k->verify;
+        cls[c].pat_sorted = rows[c].data();
+    }
+    g_emu_classes = cls.data();
+    g_emu_n_classes = n_classes;
+    uint64_t cursor = 0, total;
+    smh_pos_out po{out, capacity, &cursor};
+    if (out) {
+        total = suffix->filter_hashed ? wm_halo<true, false, true>(suffix, text, n, blocks, &po)
+                                      : wm_halo<false, false, true>(suffix, text, n, blocks, &po);
+        total = cursor;
+    } else {
+        total = suffix->filter_hashed ? wm_halo<true, false, false>(suffix, text, n, blocks)
+                                      : wm_halo<false, false, false>(suffix, text, n, blocks);
+    }
+    g_emu_classes = nullptr;
+    g_emu_n_classes = 0;
+    return total;
 }

@@ -98,3 +98,21 @@ _emu.emu_wm_positions_tuned.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.POINTER
 
 def wm_positions_tuned(wm, text, capacity, blocks=0):
     return _positions(_emu.emu_wm_positions_tuned, wm.h, text, capacity, blocks)
+
+
+_emu.emu_wm_scan_multi.restype = C.c_uint64
+_emu.emu_wm_scan_multi.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, S.u8p, C.c_uint64, C.POINTER(C.c_uint64),
+                                   C.c_uint64, C.c_uint32]
+
+
+def wm_scan_multi(suffix, classes, text, capacity=None, blocks=0):
+    """One-pass scan of a mixed-length set: `suffix` = WmTables over the patterns' last min-length symbols,
+    `classes` = one WmTables per length (ascending).  capacity None: count; else (total, positions)."""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    arr = (C.c_void_p * len(classes))(*[c.h for c in classes])
+    if capacity is None:
+        return int(_emu.emu_wm_scan_multi(suffix.h, arr, len(classes), text.ctypes.data_as(S.u8p), len(text), None, 0, blocks))
+    out = np.zeros(max(capacity, 1), dtype=np.uint64)
+    total = int(_emu.emu_wm_scan_multi(suffix.h, arr, len(classes), text.ctypes.data_as(S.u8p), len(text),
+                                       out.ctypes.data_as(C.POINTER(C.c_uint64)), capacity, blocks))
+    return total, out[:min(total, capacity)]

@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with open(os.path.join(ROOT, "tests", "golden", "ref_mixed_vectors.json")) as f:
     MIXED = json.load(f)
 IDS = [v["name"] for v in MIXED]
+ONE_PASS = {"mixed_ascii_5_20"}  # sets whose min-length suffix filter passes < 0.4 % of the columns
 
 
 @pytest.mark.parametrize("vec", MIXED, ids=IDS)
@@ -43,6 +44,30 @@ def test_oracle_and_lane_code_reproduce_every_class(vec):
             assert E.wm_scan(S.WmTables.from_patterns(flat, L, p, sigma), text, blocks=3) == got
         total += got
     assert total == vec["total"]
+
+
+@pytest.mark.parametrize("vec", [v for v in MIXED if min(c[0] for c in v["classes"]) >= 3],
+                         ids=[v["name"] for v in MIXED if min(c[0] for c in v["classes"]) >= 3])
+def test_one_pass_lane_code_reproduces_the_decomposition(vec):
+    """SMH_ALGO_WM sets are scanned in ONE pass: a block filter over the patterns' last min-length symbols
+    proposes END columns, every survivor is verified per length class.  Same total, same positions."""
+    text, patterns, lengths = cases.build_mixed(vec)
+    sigma = vec["sigma"]
+    classes = cases.split_classes(patterns, lengths)
+    Lmin = min(classes)
+    off, suf = 0, []
+    for L in lengths:
+        suf.append(patterns[off + int(L) - Lmin:off + int(L)])
+        off += int(L)
+    suffix = S.WmTables.from_patterns(np.concatenate(suf), Lmin, len(lengths), sigma)
+    handles = [S.WmTables.from_patterns(classes[L], L, len(classes[L]) // L, sigma) for L in sorted(classes)]
+    assert E.wm_scan_multi(suffix, handles, text, None, 2) == vec["total"]
+    want_pos = np.sort(np.concatenate([O.positions_bruteforce(classes[L], L, len(classes[L]) // L, text) for L in sorted(classes)]))
+    total, got = E.wm_scan_multi(suffix, handles, text, vec["total"] + 3, 3)
+    assert total == vec["total"] and np.array_equal(np.sort(got).astype(np.int64), want_pos)
+    # the handle takes the one-pass form only while the suffix filter lets few columns through
+    assert S.PatternSet(patterns, lengths, sigma, S.ALGO_WM).info().one_pass == (1 if vec["name"] in ONE_PASS else 0)
+    assert S.PatternSet(patterns, lengths, sigma, S.ALGO_AC).info().one_pass == 0
 
 
 @pytest.mark.parametrize("algo", [S.ALGO_AC, S.ALGO_WM])
