@@ -104,6 +104,38 @@ def run(cases, seed, verbose=True):
             if sb is not None:
                 assert sb.count_host(text)[0] == want, (tag, "sbom tuned")
                 assert sb.count_host(text[:200000], S.VARIANT_TABLE)[0] == O.count_bruteforce(pat, m, p, text[:200000]), (tag, "sbom table")
+        # a mixed-length set over the same text: lengths m .. m+5 (one-pass or per-class, both algorithms)
+        if it % 3 == 0 and len(text) > m + 8:
+            nl = int(rng.randint(2, 6))
+            lens = sorted(set(int(x) for x in rng.randint(m, m + 6, size=nl)))
+            mp, ml = [], []
+            for L in lens:
+                for _ in range(int(rng.randint(1, 40))):
+                    if rng.rand() < 0.6:
+                        off = int(rng.randint(0, len(text) - L))
+                        mp.append(text[off:off + L])
+                    else:
+                        mp.append(rng.randint(0, sigma, size=L).astype(np.uint8))
+                    ml.append(L)
+            order = rng.permutation(len(ml))
+            mpat = np.concatenate([mp[i] for i in order])
+            mlen = np.array([ml[i] for i in order], dtype=np.uint32)
+            wantset = 0
+            for L in lens:
+                flat = np.concatenate([mp[i] for i in order if ml[i] == L])
+                wantset += O.count_bruteforce(flat, L, len(flat) // L, text)
+            for algo in (S.ALGO_AC, S.ALGO_WM):
+                if algo == S.ALGO_WM and sigma not in (2, 4, 8, 20, 128, 256):
+                    continue
+                ps = S.PatternSet(mpat, mlen, sigma, algo)
+                assert ps.count_host(text)[0] == wantset, (tag, "pset", algo, lens, ps.info().one_pass)
+                cur = torch.zeros(1, dtype=torch.int64, device=dev)
+                out = torch.zeros(wantset + 4, dtype=torch.int64, device=dev)
+                ps.positions_device(d_text.data_ptr(), len(text), out.data_ptr(), wantset + 4, cur.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                assert int(cur.item()) == wantset, (tag, "pset positions", algo, lens)
+                checks += 2
         checks += 8
         if verbose:
             print(tag, "ok", flush=True)
