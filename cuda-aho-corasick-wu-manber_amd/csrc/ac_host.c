@@ -465,7 +465,8 @@ bad:
  * very rare (it measured 2.0 TB/s at one candidate per 260 bytes).  Relative cost per text byte:
  *     stride 1:  1 + 0.08 [K < m] + 3 * P(a 16-byte piece of a wave holds a candidate)
  *     stride 2:  0.72 + 300 * r [K < m]                       r = candidates per text byte
- *     hybrid  :  0.72 + 2.3 * P(a wave holds a lane deeper than D) + (0.13 + 300 * r) [K < m]   */
+ *     hybrid  :  0.80 + 2.0 * P(a wave holds a lane deeper than D) + (0.07 + 300 * r) [K < m]
+ *                (fit to K16D8 1.25, K16D7 2.26, K12D9 exact 0.91 / cut 0.98 of the stride-1 time) */
 
 static uint32_t entry_get(const void *t, int eb, size_t i)
 {
@@ -680,7 +681,8 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
             const double r = candidate_rate(ac, K);
             double cost;
             if (s == 1)
-                cost = 1.0 + (K < ac->m ? 0.08 : 0.0) + 3.0 * (1.0 - exp(-16.0 * 64.0 * r));
+                cost = 1.0 + (K < ac->m ? 0.08 : 0.0) + (K > 17 ? 0.05 : 0.0) /* a halo beyond 16 bytes: measured 0.317 vs 0.300 ms/GiB */
+                       + 3.0 * (1.0 - exp(-16.0 * 64.0 * r));
             else
                 cost = 0.72 + 300.0 * r;
             if (cost < best_cost) { best_cost = cost; best_s = s; best_k[s] = K; }
@@ -702,7 +704,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 const uint64_t nc = rk - nf;
                 if (nf * 32u + nc * 4u + nc / 4u + 64u > lds_budget || rk + nc / 8u > 65000u) continue;
                 const double r = candidate_rate(ac, K), q = deep_rate(ac, D);
-                const double cost = 0.72 + 2.3 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.13 + 300.0 * r : 0.0);
+                const double cost = 0.80 + 2.0 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.07 + 300.0 * r : 0.0);
                 if (cost < best_cost) { best_cost = cost; best_s = 3; best_k[3] = K; best_d = D; }
                 break;
             }
