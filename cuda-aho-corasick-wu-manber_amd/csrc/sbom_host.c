@@ -32,7 +32,9 @@ struct sbom_state **pointer_array = NULL; /* smatcher.h:55: allocated and freed 
 
 static inline int sbom_edge(const int *t, size_t A, uint32_t state, unsigned c) { return t[state * A + c] > 0; }
 
-/* returns the number of states; *patterncounter_out = patterns appended (duplicates included) */
+/* returns the number of states, 0 when a state_final_multi row would overflow (more than 199 patterns
+ * ending in one state: the reference writes past its 200-entry row there); *patterncounter_out =
+ * patterns appended (duplicates included) */
 static uint32_t sbom_fill_tables(unsigned char *const *rows, const unsigned char *flat, int m, int p_size, int alphabet,
                                  int *state_transition, unsigned int *state_final_multi, uint32_t *patterncounter_out)
 {
@@ -66,7 +68,11 @@ static uint32_t sbom_fill_tables(unsigned char *const *rows, const unsigned char
             state = next;
         }
         unsigned int *row = state_final_multi + (size_t)state * 200;
-        if (row[0] >= 199u) fail("preproc_sbom: more than 199 patterns end in one state (state_final_multi rows hold 200 entries)\n");
+        if (row[0] >= 199u) {
+            free(supply);
+            *patterncounter_out = patterncounter;
+            return 0;
+        }
         row[row[0] + 1] = patterncounter++;
         row[0] += 1;
     }
@@ -194,6 +200,12 @@ smh_sbom *smh_sbom_compile_patterns(const unsigned char *pattern_flat, int m, in
     memset(trans, -1, rows * alphabet * sizeof(int));
     uint32_t pc;
     const uint32_t idcounter = sbom_fill_tables(NULL, pattern_flat, m, p_size, alphabet, trans, fm, &pc);
+    if (!idcounter) {
+        free(trans); free(fm);
+        smh_set_error("smh_sbom_compile_patterns: more than 199 patterns end in one oracle state (the reference's "
+                      "state_final_multi rows hold 200 entries)");
+        return NULL;
+    }
     smh_sbom *sb = sbom_compile(pattern_flat, m, p_size, alphabet, trans, fm, idcounter);
     free(trans); free(fm);
     return sb;
@@ -233,6 +245,7 @@ struct sbom_table *preproc_sbom(unsigned char **pattern, int m, int p_size, int 
     if (!box || !flat) fail("Could not initialize table\n");
     uint32_t pc = 0;
     const uint32_t idcounter = sbom_fill_tables(pattern, NULL, m, p_size, alphabet, state_transition, state_final_multi, &pc);
+    if (!idcounter) fail("preproc_sbom: more than 199 patterns end in one state (state_final_multi rows hold 200 entries)\n");
     for (int j = 0; j < p_size; ++j) memcpy(flat + (size_t)j * m, pattern[j], (size_t)m);
     box->pub.idcounter = idcounter;
     box->pub.patterncounter = pc;

@@ -79,6 +79,9 @@ def test_bad_tables_are_reported():
     t.state_transition[1] = m * p + 7  # an edge out of the table
     with pytest.raises(S.SmhError, match="leaves the table"):
         S.SbomOracle.from_tables(pat, m, p, sigma, t.state_transition, t.state_final_multi, m * p + 1)
+    # the reference's 200-entry rows: 199 patterns per oracle state; the handle API reports it, it does not exit
+    with pytest.raises(S.SmhError, match="199 patterns"):
+        S.SbomOracle.from_patterns(np.tile(np.array([0, 1, 2, 3], dtype=np.uint8), 250), 4, 250, 4)
     assert S.SbomOracle.from_patterns(pat, m, p, sigma).info().tuned_engine == S.ALGO_WM
     assert S.SbomOracle.from_patterns(np.array([0, 1, 1, 0], dtype=np.uint8), 2, 2, 4).info().tuned_engine == S.ALGO_AC
     if S.device_count() == 0:
