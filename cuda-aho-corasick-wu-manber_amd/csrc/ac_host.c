@@ -464,9 +464,11 @@ bad:
  * stride 2 with K < m has to verify every candidate from the root and only pays when candidates are
  * very rare (it measured 2.0 TB/s at one candidate per 260 bytes).  Relative cost per text byte:
  *     stride 1:  1 + 0.08 [K < m] + 3 * P(a 16-byte piece of a wave holds a candidate)
- *     stride 2:  0.72 + 300 * r [K < m]                       r = candidates per text byte
- *     hybrid  :  0.80 + 2.0 * P(a wave holds a lane deeper than D) + (0.07 + 300 * r) [K < m]
- *                (fit to K16D8 1.25, K16D7 2.26, K12D9 exact 0.91 / cut 0.98 of the stride-1 time) */
+ *     stride 2:  0.62 + 300 * r [K < m]                       r = candidates per text byte
+ *     hybrid  :  0.55 (two chains per lane: halo <= 16 bytes; else 0.67) + 2.0 * P(a wave holds a lane deeper
+ *                than D) + (0.07 + 300 * r) [K < m]
+ *                (round 1 fit: K16D8 1.25, K16D7 2.26, K12D9 exact 0.91 / cut 0.98 of the stride-1 time; round 2
+ *                refit of the constant terms after the leaner step and the dynamic chunk scheduling) */
 
 static uint32_t entry_get(const void *t, int eb, size_t i)
 {
@@ -684,7 +686,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 cost = 1.0 + (K < ac->m ? 0.08 : 0.0) + (K > 17 ? 0.05 : 0.0) /* a halo beyond 16 bytes: measured 0.317 vs 0.300 ms/GiB */
                        + 3.0 * (1.0 - exp(-16.0 * 64.0 * r));
             else
-                cost = 0.72 + 300.0 * r;
+                cost = 0.62 + 300.0 * r; /* round 2: 0.180 ms/GiB against 0.289 for the exact stride-1 scan */
             if (cost < best_cost) { best_cost = cost; best_s = s; best_k[s] = K; }
             if (!force_k) break; /* the deepest K that fits is the best for this stride */
         }
@@ -704,7 +706,10 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 const uint64_t nc = rk - nf;
                 if (nf * 32u + nc * 4u + nc / 4u + 64u > lds_budget || rk + nc / 8u > 65000u) continue;
                 const double r = candidate_rate(ac, K), q = deep_rate(ac, D);
-                const double cost = 0.80 + 2.0 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.07 + 300.0 * r : 0.0);
+                /* round 2 refit (leaner step, dynamic chunk scheduling): K12D9 cut 0.220 ms/GiB with two chains per
+                 * lane (halo <= 16 bytes), 0.255 with one, against 0.289 for the exact stride-1 scan */
+                const double base = K - 1 <= 16 ? 0.55 : 0.67;
+                const double cost = base + 2.0 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.07 + 300.0 * r : 0.0);
                 if (cost < best_cost) { best_cost = cost; best_s = 3; best_k[3] = K; best_d = D; }
                 break;
             }

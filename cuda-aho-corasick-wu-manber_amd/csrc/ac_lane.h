@@ -215,11 +215,12 @@ template <typename E, int SIGMA> struct smh_fmt_s1 { /* stride 1: entry = row | 
 struct smh_fmt_s2 { /* stride 2, alphabet 4: entry = row | F1 << 14 | F2 << 15, 16 entries per row */
     static constexpr int STRIDE = 2;
     static constexpr bool SPARSE = false;
-    /* pair codes * 2 land at bits 1..4 (bytes 0,1) and 17..20 (bytes 2,3) */
-    SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 3) | (w >> 7); }
+    /* one v_lshl_or per text dword: the pair codes c1*4+c2 land at bits 8..11 (bytes 0,1) and 24..27
+     * (bytes 2,3) with a zero bit below each, so one v_bfe yields the code * 2 = the byte offset in a row */
+    SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 10) | w; }
     SMH_MEMBER uint32_t next(uint32_t e, uint32_t x, int k, const void *tab) const
     {
-        const uint32_t c = k == 0 ? (x & 0x1Eu) : smh_bfe(x, 16, 5);
+        const uint32_t c = smh_bfe(x, k == 0 ? 7 : 23, 5);
         return smh_lds_u16(tab, ((e & 0x3FFFu) << 5) | c);
     }
     SMH_MEMBER uint32_t flags(uint32_t e) const { return e >> 14; }
@@ -241,18 +242,18 @@ struct smh_fmt_s2h {
     static constexpr bool SPARSE = true;
     uint32_t nf;    /* ids >= nf are compact */
     uint32_t cbase; /* nf * 28: byte address of item slot i is i * 4 + cbase */
-    SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 3) | (w >> 7); }
+    SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 10) | w; } /* as smh_fmt_s2 */
     template <typename F>
     SMH_MEMBER uint32_t next_f(uint32_t row, uint32_t x, int k, const void *tab, F &&on_flags) const
     {
-        const uint32_t c = k == 0 ? (x & 0x1Eu) : smh_bfe(x, 16, 5); /* pair code * 2 */
+        const uint32_t c = smh_bfe(x, k == 0 ? 7 : 23, 5); /* pair code * 2 */
         /* the full-row lookup is issued for every lane before the vote (a compact row id is clamped
          * to a harmless full row), so the common path is as short as the plain stride-2 one:
          * min, shift-or, read */
-        const uint32_t rc = row < nf ? row : nf - 1u;
+        const uint32_t rc = smh_umin_uniform(nf - 1u, row);
         uint32_t t = smh_lds_u16(tab, (rc << 5) | c);
         bool deep = row >= nf;
-        if (SMH_WAVE_ANY(deep)) {
+        if (SMH_UNLIKELY(SMH_WAVE_ANY(deep))) {
             const uint32_t code = c >> 1;
             uint32_t r = row, acc = 0;
             bool done = false, moved = false;
@@ -491,7 +492,7 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
                     }
                     e[j] = fmt.next(e[j], x[j], k, tab);
                     if (EXACT && !REC) {
-                        cnt += (uint32_t)__builtin_popcount(fmt.flags(e[j]));
+                        cnt = smh_popc_add(fmt.flags(e[j]), cnt);
                     } else if (BITS || REC) {
                         const int bit = 4 * q + k * FMT::STRIDE;
                         if (bit < 32)
@@ -615,7 +616,7 @@ SMH_LANE uint64_t smh_ac_segment_match_mask(const smh_ac_verify_ctx &V, uint64_t
 /* POS: positions mode -- instead of counting, every match appends its END column to V.pos (the return
  * value is then the number of matches this lane appended; the kernels ignore it). */
 template <typename FMT, int HC, int NCH, bool EXACT, bool PREFETCH = true, int SW = 16, bool POS = false>
-SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthreads, const void *tab,
+SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chunk_sched &S, const void *tab,
                                 const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base)
 {
     if (V.n < (uint64_t)V.m) return 0;
@@ -624,7 +625,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthre
     const uint64_t chunk_bytes = (uint64_t)SEGB * 64u * NCH;
     const uint64_t n_chunks = (n_starts + chunk_bytes - 1) / chunk_bytes;
     const uint32_t lane = (uint32_t)(gthread & 63u);
-    const uint64_t wave = gthread >> 6, nwaves = nthreads >> 6;
+    const uint64_t wave = gthread >> 6;
     smh_ac_queue Q;
     Q.slots = queue_base ? queue_base + smh_uniform64(wave) * SMH_AC_QCAP : nullptr;
     Q.count = 0;
@@ -633,7 +634,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthre
     /* software pipeline: the segments of the wave's NEXT chunk are requested before the current
      * chunk is scanned, so the HBM latency of a chunk hides behind a whole chunk of lookups */
     uint32_t cur[NCH][SW], nxt[NCH][SW], cur_tail[4 * HC], nxt_tail[4 * HC];
-    uint64_t k = wave;
+    uint64_t k = S.take(n_chunks);
     bool cur_fast = false;
     if (k < n_chunks) {
         const uint64_t base = smh_uniform64(k * chunk_bytes); /* same for the 64 lanes of a wave */
@@ -648,7 +649,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, uint64_t nthre
     }
     while (k < n_chunks) {
         const uint64_t base = smh_uniform64(k * chunk_bytes);
-        const uint64_t kn = k + nwaves;
+        const uint64_t kn = S.take(n_chunks); /* taken before this chunk is scanned: its text is prefetched below */
         const uint64_t base_n = smh_uniform64(kn * chunk_bytes);
         const bool nxt_fast = kn < n_chunks && base_n + chunk_bytes + 16u * HC <= V.n;
         if (PREFETCH && nxt_fast) {

@@ -88,6 +88,62 @@ SMH_LANE uint64_t smh_uniform64(uint64_t v) { return v; }
 #endif
 
 /*
+ * Wave-chunk scheduling.  Static dealing (chunk k to wave k mod nwaves) gives every wave the same
+ * amount of text, but the waves of a CU do not run at the same speed -- the four waves of a SIMD share
+ * its issue port oldest-first -- and a launch ended 20-25 % after its MEDIAN wave had finished
+ * (tools/wavetrace.py, profiles/r02_*).  So the chunks are dealt to WORKGROUPS round-robin (chunk j * nwg +
+ * wg belongs to workgroup wg: the chip still streams one contiguous window of text) and, inside a
+ * workgroup, taken by whichever wave is free next from a counter in LDS (one ds_add_rtn per chunk, by
+ * lane 0).  take() returns a wave-uniform chunk index; indices >= the chunk count end the wave's loop.
+ * The CPU emulation deals statically, as before.
+ */
+/* Order: the LAST chunk and chunk 0 are handed out first.  They are the ones that take the bounds-checked
+ * per-lane path (no text in front of chunk 0; no halo behind the last chunk), which is some 30 us for one
+ * 4 KiB chunk: taken last, that path alone was a 30 us tail on a 200 us launch. */
+SMH_LANE uint64_t smh_sched_order(uint64_t idx, uint64_t n_chunks)
+{
+    if (idx >= n_chunks) return n_chunks; /* exhausted */
+    return idx == 0 ? n_chunks - 1 : idx - 1;
+}
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+struct smh_chunk_sched {
+    uint32_t ctr_off; /* LDS byte offset of the workgroup's counter (zeroed before the first take) */
+    uint32_t nwg, wg;
+    SMH_MEMBER uint64_t take(uint64_t n_chunks) const
+    {
+        uint32_t j = 0;
+        if ((threadIdx.x & 63u) == 0)
+            j = __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(ctr_off), 1u,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+        return smh_sched_order((uint64_t)j * nwg + wg, n_chunks);
+    }
+};
+/* place the counter behind `lds_used` bytes of dynamic LDS (the caller allocates SMH_SCHED_LDS more) and
+ * zero it; the caller's next __syncthreads() publishes it */
+#define SMH_SCHED_LDS 16u
+SMH_LANE smh_chunk_sched smh_sched_init(unsigned char *lds, uint32_t lds_used)
+{
+    const uint32_t off = (lds_used + 15u) & ~15u;
+    if (threadIdx.x == 0) *reinterpret_cast<uint32_t *>(lds + off) = 0u;
+    return smh_chunk_sched{off, gridDim.x, blockIdx.x};
+}
+#else
+struct smh_chunk_sched {
+    mutable uint64_t next;
+    uint64_t step;
+    SMH_MEMBER uint64_t take(uint64_t n_chunks) const
+    {
+        const uint64_t k = next;
+        next += step;
+        return smh_sched_order(k, n_chunks);
+    }
+};
+/* static dealing for (wave, nwaves): what the CPU emulation uses */
+SMH_LANE smh_chunk_sched smh_sched_static(uint64_t wave, uint64_t nwaves) { return smh_chunk_sched{wave, nwaves}; }
+#endif
+
+/*
  * Instruction-level helpers.  The scan kernels are VALU-issue bound (every VALU op holds a SIMD's
  * issue port for 4 cycles: profiles/r01_v2_dpp_prefetch), so the inner loops are written as the
  * exact op sequences we want and these helpers pin the instruction choice:
@@ -98,6 +154,22 @@ SMH_LANE uint64_t smh_uniform64(uint64_t v) { return v; }
  */
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 SMH_LANE uint32_t smh_bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
+/* min(wave-uniform bound, v) as ONE v_min_u32 (written as a ternary next to a compare of the same operands
+ * the compiler emits v_cmp + v_mov + v_cndmask) */
+SMH_LANE uint32_t smh_umin_uniform(uint32_t bound, uint32_t v)
+{
+    uint32_t r;
+    asm("v_min_u32_e32 %0, %1, %2" : "=v"(r) : "s"(bound), "v"(v));
+    return r;
+}
+#define SMH_UNLIKELY(x) __builtin_expect(!!(x), 0)
+/* acc + popcount(x) as ONE v_bcnt_u32_b32 (the compiler splits it into v_bcnt + a shared v_add3) */
+SMH_LANE uint32_t smh_popc_add(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 SMH_LANE uint32_t smh_lds_u16(const void *, uint32_t byte_off)
 {
     return *reinterpret_cast<const __attribute__((address_space(3))) uint16_t *>(byte_off);
@@ -108,6 +180,9 @@ SMH_LANE uint32_t smh_lds_u32(const void *, uint32_t byte_off)
 }
 #else
 SMH_LANE uint32_t smh_bfe(uint32_t x, uint32_t off, uint32_t width) { return (x >> off) & ((1u << width) - 1u); }
+SMH_LANE uint32_t smh_umin_uniform(uint32_t bound, uint32_t v) { return v < bound ? v : bound; }
+#define SMH_UNLIKELY(x) (x)
+SMH_LANE uint32_t smh_popc_add(uint32_t x, uint32_t acc) { return acc + (uint32_t)__builtin_popcount(x); }
 SMH_LANE uint32_t smh_lds_u16(const void *base, uint32_t byte_off)
 {
     uint16_t v;

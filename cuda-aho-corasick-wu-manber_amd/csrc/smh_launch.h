@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "ac_lane.h"
 #include "wm_lane.h"
 
@@ -14,6 +15,53 @@
 #define SMH_LDS_BUDGET (156u * 1024u) /* of the 160 KiB per CU; the rest is left to the runtime */
 #define SMH_MAX_HALO_CHUNKS 4          /* fast paths cover m - 1 <= 64 */
 #define SMH_DEPTH_FIRST_MIN 72         /* depth_first[] is padded to max(this, m + 2): indexed with h + 1 <= 65 and t + 1 <= m */
+
+/*
+ * Launch attributes of one kernel instantiation, per device.
+ * hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy of the code
+ * object, and it and the occupancy query cost tens of microseconds of host time during which the GPU
+ * idles between the caller's events.  So: the attribute is raised ONCE per device to the whole 160 KiB
+ * (every LDS size a plan can ask for is then launchable, and two handles with different table sizes do
+ * not undo each other's setting), and the occupancy answer is remembered per (device, LDS size).
+ * One instance per launch_one<> instantiation (a function-local static); guarded by a mutex because
+ * the multi-device driver (smh_multi.hip) launches from one host thread per GPU.
+ */
+#define SMH_MAX_DEVICES 16
+#define SMH_LDS_ATTR_MAX (160u * 1024u)
+struct smh_attr_cache {
+    struct slot { int device; uint32_t lds_bytes; int per_cu; };
+    std::mutex mu;
+    bool attr_set[SMH_MAX_DEVICES] = {};
+    slot e[4 * SMH_MAX_DEVICES];
+    int used = 0, victim = 0;
+    /* per_cu = workgroups of `block_threads` threads that fit one CU with `lds_bytes` of dynamic LDS */
+    template <typename K>
+    hipError_t get(K kern, uint32_t lds_bytes, int block_threads, int *per_cu)
+    {
+        int dev = 0;
+        hipError_t err = hipGetDevice(&dev);
+        if (err != hipSuccess) return err;
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 0 || dev >= SMH_MAX_DEVICES || !attr_set[dev]) {
+            err = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)SMH_LDS_ATTR_MAX);
+            if (err != hipSuccess) return err;
+            if (dev >= 0 && dev < SMH_MAX_DEVICES) attr_set[dev] = true;
+        }
+        for (int i = 0; i < used; ++i)
+            if (e[i].device == dev && e[i].lds_bytes == lds_bytes) {
+                *per_cu = e[i].per_cu;
+                return hipSuccess;
+            }
+        int q = 0;
+        err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, block_threads, lds_bytes);
+        if (err != hipSuccess) return err;
+        const int at = used < 4 * SMH_MAX_DEVICES ? used++ : (victim = (victim + 1) % (4 * SMH_MAX_DEVICES));
+        e[at] = slot{dev, lds_bytes, q};
+        *per_cu = q;
+        return hipSuccess;
+    }
+};
 
 struct smh_ac_launch {
     smh_ac_verify_ctx V;        /* text, n, m, K, sigma, full DFA, depth_first, trunc1 (device pointers) */
@@ -27,6 +75,7 @@ struct smh_ac_launch {
     uint64_t *d_queue;          /* smh_ac_max_blocks * 16 waves * SMH_AC_QCAP entries (NULL when exact) */
     uint64_t *d_count;
     int n_cus;
+    uint64_t *d_wave_times;     /* development aid: 3 ticks per wave (ac_kernels.inc), else NULL */
 };
 uint32_t smh_ac_max_blocks(int n_cus);
 hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream);

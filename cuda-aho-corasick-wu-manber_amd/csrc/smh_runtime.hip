@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "smh_internal.h"
 #include "smh_launch.h"
@@ -30,6 +31,7 @@
 
 struct smh_ac_dev {
     int device;
+    smh_ac_dev *next; /* the handle keeps one table set per device it has scanned on */
     void *d_table;
     void *d_scan;
     void *d_trunc1;
@@ -42,6 +44,7 @@ struct smh_ac_dev {
 
 struct smh_wm_dev {
     int device;
+    smh_wm_dev *next;
     uint32_t *d_filter;
     uint32_t *d_pair;
     uint64_t *d_queue;
@@ -54,22 +57,55 @@ struct smh_wm_dev {
     smh_wm_class *d_classes; /* SMH_WM_MAX_CLASSES entries, when the handle is the suffix filter of a mixed-length set */
 };
 
-static int g_n_cus = 0;
-static int g_n_cus_dev = -1;
+/* Device-side state is kept PER DEVICE: a handle owns one table set for every device it has been
+ * scanned on (a single process that drives all GPUs of a node -- smh_multi.hip, `smatcher -ranks R` --
+ * switches devices between launches and must not re-upload).  The lists and the CU-count cache are
+ * guarded by one mutex; launches themselves run outside it. */
+static std::mutex g_dev_mu;
+static int g_n_cus[SMH_MAX_DEVICES];
 
 static int current_cus(int *n_cus)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev != g_n_cus_dev) {
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    if (dev < 0 || dev >= SMH_MAX_DEVICES || g_n_cus[dev] == 0) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        g_n_cus = prop.multiProcessorCount;
-        g_n_cus_dev = dev;
+        const int v = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (dev < 0 || dev >= SMH_MAX_DEVICES) { *n_cus = v; return SMH_OK; }
+        g_n_cus[dev] = v;
     }
-    *n_cus = g_n_cus > 0 ? g_n_cus : 256;
+    *n_cus = g_n_cus[dev];
     return SMH_OK;
 }
+
+/* find the table set of the current device in a handle's list, or build one with `build` and publish it
+ * only when every upload succeeded (a half-built set is freed, so the next call retries cleanly) */
+template <typename D, typename Build>
+static int ensure_device_set(D **head, void (*free_one)(D *), Build build, D **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    for (D *d = *head; d; d = d->next)
+        if (d->device == dev) { *out = d; return SMH_OK; }
+    D *d = new D();
+    memset(d, 0, sizeof *d);
+    d->device = dev;
+    const int rc = build(d);
+    if (rc != SMH_OK) { free_one(d); return rc; }
+    d->next = *head;
+    *head = d;
+    *out = d;
+    return SMH_OK;
+}
+
+/* development aid (tools/wavetrace.py, not in the public headers): when set, the tuned AC kernel stores
+ * three 100 MHz timestamps per wave (start, table staged, done) into this device buffer, which must
+ * hold 3 * 16 * smh_ac_max_blocks(CUs) entries */
+static uint64_t *g_wave_trace = NULL;
+extern "C" void smh_dev_set_wave_trace(uint64_t *d_buf) { g_wave_trace = d_buf; }
 
 /* ------------------------------------------------------------------ runtime wrappers */
 extern "C" int smh_device_count(void)
@@ -200,9 +236,8 @@ static int upload(void **d, const void *h, size_t bytes, size_t pad)
 }
 
 /* ------------------------------------------------------------------ AC */
-extern "C" void smh_ac_dev_free(struct smh_ac_dev *dev)
+static void ac_dev_free_one(smh_ac_dev *dev)
 {
-    if (!dev) return;
     (void)hipFree(dev->d_table);
     if (dev->d_trunc1 != dev->d_scan) (void)hipFree(dev->d_trunc1);
     (void)hipFree(dev->d_scan);
@@ -214,45 +249,47 @@ extern "C" void smh_ac_dev_free(struct smh_ac_dev *dev)
     delete dev;
 }
 
-static int ac_ensure_device(struct smh_ac *ac)
+extern "C" void smh_ac_dev_free(struct smh_ac_dev *dev) /* the whole list */
 {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (ac->dev && ac->dev->device == dev) return SMH_OK;
-    if (ac->dev) { smh_ac_dev_free(ac->dev); ac->dev = NULL; }
-    smh_ac_dev *d = new smh_ac_dev();
-    memset(d, 0, sizeof *d);
-    d->device = dev;
-    ac->dev = d;
-    int rc;
-    int n_cus = 0;
+    while (dev) {
+        smh_ac_dev *next = dev->next;
+        ac_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+static int ac_ensure_device(struct smh_ac *ac, smh_ac_dev **out)
+{
+    int n_cus = 0, rc;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
-    /* 256 entries of slack: a text byte >= alphabet may index just past the last row */
-    if ((rc = upload(&d->d_table, ac->table, (size_t)ac->table_bytes, 256 * 4)) != SMH_OK) return rc;
-    if ((rc = upload(&d->d_scan, ac->scan_table, (size_t)ac->scan_bytes, 0)) != SMH_OK) return rc;
-    if (ac->trunc1_table == ac->scan_table) {
-        d->d_trunc1 = d->d_scan;
-    } else if ((rc = upload(&d->d_trunc1, ac->trunc1_table, (size_t)ac->trunc1_bytes, 256 * 4)) != SMH_OK) {
-        return rc;
-    }
-    if (!ac->scan_exact) {
-        const size_t qbytes = (size_t)smh_ac_max_blocks(n_cus) * (SMH_BLOCK_THREADS / 64) * SMH_AC_QCAP * 8;
-        HIP_TRY(hipMalloc((void **)&d->d_queue, qbytes));
-    }
-    size_t dflen = (size_t)ac->m + 2;
-    if (dflen < SMH_DEPTH_FIRST_MIN) dflen = SMH_DEPTH_FIRST_MIN;
-    std::vector<uint32_t> df(dflen, ac->rows);
-    for (int i = 0; i <= ac->max_depth + 1 && (size_t)i < dflen; ++i) df[i] = ac->depth_first[i];
-    if ((rc = upload((void **)&d->d_depth_first, df.data(), df.size() * 4, 0)) != SMH_OK) return rc;
-    return SMH_OK;
+    return ensure_device_set<smh_ac_dev>(&ac->dev, ac_dev_free_one, [&](smh_ac_dev *d) -> int {
+        int rc;
+        /* 256 entries of slack: a text byte >= alphabet may index just past the last row */
+        if ((rc = upload(&d->d_table, ac->table, (size_t)ac->table_bytes, 256 * 4)) != SMH_OK) return rc;
+        if ((rc = upload(&d->d_scan, ac->scan_table, (size_t)ac->scan_bytes, 0)) != SMH_OK) return rc;
+        if (ac->trunc1_table == ac->scan_table) {
+            d->d_trunc1 = d->d_scan;
+        } else if ((rc = upload(&d->d_trunc1, ac->trunc1_table, (size_t)ac->trunc1_bytes, 256 * 4)) != SMH_OK) {
+            return rc;
+        }
+        if (!ac->scan_exact) {
+            const size_t qbytes = (size_t)smh_ac_max_blocks(n_cus) * (SMH_BLOCK_THREADS / 64) * SMH_AC_QCAP * 8;
+            HIP_TRY(hipMalloc((void **)&d->d_queue, qbytes));
+        }
+        size_t dflen = (size_t)ac->m + 2;
+        if (dflen < SMH_DEPTH_FIRST_MIN) dflen = SMH_DEPTH_FIRST_MIN;
+        std::vector<uint32_t> df(dflen, ac->rows);
+        for (int i = 0; i <= ac->max_depth + 1 && (size_t)i < dflen; ++i) df[i] = ac->depth_first[i];
+        return upload((void **)&d->d_depth_first, df.data(), df.size() * 4, 0);
+    }, out);
 }
 
 /* the reference-layout tables go up on the first SMH_VARIANT_TABLE scan only: for an alphabet-256
  * automaton they are the largest object the handle owns and the tuned kernel never reads them */
-static int ac_ensure_reference_tables(struct smh_ac *ac)
+static int ac_ensure_reference_tables(struct smh_ac *ac, smh_ac_dev *d)
 {
-    smh_ac_dev *d = ac->dev;
-    if (d->d_transition) return SMH_OK;
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    if (d->d_final) return SMH_OK; /* the last of the three to go up */
     if (!ac->g_transition) {
         smh_set_error("smh_ac_scan: this handle carries no reference-layout tables (it came from preproc_ac, "
                       "whose search_ac runs the tuned kernel only); build it with smh_ac_compile_tables or "
@@ -261,10 +298,29 @@ static int ac_ensure_reference_tables(struct smh_ac *ac)
     }
     int rc;
     const size_t A = (size_t)ac->alphabet;
-    if ((rc = upload((void **)&d->d_transition, ac->g_transition, (size_t)ac->states * A * 4, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_supply, ac->g_supply, (size_t)ac->states * 4, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_final, ac->g_final, (size_t)ac->states * 4, 0)) != SMH_OK) return rc;
+    int32_t *t = NULL;
+    uint32_t *su = NULL, *fi = NULL;
+    if ((rc = upload((void **)&t, ac->g_transition, (size_t)ac->states * A * 4, 0)) != SMH_OK ||
+        (rc = upload((void **)&su, ac->g_supply, (size_t)ac->states * 4, 0)) != SMH_OK ||
+        (rc = upload((void **)&fi, ac->g_final, (size_t)ac->states * 4, 0)) != SMH_OK) {
+        (void)hipFree(t); (void)hipFree(su); (void)hipFree(fi);
+        return rc;
+    }
+    d->d_transition = t; d->d_supply = su; d->d_final = fi;
     return SMH_OK;
+}
+
+/* everything a scan of this variant needs on the current device, without launching: the legacy
+ * wrappers call it BEFORE their first event so that the reported kernel time is the kernel's
+ * (cuda/cuda_wm.cu:271-283 brackets the launch only) */
+static int wm_prepare(struct smh_wm *wm, int variant);
+static int ac_prepare(struct smh_ac *ac, int variant)
+{
+    if (variant == SMH_VARIANT_TUNED && ac->alt_wm && !ac->alt_off) return wm_prepare(ac->alt_wm, variant);
+    smh_ac_dev *d = NULL;
+    int rc = ac_ensure_device(ac, &d);
+    if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = ac_ensure_reference_tables(ac, d);
+    return rc;
 }
 
 extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
@@ -287,24 +343,25 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
     if (n < (uint64_t)ac->m) return SMH_OK;
     if (variant == SMH_VARIANT_TUNED && ac->alt_wm && !ac->alt_off) /* engine choice: ac_host.c, end of the compile */
         return smh_wm_scan(ac->alt_wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
-    int rc = ac_ensure_device(ac);
+    smh_ac_dev *dv = NULL;
+    int rc = ac_ensure_device(ac, &dv);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     if (variant == SMH_VARIANT_TABLE) {
-        if ((rc = ac_ensure_reference_tables(ac)) != SMH_OK) return rc;
+        if ((rc = ac_ensure_reference_tables(ac, dv)) != SMH_OK) return rc;
         smh_ac_table_launch L;
         L.d_text = d_text; L.n = n; L.m = ac->m; L.alphabet = ac->alphabet;
-        L.d_transition = ac->dev->d_transition; L.d_supply = ac->dev->d_supply; L.d_final = ac->dev->d_final;
+        L.d_transition = dv->d_transition; L.d_supply = dv->d_supply; L.d_final = dv->d_final;
         L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_ac_table(L, (hipStream_t)stream));
     } else if (variant == SMH_VARIANT_TUNED) {
         smh_ac_launch L = {};
         L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
-        L.V.full = ac->dev->d_table; L.V.full_entry_bytes = ac->entry_bytes; L.V.depth_first = ac->dev->d_depth_first;
-        L.V.trunc1 = ac->dev->d_trunc1; L.V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+        L.V.full = dv->d_table; L.V.full_entry_bytes = ac->entry_bytes; L.V.depth_first = dv->d_depth_first;
+        L.V.trunc1 = dv->d_trunc1; L.V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
         L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
-        L.d_scan_table = ac->dev->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = ac->dev->d_queue;
+        L.d_scan_table = dv->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = dv->d_queue;
         for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
         L.full_rows = ac->scan_full_rows;
         if (L.full_rows) /* hybrid image: compact rows are not numbered by depth; the halo's "deep enough"
@@ -313,6 +370,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
                 if (L.df.v[i] > L.full_rows) L.df.v[i] = L.full_rows;
         L.d_count = d_count; L.n_cus = n_cus;
         L.V.pos.out = NULL; L.V.pos.capacity = 0; L.V.pos.cursor = NULL;
+        L.d_wave_times = g_wave_trace;
         HIP_TRY(smh_launch_ac_dfa(L, (hipStream_t)stream));
     } else {
         smh_set_error("smh_ac_scan: unknown variant %d", variant);
@@ -334,19 +392,20 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
     }
     if (n < (uint64_t)ac->m) return SMH_OK;
     if (ac->alt_wm && !ac->alt_off) return smh_wm_positions(ac->alt_wm, d_text, n, d_positions, capacity, d_cursor, stream);
-    int rc = ac_ensure_device(ac);
+    smh_ac_dev *dv = NULL;
+    int rc = ac_ensure_device(ac, &dv);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     smh_ac_verify_ctx V = {};
     V.text = d_text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
-    V.full = ac->dev->d_table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = ac->dev->d_depth_first;
-    V.trunc1 = ac->dev->d_trunc1; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    V.full = dv->d_table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = dv->d_depth_first;
+    V.trunc1 = dv->d_trunc1; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
     /* the tuned scan kernels in positions mode: matches are recorded as bits and appended per wave */
     smh_ac_launch L = {};
     L.V = V;
     L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
-    L.d_scan_table = ac->dev->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = ac->dev->d_queue;
+    L.d_scan_table = dv->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = dv->d_queue;
     for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
     L.full_rows = ac->scan_full_rows;
     if (L.full_rows)
@@ -365,8 +424,9 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
 }
 
 /* shared by the two *_count_host helpers: text up, zeroed counter, timed launch, count down */
-template <typename Launch>
-static int count_host(const unsigned char *text, uint64_t n, uint64_t *count, double *kernel_seconds, Launch launch)
+template <typename Prepare, typename Launch>
+static int count_host(const unsigned char *text, uint64_t n, uint64_t *count, double *kernel_seconds, Prepare prepare,
+                      Launch launch)
 {
     if (!count || (n && !text)) { smh_set_error("count_host: bad arguments"); return SMH_EINVAL; }
     *count = 0;
@@ -391,6 +451,10 @@ static int count_host(const unsigned char *text, uint64_t n, uint64_t *count, do
     if (n) CH_TRY(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
     CH_TRY(hipEventCreate(&ev0));
     CH_TRY(hipEventCreate(&ev1));
+    /* table uploads happen here, outside the events: *kernel_seconds is the kernel's time, as the
+     * reference's cudaEvents bracket the launch only (cuda/cuda_wm.cu:271-283) */
+    rc = prepare();
+    if (rc != SMH_OK) goto done;
     CH_TRY(hipEventRecord(ev0, 0));
     rc = launch(d_text, d_count);
     if (rc != SMH_OK) goto done;
@@ -411,15 +475,15 @@ done:
 extern "C" int smh_ac_count_host(smh_ac *ac, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
                                  double *kernel_seconds)
 {
-    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
-        return smh_ac_scan(ac, d_text, n, d_count, variant, NULL);
-    });
+    if (!ac || ac->magic != SMH_MAGIC_AC) { smh_set_error("smh_ac_count_host: bad handle"); return SMH_EINVAL; }
+    return count_host(text, n, count, kernel_seconds,
+                      [&]() { return n < (uint64_t)ac->m || !ac->fixed_length_ok ? SMH_OK : ac_prepare(ac, variant); },
+                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_ac_scan(ac, d_text, n, d_count, variant, NULL); });
 }
 
 /* ------------------------------------------------------------------ WM */
-extern "C" void smh_wm_dev_free(struct smh_wm_dev *dev)
+static void wm_dev_free_one(smh_wm_dev *dev)
 {
-    if (!dev) return;
     (void)hipFree(dev->d_filter);
     (void)hipFree(dev->d_pair);
     (void)hipFree(dev->d_queue);
@@ -433,40 +497,70 @@ extern "C" void smh_wm_dev_free(struct smh_wm_dev *dev)
     delete dev;
 }
 
-static int wm_ensure_device(struct smh_wm *wm)
+extern "C" void smh_wm_dev_free(struct smh_wm_dev *dev) /* the whole list */
 {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (wm->dev && wm->dev->device == dev) return SMH_OK;
-    if (wm->dev) { smh_wm_dev_free(wm->dev); wm->dev = NULL; }
-    smh_wm_dev *d = new smh_wm_dev();
-    memset(d, 0, sizeof *d);
-    d->device = dev;
-    wm->dev = d;
+    while (dev) {
+        smh_wm_dev *next = dev->next;
+        wm_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+static int wm_ensure_device(struct smh_wm *wm, smh_wm_dev **out)
+{
+    return ensure_device_set<smh_wm_dev>(&wm->dev, wm_dev_free_one, [&](smh_wm_dev *d) -> int {
+        int rc;
+        const size_t fbytes = ((size_t)1 << wm->filter_log2) / 8;
+        if ((rc = upload((void **)&d->d_filter, wm->filter, fbytes, 0)) != SMH_OK) return rc;
+        if (wm->pair_table && (rc = upload((void **)&d->d_pair, wm->pair_table, 65536, 0)) != SMH_OK) return rc;
+        if (wm->verify) {
+            if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 4, 0)) != SMH_OK) return rc;
+        }
+        {
+            /* distinct patterns, each zero-padded to whole dwords (the verify stage compares dwords) */
+            const size_t row = (size_t)((wm->m + 3) / 4) * 4;
+            std::vector<unsigned char> padded((size_t)wm->distinct * row + 16, 0);
+            for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);
+            if ((rc = upload((void **)&d->d_pat_sorted, padded.data(), (size_t)wm->distinct * row, 16)) != SMH_OK) return rc;
+        }
+        return SMH_OK;
+    }, out);
+}
+
+/* the reference-layout tables (SHIFT, CSR buckets, patterns in the caller's order) go up on the first
+ * table-walking scan only: the tuned kernels never read them */
+static int wm_ensure_reference_tables(struct smh_wm *wm, smh_wm_dev *d)
+{
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    if (d->d_pat_orig) return SMH_OK; /* the last to go up */
     int rc;
-    const size_t fbytes = ((size_t)1 << wm->filter_log2) / 8;
-    if ((rc = upload((void **)&d->d_filter, wm->filter, fbytes, 0)) != SMH_OK) return rc;
-    if (wm->pair_table && (rc = upload((void **)&d->d_pair, wm->pair_table, 65536, 0)) != SMH_OK) return rc;
-    if (wm->verify) {
-        if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 4, 0)) != SMH_OK) return rc;
-    }
-    {
-        /* distinct patterns, each zero-padded to whole dwords (the verify stage compares dwords) */
-        const size_t row = (size_t)((wm->m + 3) / 4) * 4;
-        std::vector<unsigned char> padded((size_t)wm->distinct * row + 16, 0);
-        for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);
-        if ((rc = upload((void **)&d->d_pat_sorted, padded.data(), (size_t)wm->distinct * row, 16)) != SMH_OK) return rc;
-    }
     std::vector<uint16_t> sh(wm->shiftsize);
     for (uint32_t i = 0; i < wm->shiftsize; ++i) {
         int32_t v = wm->l_shift[i];
         sh[i] = (uint16_t)(v < 0 ? 0 : (v > 65535 ? 65535 : v));
     }
-    if ((rc = upload((void **)&d->d_shift, sh.data(), sh.size() * 2, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_bucket_off, wm->l_bucket_off, ((size_t)wm->shiftsize + 1) * 4, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_bucket, wm->l_bucket, (size_t)wm->l_bucket_off[wm->shiftsize] * 8, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_pat_orig, wm->pat_orig, (size_t)wm->patterns * wm->m, 0)) != SMH_OK) return rc;
+    uint16_t *ds = NULL;
+    uint32_t *dbo = NULL;
+    int32_t *db = NULL;
+    uint8_t *dp = NULL;
+    if ((rc = upload((void **)&ds, sh.data(), sh.size() * 2, 0)) != SMH_OK ||
+        (rc = upload((void **)&dbo, wm->l_bucket_off, ((size_t)wm->shiftsize + 1) * 4, 0)) != SMH_OK ||
+        (rc = upload((void **)&db, wm->l_bucket, (size_t)wm->l_bucket_off[wm->shiftsize] * 8, 0)) != SMH_OK ||
+        (rc = upload((void **)&dp, wm->pat_orig, (size_t)wm->patterns * wm->m, 0)) != SMH_OK) {
+        (void)hipFree(ds); (void)hipFree(dbo); (void)hipFree(db); (void)hipFree(dp);
+        return rc;
+    }
+    d->d_shift = ds; d->d_bucket_off = dbo; d->d_bucket = db; d->d_pat_orig = dp;
     return SMH_OK;
+}
+
+static int wm_prepare(struct smh_wm *wm, int variant)
+{
+    if (variant == SMH_VARIANT_TUNED && wm->alt_ac && !wm->alt_off) return ac_prepare(wm->alt_ac, variant);
+    smh_wm_dev *d = NULL;
+    int rc = wm_ensure_device(wm, &d);
+    if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = wm_ensure_reference_tables(wm, d);
+    return rc;
 }
 
 extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
@@ -483,22 +577,24 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
     if (n < (uint64_t)wm->m) return SMH_OK;
     if (variant == SMH_VARIANT_TUNED && wm->alt_ac && !wm->alt_off) /* engine choice: wm_host.c, end of the compile */
         return smh_ac_scan(wm->alt_ac, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
-    int rc = wm_ensure_device(wm);
+    smh_wm_dev *dv = NULL;
+    int rc = wm_ensure_device(wm, &dv);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     if (variant == SMH_VARIANT_TABLE) {
+        if ((rc = wm_ensure_reference_tables(wm, dv)) != SMH_OK) return rc;
         smh_wm_table_launch L;
-        L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = wm->dev->d_shift;
-        L.d_bucket_off = wm->dev->d_bucket_off; L.d_bucket = wm->dev->d_bucket; L.d_pat_orig = wm->dev->d_pat_orig;
+        L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = dv->d_shift;
+        L.d_bucket_off = dv->d_bucket_off; L.d_bucket = dv->d_bucket; L.d_pat_orig = dv->d_pat_orig;
         L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_wm_table(L, (hipStream_t)stream));
     } else if (variant == SMH_VARIANT_TUNED) {
         smh_wm_launch L = {};
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
-        L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
-        L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_queue = wm->dev->d_queue; L.d_count = d_count; L.n_cus = n_cus;
+        L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
+        L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
         L.po.out = NULL; L.po.capacity = 0; L.po.cursor = NULL;
         HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
     } else {
@@ -517,7 +613,8 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
     }
     if (n < (uint64_t)wm->m) return SMH_OK;
     if (wm->alt_ac && !wm->alt_off) return smh_ac_positions(wm->alt_ac, d_text, n, d_positions, capacity, d_cursor, stream);
-    int rc = wm_ensure_device(wm);
+    smh_wm_dev *dv = NULL;
+    int rc = wm_ensure_device(wm, &dv);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
@@ -527,16 +624,17 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         smh_wm_launch L = {};
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
-        L.d_filter = wm->dev->d_filter; L.d_pair = wm->dev->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = wm->dev->d_verify;
-        L.d_pat_sorted = wm->dev->d_pat_sorted; L.d_queue = wm->dev->d_queue; L.d_count = NULL; L.n_cus = n_cus;
+        L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
+        L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = NULL; L.n_cus = n_cus;
         L.po.out = d_positions; L.po.capacity = capacity; L.po.cursor = d_cursor;
         HIP_TRY(smh_launch_wm_block_positions(L, (hipStream_t)stream));
         return SMH_OK;
     }
     /* unaligned text: the reference tables walked as given, one lane per 256 columns */
+    if ((rc = wm_ensure_reference_tables(wm, dv)) != SMH_OK) return rc;
     smh_wm_table_launch L;
-    L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = wm->dev->d_shift;
-    L.d_bucket_off = wm->dev->d_bucket_off; L.d_bucket = wm->dev->d_bucket; L.d_pat_orig = wm->dev->d_pat_orig;
+    L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = dv->d_shift;
+    L.d_bucket_off = dv->d_bucket_off; L.d_bucket = dv->d_bucket; L.d_pat_orig = dv->d_pat_orig;
     L.d_count = NULL; L.n_cus = n_cus;
     HIP_TRY(smh_launch_wm_positions(L, d_positions, capacity, d_cursor, (hipStream_t)stream));
     return SMH_OK;
@@ -558,7 +656,8 @@ static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes
         return SMH_EINVAL;
     }
     if (n < (uint64_t)suffix->m) return SMH_OK;
-    int rc = wm_ensure_device(suffix);
+    smh_wm_dev *sdv = NULL;
+    int rc = wm_ensure_device(suffix, &sdv);
     if (rc != SMH_OK) return rc;
     smh_wm_class host[SMH_WM_MAX_CLASSES];
     for (int c = 0; c < n_classes; ++c) {
@@ -567,8 +666,9 @@ static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes
             smh_set_error("smh_wm_scan_multi: class %d is not a Wu-Manber handle of length >= %d", c, suffix->m);
             return SMH_EINVAL;
         }
-        if ((rc = wm_ensure_device(k)) != SMH_OK) return rc;
-        if (!k->dev->d_verify) {
+        smh_wm_dev *kdv = NULL;
+        if ((rc = wm_ensure_device(k, &kdv)) != SMH_OK) return rc;
+        if (!kdv->d_verify) {
             /* an exact class has no verify table of its own: build it now (host table exists only when the
              * filter is not exact) -- pset_host.c compiles the classes so that this cannot happen */
             smh_set_error("smh_wm_scan_multi: class %d has no verify table", c);
@@ -576,11 +676,14 @@ static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes
         }
         host[c].m = k->m;
         host[c].verify_log2 = k->verify_log2;
-        host[c].verify = k->dev->d_verify;
-        host[c].pat_sorted = k->dev->d_pat_sorted;
+        host[c].verify = kdv->d_verify;
+        host[c].pat_sorted = kdv->d_pat_sorted;
     }
-    if (!suffix->dev->d_classes) HIP_TRY(hipMalloc((void **)&suffix->dev->d_classes, sizeof host));
-    HIP_TRY(hipMemcpyAsync(suffix->dev->d_classes, host, sizeof(smh_wm_class) * (size_t)n_classes, hipMemcpyHostToDevice,
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        if (!sdv->d_classes) HIP_TRY(hipMalloc((void **)&sdv->d_classes, sizeof host));
+    }
+    HIP_TRY(hipMemcpyAsync(sdv->d_classes, host, sizeof(smh_wm_class) * (size_t)n_classes, hipMemcpyHostToDevice,
                            (hipStream_t)stream));
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
@@ -589,9 +692,9 @@ static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes
     L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
     L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4;
     L.filter_exact = 0;
-    L.d_filter = wm->dev->d_filter; L.d_pair = NULL; L.verify_log2 = 4; L.d_verify = NULL; L.d_pat_sorted = NULL;
-    L.d_queue = wm->dev->d_queue; L.d_count = d_count; L.n_cus = n_cus;
-    L.n_classes = n_classes; L.d_classes = suffix->dev->d_classes;
+    L.d_filter = sdv->d_filter; L.d_pair = NULL; L.verify_log2 = 4; L.d_verify = NULL; L.d_pat_sorted = NULL;
+    L.d_queue = sdv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
+    L.n_classes = n_classes; L.d_classes = sdv->d_classes;
     if (po) {
         L.po = *po;
         HIP_TRY(smh_launch_wm_block_positions(L, (hipStream_t)stream));
@@ -619,44 +722,55 @@ extern "C" int smh_wm_positions_multi(smh_wm *suffix, smh_wm *const *classes, in
 extern "C" int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
                                  double *kernel_seconds)
 {
-    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
-        return smh_wm_scan(wm, d_text, n, d_count, variant, NULL);
-    });
+    if (!wm || wm->magic != SMH_MAGIC_WM) { smh_set_error("smh_wm_count_host: bad handle"); return SMH_EINVAL; }
+    return count_host(text, n, count, kernel_seconds,
+                      [&]() { return n < (uint64_t)wm->m ? SMH_OK : wm_prepare(wm, variant); },
+                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_wm_scan(wm, d_text, n, d_count, variant, NULL); });
 }
 
 /* ------------------------------------------------------------------ SH */
 struct smh_sh_dev {
     int device;
+    smh_sh_dev *next;
     int32_t *d_transition;
     uint32_t *d_final;
     int32_t *d_bmbc; /* the table of the last scan (alphabet entries) */
 };
 
-extern "C" void smh_sh_dev_free(struct smh_sh_dev *dev)
+static void sh_dev_free_one(smh_sh_dev *dev)
 {
-    if (!dev) return;
     (void)hipFree(dev->d_transition);
     (void)hipFree(dev->d_final);
     (void)hipFree(dev->d_bmbc);
     delete dev;
 }
 
-static int sh_ensure_device(struct smh_sh *sh)
+extern "C" void smh_sh_dev_free(struct smh_sh_dev *dev) /* the whole list */
 {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (sh->dev && sh->dev->device == dev) return SMH_OK;
-    if (sh->dev) { smh_sh_dev_free(sh->dev); sh->dev = NULL; }
-    smh_sh_dev *d = new smh_sh_dev();
-    memset(d, 0, sizeof *d);
-    d->device = dev;
-    sh->dev = d;
-    int rc;
-    const size_t A = (size_t)sh->alphabet;
-    if ((rc = upload((void **)&d->d_transition, sh->g_transition, (size_t)sh->states * A * 4, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_final, sh->g_final, (size_t)sh->states * 4, 0)) != SMH_OK) return rc;
-    HIP_TRY(hipMalloc((void **)&d->d_bmbc, 256 * sizeof(int32_t)));
-    return SMH_OK;
+    while (dev) {
+        smh_sh_dev *next = dev->next;
+        sh_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+static int sh_ensure_device(struct smh_sh *sh, smh_sh_dev **out)
+{
+    return ensure_device_set<smh_sh_dev>(&sh->dev, sh_dev_free_one, [&](smh_sh_dev *d) -> int {
+        int rc;
+        const size_t A = (size_t)sh->alphabet;
+        if ((rc = upload((void **)&d->d_transition, sh->g_transition, (size_t)sh->states * A * 4, 0)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_final, sh->g_final, (size_t)sh->states * 4, 0)) != SMH_OK) return rc;
+        HIP_TRY(hipMalloc((void **)&d->d_bmbc, 256 * sizeof(int32_t)));
+        return SMH_OK;
+    }, out);
+}
+
+static int sh_prepare(struct smh_sh *sh, int variant)
+{
+    if (variant == SMH_VARIANT_TUNED) return sh->wm ? wm_prepare(sh->wm, variant) : ac_prepare(sh->ac, variant);
+    smh_sh_dev *d = NULL;
+    return sh_ensure_device(sh, &d);
 }
 
 extern "C" int smh_sh_scan(smh_sh *sh, const unsigned char *d_text, uint64_t n, const int *bmBc, uint64_t *d_count,
@@ -678,16 +792,17 @@ extern "C" int smh_sh_scan(smh_sh *sh, const unsigned char *d_text, uint64_t n, 
         smh_set_error("smh_sh_scan: unknown variant %d", variant);
         return SMH_EINVAL;
     }
-    if ((rc = sh_ensure_device(sh)) != SMH_OK) return rc;
+    smh_sh_dev *dv = NULL;
+    if ((rc = sh_ensure_device(sh, &dv)) != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     /* the table travels with the launch (stream-ordered copy from a pageable host buffer: the call
      * returns after the copy has been staged) */
-    HIP_TRY(hipMemcpyAsync(sh->dev->d_bmbc, bmBc ? bmBc : sh->valid_bmbc, (size_t)sh->alphabet * sizeof(int32_t),
+    HIP_TRY(hipMemcpyAsync(dv->d_bmbc, bmBc ? bmBc : sh->valid_bmbc, (size_t)sh->alphabet * sizeof(int32_t),
                            hipMemcpyHostToDevice, (hipStream_t)stream));
     smh_sh_table_launch L;
     L.d_text = d_text; L.n = n; L.m = sh->m; L.alphabet = sh->alphabet;
-    L.d_transition = sh->dev->d_transition; L.d_final = sh->dev->d_final; L.d_bmbc = sh->dev->d_bmbc;
+    L.d_transition = dv->d_transition; L.d_final = dv->d_final; L.d_bmbc = dv->d_bmbc;
     L.d_count = d_count; L.n_cus = n_cus;
     HIP_TRY(smh_launch_sh_table(L, (hipStream_t)stream));
     return SMH_OK;
@@ -696,23 +811,24 @@ extern "C" int smh_sh_scan(smh_sh *sh, const unsigned char *d_text, uint64_t n, 
 extern "C" int smh_sh_count_host(smh_sh *sh, const unsigned char *text, uint64_t n, const int *bmBc, int variant,
                                  uint64_t *count, double *kernel_seconds)
 {
-    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
-        return smh_sh_scan(sh, d_text, n, bmBc, d_count, variant, NULL);
-    });
+    if (!sh || sh->magic != SMH_MAGIC_SH) { smh_set_error("smh_sh_count_host: bad handle"); return SMH_EINVAL; }
+    return count_host(text, n, count, kernel_seconds,
+                      [&]() { return n < (uint64_t)sh->m ? SMH_OK : sh_prepare(sh, variant); },
+                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_sh_scan(sh, d_text, n, bmBc, d_count, variant, NULL); });
 }
 
 /* ------------------------------------------------------------------ SBOM */
 struct smh_sbom_dev {
     int device;
+    smh_sbom_dev *next;
     int32_t *d_transition;
     uint32_t *d_final_off;
     uint32_t *d_final_ids;
     uint8_t *d_patterns;
 };
 
-extern "C" void smh_sbom_dev_free(struct smh_sbom_dev *dev)
+static void sbom_dev_free_one(smh_sbom_dev *dev)
 {
-    if (!dev) return;
     (void)hipFree(dev->d_transition);
     (void)hipFree(dev->d_final_off);
     (void)hipFree(dev->d_final_ids);
@@ -720,23 +836,32 @@ extern "C" void smh_sbom_dev_free(struct smh_sbom_dev *dev)
     delete dev;
 }
 
-static int sbom_ensure_device(struct smh_sbom *sb)
+extern "C" void smh_sbom_dev_free(struct smh_sbom_dev *dev) /* the whole list */
 {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (sb->dev && sb->dev->device == dev) return SMH_OK;
-    if (sb->dev) { smh_sbom_dev_free(sb->dev); sb->dev = NULL; }
-    smh_sbom_dev *d = new smh_sbom_dev();
-    memset(d, 0, sizeof *d);
-    d->device = dev;
-    sb->dev = d;
-    int rc;
-    const size_t A = (size_t)sb->alphabet;
-    if ((rc = upload((void **)&d->d_transition, sb->g_transition, (size_t)sb->states * A * 4, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_final_off, sb->g_final_off, ((size_t)sb->states + 1) * 4, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_final_ids, sb->g_final_ids, (size_t)sb->listed * 4, 0)) != SMH_OK) return rc;
-    if ((rc = upload((void **)&d->d_patterns, sb->patterns, (size_t)sb->n_patterns * sb->m, 0)) != SMH_OK) return rc;
-    return SMH_OK;
+    while (dev) {
+        smh_sbom_dev *next = dev->next;
+        sbom_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+static int sbom_ensure_device(struct smh_sbom *sb, smh_sbom_dev **out)
+{
+    return ensure_device_set<smh_sbom_dev>(&sb->dev, sbom_dev_free_one, [&](smh_sbom_dev *d) -> int {
+        int rc;
+        const size_t A = (size_t)sb->alphabet;
+        if ((rc = upload((void **)&d->d_transition, sb->g_transition, (size_t)sb->states * A * 4, 0)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_final_off, sb->g_final_off, ((size_t)sb->states + 1) * 4, 0)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_final_ids, sb->g_final_ids, (size_t)sb->listed * 4, 0)) != SMH_OK) return rc;
+        return upload((void **)&d->d_patterns, sb->patterns, (size_t)sb->n_patterns * sb->m, 0);
+    }, out);
+}
+
+static int sbom_prepare(struct smh_sbom *sb, int variant)
+{
+    if (variant == SMH_VARIANT_TUNED) return sb->wm ? wm_prepare(sb->wm, variant) : ac_prepare(sb->ac, variant);
+    smh_sbom_dev *d = NULL;
+    return sbom_ensure_device(sb, &d);
 }
 
 extern "C" int smh_sbom_scan(smh_sbom *sb, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
@@ -754,14 +879,15 @@ extern "C" int smh_sbom_scan(smh_sbom *sb, const unsigned char *d_text, uint64_t
         smh_set_error("smh_sbom_scan: unknown variant %d", variant);
         return SMH_EINVAL;
     }
-    int rc = sbom_ensure_device(sb);
+    smh_sbom_dev *dv = NULL;
+    int rc = sbom_ensure_device(sb, &dv);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     smh_sbom_table_launch L;
     L.d_text = d_text; L.n = n; L.m = sb->m; L.alphabet = sb->alphabet;
-    L.d_transition = sb->dev->d_transition; L.d_final_off = sb->dev->d_final_off; L.d_final_ids = sb->dev->d_final_ids;
-    L.d_patterns = sb->dev->d_patterns; L.d_count = d_count; L.n_cus = n_cus;
+    L.d_transition = dv->d_transition; L.d_final_off = dv->d_final_off; L.d_final_ids = dv->d_final_ids;
+    L.d_patterns = dv->d_patterns; L.d_count = d_count; L.n_cus = n_cus;
     HIP_TRY(smh_launch_sbom_table(L, (hipStream_t)stream));
     return SMH_OK;
 }
@@ -769,9 +895,10 @@ extern "C" int smh_sbom_scan(smh_sbom *sb, const unsigned char *d_text, uint64_t
 extern "C" int smh_sbom_count_host(smh_sbom *sb, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
                                    double *kernel_seconds)
 {
-    return count_host(text, n, count, kernel_seconds, [&](unsigned char *d_text, uint64_t *d_count) {
-        return smh_sbom_scan(sb, d_text, n, d_count, variant, NULL);
-    });
+    if (!sb || sb->magic != SMH_MAGIC_SBOM) { smh_set_error("smh_sbom_count_host: bad handle"); return SMH_EINVAL; }
+    return count_host(text, n, count, kernel_seconds,
+                      [&]() { return n < (uint64_t)sb->m ? SMH_OK : sbom_prepare(sb, variant); },
+                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_sbom_scan(sb, d_text, n, d_count, variant, NULL); });
 }
 
 /* ------------------------------------------------------------------ legacy names (smatcher.h) */

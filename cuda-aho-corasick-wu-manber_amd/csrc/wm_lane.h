@@ -456,7 +456,7 @@ SMH_LANE uint32_t smh_wm_lane_table(const uint8_t *text, uint64_t n, uint64_t a,
 /* whole-grid work distribution for one lane; HC == 0: no fast path (m - 1 > 64).  The next chunk's
  * text is requested before the current chunk is scanned (software prefetch). */
 template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
-SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n,
+SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n,
                                 const uint32_t *filter, const smh_wm_params &P, int block_symbols,
                                 uint64_t *queue_base, const smh_pos_out *po = nullptr)
 {
@@ -465,7 +465,6 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8
     const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
     const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
     const uint32_t lane = (uint32_t)(gthread & 63u);
-    const uint64_t wave = gthread >> 6, nwaves = nthreads >> 6;
     smh_wm_queue Q;
     Q.slots = queue_base; /* this wave's slice (the kernel passes LDS) */
     Q.count = 0;
@@ -487,11 +486,11 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, uint64_t nthreads, const uint8
             w[4 * q + 3] = t.v[3];
         }
     };
-    uint64_t k = wave;
+    uint64_t k = S.take(n_chunks);
     bool cur_fast = is_fast(k);
     if (cur_fast) load(k, cur);
     while (k < n_chunks) {
-        const uint64_t kn = k + nwaves;
+        const uint64_t kn = S.take(n_chunks);
         const bool nxt_fast = is_fast(kn);
         constexpr bool PREFETCH = EXACT && H == 1; /* only where registers allow: exact filter, short pre-halo */
         if (PREFETCH && nxt_fast) load(kn, nxt);
@@ -659,17 +658,16 @@ SMH_LANE uint32_t smh_wm_pair_lane_slow(const uint8_t *text, uint64_t n, uint64_
 }
 
 template <bool PREFETCH, bool POS = false>
-SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, uint64_t nthreads, const uint8_t *text, uint64_t n, int m,
+SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n, int m,
                                      const void *tab, const uint32_t *filter_g, const smh_pos_out *po = nullptr)
 {
     if (n < (uint64_t)m) return 0;
     const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
     const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
     const uint32_t lane = (uint32_t)(gthread & 63u);
-    const uint64_t wave = gthread >> 6, nwaves = nthreads >> 6;
     uint32_t cnt = 0;
     uint32_t cur[16], nxt[16], cur_edge[2], nxt_edge[2];
-    uint64_t k = wave;
+    uint64_t k = S.take(n_chunks);
     /* chunk 0 has no text in front of it and columns < m-1 without a window: slow path */
     auto is_fast = [&](uint64_t kk) { return kk >= 1 && kk < n_chunks && (kk + 1) * chunk_bytes <= n; };
     auto load = [&](uint64_t kk, uint32_t (&w)[16], uint32_t (&edge)[2]) {
@@ -691,7 +689,7 @@ SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, uint64_t nthreads, const 
     bool cur_fast = is_fast(k);
     if (cur_fast) load(k, cur, cur_edge);
     while (k < n_chunks) {
-        const uint64_t kn = k + nwaves;
+        const uint64_t kn = S.take(n_chunks);
         const bool nxt_fast = is_fast(kn);
         if (PREFETCH && nxt_fast) load(kn, nxt, nxt_edge);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;

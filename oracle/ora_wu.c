@@ -8,6 +8,7 @@
  * [shiftsize x p_size] arrays main.c:436-439 allocates.
  */
 #include "oracle.h"
+#include <stdlib.h>
 #include <string.h>
 
 /* wu/wu.c:18-47 wu_determine_shiftsize: (alphabet-1)*21 + 1 for the listed alphabets */
@@ -140,6 +141,67 @@ uint64_t ora_search_wu(const uint8_t *const *pattern, int m, int p_size, const u
                 size_t slot = (size_t)hash1 * p_size + (size_t)i;
                 if ((int32_t)hash2 == PREFIX_value[slot] &&
                     memcmp(pattern[PREFIX_index[slot]], text + column - m + 1, (size_t)m) == 0) {
+                    ++matches;
+                    break;
+                }
+            }
+            ++column;
+        } else {
+            column += shift;
+        }
+    }
+    return matches;
+}
+
+/* ------------------------------------------------------------------ CSR form
+ * The dense [shiftsize x p_size] PREFIX tables of main.c:436-439 are 2 x 2.1 GB at alphabet 256 / 100 000
+ * patterns.  The same preprocessing into compressed rows: bucket `hash` holds its entries in the order
+ * preproc_wu2 appends them (ascending pattern index, wu/wu.c:231-247), at bucket_off[hash] ..
+ * bucket_off[hash + 1].  ora_search_wu_csr is search_wu2 (wu/wu.c:151-209) reading those rows.  Checked
+ * equal to the dense restatement and to the compiled reference on the golden vectors (tests/test_oracle.py).
+ * SHIFT must be pre-filled with m - B + 1 as for the dense form; bucket_val / bucket_idx hold p_size
+ * entries (every pattern lands in exactly one bucket: its suffix block's). */
+void ora_preproc_wu_csr(const uint8_t *pattern_flat, int m, int p_size, int B, int nbits, uint32_t shiftsize,
+                        int32_t *SHIFT, uint32_t *bucket_off, int32_t *bucket_val, int32_t *bucket_idx)
+{
+    memset(bucket_off, 0, ((size_t)shiftsize + 1) * sizeof(uint32_t));
+    for (int j = 0; j < p_size; ++j) {
+        const uint8_t *P = pattern_flat + (size_t)j * m;
+        for (int q = m; q >= B; --q) {
+            uint32_t hash = block_hash(P + q - 1, nbits);
+            int32_t shiftlen = m - q;
+            if (shiftlen < SHIFT[hash]) SHIFT[hash] = shiftlen;
+            if (shiftlen == 0) bucket_off[hash + 1]++;
+        }
+    }
+    for (uint32_t h = 0; h < shiftsize; ++h) bucket_off[h + 1] += bucket_off[h];
+    /* second pass in pattern order, so that every row keeps wu/wu.c's append order; the row cursors
+     * live in a scratch copy of the offsets */
+    uint32_t *cursor = (uint32_t *)malloc(((size_t)shiftsize + 1) * sizeof(uint32_t));
+    memcpy(cursor, bucket_off, ((size_t)shiftsize + 1) * sizeof(uint32_t));
+    for (int j = 0; j < p_size; ++j) {
+        const uint8_t *P = pattern_flat + (size_t)j * m;
+        const uint32_t k = cursor[block_hash(P + m - 1, nbits)]++;
+        bucket_val[k] = (int32_t)prefix_hash(P, nbits);
+        bucket_idx[k] = j;
+    }
+    free(cursor);
+}
+
+uint64_t ora_search_wu_csr(const uint8_t *pattern_flat, int m, const uint8_t *text, int64_t n, int nbits,
+                           const int32_t *SHIFT, const uint32_t *bucket_off, const int32_t *bucket_val,
+                           const int32_t *bucket_idx)
+{
+    uint64_t matches = 0;
+    int64_t column = m - 1;
+    while (column < n) {
+        uint32_t hash1 = block_hash(text + column, nbits);
+        int32_t shift = SHIFT[hash1];
+        if (shift == 0) {
+            uint32_t hash2 = prefix_hash(text + column - m + 1, nbits);
+            for (uint32_t k = bucket_off[hash1]; k < bucket_off[hash1 + 1]; ++k) {
+                if ((int32_t)hash2 == bucket_val[k] &&
+                    memcmp(pattern_flat + (size_t)bucket_idx[k] * m, text + column - m + 1, (size_t)m) == 0) {
                     ++matches;
                     break;
                 }

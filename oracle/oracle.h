@@ -92,6 +92,15 @@ uint64_t ora_search_wu2(const uint8_t *pattern_flat, int m, int p_size, const ui
                         int64_t n, int nbits, const int32_t *SHIFT, const int32_t *PREFIX_value,
                         const int32_t *PREFIX_index, const int32_t *PREFIX_size);
 
+/* compressed-row form of the same tables (the dense PREFIX arrays are 2 x 2.1 GB at alphabet 256 /
+ * 100 000 patterns): rows in wu/wu.c's append order; SHIFT pre-filled with m - B + 1; bucket_off has
+ * shiftsize + 1 entries, bucket_val / bucket_idx p_size entries */
+void ora_preproc_wu_csr(const uint8_t *pattern_flat, int m, int p_size, int B, int nbits, uint32_t shiftsize,
+                        int32_t *SHIFT, uint32_t *bucket_off, int32_t *bucket_val, int32_t *bucket_idx);
+uint64_t ora_search_wu_csr(const uint8_t *pattern_flat, int m, const uint8_t *text, int64_t n, int nbits,
+                           const int32_t *SHIFT, const uint32_t *bucket_off, const int32_t *bucket_val,
+                           const int32_t *bucket_idx);
+
 /* ---- byte-range sharding (main.c:375-378, 464-477) ---- */
 /* shard i of R over a text of n bytes: [begin, end) with the m-1 halo, true length (no padding) */
 void ora_shard_range(int64_t n, int R, int i, int m, int64_t *begin, int64_t *end);

@@ -65,12 +65,12 @@ static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t b
         if constexpr (STRIDE == 3) {
             const smh_fmt_s2h fmt{ac->scan_full_rows, ac->scan_full_rows * 28u};
             if constexpr (EXACT || HC <= 2)
-                total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT, true, 16, POS>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
+                total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT, true, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
         } else if constexpr (STRIDE == 2) {
-            total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT, true, 16, POS>(smh_fmt_s2{}, t, nthreads, ac->scan_table, V, df, nullptr);
+            total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT, true, 16, POS>(smh_fmt_s2{}, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
         } else {
             const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
-            total += smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, EMU_AC_NCH, EXACT, true, 16, POS>(fmt, t, nthreads, ac->scan_table, V, df, nullptr);
+            total += smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, EMU_AC_NCH, EXACT, true, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
         }
     }
     return total;
@@ -191,7 +191,7 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t)
-        total += smh_wm_thread<HASHED, EXACT, HC, FK, POS>(t, nthreads, text, n, wm->filter, P, wm->block_symbols, nullptr, po);
+        total += smh_wm_thread<HASHED, EXACT, HC, FK, POS>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->filter, P, wm->block_symbols, nullptr, po);
     return total;
 }
 
@@ -236,7 +236,7 @@ extern "C" uint64_t emu_wm_scan(const smh_wm *wm, const uint8_t *text_in, uint64
         } else if (wm->pair_table) {
             const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
             for (uint64_t t = 0; t < nthreads; ++t)
-                total += smh_wm_pair_thread<true>(t, nthreads, text, n, wm->m, wm->pair_table, wm->filter);
+                total += smh_wm_pair_thread<true>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->m, wm->pair_table, wm->filter);
         } else if (wm->filter_hashed) {
             total = wm_halo<true, false>(wm, text, n, blocks);
         } else if (wm->filter_exact) {
@@ -349,7 +349,7 @@ extern "C" uint64_t emu_wm_positions_tuned(const smh_wm *wm, const uint8_t *text
     if (wm->pair_table) {
         const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
         for (uint64_t t = 0; t < nthreads; ++t)
-            smh_wm_pair_thread<false, true>(t, nthreads, text, n, wm->m, wm->pair_table, wm->filter, &po);
+            smh_wm_pair_thread<false, true>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->m, wm->pair_table, wm->filter, &po);
     } else if (wm->filter_hashed) {
         wm_halo<true, false, true>(wm, text, n, blocks, &po);
     } else if (wm->filter_exact) {

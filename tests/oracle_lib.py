@@ -71,6 +71,10 @@ def _load():
     lib.ora_search_wu.argtypes = [C.POINTER(u8p), C.c_int, C.c_int, u8p, C.c_int64, C.c_int] + wu_tabs
     lib.ora_search_wu2.restype = C.c_uint64
     lib.ora_search_wu2.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int64, C.c_int] + wu_tabs
+    lib.ora_preproc_wu_csr.restype = None
+    lib.ora_preproc_wu_csr.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, i32p, u32p, i32p, i32p]
+    lib.ora_search_wu_csr.restype = C.c_uint64
+    lib.ora_search_wu_csr.argtypes = [u8p, C.c_int, u8p, C.c_int64, C.c_int, i32p, u32p, i32p, i32p]
     lib.ora_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, i64p, i64p]
     lib.ora_count_bruteforce.restype = C.c_uint64
     lib.ora_count_bruteforce.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int64]
@@ -211,6 +215,36 @@ def oracle_wu(pat_flat, m, p, sigma, text=None, flat=True):
             count = int(lib.ora_search_wu(arr, m, p, _ptr(text, u8p), len(text), NBITS, *t.ptrs()))
         del keep
     return count, t
+
+
+class WMTablesCSR:
+    """The same tables in compressed rows (oracle/ora_wu.c, CSR form): what makes alphabet 256 / 100 000
+    patterns checkable -- the dense arrays would be 2 x 2.1 GB."""
+
+    def __init__(self, pat_flat, m, p, sigma):
+        self.m, self.p, self.sigma = m, p, sigma
+        self.shiftsize = int(lib.ora_wu_determine_shiftsize(sigma))
+        if self.shiftsize == 0:
+            raise ValueError("The alphabet size is not supported by wu-manber")
+        self.pat = np.ascontiguousarray(pat_flat, dtype=np.uint8)
+        self.SHIFT = np.full(self.shiftsize, m - B + 1, dtype=np.int32)
+        self.bucket_off = np.zeros(self.shiftsize + 1, dtype=np.uint32)
+        self.bucket_val = np.zeros(max(p, 1), dtype=np.int32)
+        self.bucket_idx = np.zeros(max(p, 1), dtype=np.int32)
+        lib.ora_preproc_wu_csr(_ptr(self.pat, u8p), m, p, B, NBITS, self.shiftsize, _ptr(self.SHIFT, i32p),
+                               _ptr(self.bucket_off, u32p), _ptr(self.bucket_val, i32p), _ptr(self.bucket_idx, i32p))
+
+    def search(self, text):
+        """search_wu2 over the compressed rows; re-entrant (ctypes releases the GIL)."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        return int(lib.ora_search_wu_csr(_ptr(self.pat, u8p), self.m, _ptr(text, u8p), len(text), NBITS,
+                                         _ptr(self.SHIFT, i32p), _ptr(self.bucket_off, u32p),
+                                         _ptr(self.bucket_val, i32p), _ptr(self.bucket_idx, i32p)))
+
+    def digest(self):
+        """Same four digests as WMTables.digest(): SHIFT, PREFIX_size, defined PREFIX_value / PREFIX_index."""
+        sizes = np.diff(self.bucket_off.astype(np.int64)).astype(np.int32)
+        return (fnv(self.SHIFT), fnv(sizes), fnv(self.bucket_val[:self.p]), fnv(self.bucket_idx[:self.p]))
 
 
 # ------------------------------------------------------------------ misc

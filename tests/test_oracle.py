@@ -34,6 +34,10 @@ def test_oracle_reproduces_reference_vectors(vec):
         c_wu, tw = O.oracle_wu(pat, m, p, sigma, text, flat=flat)
         assert c_wu == vec[key]
         assert [hx(d) for d in tw.digest()] == vec["fnv_wm"]
+    # the compressed-row form (what checks alphabet 256 / 100 000 patterns): same tables, same count
+    csr = O.WMTablesCSR(pat, m, p, sigma)
+    assert [hx(d) for d in csr.digest()] == vec["fnv_wm"]
+    assert csr.search(text) == vec["count_wu2"]
     # the reference's two algorithms agree with each other and with the definition
     assert vec["count_ac"] == vec["count_wu"] == vec["count_wu2"]
     if n <= 70000:
@@ -107,3 +111,5 @@ def test_oracle_against_live_reference(seed):
         assert cw_o == cw_r == c_r
         assert np.array_equal(tw_o.SHIFT, tw_r.SHIFT) and np.array_equal(tw_o.PREFIX_size, tw_r.PREFIX_size)
         assert tw_o.digest() == tw_r.digest()
+    csr = O.WMTablesCSR(pat, m, p, sigma)
+    assert csr.digest() == tw_r.digest() and csr.search(text) == c_r
