@@ -213,3 +213,17 @@ def test_wm_scan_engine_choice_and_knob():
     assert dense.info().scan_engine == S.ALGO_WM        # the automaton would be verify-bound
     ascii_ = S.WmTables.from_patterns(S.corpus_patterns(12, 1000, 7, 256, 42, 1 << 24, 2), 12, 1000, 256)
     assert ascii_.info().scan_engine == S.ALGO_WM
+
+
+def test_bench_fans_out_by_itself_and_fails_loudly_without_a_gpu():
+    """`python bench.py --gpus 2` from a plain shell (WORLD_SIZE unset) starts two fresh rank processes before
+    anything touches the GPU; a failing rank (here: no HIP device) makes the parent exit non-zero instead of
+    hanging in a collective."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    if S.device_count() >= 2:
+        pytest.skip("two HIP devices visible: the fan-out would really run")
+    assert r.returncode != 0
+    assert r.stderr.count("needs a HIP device") + r.stderr.count("device(s) visible") >= 1

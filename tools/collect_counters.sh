@@ -14,7 +14,7 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WA
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 > $OUT/pmc_sq_summary.txt 2>&1
-python3 $R/tools/make_traffic_json.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/hbm_traffic.json 2> $OUT/traffic.err
+python3 $R/tools/make_traffic_json.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG > $OUT/hbm_traffic.json 2> $OUT/traffic.err
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # keep the merge-back small: the raw per-dispatch CSVs are not needed once summarised
 find $OUT -name "*counter_collection.csv" -size +8M -delete

@@ -10,8 +10,24 @@ read figure is doubled (the guide's correction).  Values are means over the disp
 import collections
 import csv
 import glob
+import hashlib
 import json
+import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_build_id():
+    """Same digest as bench.py: the sources the library under test was built from."""
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".h", ".inc", ".hip", ".c")):
+            with open(os.path.join(src, name), "rb") as f:
+                h.update(name.encode())
+                h.update(f.read())
+    return h.hexdigest()[:12]
 
 
 def load(path, counter):
@@ -37,9 +53,11 @@ def main():
         rd, wr = int(round(fk * 1024 * 2)), int(round(wk * 1024))
         out[name] = dict(FETCH_SIZE_KB_mean=fk, dispatches=len(vals), WRITE_SIZE_KB_mean=wk,
                          hbm_read_bytes=rd, hbm_write_bytes=wr, hbm_bytes=rd + wr)
-    json.dump(dict(source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
+    json.dump(dict(build_id=kernel_build_id(), profile=sys.argv[3] if len(sys.argv) > 3 else "",
+                   source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
                           "--warmup 1 --no-cpu; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests "
-                          "as 64 B); AC and wm_pair kernels scan 1 GiB per launch, the alphabet-256 wm_block kernels 256 MiB",
+                          "as 64 B); AC and wm_pair kernels of the headline sets scan 1 GiB per launch, the configs[3] / configs[4] "
+                          "instances the shard size bench.py reports",
                    kernels=out), sys.stdout, indent=1)
 
 
