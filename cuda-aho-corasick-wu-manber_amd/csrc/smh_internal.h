@@ -216,12 +216,32 @@ struct smh_wm {
     int verify_log2;      /* slots = 1 << verify_log2; 0 slots when exact */
     uint32_t *verify;     /* 2 words per slot: tag, pattern index + 1 (0 = empty) */
     unsigned char *pat_sorted; /* distinct * m */
-    /* pair filter (alphabet 4, m <= 8, exact): indexed by the code of NINE consecutive symbols
-     * (18 bits, oldest symbol highest); word i>>5 of two interleaved bit maps: bit (i&31) of
-     * pair_table[2*(i>>5)] = "the m symbols ending at the 8th symbol are a pattern", of
-     * pair_table[2*(i>>5)+1] = "the m symbols ending at the 9th symbol are a pattern".  One LDS
-     * lookup answers two end columns.  64 KiB. */
+    /* pair filter (alphabet 4, m <= 8, exact): indexed by the code i of NINE consecutive symbols (18 bits, oldest
+     * symbol highest).  The seven oldest symbols select the dword pair_table[i >> 4]; inside it the newest two
+     * symbols (the pair, i & 15) select two adjacent bits: bit 2 * pair = "the m symbols ending at the 8th
+     * symbol are a pattern", bit 2 * pair + 1 = "... ending at the 9th symbol".  One LDS lookup (ds_read_b32)
+     * answers two end columns.  64 KiB. */
     uint32_t *pair_table;
+    /* gram filter (q-gram shift-and; 128 KiB of LDS).  For every text column ONE table lookup yields a byte F
+     * whose bit 7-j says "the q-gram that ends here is the q-gram that ends j symbols before the end of some
+     * pattern" (plane j, j < gram_planes; the low 8 - gram_planes bits are always set), and the lane state
+     * T = ((T << 1) | 1) & F has bit 7 set exactly when the last gram_planes q-grams are in their planes in
+     * order: the column is a candidate and goes to the verify table.  The idea of the reference's sog/sog8.c
+     * (3-gram bit table T8, smatcher.h:77-80, shift-or state) with positional planes over the patterns' tail.
+     *   SMH_GRAM_PAIR  alphabet 4: 7-symbol grams, table indexed by EIGHT consecutive symbols (16 bits), 16-bit
+     *                  entries: low byte = F of the older seven symbols' column, high byte = F of the next
+     *                  column -- one lookup serves two columns
+     *   SMH_GRAM_OCT   alphabet 4: 8-symbol grams, 8-bit entries indexed by the gram, one lookup per column: for
+     *                  pattern counts at which the 7-symbol planes fill up (8000 patterns: 39 % full, and
+     *                  overlapping grams pass together: 0.4 % of the columns survive eight planes; the 8-symbol
+     *                  planes are 12 % full and 1e-7 survive)
+     *   SMH_GRAM_BYTE  8-bit symbols: 3-byte grams, index = top 17 bits of (gram as a little-endian 24-bit
+     *                  number) * SMH_GRAM_MUL mod 2^32, 8-bit entries */
+    int gram_kind;
+    int gram_planes;
+    void *gram_table;
+    uint32_t gram_bytes;
+    double gram_density; /* fraction of columns expected to reach the verify stage on uniform text */
     /* reference-layout tables */
     uint32_t shiftsize;
     uint32_t shift_zero;
@@ -253,6 +273,12 @@ static inline uint32_t smh_fnv1a32(const unsigned char *s, int len)
 }
 
 uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
+#define SMH_GRAM_NONE 0
+#define SMH_GRAM_PAIR 1
+#define SMH_GRAM_BYTE 2
+#define SMH_GRAM_OCT 3 /* alphabet 4: 8-symbol grams, table indexed by the gram (16 bits), 8-bit entries, one lookup per column */
+#define SMH_GRAM_BYTES (128u * 1024u)
+#define SMH_GRAM_MUL 0x9E3779u /* 24-bit multiplier of the byte-gram index (v_mul_u32_u24) */
 
 #ifdef __cplusplus
 }

@@ -47,6 +47,7 @@ struct smh_wm_dev {
     smh_wm_dev *next;
     uint32_t *d_filter;
     uint32_t *d_pair;
+    uint32_t *d_gram;
     uint64_t *d_queue;
     uint32_t *d_verify;
     uint8_t *d_pat_sorted;
@@ -486,6 +487,7 @@ static void wm_dev_free_one(smh_wm_dev *dev)
 {
     (void)hipFree(dev->d_filter);
     (void)hipFree(dev->d_pair);
+    (void)hipFree(dev->d_gram);
     (void)hipFree(dev->d_queue);
     (void)hipFree(dev->d_verify);
     (void)hipFree(dev->d_pat_sorted);
@@ -513,6 +515,7 @@ static int wm_ensure_device(struct smh_wm *wm, smh_wm_dev **out)
         const size_t fbytes = ((size_t)1 << wm->filter_log2) / 8;
         if ((rc = upload((void **)&d->d_filter, wm->filter, fbytes, 0)) != SMH_OK) return rc;
         if (wm->pair_table && (rc = upload((void **)&d->d_pair, wm->pair_table, 65536, 0)) != SMH_OK) return rc;
+        if (wm->gram_table && (rc = upload((void **)&d->d_gram, wm->gram_table, wm->gram_bytes, 0)) != SMH_OK) return rc;
         if (wm->verify) {
             if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 4, 0)) != SMH_OK) return rc;
         }
@@ -594,6 +597,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
         L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
+        L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind;
         L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
         L.po.out = NULL; L.po.capacity = 0; L.po.cursor = NULL;
         HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
@@ -625,6 +629,7 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
         L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
+        L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind;
         L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = NULL; L.n_cus = n_cus;
         L.po.out = d_positions; L.po.capacity = capacity; L.po.cursor = d_cursor;
         HIP_TRY(smh_launch_wm_block_positions(L, (hipStream_t)stream));

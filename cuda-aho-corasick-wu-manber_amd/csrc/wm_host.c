@@ -86,6 +86,7 @@ void smh_wm_host_free(struct smh_wm *wm)
     if (!wm) return;
     free(wm->filter);
     free(wm->pair_table);
+    free(wm->gram_table);
     free(wm->verify);
     free(wm->pat_sorted);
     free(wm->l_shift);
@@ -138,6 +139,149 @@ static uint32_t block_code(const unsigned char *s_last, int w, int bits)
 }
 
 #define SMH_WM_FILTER_LOG2_MAX 20 /* 2^20 bits = 128 KiB of LDS */
+
+/* ---- gram filter (smh_internal.h): plane j holds the q-grams that end j symbols before the patterns' ends.
+ * Planes of overlapping grams do not pass independently (two grams that share q-1 symbols are both in their
+ * planes far more often than the product of the plane loads says: 8000 DNA patterns, 7-symbol grams, eight
+ * planes 39 % full each: 0.41 % of random columns survive, not 0.05 %), so the fraction of columns that will
+ * reach the verify stage is MEASURED here by running the recurrence over pseudo-random text. */
+static uint64_t gram_rng(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static double gram_survivors(int kind, const void *tab, int alphabet)
+{
+    enum { COLS = 1 << 18 };
+    uint64_t seed = 0x5EEDull, hits = 0;
+    uint32_t T = 0, code = 0, k0 = 0, k1 = 0;
+    for (int x = 0; x < COLS; ++x) {
+        const uint32_t c = (uint32_t)(gram_rng(&seed) % (uint64_t)alphabet);
+        uint32_t F;
+        if (kind == SMH_GRAM_PAIR) {
+            code = ((code << 2) | c) & 0x3FFFu;                     /* the 7 symbols ending here */
+            F = ((const uint16_t *)tab)[code << 2] & 0xFFu;
+        } else if (kind == SMH_GRAM_OCT) {
+            code = ((code << 2) | c) & 0xFFFFu;
+            F = ((const uint8_t *)tab)[code];
+        } else {
+            const uint32_t key = k0 | (k1 << 8) | (c << 16);
+            k0 = k1;
+            k1 = c;
+            F = ((const uint8_t *)tab)[(uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15];
+        }
+        T = ((T << 1) | 1u) & F;
+        if (x >= 16) hits += (T >> 7) & 1u;
+    }
+    return (double)hits / (double)(COLS - 16);
+}
+
+/* scan time (ms per GiB on MI355X, profiles/r02_*) of each form + what a surviving column costs in the verify
+ * stage; the form with the lowest estimate is kept, or none when the handle's block filter is estimated faster */
+/* verify stage: ms per GiB per unit of survivor fraction, growing with the window the stage has to fetch and hash
+ * (fits to 8000 DNA patterns m = 16 / 32 and 100 000 byte patterns m = 5 / 12 / 20, profiles/r02_*) */
+#define SMH_GRAM_VERIFY_MS(m) (12.0 + 3.0 * (m))
+#define SMH_HASHED_VERIFY_MS(m) (6.0 + 1.05 * (m))
+#define SMH_DIRECT_VERIFY_MS(m) ((m) > 4 ? 1.9 * (m) - 3.0 : 4.6)
+
+static int build_gram_filter(struct smh_wm *wm, double other_ms)
+{
+    const int m = wm->m, d = wm->distinct;
+    const unsigned char *pats = wm->pat_sorted;
+    void *best = NULL;
+    int best_kind = SMH_GRAM_NONE, best_planes = 0;
+    uint32_t best_bytes = 0;
+    double best_ms = other_ms, best_dens = 0.0;
+    /* development knob: SMH_WM_TUNE="gram=K" keeps form K whenever the set can use it (0: never a gram filter) */
+    int force = -1;
+    {
+        const char *t = getenv("SMH_WM_TUNE"), *g = t ? strstr(t, "gram=") : NULL;
+        if (g) force = atoi(g + 5);
+    }
+    if (force == 0) return 0;
+    if (force > 0) best_ms = 1e30;
+#define GRAM_WANTED(kind) (force < 0 || force == (kind))
+    if (wm->alphabet == 4 && m >= 9 && GRAM_WANTED(SMH_GRAM_PAIR)) {
+        /* 7-symbol grams; planes 0 .. J-1 need the gram that ends j before the end to start at >= 0 */
+        int J = m - 6;
+        if (J > 8) J = 8;
+        uint8_t *f7 = (uint8_t *)malloc(16384);
+        uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES);
+        if (!f7 || !tab) { free(f7); free(tab); return -1; }
+        memset(f7, (1 << (8 - J)) - 1, 16384);
+        for (int p = 0; p < d; ++p)
+            for (int j = 0; j < J; ++j) {
+                const unsigned char *g = pats + (size_t)p * m + (m - 7 - j);
+                uint32_t code = 0;
+                for (int i = 0; i < 7; ++i) code = (code << 2) | g[i];
+                f7[code] |= (uint8_t)(1u << (7 - j));
+            }
+        for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(f7[x >> 2] | ((uint32_t)f7[x & 0x3FFFu] << 8));
+        free(f7);
+        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4), ms = 0.205 + SMH_GRAM_VERIFY_MS(m) * dens;
+        if (ms < best_ms) {
+            free(best);
+            best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
+        } else {
+            free(tab);
+        }
+    }
+    if (wm->alphabet == 4 && m >= 10 && GRAM_WANTED(SMH_GRAM_OCT)) {
+        int J = m - 7;
+        if (J > 8) J = 8;
+        uint8_t *tab = (uint8_t *)malloc(65536);
+        if (!tab) { free(best); return -1; }
+        memset(tab, (1 << (8 - J)) - 1, 65536);
+        for (int p = 0; p < d; ++p)
+            for (int j = 0; j < J; ++j) {
+                const unsigned char *g = pats + (size_t)p * m + (m - 8 - j);
+                uint32_t code = 0;
+                for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
+                tab[code] |= (uint8_t)(1u << (7 - j));
+            }
+        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4), ms = 0.30 + SMH_GRAM_VERIFY_MS(m) * dens;
+        if (ms < best_ms) {
+            free(best);
+            best = tab; best_kind = SMH_GRAM_OCT; best_planes = J; best_bytes = 65536; best_ms = ms; best_dens = dens;
+        } else {
+            free(tab);
+        }
+    }
+    if (wm->bits_per_symbol >= 7 && m >= 5 && GRAM_WANTED(SMH_GRAM_BYTE)) {
+        int J = m - 2;
+        if (J > 8) J = 8;
+        uint8_t *tab = (uint8_t *)malloc(SMH_GRAM_BYTES);
+        if (!tab) { free(best); return -1; }
+        memset(tab, (1 << (8 - J)) - 1, SMH_GRAM_BYTES);
+        for (int p = 0; p < d; ++p)
+            for (int j = 0; j < J; ++j) {
+                const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
+                const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
+                const uint32_t idx = (uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15; /* low 32 bits of the product, top 17 */
+                tab[idx] |= (uint8_t)(1u << (7 - j));
+            }
+        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet), ms = 0.33 + SMH_GRAM_VERIFY_MS(m) * dens;
+        if (ms < best_ms) {
+            free(best);
+            best = tab; best_kind = SMH_GRAM_BYTE; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
+        } else {
+            free(tab);
+        }
+    }
+#undef GRAM_WANTED
+    if (getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "debug"))
+        fprintf(stderr, "gram filter: block filter est %.3f ms/GiB; kept form %d, %d planes, survivors %.5f, est %.3f ms/GiB\n",
+                other_ms, best_kind, best_planes, best_dens, best_ms);
+    wm->gram_kind = best_kind;
+    wm->gram_planes = best_planes;
+    wm->gram_table = best;
+    wm->gram_bytes = best_bytes;
+    wm->gram_density = best_dens;
+    return 0;
+}
 
 struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int p_size, int alphabet,
                                    const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
@@ -337,14 +481,14 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
 
     /* ---- pair filter: one lookup for two end columns (see smh_internal.h) ---- */
     if (wm->filter_exact && alphabet == 4 && m <= 8 && !wm->filter_hashed) {
-        wm->pair_table = (uint32_t *)calloc(2u * 8192u, sizeof(uint32_t));
+        wm->pair_table = (uint32_t *)calloc(16384u, sizeof(uint32_t));
         if (!wm->pair_table) goto oom;
         const uint32_t mmask = (1u << (2 * m)) - 1u;
         for (uint32_t i = 0; i < (1u << 18); ++i) {
             /* the exact direct filter is indexed by the m-symbol code, oldest symbol highest */
-            const uint32_t c1 = (i >> 2) & mmask, c2 = i & mmask;
-            if ((wm->filter[c1 >> 5] >> (c1 & 31u)) & 1u) wm->pair_table[2u * (i >> 5)] |= 1u << (i & 31u);
-            if ((wm->filter[c2 >> 5] >> (c2 & 31u)) & 1u) wm->pair_table[2u * (i >> 5) + 1u] |= 1u << (i & 31u);
+            const uint32_t c1 = (i >> 2) & mmask, c2 = i & mmask, pair = i & 15u;
+            if ((wm->filter[c1 >> 5] >> (c1 & 31u)) & 1u) wm->pair_table[i >> 4] |= 1u << (2u * pair);
+            if ((wm->filter[c2 >> 5] >> (c2 & 31u)) & 1u) wm->pair_table[i >> 4] |= 1u << (2u * pair + 1u);
         }
     }
 
@@ -362,12 +506,32 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         size_t slots = (size_t)1 << lg;
         wm->verify = (uint32_t *)calloc(slots, sizeof(uint32_t));
         if (!wm->verify) goto oom;
+        /* 16-byte buckets of four slots, filled in order: one 16-byte load shows a probe all four tags, and a
+         * bucket whose last slot is empty ends an unsuccessful search (linear probing over single slots needed
+         * up to ten dependent loads for the unluckiest of the 128 columns of a drain) */
+        const size_t nb = slots / 4;
         for (int j = 0; j < d; ++j) {
             uint32_t tag = smh_wm_tag(wm->pat_sorted + (size_t)j * m, m);
-            size_t s = (size_t)((tag * SMH_HASH_MUL) >> (32 - lg));
-            while (wm->verify[s]) s = (s + 1) & (slots - 1);
-            wm->verify[s] = ((tag & 0xFFFu) << 20) | ((uint32_t)j + 1u);
+            size_t b = (size_t)((tag * SMH_HASH_MUL) >> (32 - (lg - 2)));
+            for (;;) {
+                uint32_t *q = wm->verify + 4 * b;
+                int k = 0;
+                while (k < 4 && q[k]) ++k;
+                if (k < 4) { q[k] = ((tag & 0xFFFu) << 20) | ((uint32_t)j + 1u); break; }
+                b = (b + 1) & (nb - 1);
+            }
         }
+    }
+
+    /* ---- gram filter: taken when this path would otherwise scan with a NON-exact filter and the gram filter
+     *      lets fewer columns through (it also costs less per column: one lookup per two columns on the
+     *      4-letter alphabet, no hash arithmetic beyond one 24-bit multiply on byte symbols) ---- */
+    if (!wm->filter_exact && !wm->pair_table) {
+        /* this path's block filter, same units: a non-exact direct filter scans at 0.40 ms/GiB, the hashed
+         * byte-block filter at 0.55, and their survivors cost the same verify stage */
+        const double other_ms = wm->filter_hashed ? 0.55 + SMH_HASHED_VERIFY_MS(m) * wm->filter_density
+                                                  : 0.40 + SMH_DIRECT_VERIFY_MS(m) * wm->filter_density;
+        if (build_gram_filter(wm, other_ms) != 0) goto oom;
     }
 
     /* Scan-engine choice, the mirror image of the one in ac_host.c: a small-alphabet set of LONG patterns
@@ -429,6 +593,8 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->verify_slots = wm->filter_exact ? 0u : (1u << wm->verify_log2);
     out->lds_bytes = (uint32_t)(((size_t)1 << wm->filter_log2) / 8);
     out->scan_engine = wm->alt_ac && !wm->alt_off ? SMH_ALGO_AC : SMH_ALGO_WM;
+    out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
+    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_bytes;
     return SMH_OK;
 }
 

@@ -26,6 +26,8 @@
 #include "lane_common.h"
 
 #define SMH_WM_HASH_MUL 0x9E3779B1u /* == SMH_HASH_MUL in smh_internal.h */
+#define SMH_GRAM_MUL_DEV 0x9E3779u  /* == SMH_GRAM_MUL in smh_internal.h */
+#include <utility>
 
 struct smh_wm_params {
     int m;
@@ -35,7 +37,7 @@ struct smh_wm_params {
     int filter_k;        /* hashed filter: bits per key inside one 32-bit word (2..4) */
     int filter_le4;      /* hashed filter keyed by the block's 4 bytes as a little-endian dword (8-bit symbols) */
     int verify_log2;     /* slots = 1 << verify_log2 */
-    const uint32_t *verify;      /* HBM: one word per slot, tag (12 bits) << 20 | pattern + 1; 0 = empty */
+    const uint32_t *verify;      /* HBM: 16-byte buckets of four slots, slot = tag (12 bits) << 20 | pattern + 1; 0 = empty */
     const uint8_t *pat_sorted;   /* HBM: distinct patterns, each zero-padded to ((m+3)/4)*4 bytes */
     /* mixed-length sets scanned in ONE pass (smh_pset, SMH_ALGO_WM): the filter is built over the
      * patterns' last min-length symbols, and a surviving column is verified once per length class */
@@ -82,21 +84,24 @@ SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_pa
     const uint32_t *aligned = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
     const uint32_t shift_bits = (uint32_t)(s0 & 3u) * 8u;
     const int nd = (P.m + 3) >> 2;
-    const uint32_t mask = (1u << P.verify_log2) - 1u;
     uint32_t tag = 0x811C9DC5u;
     for (int j = 0; j < nd; ++j) tag = smh_wm_mix(tag, smh_window_dword(aligned, shift_bits, j, P.m));
-    uint32_t s = (tag * SMH_WM_HASH_MUL) >> (32 - P.verify_log2);
+    uint32_t b = (tag * SMH_WM_HASH_MUL) >> (32 - (P.verify_log2 - 2)); /* bucket of four slots */
+    const uint32_t bmask = (1u << (P.verify_log2 - 2)) - 1u;
     for (;;) {
-        const uint32_t slot = P.verify[s]; /* 12 tag bits | pattern + 1 (20 bits); 0 = empty */
-        const uint32_t sidx = slot & 0xFFFFFu;
-        if (slot == 0) return 0;
-        if ((slot >> 20) == (tag & 0xFFFu)) {
-            const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx - 1) * (uint32_t)nd;
-            uint32_t diff = 0;
-            for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(aligned, shift_bits, j, P.m);
-            if (diff == 0) return 1;
+        const smh_u32x4 q4 = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t slot = q4.v[k]; /* 12 tag bits | pattern + 1 (20 bits); 0 = empty */
+            if (slot != 0 && (slot >> 20) == (tag & 0xFFFu)) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)((slot & 0xFFFFFu) - 1) * (uint32_t)nd;
+                uint32_t diff = 0;
+                for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(aligned, shift_bits, j, P.m);
+                if (diff == 0) return 1;
+            }
         }
-        s = (s + 1) & mask;
+        if (q4.v[3] == 0) return 0; /* slots fill in order: a bucket with a free slot ends the search */
+        b = (b + 1) & bmask;
     }
 }
 
@@ -198,48 +203,50 @@ SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, 
     const uint32_t *al1 = reinterpret_cast<const uint32_t *>(text + (b1 & ~(uint64_t)3));
     const uint32_t sh0 = (uint32_t)(b0 & 3u) * 8u, sh1 = (uint32_t)(b1 & 3u) * 8u;
     const int nd = (P.m + 3) >> 2;
-    const uint32_t mask = (1u << P.verify_log2) - 1u;
     uint32_t tag0 = 0x811C9DC5u, tag1 = 0x811C9DC5u;
     for (int j = 0; j < nd; ++j) {
         const uint32_t v0 = smh_window_dword(al0, sh0, j, P.m), v1 = smh_window_dword(al1, sh1, j, P.m);
         tag0 = smh_wm_mix(tag0, v0);
         tag1 = smh_wm_mix(tag1, v1);
     }
-    uint32_t s0 = (tag0 * SMH_WM_HASH_MUL) >> (32 - P.verify_log2), s1 = (tag1 * SMH_WM_HASH_MUL) >> (32 - P.verify_log2);
+    const uint32_t bshift = 32u - (uint32_t)(P.verify_log2 - 2), bmask = (1u << (P.verify_log2 - 2)) - 1u;
+    uint32_t b0q = (tag0 * SMH_WM_HASH_MUL) >> bshift, b1q = (tag1 * SMH_WM_HASH_MUL) >> bshift;
     uint32_t r0 = 0;
     bool a0 = true, a1 = true;
     r1 = 0;
+    const uint8_t *vt = reinterpret_cast<const uint8_t *>(P.verify);
     for (;;) {
-        const uint32_t slot0 = P.verify[s0], slot1 = P.verify[s1];
-        const uint32_t stag0 = slot0 >> 20, sidx0 = slot0 & 0xFFFFFu;
-        const uint32_t stag1 = slot1 >> 20, sidx1 = slot1 & 0xFFFFFu;
+        /* both chains' buckets in flight together (one 16-byte load each) */
+        const smh_u32x4 q0 = smh_load16(vt + 16u * (uint64_t)b0q), q1 = smh_load16(vt + 16u * (uint64_t)b1q);
         if (a0) {
-            if (sidx0 == 0) {
-                a0 = false;
-            } else {
-                if (stag0 == (tag0 & 0xFFFu)) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx0 - 1) * (uint32_t)nd;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t slot = q0.v[k];
+                if (slot != 0 && (slot >> 20) == (tag0 & 0xFFFu)) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)((slot & 0xFFFFFu) - 1) * (uint32_t)nd;
                     uint32_t diff = 0;
                     for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(al0, sh0, j, P.m);
-                    if (diff == 0) { r0 = 1; a0 = false; }
+                    if (diff == 0) r0 = 1;
                 }
-                s0 = (s0 + 1) & mask;
             }
+            if (r0 || q0.v[3] == 0) a0 = false;
+            b0q = (b0q + 1) & bmask;
         }
         if (a1) {
-            if (sidx1 == 0) {
-                a1 = false;
-            } else {
-                if (stag1 == (tag1 & 0xFFFu)) {
-                    const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)(sidx1 - 1) * (uint32_t)nd;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t slot = q1.v[k];
+                if (slot != 0 && (slot >> 20) == (tag1 & 0xFFFu)) {
+                    const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)((slot & 0xFFFFFu) - 1) * (uint32_t)nd;
                     uint32_t diff = 0;
                     for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(al1, sh1, j, P.m);
-                    if (diff == 0) { r1 = 1; a1 = false; }
+                    if (diff == 0) r1 = 1;
                 }
-                s1 = (s1 + 1) & mask;
             }
+            if (r1 || q1.v[3] == 0) a1 = false;
+            b1q = (b1q + 1) & bmask;
         }
-        if (!(a0 || a1)) break;
+        if (!SMH_WAVE_ANY(a0 || a1)) break;
     }
     return r0;
 }
@@ -575,23 +582,20 @@ SMH_LANE void smh_lds_u32x2(const void *base, uint32_t byte_off, uint32_t &lo, u
 }
 #endif
 
-/* pair codes (4 bits: first symbol high) of a text dword: x = (w << 3) | (w >> 7) puts them at bits 1..4 and 17..20 */
-SMH_LANE uint32_t smh_wm_pairs_prep(uint32_t w) { return (w << 3) | (w >> 7); }
+/* Pair filter lookups (table layout: smh_internal.h).  x = (w << 10) | w puts the pair codes (4 bits, first
+ * symbol high) of a text dword at bits 8..11 and 24..27 with zero bits below them, so that one v_bfe yields the
+ * code times 2 or times 4.  `c2` is the rolling code of the symbols seen so far, times 4: its low 16 bits ARE
+ * the byte address of the dword that the seven symbols before the new pair select.  Per pair of columns:
+ * v_and (address), ds_read_b32, v_bfe (pair * 4), v_lshl_or (roll), v_bfe (pair * 2), v_bfe (the two answers),
+ * v_bcnt (count). */
+SMH_LANE uint32_t smh_wm_pairs_prep(uint32_t w) { return (w << 10) | w; }
 
-SMH_LANE uint32_t smh_wm_pair_step(uint32_t &code, uint32_t x, int k, const void *tab)
+/* the two answers for the pair k of x as two bits (bit 0 = the pair's first column, bit 1 = its second) */
+SMH_LANE uint32_t smh_wm_pair_step_bits(uint32_t &c2, uint32_t x, int k, const void *tab)
 {
-    code = (code << 4) | smh_bfe(x, k == 0 ? 1 : 17, 4);
-    uint32_t lo, hi;
-    smh_lds_u32x2(tab, (code >> 2) & 0xFFF8u, lo, hi); /* ((code & 0x3FFFF) >> 5) * 8 */
-    return smh_bfe(lo, code & 31u, 1) + smh_bfe(hi, code & 31u, 1);
-}
-/* positions mode: the two answers as two bits (bit 0 = the pair's first column, bit 1 = its second) */
-SMH_LANE uint32_t smh_wm_pair_step_bits(uint32_t &code, uint32_t x, int k, const void *tab)
-{
-    code = (code << 4) | smh_bfe(x, k == 0 ? 1 : 17, 4);
-    uint32_t lo, hi;
-    smh_lds_u32x2(tab, (code >> 2) & 0xFFF8u, lo, hi);
-    return smh_bfe(lo, code & 31u, 1) | (smh_bfe(hi, code & 31u, 1) << 1);
+    const uint32_t word = smh_lds_u32(tab, c2 & 0xFFFCu);
+    c2 = (c2 << 4) | smh_bfe(x, k == 0 ? 6 : 22, 6);
+    return smh_bfe(word, smh_bfe(x, k == 0 ? 7 : 23, 5), 2);
 }
 
 /* fast path: the 64 END columns of the segment at a (a >= 8, a + 64 <= n, first column >= m-1) */
@@ -600,21 +604,21 @@ SMH_LANE uint32_t smh_wm_pair_lane_fast(const uint8_t *text, uint64_t a, const u
                                         const uint32_t (&edge)[2], const void *tab, const smh_pos_out *po = nullptr)
 {
     /* prime the rolling code with the 8 symbols in front of the segment */
-    uint32_t code = 0, cnt = 0;
+    uint32_t c2 = 0, cnt = 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t pw = smh_prev_lane_word(w[14 + q], edge[q], text, a - 8u + 4u * q);
         const uint32_t x = smh_wm_pairs_prep(pw);
-        code = (code << 4) | smh_bfe(x, 1, 4);
-        code = (code << 4) | smh_bfe(x, 17, 4);
+        c2 = (c2 << 4) | smh_bfe(x, 6, 6);
+        c2 = (c2 << 4) | smh_bfe(x, 22, 6);
     }
-    /* `code` now holds symbols a-8 .. a-1; the lookup after the pair (a+2i, a+2i+1) sees a+2i-7 .. a+2i+1 */
+    /* `c2` now holds symbols a-8 .. a-1; the lookup for the pair (a+2i, a+2i+1) sees a+2i-7 .. a+2i+1 */
     if constexpr (POS) {
         uint32_t mlo = 0, mhi = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const uint32_t x = smh_wm_pairs_prep(w[q]);
-            const uint32_t b0 = smh_wm_pair_step_bits(code, x, 0, tab), b1 = smh_wm_pair_step_bits(code, x, 1, tab);
+            const uint32_t b0 = smh_wm_pair_step_bits(c2, x, 0, tab), b1 = smh_wm_pair_step_bits(c2, x, 1, tab);
             const uint32_t four = b0 | (b1 << 2);
             if (q < 8)
                 mlo |= four << (4 * q);
@@ -626,8 +630,8 @@ SMH_LANE uint32_t smh_wm_pair_lane_fast(const uint8_t *text, uint64_t a, const u
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const uint32_t x = smh_wm_pairs_prep(w[q]);
-        cnt += smh_wm_pair_step(code, x, 0, tab);
-        cnt += smh_wm_pair_step(code, x, 1, tab);
+        cnt = smh_popc_add(smh_wm_pair_step_bits(c2, x, 0, tab), cnt);
+        cnt = smh_popc_add(smh_wm_pair_step_bits(c2, x, 1, tab), cnt);
     }
     return cnt;
     }
@@ -716,6 +720,289 @@ SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, const smh_chunk_sched &S,
         k = kn;
     }
     return cnt;
+}
+
+/* ------------------------------------------------------------------ gram filter (q-gram shift-and)
+ * smh_internal.h "gram filter" describes the tables.  A lane owns the 64 END columns of its segment, keeps the
+ * shift-and state T in one register and never looks back further than the q-1 symbols in front of the segment
+ * (they come out of the previous lane's registers, as in the pair kernel): the state it would have inherited
+ * from the columns before the segment is ASSUMED all-alive, and the first seven candidate bits are corrected
+ * afterwards with the previous lane's final state (one DPP move) -- bit 6-t of that state is exactly the
+ * factor the assumption replaced in column t.  Lane 0 of a wave has no neighbour and keeps the assumption: a
+ * few more columns reach the verify stage, which is exact, so the count does not change.
+ * The state register also carries the candidate flags: table bytes are OR-ed with 0xFFFFFF00 before the AND, so
+ * bit 7 (candidate) just keeps shifting up and 24 columns' flags are collected with one bit-reverse. */
+#define SMH_GRAM_KEEP 0xFFFFFF00u
+
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+SMH_LANE uint32_t smh_lds_u8(const void *, uint32_t byte_off)
+{
+    return *reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(byte_off);
+}
+SMH_LANE uint32_t smh_bitrev32(uint32_t v) { return __builtin_bitreverse32(v); }
+SMH_LANE uint32_t smh_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+#else
+SMH_LANE uint32_t smh_lds_u8(const void *base, uint32_t byte_off) { return ((const uint8_t *)base)[byte_off]; }
+SMH_LANE uint32_t smh_bitrev32(uint32_t v)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i);
+    return r;
+}
+SMH_LANE uint32_t smh_mul24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }
+#endif
+
+/* one column of the recurrence; F = the table byte (bits above 7 ignored) */
+SMH_LANE uint32_t smh_gram_step(uint32_t T, uint32_t F) { return ((T << 1) | 1u) & (F | SMH_GRAM_KEEP); }
+
+/* candidate flags of the last `cols` (<= 24) columns, bit c = the c-th of them (oldest first) */
+SMH_LANE uint32_t smh_gram_flags(uint32_t T, int cols)
+{
+    /* after the group's last column, bit 7 + t of T is the flag of the column t before it */
+    return (smh_bitrev32(T) >> (25 - cols)) & ((1u << cols) - 1u);
+}
+
+/* byte-gram key of column i of the segment: the three bytes that end there, as the low 24 bits of a dword.
+ * `pre` holds the four bytes in front of the segment. */
+template <int I>
+SMH_LANE uint32_t smh_gram_key(const uint32_t (&w)[16], uint32_t pre)
+{
+    if constexpr (I == 0) return smh_alignbyte(w[0], pre, 2u);
+    else if constexpr (I == 1) return smh_alignbyte(w[0], pre, 3u);
+    else {
+        constexpr int first = I - 2, d = first >> 2, r = first & 3;
+        if constexpr (r == 0) return w[d];
+        else if constexpr (d == 15) return smh_alignbyte(0u, w[15], (uint32_t)r); /* the byte past the segment is not part of the gram */
+        else return smh_alignbyte(w[d + 1], w[d], (uint32_t)r);
+    }
+}
+
+template <int... Is>
+SMH_LANE void smh_gram_byte_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &T, uint32_t (&fl)[3],
+                                    std::integer_sequence<int, Is...>)
+{
+    /* columns in order; flags are collected after columns 23, 47 and 63 */
+    ((T = smh_gram_step(T, smh_lds_u8(tab, smh_mul24(smh_gram_key<Is>(w, pre), SMH_GRAM_MUL_DEV) >> 15)),
+      (Is == 23 ? (void)(fl[0] = smh_gram_flags(T, 24)) : Is == 47 ? (void)(fl[1] = smh_gram_flags(T, 24))
+                                                        : Is == 63 ? (void)(fl[2] = smh_gram_flags(T, 16)) : (void)0)),
+     ...);
+}
+
+/* state the lane would have inherited from the columns in front of its segment (low 7 bits), true value:
+ * the CPU emulation and the bounds-checked path compute it by running the recurrence over those columns */
+template <int KIND>
+SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const void *tab)
+{
+    uint32_t T = 0x7Fu;
+    if (KIND == 3) {
+        if (a < 15) return T;
+        for (uint64_t x = a - 7; x < a; ++x) {
+            uint32_t code = 0;
+            for (int i = 7; i >= 0; --i) code = (code << 2) | (text[x - (uint64_t)i] & 3u);
+            T = smh_gram_step(T, smh_lds_u8(tab, code));
+        }
+    } else if (KIND == 1) {
+        if (a < 14) return T; /* columns without seven symbols in front of them: keep the assumption (superset) */
+        for (uint64_t x = a - 7; x < a; ++x) {
+            uint32_t code = 0;
+            for (int i = 6; i >= 0; --i) code = (code << 2) | (text[x - (uint64_t)i] & 3u);
+            /* F of the 7-gram ending at x is the LOW byte of any entry whose older seven symbols are that gram */
+            T = smh_gram_step(T, smh_lds_u16(tab, (code << 2) << 1) & 0xFFu);
+        }
+    } else {
+        if (a < 10) return T;
+        for (uint64_t x = a - 7; x < a; ++x) {
+            const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
+            T = smh_gram_step(T, smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15));
+        }
+    }
+    return T & 0x7Fu;
+}
+
+/* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
+ * `edge` = the 8 bytes in front of the wave-chunk (wave-uniform).  Returns nothing: candidates go to the queue. */
+template <int KIND, bool POS>
+SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&edge)[2],
+                                    const void *tab, const smh_wm_params &P, smh_wm_queue &Q)
+{
+    uint32_t T = 0x7Fu, fl[3] = {0, 0, 0};
+    const uint32_t pre0 = smh_prev_lane_word(w[14], edge[0], text, a - 8u);
+    const uint32_t pre1 = smh_prev_lane_word(w[15], edge[1], text, a - 4u);
+    if constexpr (KIND == 1) {
+        /* rolling code * 2 (16-bit entries) of the last eight symbols; primed with the eight in front */
+        uint32_t code2 = 0;
+        {
+            const uint32_t x0 = (pre0 << 10) | pre0, x1 = (pre1 << 10) | pre1;
+            code2 = (code2 << 4) | smh_bfe(x0, 7, 5);
+            code2 = (code2 << 4) | smh_bfe(x0, 23, 5);
+            code2 = (code2 << 4) | smh_bfe(x1, 7, 5);
+            code2 = (code2 << 4) | smh_bfe(x1, 23, 5);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = (w[q] << 10) | w[q]; /* pair codes * 2 at bits 7..11 and 23..27 (ac_lane.h smh_fmt_s2) */
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                code2 = (code2 << 4) | smh_bfe(x, k == 0 ? 7 : 23, 5);
+                const uint32_t e = smh_lds_u16(tab, code2 & 0x1FFFEu);
+                T = smh_gram_step(T, e);      /* column a + 4q + 2k     : low byte  */
+                T = smh_gram_step(T, e >> 8); /* column a + 4q + 2k + 1 : high byte */
+            }
+            if (q == 5) fl[0] = smh_gram_flags(T, 24);
+            if (q == 11) fl[1] = smh_gram_flags(T, 24);
+            if (q == 15) fl[2] = smh_gram_flags(T, 16);
+        }
+    } else if constexpr (KIND == 3) {
+        /* 8-symbol grams, one lookup per column: the rolling code takes a pair of symbols per update; the column
+         * of the pair's first symbol is indexed by the code without its newest symbol */
+        uint32_t code = 0;
+        {
+            const uint32_t x0 = (pre0 << 10) | pre0, x1 = (pre1 << 10) | pre1;
+            code = (code << 4) | smh_bfe(x0, 8, 4);
+            code = (code << 4) | smh_bfe(x0, 24, 4);
+            code = (code << 4) | smh_bfe(x1, 8, 4);
+            code = (code << 4) | smh_bfe(x1, 24, 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = (w[q] << 10) | w[q];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                code = (code << 4) | smh_bfe(x, k == 0 ? 8 : 24, 4);
+                const uint32_t e0 = smh_lds_u8(tab, smh_bfe(code, 2, 16)), e1 = smh_lds_u8(tab, code & 0xFFFFu);
+                T = smh_gram_step(T, e0);
+                T = smh_gram_step(T, e1);
+            }
+            if (q == 5) fl[0] = smh_gram_flags(T, 24);
+            if (q == 11) fl[1] = smh_gram_flags(T, 24);
+            if (q == 15) fl[2] = smh_gram_flags(T, 16);
+        }
+    } else {
+        (void)pre0;
+        smh_gram_byte_columns(w, pre1, tab, T, fl, std::make_integer_sequence<int, 64>{});
+    }
+    /* correct the first seven columns with the state the previous lane ended in */
+    uint32_t prevT;
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    prevT = (uint32_t)__builtin_amdgcn_update_dpp((int)0x7F, (int)T, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#else
+    prevT = smh_gram_state_before<KIND>(text, a, tab);
+#endif
+    const uint32_t fix7 = smh_bitrev32(prevT & 0x7Fu) >> 25; /* bit t = bit 6-t of the inherited state */
+    uint64_t msk = (uint64_t)((fl[0] & (fix7 | ~0x7Fu)) | (fl[1] << 24)) | ((uint64_t)(fl[1] >> 8) << 32) | ((uint64_t)fl[2] << 48);
+    while (SMH_WAVE_ANY(msk != 0)) {
+        if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
+        const bool have = msk != 0;
+        const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
+        smh_wm_emit(Q, text, P, have, a + b);
+        msk &= msk - 1u;
+    }
+}
+
+/* bounds-checked path for the text's first and last chunks: the same recurrence column by column from memory,
+ * with the true inherited state; candidates are verified on the spot */
+template <int KIND>
+SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const void *tab, const smh_wm_params &P,
+                                        uint64_t *match_mask = nullptr)
+{
+    if (match_mask) *match_mask = 0;
+    if (a >= n) return 0;
+    uint64_t end = a + SMH_SEG;
+    if (end > n) end = n;
+    const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
+    uint32_t T = smh_gram_state_before<KIND>(text, a, tab), cnt = 0;
+    for (uint64_t e = a; e < end; ++e) {
+        uint32_t F = 0xFFu; /* a column without a whole gram in front of it cannot be ruled out */
+        if (e + 1 >= q) {
+            if (KIND == 3) {
+                uint32_t code = 0;
+                for (int i = 7; i >= 0; --i) code = (code << 2) | (text[e - (uint64_t)i] & 3u);
+                F = smh_lds_u8(tab, code);
+            } else if (KIND == 1) {
+                uint32_t code = 0;
+                for (int i = 6; i >= 0; --i) code = (code << 2) | (text[e - (uint64_t)i] & 3u);
+                F = smh_lds_u16(tab, (code << 2) << 1) & 0xFFu;
+            } else {
+                const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
+                F = smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15);
+            }
+        }
+        T = smh_gram_step(T, F);
+        if (((T >> 7) & 1u) && e + 1 >= (uint64_t)P.m) {
+            const uint32_t hit = smh_wm_verify(text, e, P);
+            cnt += hit;
+            if (match_mask && hit) *match_mask |= 1ull << (e - a);
+        }
+    }
+    return cnt;
+}
+
+template <int KIND, bool POS = false>
+SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n,
+                                     const void *tab, const smh_wm_params &P, uint64_t *queue_base, const smh_pos_out *po = nullptr,
+                                     uint32_t smh_gram_drain_at = 64u)
+{
+    if (n < (uint64_t)P.m) return 0;
+    const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
+    const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
+    const uint32_t lane = (uint32_t)(gthread & 63u);
+    smh_wm_queue Q;
+    Q.slots = queue_base;
+    Q.count = 0;
+    Q.matches = 0;
+    Q.po = POS ? po : nullptr;
+    uint32_t cnt = 0;
+    uint32_t cur[16], nxt[16], cur_edge[2], nxt_edge[2];
+    uint64_t k = S.take(n_chunks);
+    /* the fast path needs eight bytes in front of the chunk and, for the columns to have full windows, m - 1 of
+     * them: chunk 0 is excluded (m - 1 <= 4095 is checked by the launcher); the last chunk only when partial */
+    auto is_fast = [&](uint64_t kk) { return kk >= 1 && kk < n_chunks && (kk + 1) * chunk_bytes <= n; };
+    auto load = [&](uint64_t kk, uint32_t (&w)[16], uint32_t (&edge)[2]) {
+        const uint64_t base = smh_uniform64(kk * chunk_bytes);
+        const uint8_t *p = text + base + (uint64_t)lane * SMH_SEG;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const smh_u32x4 t = smh_load16(p + 16u * q);
+            w[4 * q + 0] = t.v[0];
+            w[4 * q + 1] = t.v[1];
+            w[4 * q + 2] = t.v[2];
+            w[4 * q + 3] = t.v[3];
+        }
+        const smh_u32x4 t = smh_load16(text + base - 16u);
+        edge[0] = t.v[2];
+        edge[1] = t.v[3];
+    };
+    bool cur_fast = is_fast(k);
+    if (cur_fast) load(k, cur, cur_edge);
+    while (k < n_chunks) {
+        const uint64_t kn = S.take(n_chunks);
+        const bool nxt_fast = is_fast(kn);
+        /* the verify stage runs HERE, between chunks and before the next chunk's text is requested: its loads
+         * return in order behind everything the wave has in flight, so a drain entered while a prefetch is
+         * outstanding also waits for that prefetch (measured: 2-3 x the cost per surviving column) */
+        if (Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
+        if (nxt_fast) load(kn, nxt, nxt_edge);
+        const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
+        if (cur_fast) {
+            smh_wm_gram_lane_fast<KIND, POS>(text, a, cur, cur_edge, tab, P, Q);
+        } else if (POS) {
+            uint64_t mm;
+            smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P, &mm);
+            cnt += smh_append_bits(mm, a, *po);
+        } else {
+            cnt += smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P);
+        }
+        if (nxt_fast) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
+            cur_edge[0] = nxt_edge[0];
+            cur_edge[1] = nxt_edge[1];
+        }
+        cur_fast = nxt_fast;
+        k = kn;
+    }
+    smh_wm_drain(Q, text, P);
+    return cnt + Q.matches;
 }
 
 /* ------------------------------------------------------------------ match positions

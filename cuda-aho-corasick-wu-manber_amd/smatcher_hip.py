@@ -49,7 +49,7 @@ class WmInfo(C.Structure):
                 ("block_symbols", C.c_uint32), ("filter_log2", C.c_uint32),
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("gram_planes", C.c_uint32)]
 
 
 class PsetInfo(C.Structure):

@@ -195,6 +195,35 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     return total;
 }
 
+/* gram filter (q-gram shift-and): same lane code, true inherited states instead of the DPP correction */
+static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po)
+{
+    smh_wm_params P = {};
+    P.m = wm->m;
+    P.bits = wm->bits_per_symbol;
+    P.verify_log2 = wm->verify_log2;
+    P.verify = wm->verify;
+    const size_t row = (size_t)((wm->m + 3) / 4) * 4;
+    std::vector<uint8_t> padded((size_t)wm->distinct * row + 16, 0);
+    for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);
+    P.pat_sorted = padded.data();
+    const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
+    uint64_t total = 0;
+    for (uint64_t t = 0; t < nthreads; ++t) {
+        const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
+        if (wm->gram_kind == SMH_GRAM_PAIR)
+            total += po ? smh_wm_gram_thread<1, true>(t, S, text, n, wm->gram_table, P, nullptr, po)
+                        : smh_wm_gram_thread<1, false>(t, S, text, n, wm->gram_table, P, nullptr, po);
+        else if (wm->gram_kind == SMH_GRAM_OCT)
+            total += po ? smh_wm_gram_thread<3, true>(t, S, text, n, wm->gram_table, P, nullptr, po)
+                        : smh_wm_gram_thread<3, false>(t, S, text, n, wm->gram_table, P, nullptr, po);
+        else
+            total += po ? smh_wm_gram_thread<2, true>(t, S, text, n, wm->gram_table, P, nullptr, po)
+                        : smh_wm_gram_thread<2, false>(t, S, text, n, wm->gram_table, P, nullptr, po);
+    }
+    return total;
+}
+
 template <bool HASHED, bool EXACT, bool POS = false>
 static uint64_t wm_halo(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po = nullptr)
 {
@@ -237,6 +266,8 @@ extern "C" uint64_t emu_wm_scan(const smh_wm *wm, const uint8_t *text_in, uint64
             const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
             for (uint64_t t = 0; t < nthreads; ++t)
                 total += smh_wm_pair_thread<true>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->m, wm->pair_table, wm->filter);
+        } else if (wm->gram_kind != SMH_GRAM_NONE) {
+            total = wm_gram_grid(wm, text, n, blocks, nullptr);
         } else if (wm->filter_hashed) {
             total = wm_halo<true, false>(wm, text, n, blocks);
         } else if (wm->filter_exact) {
@@ -350,6 +381,8 @@ extern "C" uint64_t emu_wm_positions_tuned(const smh_wm *wm, const uint8_t *text
         const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
         for (uint64_t t = 0; t < nthreads; ++t)
             smh_wm_pair_thread<false, true>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->m, wm->pair_table, wm->filter, &po);
+    } else if (wm->gram_kind != SMH_GRAM_NONE) {
+        wm_gram_grid(wm, text, n, blocks, &po);
     } else if (wm->filter_hashed) {
         wm_halo<true, false, true>(wm, text, n, blocks, &po);
     } else if (wm->filter_exact) {
