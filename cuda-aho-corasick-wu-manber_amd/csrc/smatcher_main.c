@@ -423,6 +423,37 @@ int main(int argc, char **argv)
         }
     }
 
+    /* The same R byte ranges once more, this time the way the reference's MPI job runs them: all at once, one
+     * device per rank, text shards resident, ONE all-reduce of the 64-bit counts (main.c:464-489, 654-657 with
+     * RCCL for MPI).  Needs R devices; with fewer the ranks above have run one after the other. */
+    if (devices >= ranks && (run_ac || run_wm)) {
+        smh_multi *mg = NULL;
+        if (smh_multi_create(&mg, NULL, ranks, 0) != SMH_OK || smh_multi_load_text(mg, textFull, (uint64_t)nFull, m - 1) != SMH_OK) {
+            fprintf(stderr, "multi-device run: %s\n", smh_last_error());
+            exit(1);
+        }
+        uint64_t total = 0, per[SMH_MULTI_MAX_DEVICES];
+        double secs = 0;
+        if (run_ac) {
+            smh_ac *h = smh_ac_compile_patterns(pattern2, m, p_size, alphabet);
+            if (!h || smh_multi_ac_count(mg, h, &total, per, &secs) != SMH_OK) { fprintf(stderr, "multi-device ac: %s\n", smh_last_error()); exit(1); }
+            printf("multi-device ac (%d devices, %s) matches \t%llu\t time \t%f\n", ranks, smh_multi_uses_rccl(mg) ? "RCCL all-reduce" : "host sum",
+                   (unsigned long long)total, secs);
+            if ((long long)total != ac_sum) { fprintf(stderr, "multi-device ac counted %llu, the ranks one by one %lld\n", (unsigned long long)total, ac_sum); exit(1); }
+            smh_ac_free(h);
+        }
+        if (run_wm) {
+            smh_wm *h = smh_wm_compile(pattern2, m, p_size, alphabet);
+            if (!h || smh_multi_wm_count(mg, h, &total, per, &secs) != SMH_OK) { fprintf(stderr, "multi-device wm: %s\n", smh_last_error()); exit(1); }
+            printf("multi-device wm (%d devices, %s) matches \t%llu\t time \t%f\n", ranks, smh_multi_uses_rccl(mg) ? "RCCL all-reduce" : "host sum",
+                   (unsigned long long)total, secs);
+            if ((long long)total != wm_sum) { fprintf(stderr, "multi-device wm counted %llu, the ranks one by one %lld\n", (unsigned long long)total, wm_sum); exit(1); }
+            smh_wm_free(h);
+        }
+        smh_multi_free(mg);
+        fflush(stdout);
+    }
+
     /* main.c:662-670 */
     if (run_ac) printf("Total results (ac): %lld.\n", ac_sum);
     if (run_sh) printf("Total results (sh): %lld.\n", sh_sum);

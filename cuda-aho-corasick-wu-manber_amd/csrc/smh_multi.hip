@@ -1,0 +1,357 @@
+/*
+ * csrc/smh_multi.hip -- one process, all GPUs of a node: the reference driver's MPI layer for this path,
+ * natively.
+ *
+ * The reference spreads a text over ranks with MPI_Scatterv, every rank scans its byte range plus an m-1
+ * halo, and one MPI_Reduce(MPI_INT, MPI_SUM) adds the counts (main.c:464-489, 654-657).  Here ONE host
+ * process owns every device: per device a stream, a resident text shard (the main.c:467-477 ranges with the
+ * true length of the last one) and a 64-bit counter; a scan call launches the tuned kernel on every device
+ * (asynchronously, so the devices run side by side) and the counts meet in ONE ncclAllReduce(ncclUint64,
+ * ncclSum) over an RCCL communicator created with ncclCommInitAll -- 8 bytes over xGMI, the only exchange.
+ * Handles keep one table set per device (smh_runtime.hip), so the same compiled automaton serves all shards.
+ *
+ * RCCL is bound at run time (dlopen of librccl.so.1: the library a PyTorch process has already loaded, or
+ * ROCm's), so that single-GPU users of libsmatcher_hip.so do not load it.  Without it smh_multi_create fails
+ * unless the caller allows the host-side sum (flag SMH_MULTI_HOST_SUM), which is what the CPU-only build
+ * check uses.
+ */
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+#include <mutex>
+#include <vector>
+#include "smh_internal.h"
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            smh_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return SMH_ENODEV;                                                            \
+        }                                                                                 \
+    } while (0)
+
+/* the five RCCL entry points this file uses */
+struct smh_rccl_api {
+    void *lib;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
+    ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    ncclResult_t (*GroupStart)(void);
+    ncclResult_t (*GroupEnd)(void);
+    const char *(*GetErrorString)(ncclResult_t);
+};
+static smh_rccl_api g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load(void)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.lib) return SMH_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *lib = NULL;
+    for (size_t i = 0; i < sizeof names / sizeof names[0] && !lib; ++i) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        smh_set_error("smh_multi: RCCL not found (%s)", dlerror());
+        return SMH_ENODEV;
+    }
+    smh_rccl_api a = {};
+    a.lib = lib;
+    a.CommInitAll = (decltype(a.CommInitAll))dlsym(lib, "ncclCommInitAll");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(lib, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(lib, "ncclGroupEnd");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!a.CommInitAll || !a.CommDestroy || !a.AllReduce || !a.GroupStart || !a.GroupEnd || !a.GetErrorString) {
+        smh_set_error("smh_multi: librccl lacks an expected symbol");
+        dlclose(lib);
+        return SMH_ENODEV;
+    }
+    g_rccl = a;
+    return SMH_OK;
+}
+
+#define NCCL_TRY(expr)                                                                        \
+    do {                                                                                      \
+        ncclResult_t r_ = (expr);                                                             \
+        if (r_ != ncclSuccess) {                                                              \
+            smh_set_error("%s: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+            return SMH_ENODEV;                                                                \
+        }                                                                                     \
+    } while (0)
+
+struct smh_multi_dev {
+    int device;
+    hipStream_t stream;
+    unsigned char *d_text; /* this device's byte range + halo, 16-byte aligned, 64 readable bytes of slack */
+    uint64_t begin;        /* first byte of the range in the whole text */
+    uint64_t bytes;        /* bytes resident: range + min(halo, what follows it) */
+    uint64_t *d_count;     /* [0] this device's count, [1] the all-reduced sum */
+    ncclComm_t comm;
+};
+
+struct smh_multi {
+    uint32_t magic;
+    int n;
+    int rccl;
+    uint64_t n_total; /* length of the whole text */
+    uint64_t per;     /* ceil(n_total / n): main.c:375-378 */
+    int halo;         /* bytes kept beyond every range: scans with m - 1 <= halo are possible */
+    std::vector<smh_multi_dev> dev;
+};
+#define SMH_MAGIC_MULTI 0x4d554c54u /* "MULT" */
+
+static int check(const smh_multi *mg, const char *who)
+{
+    if (!mg || mg->magic != SMH_MAGIC_MULTI) {
+        smh_set_error("%s: bad handle", who);
+        return SMH_EINVAL;
+    }
+    return SMH_OK;
+}
+
+extern "C" void smh_multi_free(smh_multi *mg)
+{
+    if (!mg || mg->magic != SMH_MAGIC_MULTI) return;
+    for (auto &d : mg->dev) {
+        if (hipSetDevice(d.device) != hipSuccess) continue;
+        if (d.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d.comm);
+        (void)hipFree(d.d_text);
+        (void)hipFree(d.d_count);
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+    }
+    mg->magic = 0;
+    delete mg;
+}
+
+extern "C" int smh_multi_create(smh_multi **out, const int *devices, int n_devices, int flags)
+{
+    if (!out || n_devices < 1 || n_devices > SMH_MULTI_MAX_DEVICES) {
+        smh_set_error("smh_multi_create: bad arguments");
+        return SMH_EINVAL;
+    }
+    *out = NULL;
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess) visible = 0;
+    std::vector<int> ids(n_devices);
+    for (int i = 0; i < n_devices; ++i) {
+        ids[i] = devices ? devices[i] : i;
+        if (ids[i] < 0 || ids[i] >= visible) {
+            smh_set_error("smh_multi_create: device %d of %d asked for, %d visible", ids[i], n_devices, visible);
+            return SMH_ENODEV;
+        }
+        for (int j = 0; j < i; ++j)
+            if (ids[j] == ids[i]) {
+                smh_set_error("smh_multi_create: device %d listed twice (an RCCL communicator takes a device once)", ids[i]);
+                return SMH_EINVAL;
+            }
+    }
+    int rccl = 1;
+    if (rccl_load() != SMH_OK) {
+        if (!(flags & SMH_MULTI_HOST_SUM)) return SMH_ENODEV;
+        rccl = 0;
+    }
+    if (flags & SMH_MULTI_NO_RCCL) rccl = 0;
+    smh_multi *mg = new smh_multi();
+    mg->magic = SMH_MAGIC_MULTI;
+    mg->n = n_devices;
+    mg->rccl = rccl;
+    mg->n_total = 0;
+    mg->per = 0;
+    mg->halo = 0;
+    mg->dev.resize(n_devices);
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    for (int i = 0; i < n_devices; ++i) {
+        smh_multi_dev &d = mg->dev[i];
+        d = smh_multi_dev{};
+        d.device = ids[i];
+        hipError_t e = hipSetDevice(d.device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&d.d_count, 64);
+        if (e == hipSuccess) e = hipMemset(d.d_count, 0, 64);
+        if (e != hipSuccess) {
+            smh_set_error("smh_multi_create: device %d: %s", d.device, hipGetErrorString(e));
+            smh_multi_free(mg);
+            (void)hipSetDevice(prev);
+            return SMH_ENODEV;
+        }
+    }
+    if (rccl) {
+        std::vector<ncclComm_t> comms(n_devices);
+        const ncclResult_t r = g_rccl.CommInitAll(comms.data(), n_devices, ids.data());
+        if (r != ncclSuccess) {
+            smh_set_error("ncclCommInitAll(%d devices): %s", n_devices, g_rccl.GetErrorString(r));
+            smh_multi_free(mg);
+            (void)hipSetDevice(prev);
+            return SMH_ENODEV;
+        }
+        for (int i = 0; i < n_devices; ++i) mg->dev[i].comm = comms[i];
+    }
+    (void)hipSetDevice(prev);
+    *out = mg;
+    return SMH_OK;
+}
+
+extern "C" int smh_multi_device_count(const smh_multi *mg) { return mg && mg->magic == SMH_MAGIC_MULTI ? mg->n : 0; }
+extern "C" int smh_multi_uses_rccl(const smh_multi *mg) { return mg && mg->magic == SMH_MAGIC_MULTI ? mg->rccl : 0; }
+
+/* (re)allocate every device's shard for a text of n_total bytes; ranges as main.c:467-477 */
+static int place(smh_multi *mg, uint64_t n_total, int halo)
+{
+    if (halo < 0) halo = 0;
+    mg->n_total = n_total;
+    mg->per = (n_total + (uint64_t)mg->n - 1) / (uint64_t)mg->n;
+    mg->halo = halo;
+    for (int i = 0; i < mg->n; ++i) {
+        smh_multi_dev &d = mg->dev[i];
+        HIP_TRY(hipSetDevice(d.device));
+        (void)hipFree(d.d_text);
+        d.d_text = NULL;
+        d.begin = (uint64_t)i * mg->per;
+        if (d.begin > n_total) d.begin = n_total;
+        uint64_t end = d.begin + mg->per + (uint64_t)halo;
+        if (end > n_total) end = n_total;
+        d.bytes = end - d.begin;
+        HIP_TRY(hipMalloc((void **)&d.d_text, ((d.bytes + 15) / 16) * 16 + 64));
+    }
+    return SMH_OK;
+}
+
+extern "C" int smh_multi_load_text(smh_multi *mg, const unsigned char *text, uint64_t n, int halo)
+{
+    int rc = check(mg, "smh_multi_load_text");
+    if (rc != SMH_OK) return rc;
+    if (n && !text) { smh_set_error("smh_multi_load_text: NULL text"); return SMH_EINVAL; }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    rc = place(mg, n, halo);
+    for (int i = 0; rc == SMH_OK && i < mg->n; ++i) {
+        smh_multi_dev &d = mg->dev[i];
+        if (hipSetDevice(d.device) != hipSuccess ||
+            (d.bytes && hipMemcpyAsync(d.d_text, text + d.begin, d.bytes, hipMemcpyHostToDevice, d.stream) != hipSuccess)) {
+            smh_set_error("smh_multi_load_text: copy to device %d failed", d.device);
+            rc = SMH_ENODEV;
+        }
+    }
+    for (int i = 0; i < mg->n; ++i)
+        if (hipSetDevice(mg->dev[i].device) == hipSuccess) (void)hipStreamSynchronize(mg->dev[i].stream);
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int smh_multi_generate_text(smh_multi *mg, uint64_t n_total, uint64_t seed, int alphabet, int halo)
+{
+    int rc = check(mg, "smh_multi_generate_text");
+    if (rc != SMH_OK) return rc;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    rc = place(mg, n_total, halo);
+    for (int i = 0; rc == SMH_OK && i < mg->n; ++i) {
+        smh_multi_dev &d = mg->dev[i];
+        if (hipSetDevice(d.device) != hipSuccess) { smh_set_error("smh_multi_generate_text: hipSetDevice"); rc = SMH_ENODEV; break; }
+        /* every shard is generated where it will be scanned: nothing crosses PCIe or xGMI */
+        rc = smh_corpus_text_device(d.d_text, d.bytes, d.begin, seed, alphabet, d.stream);
+    }
+    for (int i = 0; i < mg->n; ++i)
+        if (hipSetDevice(mg->dev[i].device) == hipSuccess) (void)hipStreamSynchronize(mg->dev[i].stream);
+    (void)hipSetDevice(prev);
+    return rc;
+}
+
+/* launch `scan(device text, shard length, device counter, stream)` on every device, reduce, read back */
+template <typename Scan>
+static int count_all(smh_multi *mg, int m, uint64_t *total, uint64_t *per_device, double *seconds, Scan scan)
+{
+    if (!total) { smh_set_error("smh_multi: NULL result"); return SMH_EINVAL; }
+    if (m - 1 > mg->halo) {
+        smh_set_error("smh_multi: pattern length %d needs a halo of %d bytes, the text was placed with %d", m, m - 1, mg->halo);
+        return SMH_EINVAL;
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = SMH_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; rc == SMH_OK && i < mg->n; ++i) {
+        smh_multi_dev &d = mg->dev[i];
+        /* shard i scans [begin, min(begin + per + m - 1, n)): the true length, where the reference passes the
+         * padded one (main.c:376,630) */
+        uint64_t len = mg->per + (uint64_t)(m - 1);
+        if (d.begin + len > mg->n_total) len = mg->n_total - d.begin;
+        if (hipSetDevice(d.device) != hipSuccess || hipMemsetAsync(d.d_count, 0, 16, d.stream) != hipSuccess) {
+            smh_set_error("smh_multi: device %d: hipSetDevice / memset failed", d.device);
+            rc = SMH_ENODEV;
+            break;
+        }
+        rc = scan(d.d_text, len, d.d_count, (void *)d.stream); /* asynchronous: the devices scan side by side */
+    }
+    if (rc == SMH_OK && mg->rccl) {
+        /* the MPI_Reduce of main.c:656 as one RCCL all-reduce of a 64-bit count per device */
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int i = 0; r == ncclSuccess && i < mg->n; ++i) {
+            smh_multi_dev &d = mg->dev[i];
+            r = g_rccl.AllReduce(d.d_count, d.d_count + 1, 1, ncclUint64, ncclSum, d.comm, d.stream);
+        }
+        const ncclResult_t re = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = re;
+        if (r != ncclSuccess) {
+            smh_set_error("ncclAllReduce: %s", g_rccl.GetErrorString(r));
+            rc = SMH_ENODEV;
+        }
+    }
+    uint64_t host[SMH_MULTI_MAX_DEVICES][2];
+    memset(host, 0, sizeof host);
+    for (int i = 0; i < mg->n; ++i) {
+        smh_multi_dev &d = mg->dev[i];
+        if (hipSetDevice(d.device) != hipSuccess) { rc = rc == SMH_OK ? SMH_ENODEV : rc; continue; }
+        if (hipMemcpyAsync(host[i], d.d_count, 16, hipMemcpyDeviceToHost, d.stream) != hipSuccess ||
+            hipStreamSynchronize(d.stream) != hipSuccess) {
+            if (rc == SMH_OK) { smh_set_error("smh_multi: device %d: %s", d.device, hipGetErrorString(hipGetLastError())); rc = SMH_ENODEV; }
+        }
+    }
+    if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    (void)hipSetDevice(prev);
+    if (rc != SMH_OK) return rc;
+    uint64_t sum = 0;
+    for (int i = 0; i < mg->n; ++i) {
+        sum += host[i][0];
+        if (per_device) per_device[i] = host[i][0];
+    }
+    if (mg->rccl) {
+        for (int i = 0; i < mg->n; ++i)
+            if (host[i][1] != sum) { /* every rank holds the reduced total, and it is the sum of the shard counts */
+                smh_set_error("smh_multi: device %d holds %llu after the all-reduce, the shard counts add up to %llu",
+                              mg->dev[i].device, (unsigned long long)host[i][1], (unsigned long long)sum);
+                return SMH_ENODEV;
+            }
+    }
+    *total = sum;
+    return SMH_OK;
+}
+
+extern "C" int smh_multi_ac_count(smh_multi *mg, smh_ac *ac, uint64_t *total, uint64_t *per_device, double *seconds)
+{
+    int rc = check(mg, "smh_multi_ac_count");
+    if (rc != SMH_OK) return rc;
+    smh_ac_info info;
+    if ((rc = smh_ac_get_info(ac, &info)) != SMH_OK) return rc;
+    return count_all(mg, (int)info.m, total, per_device, seconds, [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
+        return smh_ac_scan(ac, t, len, c, SMH_VARIANT_TUNED, s);
+    });
+}
+
+extern "C" int smh_multi_wm_count(smh_multi *mg, smh_wm *wm, uint64_t *total, uint64_t *per_device, double *seconds)
+{
+    int rc = check(mg, "smh_multi_wm_count");
+    if (rc != SMH_OK) return rc;
+    smh_wm_info info;
+    if ((rc = smh_wm_get_info(wm, &info)) != SMH_OK) return rc;
+    return count_all(mg, (int)info.m, total, per_device, seconds, [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
+        return smh_wm_scan(wm, t, len, c, SMH_VARIANT_TUNED, s);
+    });
+}

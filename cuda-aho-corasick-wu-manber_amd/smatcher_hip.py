@@ -96,7 +96,9 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
                "smh_pset_free", "smh_sh_compile_tables", "smh_sh_compile_patterns", "smh_sh_get_info",
                "smh_sh_valid_bmbc", "smh_sh_scan", "smh_sh_count_host", "smh_sh_free", "smh_sbom_compile_tables",
-               "smh_sbom_compile_patterns", "smh_sbom_get_info", "smh_sbom_scan", "smh_sbom_count_host", "smh_sbom_free"]
+               "smh_sbom_compile_patterns", "smh_sbom_get_info", "smh_sbom_scan", "smh_sbom_count_host", "smh_sbom_free",
+               "smh_multi_create", "smh_multi_device_count", "smh_multi_uses_rccl", "smh_multi_load_text",
+               "smh_multi_generate_text", "smh_multi_ac_count", "smh_multi_wm_count", "smh_multi_free"]
 
 
 def _load():
@@ -222,6 +224,15 @@ def _load():
         g = getattr(lib, "cuda_wm%d" % k)
         g.restype = C.c_int
         g.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int] + tabs + [dblp]
+    lib.smh_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.smh_multi_device_count.argtypes = [C.c_void_p]
+    lib.smh_multi_uses_rccl.argtypes = [C.c_void_p]
+    lib.smh_multi_load_text.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int]
+    lib.smh_multi_generate_text.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    lib.smh_multi_ac_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), dblp]
+    lib.smh_multi_wm_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), dblp]
+    lib.smh_multi_free.restype = None
+    lib.smh_multi_free.argtypes = [C.c_void_p]
     return lib
 
 
@@ -424,6 +435,57 @@ class PatternSet:
         if self.h:
             lib.smh_pset_free(self.h)
             self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+MULTI_HOST_SUM, MULTI_NO_RCCL = 1, 2
+
+
+class MultiGpu:
+    """smh_multi_*: one process, several GPUs -- byte-range shards resident per device, counts added with one RCCL
+    all-reduce (the reference driver's MPI_Scatterv / MPI_Reduce, main.c:464-489, 654-657)."""
+
+    def __init__(self, n_devices, devices=None, flags=0):
+        self.h = C.c_void_p()
+        arr = (C.c_int * n_devices)(*devices) if devices is not None else None
+        _check(lib.smh_multi_create(C.byref(self.h), arr, n_devices, flags), "smh_multi_create")
+
+    @property
+    def devices(self):
+        return int(lib.smh_multi_device_count(self.h))
+
+    @property
+    def uses_rccl(self):
+        return bool(lib.smh_multi_uses_rccl(self.h))
+
+    def load_text(self, text, halo):
+        a, p = _u8(text)
+        _check(lib.smh_multi_load_text(self.h, p, len(a), halo), "smh_multi_load_text")
+
+    def generate_text(self, n_total, seed, alphabet, halo):
+        _check(lib.smh_multi_generate_text(self.h, n_total, seed, alphabet, halo), "smh_multi_generate_text")
+
+    def _count(self, fn, handle, what):
+        total, secs = C.c_uint64(), C.c_double()
+        per = (C.c_uint64 * self.devices)()
+        _check(fn(self.h, handle.h, C.byref(total), per, C.byref(secs)), what)
+        return int(total.value), [int(x) for x in per], secs.value
+
+    def ac_count(self, ac):
+        return self._count(lib.smh_multi_ac_count, ac, "smh_multi_ac_count")
+
+    def wm_count(self, wm):
+        return self._count(lib.smh_multi_wm_count, wm, "smh_multi_wm_count")
+
+    def close(self):
+        if self.h:
+            lib.smh_multi_free(self.h)
+            self.h = C.c_void_p()
 
     def __del__(self):
         try:

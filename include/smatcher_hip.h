@@ -176,6 +176,30 @@ int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int var
                       uint64_t *count, double *kernel_seconds);
 void smh_wm_free(smh_wm *wm);
 
+/* ---- one process, several GPUs: the reference driver's MPI layer for this path (main.c:464-489, 654-657) ----
+ * The text is split into byte ranges, one per device, each with `halo` bytes of the next range behind it
+ * (main.c:467-477; every scan uses the TRUE length of its range); a count call launches the tuned kernel on
+ * every device side by side and adds the 64-bit counts with ONE ncclAllReduce(ncclUint64, ncclSum) over an
+ * RCCL communicator of the devices (ncclCommInitAll) -- the MPI_Reduce of main.c:656 over xGMI.  Handles are
+ * shared: a compiled automaton keeps one table set per device.  Call from one host thread. */
+typedef struct smh_multi smh_multi;
+#define SMH_MULTI_MAX_DEVICES 16
+#define SMH_MULTI_HOST_SUM 1 /* smh_multi_create: when RCCL cannot be loaded, add the counts on the host instead of failing */
+#define SMH_MULTI_NO_RCCL 2  /* never create a communicator (host sum); for comparison runs */
+/* devices == NULL: devices 0 .. n_devices-1 */
+int smh_multi_create(smh_multi **out, const int *devices, int n_devices, int flags);
+int smh_multi_device_count(const smh_multi *mg);
+int smh_multi_uses_rccl(const smh_multi *mg);
+/* place a text: copied from the host, or the synthetic corpus generated range by range on its own device;
+ * later scans need pattern length - 1 <= halo */
+int smh_multi_load_text(smh_multi *mg, const unsigned char *text, uint64_t n, int halo);
+int smh_multi_generate_text(smh_multi *mg, uint64_t n_total, uint64_t seed, int alphabet, int halo);
+/* *total = the all-reduced count (checked against the sum of the per-device counts), per_device[i] (optional,
+ * smh_multi_device_count entries) = device i's own count, *seconds (optional) = wall time of launches + reduce */
+int smh_multi_ac_count(smh_multi *mg, smh_ac *ac, uint64_t *total, uint64_t *per_device, double *seconds);
+int smh_multi_wm_count(smh_multi *mg, smh_wm *wm, uint64_t *total, uint64_t *per_device, double *seconds);
+void smh_multi_free(smh_multi *mg);
+
 /* ---- Set-Horspool (sh/sh.c, cuda/cuda_sh.cu) ----
  * The reversed trie of the patterns plus a bad-character table.  SMH_VARIANT_TABLE walks the
  * reference-layout trie as given with the caller's bmBc driving a per-lane skip loop;
