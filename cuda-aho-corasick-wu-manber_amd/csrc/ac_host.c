@@ -405,9 +405,9 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
             if (!ac->g_transition || !ac->g_supply || !ac->g_final) goto oom;
             memcpy(ac->g_transition, trans, keep * A * sizeof(int32_t));
         } else {
-            /* shrinking in place; a failed shrink leaves the original block valid */
-            void *t = realloc((void *)trans, keep * A * sizeof(int32_t));
-            ac->g_transition = (int32_t *)(t ? t : (void *)trans);
+            /* patched in place; the block is shrunk to the ids in use only once the compile can no longer
+             * fail (below), so that on every failure path the caller still owns exactly what it passed in */
+            ac->g_transition = (int32_t *)trans;
             ac->g_supply = (uint32_t *)supply;
             ac->g_final = (uint32_t *)final;
         }
@@ -440,6 +440,11 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
             free(pats);
         }
         --smh_alt_engine_depth;
+    }
+    if (ref_mode == SMH_AC_REF_ADOPT && ac->g_transition) {
+        /* nothing can fail any more: ownership has passed, shrink the adopted block (a failed shrink leaves it valid) */
+        void *t = realloc(ac->g_transition, (size_t)ac->states * (size_t)alphabet * sizeof(int32_t));
+        if (t) ac->g_transition = (int32_t *)t;
     }
     return ac;
 
@@ -738,16 +743,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
     }
     const int K = best_k[best_s];
     const uint32_t rk = K >= ac->m ? ac->rows : ac->depth_first[K + 1];
-    if (ac->trunc1_table != ac->scan_table) free(ac->trunc1_table);
-    free(ac->scan_table);
-    ac->scan_table = ac->trunc1_table = NULL;
-    ac->scan_depth = K;
-    ac->scan_stride = best_s == 3 ? 2 : best_s;
-    ac->scan_full_rows = hyb_nf;
-    ac->scan_exact = K >= ac->m;
-    ac->scan_rows = rk;
-    ac->scan_candidate_rate = candidate_rate(ac, K);
-    ac->scan_cost = best_cost;
+    /* the new tables are built first and installed together: a failure leaves the handle's current plan intact */
     /* stride-1 depth-K table */
     const int eb1 = rk <= 32768 ? 2 : 4;
     const size_t n1 = (size_t)rk * A;
@@ -760,6 +756,29 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
             if (eb1 == 2) ((uint16_t *)t1)[(size_t)r * A + c] = (uint16_t)(t | (flag ? 0x8000u : 0u));
             else ((uint32_t *)t1)[(size_t)r * A + c] = t | (flag ? 0x80000000u : 0u);
         }
+    uint16_t *t2 = NULL;
+    if (best_s == 2) {
+        const size_t n2 = (size_t)rk * 16;
+        t2 = (uint16_t *)calloc(n2 * 2 + 16, 1);
+        if (!t2) { free(t1); smh_set_error("smh_ac_plan_scan: out of memory"); return SMH_ENOMEM; }
+        for (uint32_t r = 0; r < rk; ++r)
+            for (int c1 = 0; c1 < 4; ++c1)
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    int f1, f2;
+                    uint32_t r1 = trunc_step(ac, K, r, c1, &f1);
+                    uint32_t r2 = trunc_step(ac, K, r1, c2, &f2);
+                    t2[(size_t)r * 16 + c1 * 4 + c2] = (uint16_t)(r2 | (f1 ? 0x4000u : 0u) | (f2 ? 0x8000u : 0u));
+                }
+    }
+    if (ac->trunc1_table != ac->scan_table) free(ac->trunc1_table);
+    free(ac->scan_table);
+    ac->scan_depth = K;
+    ac->scan_stride = best_s == 3 ? 2 : best_s;
+    ac->scan_full_rows = hyb_nf;
+    ac->scan_exact = K >= ac->m;
+    ac->scan_rows = rk;
+    ac->scan_candidate_rate = candidate_rate(ac, K);
+    ac->scan_cost = best_cost;
     ac->trunc1_table = t1;
     ac->trunc1_entry_bytes = eb1;
     ac->trunc1_bytes = (uint64_t)n1 * eb1;
@@ -772,20 +791,9 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
         ac->scan_entry_bytes = 2;
         ac->scan_bytes = hyb_bytes;
     } else {
-        const size_t n2 = (size_t)rk * 16;
-        uint16_t *t2 = (uint16_t *)calloc(n2 * 2 + 16, 1);
-        if (!t2) { smh_set_error("smh_ac_plan_scan: out of memory"); return SMH_ENOMEM; }
-        for (uint32_t r = 0; r < rk; ++r)
-            for (int c1 = 0; c1 < 4; ++c1)
-                for (int c2 = 0; c2 < 4; ++c2) {
-                    int f1, f2;
-                    uint32_t r1 = trunc_step(ac, K, r, c1, &f1);
-                    uint32_t r2 = trunc_step(ac, K, r1, c2, &f2);
-                    t2[(size_t)r * 16 + c1 * 4 + c2] = (uint16_t)(r2 | (f1 ? 0x4000u : 0u) | (f2 ? 0x8000u : 0u));
-                }
         ac->scan_table = t2;
         ac->scan_entry_bytes = 2;
-        ac->scan_bytes = (uint32_t)((n2 * 2 + 15) & ~(size_t)15);
+        ac->scan_bytes = (uint32_t)(((size_t)rk * 16 * 2 + 15) & ~(size_t)15);
     }
     return SMH_OK;
 }
@@ -869,10 +877,12 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
         smh_set_error("smh_ac_set_scan_plan: patterns are not all of length m");
         return SMH_EUNSUP;
     }
+    const int rc = smh_ac_plan_scan(ac, SMH_AC_LDS_BUDGET, stride, depth);
+    if (rc != SMH_OK) return rc; /* the handle keeps its current plan and device tables */
     if (ac->dev) smh_ac_dev_free(ac->dev); /* device copies are rebuilt on the next scan */
     ac->dev = NULL;
     ac->alt_off = stride != 0 || depth != 0; /* a forced plan means "run the automaton kernels" */
-    return smh_ac_plan_scan(ac, SMH_AC_LDS_BUDGET, stride, depth);
+    return SMH_OK;
 }
 
 void smh_ac_free(smh_ac *ac)

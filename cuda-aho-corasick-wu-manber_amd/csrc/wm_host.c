@@ -1,3 +1,4 @@
+#define _GNU_SOURCE /* qsort_r */
 /*
  * csrc/wm_host.c -- host side of the Wu-Manber path (plain C).
  *
@@ -119,8 +120,8 @@ static uint32_t smh_wm_tag(const unsigned char *p, int m)
     return h;
 }
 
-static int g_sort_m;
-static int cmp_rows(const void *a, const void *b) { return memcmp(a, b, (size_t)g_sort_m); }
+/* row length travels with the call (qsort_r): concurrent compiles with different m share nothing */
+static int cmp_rows(const void *a, const void *b, void *m) { return memcmp(a, b, (size_t)*(const int *)m); }
 
 static int ceil_log2_u32(uint32_t v)
 {
@@ -378,8 +379,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
     wm->pat_sorted = (unsigned char *)malloc((size_t)p_size * m);
     if (!wm->pat_sorted) goto oom;
     memcpy(wm->pat_sorted, pattern_flat, (size_t)p_size * m);
-    g_sort_m = m;
-    qsort(wm->pat_sorted, (size_t)p_size, (size_t)m, cmp_rows);
+    qsort_r(wm->pat_sorted, (size_t)p_size, (size_t)m, cmp_rows, &m);
     int d = 0;
     for (int j = 0; j < p_size; ++j)
         if (j == 0 || memcmp(wm->pat_sorted + (size_t)j * m, wm->pat_sorted + (size_t)(d - 1) * m, (size_t)m) != 0) {

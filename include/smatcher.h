@@ -15,8 +15,8 @@
  * print a message and exit(1), which is the reference's own error convention
  * (cuda/cuda.h:26-47, fail()).
  *
- * The sibling algorithms of the reference (Set-Horspool, SBOM, SOG, KMP, BM;
- * smatcher.h:93-99,108-133) are outside this library's scope and not declared.
+ * Of the reference's sibling algorithms, Set-Horspool and SBOM are declared further down with the reference's
+ * shapes (smatcher.h:55-69,93-99); SOG, KMP and BM (smatcher.h:108-133) are not part of this library.
  *
  * 64-bit text lengths / counts, resident-text handles, streams and the
  * multi-GPU shard helpers live in smatcher_hip.h.
@@ -24,10 +24,17 @@
 #ifndef SMATCHER_H
 #define SMATCHER_H
 
+/* the system headers the reference header gives its includers (smatcher.h:20-29): main.c relies on them
+ * (ceil, stat, ...) without including them itself */
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
+#include <unistd.h>
+#include <sys/types.h>
+#include <sys/stat.h>
+#include <inttypes.h>
+#include <math.h>
 
 #ifdef __cplusplus
 extern "C" {

@@ -17,6 +17,12 @@
  *   - the byte-range shard formula of main.c:375-378,464-477 with true shard
  *     lengths, for one-process-per-GPU drivers that sum counts with RCCL.
  *
+ * Text and pattern bytes are symbol codes 0 .. alphabet-1, as in the reference (which indexes next[alphabet]
+ * with the raw byte, ac/ac.c:136,209, and is undefined beyond it).  Here a text byte >= alphabet is never used as
+ * an out-of-range index -- every table address is masked or clamped -- but WHICH windows containing such a
+ * byte count as matches is unspecified and may differ between scan plans and engines; validate the text
+ * where that matters.  Pattern symbols >= alphabet are refused at compile time (SMH_EINVAL).
+ *
  * Plain C types only; `stream` arguments are hipStream_t passed as void*
  * (NULL = the default stream).  Functions returning int return SMH_OK (0) or a
  * negative SMH_E* code and leave a message for smh_last_error(); nothing here
