@@ -43,6 +43,9 @@ struct smh_pset {
      * count is the same sum over classes; the text is read once instead of once per length. */
     smh_wm *suffix;
     smh_wm **class_wm;
+    /* SMH_ALGO_AC sets with 2 or more lengths: ONE pass with one automaton whose states carry joined output
+     * counts (acm_host.c); NULL when no cut of it fits LDS, then one scan per class */
+    struct smh_acm *acm;
 };
 
 static int cmp_u32(const void *a, const void *b)
@@ -59,6 +62,7 @@ void smh_pset_free(smh_pset *set)
         smh_wm_free(set->cls[i].wm);
     }
     smh_wm_free(set->suffix);
+    smh_acm_free(set->acm);
     free(set->class_wm);
     free(set->cls);
     set->magic = 0;
@@ -143,6 +147,10 @@ smh_pset *smh_pset_compile(const unsigned char *patterns, const uint32_t *length
             set->suffix = NULL;
         }
     }
+    if (algorithm == SMH_ALGO_AC && n_classes >= 2) {
+        set->acm = smh_acm_compile(patterns, lengths, p_size, alphabet); /* NULL: stay with one scan per class */
+        if (getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "classes")) { smh_acm_free(set->acm); set->acm = NULL; }
+    }
     free(sorted);
     free(flat);
     return set;
@@ -170,7 +178,7 @@ int smh_pset_get_info(const smh_pset *set, smh_pset_info *out)
     out->patterns = set->patterns;
     out->min_length = set->cls[0].length;
     out->max_length = set->cls[set->n_classes - 1].length;
-    out->one_pass = set->suffix != NULL;
+    out->one_pass = set->suffix != NULL || set->acm != NULL;
     return SMH_OK;
 }
 
@@ -191,6 +199,7 @@ int smh_pset_scan(smh_pset *set, const unsigned char *d_text, uint64_t n, uint64
     if (!pset_ok(set, "smh_pset_scan")) return SMH_EINVAL;
     if (set->suffix && ((uintptr_t)d_text & 15u) == 0)
         return smh_wm_scan_multi(set->suffix, set->class_wm, (int)set->n_classes, d_text, n, d_count, stream);
+    if (set->acm && ((uintptr_t)d_text & 15u) == 0) return smh_acm_scan(set->acm, d_text, n, d_count, stream);
     for (uint32_t c = 0; c < set->n_classes; ++c) {
         struct smh_pset_class *k = &set->cls[c];
         const int rc = k->wm ? smh_wm_scan(k->wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream)

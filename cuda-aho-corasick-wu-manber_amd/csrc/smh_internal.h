@@ -117,6 +117,31 @@ extern _Thread_local int smh_alt_engine_depth;
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
 
+/* ------------------------------------------------------------------ mixed-length automaton (acm_host.c)
+ * One Aho-Corasick automaton with joined (suffix-closed) output COUNTS for a set of patterns of different
+ * lengths, cut at depth K for LDS; see acm_host.c for the construction and acm_lane.h for the scan. */
+#define SMH_MAGIC_ACM 0x41434d58u /* "ACMX" */
+struct smh_acm_dev;
+struct smh_acm {
+    uint32_t magic;
+    int alphabet;
+    int max_len;
+    int K;               /* depth of the LDS automaton */
+    int exact;           /* K >= max_len: the scan alone counts everything */
+    uint32_t nodes;      /* trie nodes, breadth-first ids, root 0 */
+    uint32_t scan_rows;  /* nodes of depth <= K == rows of the LDS table */
+    int entry_bytes;     /* 2: candidate << 15 | count << 13 | row;  4: candidate << 31 | count << 24 | row */
+    void *scan;          /* scan_rows * alphabet entries */
+    uint32_t scan_bytes; /* padded to 16 */
+    uint32_t *g_goto;    /* nodes * alphabet: child id or 0 (goto edges only) */
+    uint8_t *g_final;    /* nodes: 1 when a pattern ends at the node */
+    struct smh_acm_dev *dev;
+};
+struct smh_acm *smh_acm_compile(const unsigned char *patterns, const uint32_t *lengths, int p_size, int alphabet);
+void smh_acm_free(struct smh_acm *a);
+void smh_acm_dev_free(struct smh_acm_dev *dev); /* smh_runtime.hip */
+int smh_acm_scan(struct smh_acm *a, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream);
+
 /* ------------------------------------------------------------------ SH (Set-Horspool, sh_host.c)
  * The reversed trie as the reference lays it out (for the table-walking kernel), the patterns read
  * back from it, the valid bad-character table, and the tuned engine that scans them. */

@@ -10,6 +10,7 @@
 #include <mutex>
 #include "ac_lane.h"
 #include "wm_lane.h"
+#include "acm_lane.h"
 
 #define SMH_BLOCK_THREADS 1024
 #define SMH_LDS_BUDGET (156u * 1024u) /* of the 160 KiB per CU; the rest is left to the runtime */
@@ -96,6 +97,18 @@ struct smh_ac_table_launch {
 hipError_t smh_launch_ac_table(const smh_ac_table_launch &L, hipStream_t stream);
 hipError_t smh_launch_ac_positions(const smh_ac_verify_ctx &V, uint64_t *d_positions, uint64_t capacity,
                                    uint64_t *d_cursor, int n_cus, hipStream_t stream);
+
+struct smh_acm_launch {
+    smh_acm_ctx C;          /* text, n, K, max_len, sigma, goto trie (device pointers) */
+    int entry_bytes;
+    const void *d_scan;     /* LDS image */
+    uint32_t lds_bytes;     /* multiple of 16 */
+    uint64_t *d_queue;      /* smh_acm_max_blocks * 16 waves * SMH_ACM_QCAP entries */
+    uint64_t *d_count;
+    int n_cus;
+};
+uint32_t smh_acm_max_blocks(int n_cus);
+hipError_t smh_launch_acm(const smh_acm_launch &L, hipStream_t stream);
 
 struct smh_sh_table_launch {
     const uint8_t *d_text;

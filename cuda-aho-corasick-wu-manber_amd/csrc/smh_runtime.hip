@@ -733,6 +733,62 @@ extern "C" int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t
                       [&](unsigned char *d_text, uint64_t *d_count) { return smh_wm_scan(wm, d_text, n, d_count, variant, NULL); });
 }
 
+/* ------------------------------------------------------------------ mixed-length automaton (acm_host.c) */
+struct smh_acm_dev {
+    int device;
+    smh_acm_dev *next;
+    void *d_scan;
+    uint32_t *d_goto;
+    uint8_t *d_final;
+    uint64_t *d_queue;
+};
+
+static void acm_dev_free_one(smh_acm_dev *dev)
+{
+    (void)hipFree(dev->d_scan);
+    (void)hipFree(dev->d_goto);
+    (void)hipFree(dev->d_final);
+    (void)hipFree(dev->d_queue);
+    delete dev;
+}
+
+extern "C" void smh_acm_dev_free(struct smh_acm_dev *dev) /* the whole list */
+{
+    while (dev) {
+        smh_acm_dev *next = dev->next;
+        acm_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+extern "C" int smh_acm_scan(struct smh_acm *a, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream)
+{
+    if (!a || a->magic != SMH_MAGIC_ACM || !d_count || (n && !d_text) || ((uintptr_t)d_text & 15u) != 0) {
+        smh_set_error("smh_acm_scan: bad arguments (the text must be 16-byte aligned)");
+        return SMH_EINVAL;
+    }
+    if (n == 0) return SMH_OK;
+    int n_cus = 0, rc;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_acm_dev *dv = NULL;
+    rc = ensure_device_set<smh_acm_dev>(&a->dev, acm_dev_free_one, [&](smh_acm_dev *d) -> int {
+        int rc;
+        if ((rc = upload(&d->d_scan, a->scan, (size_t)a->scan_bytes, 256 * 4)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_goto, a->g_goto, (size_t)a->nodes * (size_t)a->alphabet * 4, 256 * 4)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_final, a->g_final, (size_t)a->nodes, 16)) != SMH_OK) return rc;
+        HIP_TRY(hipMalloc((void **)&d->d_queue, (size_t)smh_acm_max_blocks(n_cus) * (SMH_BLOCK_THREADS / 64) * SMH_ACM_QCAP * 8));
+        return SMH_OK;
+    }, &dv);
+    if (rc != SMH_OK) return rc;
+    smh_acm_launch L = {};
+    L.C.text = d_text; L.C.n = n; L.C.K = a->K; L.C.max_len = a->max_len; L.C.sigma = a->alphabet;
+    L.C.g_goto = dv->d_goto; L.C.g_final = dv->d_final;
+    L.entry_bytes = a->entry_bytes; L.d_scan = dv->d_scan; L.lds_bytes = a->scan_bytes;
+    L.d_queue = dv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
+    HIP_TRY(smh_launch_acm(L, (hipStream_t)stream));
+    return SMH_OK;
+}
+
 /* ------------------------------------------------------------------ SH */
 struct smh_sh_dev {
     int device;

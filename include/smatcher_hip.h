@@ -281,9 +281,11 @@ typedef struct smh_pset_info {
     uint32_t patterns;     /* as given */
     uint32_t min_length;
     uint32_t max_length;
-    uint32_t one_pass;     /* 1: SMH_ALGO_WM set with 2..32 lengths, all >= 3 -- the text is read ONCE: a block filter
+    uint32_t one_pass;     /* 1: the text is read ONCE.  SMH_ALGO_WM sets with 2..32 lengths, all >= 3: a block filter
                             * over the patterns' last min-length symbols proposes END columns, each survivor is
-                            * verified per length class.  0: one scan per class. */
+                            * verified per length class.  SMH_ALGO_AC sets: one automaton whose states carry joined
+                            * (suffix-closed) output counts, cut at the deepest level that fits LDS, longer patterns
+                            * verified along the goto trie.  0: one scan per class. */
     uint32_t reserved;
 } smh_pset_info;
 

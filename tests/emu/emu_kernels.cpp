@@ -432,3 +432,32 @@ extern "C" uint64_t emu_wm_scan_multi(const smh_wm *suffix, const smh_wm *const 
     g_emu_n_classes = 0;
     return total;
 }
+
+/* ------------------------------------------------------------------ mixed-length automaton (acm_host.c, acm_lane.h) */
+#include "acm_lane.h"
+
+extern "C" uint64_t emu_acm_scan(const smh_acm *a, const uint8_t *text_in, uint64_t n, uint32_t blocks)
+{
+    if (!blocks) blocks = 3;
+    uint64_t result[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        smh_acm_ctx C;
+        C.text = g.text; C.n = n; C.K = a->K; C.max_len = a->max_len; C.sigma = a->alphabet;
+        C.g_goto = a->g_goto; C.g_final = a->g_final;
+        const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
+        uint64_t total = 0;
+        for (uint64_t t = 0; t < nthreads; ++t) {
+            const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
+            if (a->entry_bytes == 2)
+                total += a->alphabet == 4 ? smh_acm_thread<uint16_t, 4>(t, S, a->scan, a->scan, C, nullptr)
+                                          : smh_acm_thread<uint16_t, 0>(t, S, a->scan, a->scan, C, nullptr);
+            else
+                total += a->alphabet == 4 ? smh_acm_thread<uint32_t, 4>(t, S, a->scan, a->scan, C, nullptr)
+                                          : smh_acm_thread<uint32_t, 0>(t, S, a->scan, a->scan, C, nullptr);
+        }
+        guard_free(g);
+        result[mode] = total;
+    }
+    return result[0] == result[1] ? result[0] : ~0ull;
+}

@@ -116,3 +116,25 @@ def wm_scan_multi(suffix, classes, text, capacity=None, blocks=0):
     total = int(_emu.emu_wm_scan_multi(suffix.h, arr, len(classes), text.ctypes.data_as(S.u8p), len(text),
                                        out.ctypes.data_as(C.POINTER(C.c_uint64)), capacity, blocks))
     return total, out[:min(total, capacity)]
+
+
+# ---- mixed-length automaton (csrc/acm_host.c): internal entry points of the library, bound here for the tests
+S.lib.smh_acm_compile.restype = C.c_void_p
+S.lib.smh_acm_compile.argtypes = [S.u8p, C.POINTER(C.c_uint32), C.c_int, C.c_int]
+S.lib.smh_acm_free.restype = None
+S.lib.smh_acm_free.argtypes = [C.c_void_p]
+_emu.emu_acm_scan.restype = C.c_uint64
+_emu.emu_acm_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_uint32]
+
+
+def acm_compile(patterns, lengths, sigma):
+    """-> handle (int) or None when no cut of the automaton is worth one pass (message in smh_last_error)"""
+    patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    h = S.lib.smh_acm_compile(patterns.ctypes.data_as(S.u8p), lengths.ctypes.data_as(C.POINTER(C.c_uint32)), len(lengths), sigma)
+    return h
+
+
+def acm_scan(h, text, blocks=0):
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    return int(_emu.emu_acm_scan(h, text.ctypes.data_as(S.u8p), len(text), blocks))

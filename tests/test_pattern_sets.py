@@ -23,6 +23,9 @@ with open(os.path.join(ROOT, "tests", "golden", "ref_mixed_vectors.json")) as f:
     MIXED = json.load(f)
 IDS = [v["name"] for v in MIXED]
 ONE_PASS = {"mixed_ascii_5_20"}  # sets whose min-length suffix filter passes < 0.4 % of the columns
+# SMH_ALGO_AC sets: one automaton with joined output counts whenever a cut of it fits LDS with few candidates
+# (alphabet 256: a row costs 512 bytes, only depth 1 fits, every position would be a candidate: per class)
+ONE_PASS_AC = {"mixed_dna_8_32", "mixed_protein", "mixed_len_1_2", "mixed_prefix_hazard"}
 
 
 @pytest.mark.parametrize("vec", MIXED, ids=IDS)
@@ -67,7 +70,58 @@ def test_one_pass_lane_code_reproduces_the_decomposition(vec):
     assert total == vec["total"] and np.array_equal(np.sort(got).astype(np.int64), want_pos)
     # the handle takes the one-pass form only while the suffix filter lets few columns through
     assert S.PatternSet(patterns, lengths, sigma, S.ALGO_WM).info().one_pass == (1 if vec["name"] in ONE_PASS else 0)
-    assert S.PatternSet(patterns, lengths, sigma, S.ALGO_AC).info().one_pass == 0
+    assert S.PatternSet(patterns, lengths, sigma, S.ALGO_AC).info().one_pass == (1 if vec["name"] in ONE_PASS_AC else 0)
+
+
+@pytest.mark.parametrize("vec", MIXED, ids=IDS)
+def test_one_pass_automaton_reproduces_the_decomposition(vec):
+    """SMH_ALGO_AC sets: ONE automaton whose states carry joined (suffix-closed) output counts -- what ac/ac.c:118
+    leaves out -- cut at the deepest level that fits LDS; longer patterns are verified along the goto trie.  The
+    emulated lane code must give the sum of the reference's per-class counts, including the set in which short
+    patterns are prefixes and suffixes of longer ones."""
+    text, patterns, lengths = cases.build_mixed(vec)
+    h = E.acm_compile(patterns, lengths, vec["sigma"])
+    assert bool(h) == (vec["name"] in ONE_PASS_AC)
+    if not h:
+        assert "candidates" in S.lib.smh_last_error().decode()
+        return
+    for blocks in (1, 3):
+        assert E.acm_scan(h, text, blocks) == vec["total"]
+    assert E.acm_scan(h, text[:40], 1) == sum(O.count_bruteforce(f, L, len(f) // L, text[:40])
+                                             for L, f in cases.split_classes(patterns, lengths).items() if L <= 40)
+    S.lib.smh_acm_free(h)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_one_pass_automaton_on_random_sets(seed):
+    """random sets (nested prefixes / suffixes, duplicates, lengths 1..40, several alphabets) against the definition:
+    sum over length classes of the brute-force count"""
+    rng = np.random.RandomState(100 + seed)
+    sigma = [2, 4, 4, 8, 20, 4, 4, 2][seed]
+    n = int(rng.randint(5000, 400000))
+    text = O.gen_text(n, 900 + seed, sigma)
+    lengths, pats = [], []
+    for j in range(int(rng.randint(2, 300))):
+        L = int(rng.randint(1, 41))
+        kind = rng.randint(0, 4)
+        if kind == 0 and pats:  # a prefix or suffix of an earlier pattern, or the pattern again
+            q = pats[rng.randint(0, len(pats))]
+            L = int(rng.randint(1, len(q) + 1))
+            pat = q[:L] if rng.randint(0, 2) else q[len(q) - L:]
+        elif kind <= 2 and L < n:
+            off = int(rng.randint(0, n - L))
+            pat = text[off:off + L]
+        else:
+            pat = rng.randint(0, sigma, size=L).astype(np.uint8)
+        pats.append(np.array(pat, dtype=np.uint8))
+        lengths.append(len(pat))
+    patterns = np.concatenate(pats)
+    want = sum(O.count_bruteforce(f, L, len(f) // L, text) for L, f in cases.split_classes(patterns, np.array(lengths)).items())
+    h = E.acm_compile(patterns, lengths, sigma)
+    if not h:
+        pytest.skip(S.lib.smh_last_error().decode())
+    assert E.acm_scan(h, text, 2) == want
+    S.lib.smh_acm_free(h)
 
 
 @pytest.mark.parametrize("algo", [S.ALGO_AC, S.ALGO_WM])
