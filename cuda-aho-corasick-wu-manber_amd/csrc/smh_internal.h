@@ -205,6 +205,24 @@ struct smh_sbom_table_box { /* handed out by preproc_sbom: the public struct fir
 void smh_sbom_host_free(struct smh_sbom *sb);
 void smh_sbom_dev_free(struct smh_sbom_dev *dev); /* smh_runtime.hip */
 
+/* ------------------------------------------------------------------ SOG (sog_host.c)
+ * The caller's tables as given (T8, sorted hashes, their permutation, the 2-level bitmap), the patterns, and
+ * the tuned engine that scans them. */
+#define SMH_MAGIC_SOG 0x534f4738u /* "SOG8" */
+struct smh_sog_dev;
+struct smh_sog {
+    uint32_t magic;
+    uint32_t n_patterns;
+    uint8_t *t8;       /* 2^24 */
+    uint32_t *hs;      /* n_patterns, ascending */
+    int32_t *index;    /* n_patterns */
+    uint8_t *hs2;      /* 8192 */
+    unsigned char *patterns; /* n_patterns * 8, the caller's order (scanner_index refers to it) */
+    struct smh_wm *wm;
+    struct smh_sog_dev *dev;
+};
+void smh_sog_dev_free(struct smh_sog_dev *dev); /* smh_runtime.hip */
+
 /* ------------------------------------------------------------------ WM
  * Device tables (DESIGN.md "WM layout"):
  *   filter   : bit set in LDS indexed by the code of the window's last

@@ -137,6 +137,20 @@ struct smh_sbom_table_launch {
 };
 hipError_t smh_launch_sbom_table(const smh_sbom_table_launch &L, hipStream_t stream);
 
+struct smh_sog_table_launch {
+    const uint8_t *d_text;
+    uint64_t n;
+    const uint8_t *d_t8;       /* 2^24 bytes */
+    const uint32_t *d_hs;      /* sorted pattern hashes */
+    const int32_t *d_index;
+    const uint8_t *d_hs2;      /* 8192 bytes */
+    const uint8_t *d_patterns; /* p_size * 8 */
+    int p_size;
+    uint64_t *d_count;
+    int n_cus;
+};
+hipError_t smh_launch_sog_table(const smh_sog_table_launch &L, hipStream_t stream);
+
 struct smh_wm_launch {
     const uint8_t *d_text;
     uint64_t n;

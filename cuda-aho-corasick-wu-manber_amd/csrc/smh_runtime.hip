@@ -962,6 +962,88 @@ extern "C" int smh_sbom_count_host(smh_sbom *sb, const unsigned char *text, uint
                       [&](unsigned char *d_text, uint64_t *d_count) { return smh_sbom_scan(sb, d_text, n, d_count, variant, NULL); });
 }
 
+/* ------------------------------------------------------------------ SOG */
+struct smh_sog_dev {
+    int device;
+    smh_sog_dev *next;
+    uint8_t *d_t8;
+    uint32_t *d_hs;
+    int32_t *d_index;
+    uint8_t *d_hs2;
+    uint8_t *d_patterns;
+};
+
+static void sog_dev_free_one(smh_sog_dev *dev)
+{
+    (void)hipFree(dev->d_t8);
+    (void)hipFree(dev->d_hs);
+    (void)hipFree(dev->d_index);
+    (void)hipFree(dev->d_hs2);
+    (void)hipFree(dev->d_patterns);
+    delete dev;
+}
+
+extern "C" void smh_sog_dev_free(struct smh_sog_dev *dev) /* the whole list */
+{
+    while (dev) {
+        smh_sog_dev *next = dev->next;
+        sog_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+static int sog_ensure_device(struct smh_sog *sg, smh_sog_dev **out)
+{
+    return ensure_device_set<smh_sog_dev>(&sg->dev, sog_dev_free_one, [&](smh_sog_dev *d) -> int {
+        int rc;
+        if ((rc = upload((void **)&d->d_t8, sg->t8, (size_t)1 << 24, 0)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_hs, sg->hs, (size_t)sg->n_patterns * 4, 0)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_index, sg->index, (size_t)sg->n_patterns * 4, 0)) != SMH_OK) return rc;
+        if ((rc = upload((void **)&d->d_hs2, sg->hs2, 8192, 0)) != SMH_OK) return rc;
+        return upload((void **)&d->d_patterns, sg->patterns, (size_t)sg->n_patterns * 8, 0);
+    }, out);
+}
+
+static int sog_prepare(struct smh_sog *sg, int variant)
+{
+    if (variant == SMH_VARIANT_TUNED) return wm_prepare(sg->wm, variant);
+    smh_sog_dev *d = NULL;
+    return sog_ensure_device(sg, &d);
+}
+
+extern "C" int smh_sog_scan(smh_sog *sg, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant, void *stream)
+{
+    if (!sg || sg->magic != SMH_MAGIC_SOG || !d_count || (n && !d_text)) {
+        smh_set_error("smh_sog_scan: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (n < 8) return SMH_OK;
+    if (variant == SMH_VARIANT_TUNED) return smh_wm_scan(sg->wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
+    if (variant != SMH_VARIANT_TABLE) {
+        smh_set_error("smh_sog_scan: unknown variant %d", variant);
+        return SMH_EINVAL;
+    }
+    smh_sog_dev *dv = NULL;
+    int rc = sog_ensure_device(sg, &dv);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_sog_table_launch L;
+    L.d_text = d_text; L.n = n; L.d_t8 = dv->d_t8; L.d_hs = dv->d_hs; L.d_index = dv->d_index; L.d_hs2 = dv->d_hs2;
+    L.d_patterns = dv->d_patterns; L.p_size = (int)sg->n_patterns; L.d_count = d_count; L.n_cus = n_cus;
+    HIP_TRY(smh_launch_sog_table(L, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_sog_count_host(smh_sog *sg, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
+                                  double *kernel_seconds)
+{
+    if (!sg || sg->magic != SMH_MAGIC_SOG) { smh_set_error("smh_sog_count_host: bad handle"); return SMH_EINVAL; }
+    return count_host(text, n, count, kernel_seconds,
+                      [&]() { return n < 8 ? SMH_OK : sog_prepare(sg, variant); },
+                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_sog_scan(sg, d_text, n, d_count, variant, NULL); });
+}
+
 /* ------------------------------------------------------------------ legacy names (smatcher.h) */
 static void die_with_error(const char *where)
 {
@@ -1148,3 +1230,42 @@ SMH_CUDA_SBOM(2, SMH_VARIANT_TABLE)
 SMH_CUDA_SBOM(3, SMH_VARIANT_TUNED)
 SMH_CUDA_SBOM(4, SMH_VARIANT_TUNED)
 SMH_CUDA_SBOM(5, SMH_VARIANT_TUNED)
+
+/* smatcher.h:109 / sog/sog8.c:97-115 -- the number of 8-byte windows that equal a pattern, computed by the tuned kernels */
+static uint64_t sog_any(int variant, uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2,
+                        const unsigned char *pattern_flat, int m, unsigned char *text, int n, int p_size, double *secs)
+{
+    if (m != 8) fail("SOG is built for patterns of length 8 (sog/sog8.c)\n");
+    smh_sog *sg = smh_sog_compile_tables(T8, scanner_hs, scanner_index, scanner_hs2, pattern_flat, p_size);
+    if (!sg) die_with_error("sog");
+    uint64_t count = 0;
+    if (smh_sog_count_host(sg, text, n < 0 ? 0 : (uint64_t)n, variant, &count, secs) != SMH_OK) die_with_error("sog");
+    smh_sog_free(sg);
+    return count;
+}
+
+extern "C" unsigned int search_sog8(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2,
+                                    unsigned char **pattern, int m, unsigned char *text, int n, int p_size, int B)
+{
+    (void)B;
+    if (m != 8 || p_size < 1 || !pattern) fail("search_sog8: bad arguments (m must be 8)\n");
+    std::vector<unsigned char> flat((size_t)p_size * 8);
+    for (int j = 0; j < p_size; ++j) memcpy(flat.data() + (size_t)j * 8, pattern[j], 8);
+    return (unsigned int)sog_any(SMH_VARIANT_TUNED, T8, scanner_hs, scanner_index, scanner_hs2, flat.data(), m, text, n, p_size, NULL);
+}
+
+#define SMH_CUDA_SOG(K, VARIANT)                                                                                      \
+    extern "C" void cuda_sog##K(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2,          \
+                                unsigned char *pattern, int m, unsigned char *text, int n, int p_size, int B)         \
+    {                                                                                                                  \
+        (void)B;                                                                                                       \
+        double secs = 0.0;                                                                                             \
+        const uint64_t c = sog_any(VARIANT, T8, scanner_hs, scanner_index, scanner_hs2, pattern, m, text, n, p_size, &secs); \
+        printf("Kernel %d matches \t%i\t time \t%f\n", K, (int)c, secs); /* cuda/cuda_sog.cu:314 */                  \
+        fflush(stdout);                                                                                                \
+    }
+SMH_CUDA_SOG(1, SMH_VARIANT_TABLE)
+SMH_CUDA_SOG(2, SMH_VARIANT_TABLE)
+SMH_CUDA_SOG(3, SMH_VARIANT_TUNED)
+SMH_CUDA_SOG(4, SMH_VARIANT_TUNED)
+SMH_CUDA_SOG(5, SMH_VARIANT_TUNED)

@@ -84,7 +84,8 @@ LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_s
                    "shiftsize"]
                   + ["cuda_ac%d" % k for k in range(1, 6)] + ["cuda_wm%d" % k for k in range(1, 6)]
                   + ["preBmBc", "preproc_sh", "search_sh", "free_sh"] + ["cuda_sh%d" % k for k in range(1, 6)]
-                  + ["preproc_sbom", "search_sbom", "free_sbom", "pointer_array"] + ["cuda_sbom%d" % k for k in range(1, 6)])
+                  + ["preproc_sbom", "search_sbom", "free_sbom", "pointer_array"] + ["cuda_sbom%d" % k for k in range(1, 6)]
+                  + ["preproc_sog8", "search_sog8"] + ["cuda_sog%d" % k for k in range(1, 6)])
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
                "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
@@ -97,6 +98,7 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_pset_free", "smh_sh_compile_tables", "smh_sh_compile_patterns", "smh_sh_get_info",
                "smh_sh_valid_bmbc", "smh_sh_scan", "smh_sh_count_host", "smh_sh_free", "smh_sbom_compile_tables",
                "smh_sbom_compile_patterns", "smh_sbom_get_info", "smh_sbom_scan", "smh_sbom_count_host", "smh_sbom_free",
+               "smh_sog_compile_tables", "smh_sog_scan", "smh_sog_count_host", "smh_sog_free",
                "smh_multi_create", "smh_multi_device_count", "smh_multi_uses_rccl", "smh_multi_load_text",
                "smh_multi_generate_text", "smh_multi_ac_count", "smh_multi_wm_count", "smh_multi_free"]
 
@@ -224,6 +226,20 @@ def _load():
         g = getattr(lib, "cuda_wm%d" % k)
         g.restype = C.c_int
         g.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int] + tabs + [dblp]
+    lib.preproc_sog8.restype = None
+    lib.preproc_sog8.argtypes = [u8p, u32p, i32p, u8p, C.POINTER(u8p), C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+    lib.search_sog8.restype = C.c_uint
+    lib.search_sog8.argtypes = [u8p, u32p, i32p, u8p, C.POINTER(u8p), C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+    for k in range(1, 6):
+        f = getattr(lib, "cuda_sog%d" % k)
+        f.restype = None
+        f.argtypes = [u8p, u32p, i32p, u8p, u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+    lib.smh_sog_compile_tables.restype = C.c_void_p
+    lib.smh_sog_compile_tables.argtypes = [u8p, u32p, i32p, u8p, u8p, C.c_int]
+    lib.smh_sog_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
+    lib.smh_sog_count_host.argtypes = [C.c_void_p, u8p, C.c_uint64, C.c_int, C.POINTER(C.c_uint64), dblp]
+    lib.smh_sog_free.restype = None
+    lib.smh_sog_free.argtypes = [C.c_void_p]
     lib.smh_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
     lib.smh_multi_device_count.argtypes = [C.c_void_p]
     lib.smh_multi_uses_rccl.argtypes = [C.c_void_p]
@@ -434,6 +450,46 @@ class PatternSet:
     def close(self):
         if self.h:
             lib.smh_pset_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SogTables:
+    """SOG (sog/sog8.c): the caller-owned tables filled by preproc_sog8, and a handle over them."""
+
+    def __init__(self, pat_flat, p):
+        self.p = p
+        self.pat, _ = _u8(pat_flat)
+        self.T8 = np.zeros(1 << 24, dtype=np.uint8)
+        self.scanner_hs = np.zeros(p, dtype=np.uint32)
+        self.scanner_index = np.zeros(p, dtype=np.int32)
+        self.scanner_hs2 = np.zeros(32 * 256, dtype=np.uint8)
+        rows = self.pat.reshape(p, 8)
+        self._rows = [np.ascontiguousarray(r) for r in rows]
+        self.ptrs = (u8p * p)(*[r.ctypes.data_as(u8p) for r in self._rows])
+        lib.preproc_sog8(*self.tables(), self.ptrs, 8, None, 0, p, 3)
+        self.h = lib.smh_sog_compile_tables(*self.tables(), self.pat.ctypes.data_as(u8p), p)
+        if not self.h:
+            raise SmhError("smh_sog_compile_tables: " + lib.smh_last_error().decode())
+
+    def tables(self):
+        return (self.T8.ctypes.data_as(u8p), self.scanner_hs.ctypes.data_as(u32p), self.scanner_index.ctypes.data_as(i32p),
+                self.scanner_hs2.ctypes.data_as(u8p))
+
+    def count_host(self, text, variant=VARIANT_TUNED):
+        a, p = _u8(text)
+        cnt, secs = C.c_uint64(), C.c_double()
+        _check(lib.smh_sog_count_host(self.h, p, len(a), variant, C.byref(cnt), C.byref(secs)), "smh_sog_count_host")
+        return int(cnt.value), secs.value
+
+    def close(self):
+        if self.h:
+            lib.smh_sog_free(self.h)
             self.h = None
 
     def __del__(self):

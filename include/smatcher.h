@@ -16,7 +16,8 @@
  * (cuda/cuda.h:26-47, fail()).
  *
  * Of the reference's sibling algorithms, Set-Horspool and SBOM are declared further down with the reference's
- * shapes (smatcher.h:55-69,93-99); SOG, KMP and BM (smatcher.h:108-133) are not part of this library.
+ * shapes (smatcher.h:55-69,93-99), and so is SOG (smatcher.h:75-80,108-109); KMP and BM (smatcher.h:131-133) are
+ * single-pattern helpers outside this library.
  *
  * 64-bit text lengths / counts, resident-text handles, streams and the
  * multi-GPU shard helpers live in smatcher_hip.h.
@@ -188,6 +189,32 @@ void cuda_sbom4(unsigned char *pattern, int m, unsigned char *text, int n, int p
                 int *state_transition, unsigned int *state_final_multi);
 void cuda_sbom5(unsigned char *pattern, int m, unsigned char *text, int n, int p_size, int alphabet,
                 int *state_transition, unsigned int *state_final_multi);
+
+/* ------------------------------------------------------------------ SOG (shift-or with 3-grams, m = 8)
+ * smatcher.h:75-80,108-109; sog/sog8.c; cuda/cuda_sog.cu:221-831.  Tables are caller-owned (main.c:495-515):
+ * T8 SIZE_3GRAM_TABLE bytes, scanner_hs and scanner_index p_size entries, scanner_hs2 32 * 256 bytes.
+ * preproc_sog8 fills T8, scanner_hs and scanner_index exactly as the reference does; scanner_hs2 gets DEFINED
+ * contents -- the bit search_sog8 tests, from the pattern's real hash -- where the reference computes it from
+ * an uninitialised variable (sog/sog8.c:124,135), which makes its own match count depend on stack contents.
+ * search_sog8 / cuda_sog1..5 return / print the number of 8-byte windows of the text that equal a pattern. */
+#define SIZE_3GRAM_TABLE 0x1000000
+#define CHAR_WIDTH_3GRAM 8
+#define GET3GRAM(address) ((((uint32_t)(address)[0])) + (((uint32_t)((address)[1])) << CHAR_WIDTH_3GRAM) + (((uint32_t)((address)[2])) << (CHAR_WIDTH_3GRAM << 1)))
+void preproc_sog8(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2, unsigned char **pattern,
+                  int m, unsigned char *text, int n, int p_size, int B);
+unsigned int search_sog8(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2,
+                         unsigned char **pattern, int m, unsigned char *text, int n, int p_size, int B);
+/* cuda/cuda_sog.cu: `pattern` is the flat p_size x m array (main.c:457-459); prints "Kernel K matches \t%i\t time \t%f\n" */
+void cuda_sog1(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2, unsigned char *pattern,
+               int m, unsigned char *text, int n, int p_size, int B);
+void cuda_sog2(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2, unsigned char *pattern,
+               int m, unsigned char *text, int n, int p_size, int B);
+void cuda_sog3(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2, unsigned char *pattern,
+               int m, unsigned char *text, int n, int p_size, int B);
+void cuda_sog4(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2, unsigned char *pattern,
+               int m, unsigned char *text, int n, int p_size, int B);
+void cuda_sog5(uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2, unsigned char *pattern,
+               int m, unsigned char *text, int n, int p_size, int B);
 
 #ifdef __cplusplus
 }

@@ -182,6 +182,19 @@ int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t n, int var
                       uint64_t *count, double *kernel_seconds);
 void smh_wm_free(smh_wm *wm);
 
+/* ---- SOG (sog/sog8.c, cuda/cuda_sog.cu): shift-or over 3-grams, patterns of length 8 ----
+ * SMH_VARIANT_TABLE walks the caller's tables as given -- T8 from HBM with the shift-or state per lane, then the
+ * 2-level bitmap, the binary search over the sorted hashes and the 8-byte compare (sog/sog8.c:51-115);
+ * SMH_VARIANT_TUNED scans the same patterns with the tuned Wu-Manber kernels.  Both return the number of 8-byte
+ * windows that equal a pattern.  (The reference's own count is not a function of its inputs: sog/sog8.c:135 sets
+ * the bitmap from an uninitialised variable; preproc_sog8 in smatcher.h documents the defined contents.) */
+typedef struct smh_sog smh_sog;
+smh_sog *smh_sog_compile_tables(const uint8_t *T8, const uint32_t *scanner_hs, const int *scanner_index,
+                                const uint8_t *scanner_hs2, const unsigned char *pattern_flat, int p_size);
+int smh_sog_scan(smh_sog *sg, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant, void *stream);
+int smh_sog_count_host(smh_sog *sg, const unsigned char *text, uint64_t n, int variant, uint64_t *count, double *kernel_seconds);
+void smh_sog_free(smh_sog *sg);
+
 /* ---- one process, several GPUs: the reference driver's MPI layer for this path (main.c:464-489, 654-657) ----
  * The text is split into byte ranges, one per device, each with `halo` bytes of the next range behind it
  * (main.c:467-477; every scan uses the TRUE length of its range); a count call launches the tuned kernel on

@@ -75,6 +75,16 @@ void ora_preproc_sbom(const uint8_t *const *pattern, int m, int p_size, int alph
 uint64_t ora_search_sbom(const uint8_t *pattern_flat, int m, const uint8_t *text, int64_t n, int alphabet,
                          const int32_t *state_transition, const uint32_t *state_final_multi);
 
+/* ---- SOG, 8-byte patterns (sog/sog8.c) ---- */
+/* T8: 2^24 bytes, scanner_hs / scanner_index: p_size entries, scanner_hs2: 8192 bytes (main.c:495-515).  The
+ * 2-level bitmap is set from the pattern's real hash (the reference reads an uninitialised variable there,
+ * sog/sog8.c:124,135); everything else as the reference. */
+void ora_preproc_sog8(uint8_t *T8, uint32_t *scanner_hs, int32_t *scanner_index, uint8_t *scanner_hs2,
+                      const uint8_t *const *pattern, int p_size);
+uint64_t ora_search_sog8(const uint8_t *T8, const uint32_t *scanner_hs, const int32_t *scanner_index,
+                         const uint8_t *scanner_hs2, const uint8_t *const *pattern, const uint8_t *text, int64_t n,
+                         int p_size);
+
 /* ---- Wu-Manber (wu/wu.c) ---- */
 /* returns the table length for an alphabet, 0 if unsupported (reference calls fail()) */
 uint32_t ora_wu_determine_shiftsize(int alphabet);

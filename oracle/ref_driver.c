@@ -168,3 +168,23 @@ unsigned long long ref_run_sbom(const unsigned char *pat_flat, int m, int p_size
     free(pattern);
     return matches;
 }
+
+/* SOG, main.c:300-322 (multisog): the tables are caller-owned (main.c:495-515).  Only preproc_sog8's T8,
+ * scanner_hs and scanner_index are deterministic in the reference (its scanner_hs2 depends on an uninitialised
+ * variable, sog/sog8.c:124,135); the count search_sog8 returns with that bitmap is reported as well, for the
+ * record -- tests pin the tables, not this count. */
+unsigned long long ref_run_sog8(const unsigned char *pat_flat, int p_size, const unsigned char *text, int n,
+                                uint8_t *T8, uint32_t *scanner_hs, int *scanner_index, uint8_t *scanner_hs2)
+{
+    const int m = 8, B = 3;
+    unsigned char **pattern = (unsigned char **)malloc((size_t)p_size * sizeof(unsigned char *));
+    for (int j = 0; j < p_size; j++) {
+        pattern[j] = (unsigned char *)calloc((size_t)m + 1, 1);
+        memcpy(pattern[j], pat_flat + (size_t)j * m, (size_t)m);
+    }
+    preproc_sog8(T8, scanner_hs, scanner_index, scanner_hs2, pattern, m, (unsigned char *)text, n, p_size, B);
+    unsigned int matches = text ? search_sog8(T8, scanner_hs, scanner_index, scanner_hs2, pattern, m, (unsigned char *)text, n, p_size, B) : 0;
+    for (int j = 0; j < p_size; j++) free(pattern[j]);
+    free(pattern);
+    return matches;
+}

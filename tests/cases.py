@@ -158,3 +158,14 @@ def split_classes(patterns, lengths):
         out.setdefault(int(L), []).append(patterns[off:off + int(L)])
         off += int(L)
     return {L: np.ascontiguousarray(np.concatenate(v), dtype=np.uint8) for L, v in out.items()}
+
+
+def sog_cases():
+    """SOG inputs (sog/sog8.c: patterns of length 8 over raw bytes): built with build()."""
+    out = []
+    for name, n, p, sigma, pat in [("sog_dna_100", 300007, 100, 4, "mixed"), ("sog_dna_1000", 500009, 1000, 4, "mixed"),
+                                   ("sog_protein_500", 400003, 500, 20, "mixed"), ("sog_ascii_2000", 600011, 2000, 256, "mixed"),
+                                   ("sog_dups", 200003, 64, 4, "dups"), ("sog_binary", 150001, 40, 2, "mixed"),
+                                   ("sog_short_text", 11, 3, 4, "first_window"), ("sog_one", 70001, 1, 8, "mixed")]:
+        out.append(dict(name=name, n=n, p=p, m=8, sigma=sigma, text="uniform", text_seed=4242, pat=pat, pat_seed=77))
+    return out

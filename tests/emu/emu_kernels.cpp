@@ -461,3 +461,23 @@ extern "C" uint64_t emu_acm_scan(const smh_acm *a, const uint8_t *text_in, uint6
     }
     return result[0] == result[1] ? result[0] : ~0ull;
 }
+
+/* ------------------------------------------------------------------ SOG table walk (sog_lane.h) */
+#include "sog_lane.h"
+
+extern "C" uint64_t emu_sog_scan(const smh_sog *sg, const uint8_t *text_in, uint64_t n, uint32_t blocks)
+{
+    if (n < 8) return 0;
+    if (!blocks) blocks = 3;
+    uint64_t result[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        const uint64_t nthreads = (uint64_t)blocks * 256;
+        uint64_t total = 0;
+        for (uint64_t t = 0; t < nthreads; ++t)
+            total += smh_sog_table_thread(t, nthreads, g.text, n, sg->t8, sg->hs, sg->index, sg->hs2, sg->patterns, (int)sg->n_patterns);
+        guard_free(g);
+        result[mode] = total;
+    }
+    return result[0] == result[1] ? result[0] : ~0ull;
+}

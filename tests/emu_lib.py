@@ -138,3 +138,13 @@ def acm_compile(patterns, lengths, sigma):
 def acm_scan(h, text, blocks=0):
     text = np.ascontiguousarray(text, dtype=np.uint8)
     return int(_emu.emu_acm_scan(h, text.ctypes.data_as(S.u8p), len(text), blocks))
+
+
+_emu.emu_sog_scan.restype = C.c_uint64
+_emu.emu_sog_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_uint32]
+
+
+def sog_scan(sg, text, blocks=0):
+    """the table-walking SOG lane code (sog_lane.h) over the handle's tables"""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    return int(_emu.emu_sog_scan(sg.h, text.ctypes.data_as(S.u8p), len(text), blocks))

@@ -75,6 +75,10 @@ def _load():
     lib.ora_preproc_wu_csr.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, i32p, u32p, i32p, i32p]
     lib.ora_search_wu_csr.restype = C.c_uint64
     lib.ora_search_wu_csr.argtypes = [u8p, C.c_int, u8p, C.c_int64, C.c_int, i32p, u32p, i32p, i32p]
+    lib.ora_preproc_sog8.restype = None
+    lib.ora_preproc_sog8.argtypes = [u8p, u32p, i32p, u8p, C.POINTER(u8p), C.c_int]
+    lib.ora_search_sog8.restype = C.c_uint64
+    lib.ora_search_sog8.argtypes = [u8p, u32p, i32p, u8p, C.POINTER(u8p), u8p, C.c_int64, C.c_int]
     lib.ora_shard_range.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_int, i64p, i64p]
     lib.ora_count_bruteforce.restype = C.c_uint64
     lib.ora_count_bruteforce.argtypes = [u8p, C.c_int, C.c_int, u8p, C.c_int64]
@@ -245,6 +249,44 @@ class WMTablesCSR:
         """Same four digests as WMTables.digest(): SHIFT, PREFIX_size, defined PREFIX_value / PREFIX_index."""
         sizes = np.diff(self.bucket_off.astype(np.int64)).astype(np.int32)
         return (fnv(self.SHIFT), fnv(sizes), fnv(self.bucket_val[:self.p]), fnv(self.bucket_idx[:self.p]))
+
+
+# ------------------------------------------------------------------ SOG (sog/sog8.c)
+class SogTables:
+    """Caller-owned tables as main.c:495-515 allocates them."""
+
+    def __init__(self, p):
+        self.p = p
+        self.T8 = np.zeros(1 << 24, dtype=np.uint8)
+        self.scanner_hs = np.zeros(p, dtype=np.uint32)
+        self.scanner_index = np.zeros(p, dtype=np.int32)
+        self.scanner_hs2 = np.zeros(32 * 256, dtype=np.uint8)
+
+    def ptrs(self):
+        return (_ptr(self.T8, u8p), _ptr(self.scanner_hs, u32p), _ptr(self.scanner_index, i32p), _ptr(self.scanner_hs2, u8p))
+
+
+def oracle_sog8(pat_flat, p, text=None):
+    """-> (count or None, SogTables) from the restatement (2-level bitmap from the real hash)"""
+    t = SogTables(p)
+    arr, keep = _pattern_ptrs(pat_flat, 8, p, pad=0)
+    lib.ora_preproc_sog8(*t.ptrs(), arr, p)
+    cnt = None
+    if text is not None:
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        cnt = int(lib.ora_search_sog8(*t.ptrs(), arr, _ptr(text, u8p), len(text), p))
+    del keep
+    return cnt, t
+
+
+def ref_sog8(pat_flat, p, text, tabs):
+    """the reference's own preproc_sog8 + search_sog8 (count undefined: see ora_sog.c); fills `tabs`"""
+    r = ref()
+    r.ref_run_sog8.restype = C.c_ulonglong
+    r.ref_run_sog8.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, u32p, i32p, u8p]
+    pat_flat = np.ascontiguousarray(pat_flat, dtype=np.uint8)
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    return int(r.ref_run_sog8(_ptr(pat_flat, u8p), p, _ptr(text, u8p), len(text), *tabs.ptrs()))
 
 
 # ------------------------------------------------------------------ misc

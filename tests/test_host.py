@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     for hdr in ("smatcher.h", "smatcher_hip.h"):
         src = open(os.path.join(ROOT, "include", hdr)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        declared |= set(re.findall(r"\b((?:smh_|cuda_ac|cuda_wm|cuda_sh|cuda_sbom|preproc_|search_|free_ac|free_sh|free_sbom|preBmBc|wu_determine|fail)\w*)\s*\(", src))
+        declared |= set(re.findall(r"\b((?:smh_|cuda_ac|cuda_wm|cuda_sh|cuda_sbom|cuda_sog|preproc_|search_|free_ac|free_sh|free_sbom|preBmBc|wu_determine|fail)\w*)\s*\(", src))
     declared |= {"m_nBitsInShift", "shiftsize", "pointer_array"}
     assert declared >= set(S.LEGACY_SYMBOLS + S.EXT_SYMBOLS)
     for name in sorted(declared):
