@@ -265,15 +265,16 @@ struct smh_wm {
      * symbol are a pattern", bit 2 * pair + 1 = "... ending at the 9th symbol".  One LDS lookup (ds_read_b32)
      * answers two end columns.  64 KiB. */
     uint32_t *pair_table;
-    /* gram filter (q-gram shift-and; 128 KiB of LDS).  For every text column ONE table lookup yields a byte F
-     * whose bit 7-j says "the q-gram that ends here is the q-gram that ends j symbols before the end of some
-     * pattern" (plane j, j < gram_planes; the low 8 - gram_planes bits are always set), and the lane state
-     * T = ((T << 1) | 1) & F has bit 7 set exactly when the last gram_planes q-grams are in their planes in
+    /* gram filter (q-gram shift-or; 64 or 128 KiB of LDS).  For every text column ONE table lookup yields a byte G
+     * whose bit 7-j is CLEAR when "the q-gram that ends here is the q-gram that ends j symbols before the end of
+     * some pattern" (plane j, j < gram_planes; the low 8 - gram_planes bits are always clear), and the lane state
+     * S = (S << 1) | G has bit 7 clear exactly when the last gram_planes q-grams are in their planes in
      * order: the column is a candidate and goes to the verify table.  The idea of the reference's sog/sog8.c
      * (3-gram bit table T8, smatcher.h:77-80, shift-or state) with positional planes over the patterns' tail.
      *   SMH_GRAM_PAIR  alphabet 4: 7-symbol grams, table indexed by EIGHT consecutive symbols (16 bits), 16-bit
-     *                  entries: low byte = F of the older seven symbols' column, high byte = F of the next
-     *                  column -- one lookup serves two columns
+     *                  entries (G of the older seven symbols' column << 1) | G of the next column -- one lookup
+     *                  and ONE v_lshl_or serve two columns; behind the 128 KiB image, 16 KiB of per-gram bytes G for
+     *                  the bounds-checked path (never staged in LDS)
      *   SMH_GRAM_OCT   alphabet 4: 8-symbol grams, 8-bit entries indexed by the gram, one lookup per column: for
      *                  pattern counts at which the 7-symbol planes fill up (8000 patterns: 39 % full, and
      *                  overlapping grams pass together: 0.4 % of the columns survive eight planes; the 8-symbol

@@ -158,24 +158,24 @@ static double gram_survivors(int kind, const void *tab, int alphabet)
 {
     enum { COLS = 1 << 18 };
     uint64_t seed = 0x5EEDull, hits = 0;
-    uint32_t T = 0, code = 0, k0 = 0, k1 = 0;
+    uint32_t S = ~0u, code = 0, k0 = 0, k1 = 0;
     for (int x = 0; x < COLS; ++x) {
         const uint32_t c = (uint32_t)(gram_rng(&seed) % (uint64_t)alphabet);
-        uint32_t F;
+        uint32_t G;
         if (kind == SMH_GRAM_PAIR) {
             code = ((code << 2) | c) & 0x3FFFu;                     /* the 7 symbols ending here */
-            F = ((const uint16_t *)tab)[code << 2] & 0xFFu;
+            G = ((const uint8_t *)tab)[SMH_GRAM_BYTES + code];      /* the per-gram bytes behind the LDS image */
         } else if (kind == SMH_GRAM_OCT) {
             code = ((code << 2) | c) & 0xFFFFu;
-            F = ((const uint8_t *)tab)[code];
+            G = ((const uint8_t *)tab)[code];
         } else {
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
             k0 = k1;
             k1 = c;
-            F = ((const uint8_t *)tab)[(uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15];
+            G = ((const uint8_t *)tab)[(uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15];
         }
-        T = ((T << 1) | 1u) & F;
-        if (x >= 16) hits += (T >> 7) & 1u;
+        S = (S << 1) | G;                                           /* shift-or: bit 7 clear = candidate */
+        if (x >= 16) hits += ((S >> 7) & 1u) ^ 1u;
     }
     return (double)hits / (double)(COLS - 16);
 }
@@ -209,23 +209,24 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
         /* 7-symbol grams; planes 0 .. J-1 need the gram that ends j before the end to start at >= 0 */
         int J = m - 6;
         if (J > 8) J = 8;
-        uint8_t *f7 = (uint8_t *)malloc(16384);
-        uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES);
-        if (!f7 || !tab) { free(f7); free(tab); return -1; }
-        memset(f7, (1 << (8 - J)) - 1, 16384);
+        /* LDS image (128 KiB of 16-bit entries) + the per-gram bytes G (16 KiB, HBM only: bounds-checked path) */
+        uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES + 16384);
+        if (!tab) return -1;
+        uint8_t *g7 = (uint8_t *)tab + SMH_GRAM_BYTES;
+        memset(g7, 0xFF & ~((1 << (8 - J)) - 1), 16384); /* bit 7-j SET = the gram is NOT in plane j; unused planes clear */
         for (int p = 0; p < d; ++p)
             for (int j = 0; j < J; ++j) {
                 const unsigned char *g = pats + (size_t)p * m + (m - 7 - j);
                 uint32_t code = 0;
                 for (int i = 0; i < 7; ++i) code = (code << 2) | g[i];
-                f7[code] |= (uint8_t)(1u << (7 - j));
+                g7[code] &= (uint8_t)~(1u << (7 - j));
             }
-        for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(f7[x >> 2] | ((uint32_t)f7[x & 0x3FFFu] << 8));
-        free(f7);
+        /* entry of eight symbols = (G of the older seven << 1) | G of the newer seven: one v_lshl_or does both columns */
+        for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(((uint32_t)g7[x >> 2] << 1) | g7[x & 0x3FFFu]);
         const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4), ms = 0.205 + SMH_GRAM_VERIFY_MS(m) * dens;
         if (ms < best_ms) {
             free(best);
-            best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
+            best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES + 16384; best_ms = ms; best_dens = dens;
         } else {
             free(tab);
         }
@@ -235,13 +236,13 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
         if (J > 8) J = 8;
         uint8_t *tab = (uint8_t *)malloc(65536);
         if (!tab) { free(best); return -1; }
-        memset(tab, (1 << (8 - J)) - 1, 65536);
+        memset(tab, 0xFF & ~((1 << (8 - J)) - 1), 65536);
         for (int p = 0; p < d; ++p)
             for (int j = 0; j < J; ++j) {
                 const unsigned char *g = pats + (size_t)p * m + (m - 8 - j);
                 uint32_t code = 0;
                 for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
-                tab[code] |= (uint8_t)(1u << (7 - j));
+                tab[code] &= (uint8_t)~(1u << (7 - j));
             }
         const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4), ms = 0.30 + SMH_GRAM_VERIFY_MS(m) * dens;
         if (ms < best_ms) {
@@ -256,13 +257,13 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
         if (J > 8) J = 8;
         uint8_t *tab = (uint8_t *)malloc(SMH_GRAM_BYTES);
         if (!tab) { free(best); return -1; }
-        memset(tab, (1 << (8 - J)) - 1, SMH_GRAM_BYTES);
+        memset(tab, 0xFF & ~((1 << (8 - J)) - 1), SMH_GRAM_BYTES);
         for (int p = 0; p < d; ++p)
             for (int j = 0; j < J; ++j) {
                 const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
                 const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
                 const uint32_t idx = (uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15; /* low 32 bits of the product, top 17 */
-                tab[idx] |= (uint8_t)(1u << (7 - j));
+                tab[idx] &= (uint8_t)~(1u << (7 - j));
             }
         const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet), ms = 0.33 + SMH_GRAM_VERIFY_MS(m) * dens;
         if (ms < best_ms) {
@@ -594,7 +595,7 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->lds_bytes = (uint32_t)(((size_t)1 << wm->filter_log2) / 8);
     out->scan_engine = wm->alt_ac && !wm->alt_off ? SMH_ALGO_AC : SMH_ALGO_WM;
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
-    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_bytes;
+    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : SMH_GRAM_BYTES;
     return SMH_OK;
 }
 

@@ -43,6 +43,7 @@ struct smh_wm_params {
      * patterns' last min-length symbols, and a surviving column is verified once per length class */
     int n_classes;                       /* 0 = a single-length set: verify / pat_sorted above */
     const struct smh_wm_class *classes;  /* HBM */
+    const uint8_t *gram_g7;              /* HBM: pair-gram filter only, the byte G of every 7-symbol gram (bounds-checked path) */
 };
 
 #define SMH_WM_MAX_CLASSES 32 /* distinct lengths of a mixed-length set scanned in one pass */
@@ -722,17 +723,19 @@ SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, const smh_chunk_sched &S,
     return cnt;
 }
 
-/* ------------------------------------------------------------------ gram filter (q-gram shift-and)
+/* ------------------------------------------------------------------ gram filter (q-gram shift-or)
  * smh_internal.h "gram filter" describes the tables.  A lane owns the 64 END columns of its segment, keeps the
- * shift-and state T in one register and never looks back further than the q-1 symbols in front of the segment
- * (they come out of the previous lane's registers, as in the pair kernel): the state it would have inherited
- * from the columns before the segment is ASSUMED all-alive, and the first seven candidate bits are corrected
- * afterwards with the previous lane's final state (one DPP move) -- bit 6-t of that state is exactly the
- * factor the assumption replaced in column t.  Lane 0 of a wave has no neighbour and keeps the assumption: a
- * few more columns reach the verify stage, which is exact, so the count does not change.
- * The state register also carries the candidate flags: table bytes are OR-ed with 0xFFFFFF00 before the AND, so
- * bit 7 (candidate) just keeps shifting up and 24 columns' flags are collected with one bit-reverse. */
-#define SMH_GRAM_KEEP 0xFFFFFF00u
+ * shift-or state S in one register (bit b CLEAR = "the last b+1 grams are in planes b .. 0 in order"; a column is a
+ * candidate when bit 7 is clear after its step) and never looks back further than the q-1 symbols in front of the
+ * segment (they come out of the previous lane's registers, as in the pair kernel): the state it would have
+ * inherited from the columns before the segment is ASSUMED all-alive (low seven bits clear), and the first seven
+ * candidate bits are corrected afterwards with the previous lane's final state (one DPP move) -- bit 6-t of that
+ * state is exactly the term the assumption replaced in column t.  Lane 0 of a wave has no neighbour and keeps the
+ * assumption: a few more columns reach the verify stage, which is exact, so the count does not change.
+ * One column costs ONE v_lshl_or_b32: S = (S << 1) | G with G the table byte (zero-extended by ds_read_u8), so the
+ * candidate bits just keep shifting up the register and 24 columns' flags are collected with one bit-reverse.  The
+ * pair form does TWO columns with one v_lshl_or_b32: its 16-bit entry is (G_first << 1) | G_second. */
+#define SMH_GRAM_S0 0xFFFFFF80u /* no candidates behind, all seven inherited terms alive */
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 SMH_LANE uint32_t smh_lds_u8(const void *, uint32_t byte_off)
@@ -752,14 +755,16 @@ SMH_LANE uint32_t smh_bitrev32(uint32_t v)
 SMH_LANE uint32_t smh_mul24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }
 #endif
 
-/* one column of the recurrence; F = the table byte (bits above 7 ignored) */
-SMH_LANE uint32_t smh_gram_step(uint32_t T, uint32_t F) { return ((T << 1) | 1u) & (F | SMH_GRAM_KEEP); }
+/* one column of the recurrence; G = the table byte (zero-extended) */
+SMH_LANE uint32_t smh_gram_step(uint32_t S, uint32_t G) { return (S << 1) | G; }
+/* two columns; E = (G of the first << 1) | G of the second */
+SMH_LANE uint32_t smh_gram_step2(uint32_t S, uint32_t E) { return (S << 2) | E; }
 
-/* candidate flags of the last `cols` (<= 24) columns, bit c = the c-th of them (oldest first) */
-SMH_LANE uint32_t smh_gram_flags(uint32_t T, int cols)
+/* candidate flags of the last `cols` (<= 24) columns, bit c SET = the c-th of them (oldest first) is a candidate */
+SMH_LANE uint32_t smh_gram_flags(uint32_t S, int cols)
 {
-    /* after the group's last column, bit 7 + t of T is the flag of the column t before it */
-    return (smh_bitrev32(T) >> (25 - cols)) & ((1u << cols) - 1u);
+    /* after the group's last column, bit 7 + t of S is the (inverted) flag of the column t before it */
+    return (smh_bitrev32(~S) >> (25 - cols)) & ((1u << cols) - 1u);
 }
 
 /* byte-gram key of column i of the segment: the three bytes that end there, as the low 24 bits of a dword.
@@ -788,35 +793,35 @@ SMH_LANE void smh_gram_byte_columns(const uint32_t (&w)[16], uint32_t pre, const
      ...);
 }
 
-/* state the lane would have inherited from the columns in front of its segment (low 7 bits), true value:
- * the CPU emulation and the bounds-checked path compute it by running the recurrence over those columns */
+/* state the lane would have inherited from the columns in front of its segment (low 7 bits, 0 = alive), true
+ * value: the CPU emulation and the bounds-checked path compute it by running the recurrence over those columns.
+ * `tab` = the LDS image; `g7` = the pair form's per-gram bytes in HBM (smh_wm_params::gram_g7). */
 template <int KIND>
-SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const void *tab)
+SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const void *tab, const uint8_t *g7)
 {
-    uint32_t T = 0x7Fu;
+    uint32_t S = 0u;
     if (KIND == 3) {
-        if (a < 15) return T;
+        if (a < 15) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
             uint32_t code = 0;
             for (int i = 7; i >= 0; --i) code = (code << 2) | (text[x - (uint64_t)i] & 3u);
-            T = smh_gram_step(T, smh_lds_u8(tab, code));
+            S = smh_gram_step(S, smh_lds_u8(tab, code));
         }
     } else if (KIND == 1) {
-        if (a < 14) return T; /* columns without seven symbols in front of them: keep the assumption (superset) */
+        if (a < 14) return S; /* columns without seven symbols in front of them: keep the assumption (superset) */
         for (uint64_t x = a - 7; x < a; ++x) {
             uint32_t code = 0;
             for (int i = 6; i >= 0; --i) code = (code << 2) | (text[x - (uint64_t)i] & 3u);
-            /* F of the 7-gram ending at x is the LOW byte of any entry whose older seven symbols are that gram */
-            T = smh_gram_step(T, smh_lds_u16(tab, (code << 2) << 1) & 0xFFu);
+            S = smh_gram_step(S, g7[code]);
         }
     } else {
-        if (a < 10) return T;
+        if (a < 10) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
             const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
-            T = smh_gram_step(T, smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15));
+            S = smh_gram_step(S, smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15));
         }
     }
-    return T & 0x7Fu;
+    return S & 0x7Fu;
 }
 
 /* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
@@ -825,11 +830,12 @@ template <int KIND, bool POS>
 SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&edge)[2],
                                     const void *tab, const smh_wm_params &P, smh_wm_queue &Q)
 {
-    uint32_t T = 0x7Fu, fl[3] = {0, 0, 0};
+    uint32_t T = SMH_GRAM_S0, fl[3] = {0, 0, 0};
     const uint32_t pre0 = smh_prev_lane_word(w[14], edge[0], text, a - 8u);
     const uint32_t pre1 = smh_prev_lane_word(w[15], edge[1], text, a - 4u);
     if constexpr (KIND == 1) {
-        /* rolling code * 2 (16-bit entries) of the last eight symbols; primed with the eight in front */
+        /* rolling code * 2 (16-bit entries) of the last eight symbols; primed with the eight in front.  Per PAIR
+         * of columns: v_bfe + v_lshl_or (code), v_and (address), ds_read_u16, v_lshl_or (both columns' steps). */
         uint32_t code2 = 0;
         {
             const uint32_t x0 = (pre0 << 10) | pre0, x1 = (pre1 << 10) | pre1;
@@ -843,10 +849,9 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
             const uint32_t x = (w[q] << 10) | w[q]; /* pair codes * 2 at bits 7..11 and 23..27 (ac_lane.h smh_fmt_s2) */
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                code2 = (code2 << 4) | smh_bfe(x, k == 0 ? 7 : 23, 5);
-                const uint32_t e = smh_lds_u16(tab, code2 & 0x1FFFEu);
-                T = smh_gram_step(T, e);      /* column a + 4q + 2k     : low byte  */
-                T = smh_gram_step(T, e >> 8); /* column a + 4q + 2k + 1 : high byte */
+                /* the code is kept masked, so it IS the byte address: v_bfe, v_lshlrev, v_and_or per lookup */
+                code2 = ((code2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
+                T = smh_gram_step2(T, smh_lds_u16(tab, code2)); /* columns a + 4q + 2k and + 1 */
             }
             if (q == 5) fl[0] = smh_gram_flags(T, 24);
             if (q == 11) fl[1] = smh_gram_flags(T, 24);
@@ -884,11 +889,11 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     /* correct the first seven columns with the state the previous lane ended in */
     uint32_t prevT;
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-    prevT = (uint32_t)__builtin_amdgcn_update_dpp((int)0x7F, (int)T, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    prevT = (uint32_t)__builtin_amdgcn_update_dpp((int)SMH_GRAM_S0, (int)T, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #else
-    prevT = smh_gram_state_before<KIND>(text, a, tab);
+    prevT = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7);
 #endif
-    const uint32_t fix7 = smh_bitrev32(prevT & 0x7Fu) >> 25; /* bit t = bit 6-t of the inherited state */
+    const uint32_t fix7 = smh_bitrev32(~prevT & 0x7Fu) >> 25; /* bit t SET = bit 6-t of the inherited state alive */
     uint64_t msk = (uint64_t)((fl[0] & (fix7 | ~0x7Fu)) | (fl[1] << 24)) | ((uint64_t)(fl[1] >> 8) << 32) | ((uint64_t)fl[2] << 48);
     while (SMH_WAVE_ANY(msk != 0)) {
         if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
@@ -910,25 +915,25 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     uint64_t end = a + SMH_SEG;
     if (end > n) end = n;
     const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
-    uint32_t T = smh_gram_state_before<KIND>(text, a, tab), cnt = 0;
+    uint32_t T = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7), cnt = 0;
     for (uint64_t e = a; e < end; ++e) {
-        uint32_t F = 0xFFu; /* a column without a whole gram in front of it cannot be ruled out */
+        uint32_t G = 0u; /* a column without a whole gram in front of it cannot be ruled out */
         if (e + 1 >= q) {
             if (KIND == 3) {
                 uint32_t code = 0;
                 for (int i = 7; i >= 0; --i) code = (code << 2) | (text[e - (uint64_t)i] & 3u);
-                F = smh_lds_u8(tab, code);
+                G = smh_lds_u8(tab, code);
             } else if (KIND == 1) {
                 uint32_t code = 0;
                 for (int i = 6; i >= 0; --i) code = (code << 2) | (text[e - (uint64_t)i] & 3u);
-                F = smh_lds_u16(tab, (code << 2) << 1) & 0xFFu;
+                G = P.gram_g7[code];
             } else {
                 const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
-                F = smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15);
+                G = smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15);
             }
         }
-        T = smh_gram_step(T, F);
-        if (((T >> 7) & 1u) && e + 1 >= (uint64_t)P.m) {
+        T = smh_gram_step(T, G);
+        if (!((T >> 7) & 1u) && e + 1 >= (uint64_t)P.m) {
             const uint32_t hit = smh_wm_verify(text, e, P);
             cnt += hit;
             if (match_mask && hit) *match_mask |= 1ull << (e - a);

@@ -171,7 +171,7 @@ static int g_emu_n_classes = 0;
 template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
 static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po = nullptr)
 {
-    smh_wm_params P;
+    smh_wm_params P = {};
     P.m = wm->m;
     P.bits = wm->bits_per_symbol;
     const int wbits = wm->block_symbols * wm->bits_per_symbol;
@@ -195,7 +195,7 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     return total;
 }
 
-/* gram filter (q-gram shift-and): same lane code, true inherited states instead of the DPP correction */
+/* gram filter (q-gram shift-or): same lane code, true inherited states instead of the DPP correction */
 static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po)
 {
     smh_wm_params P = {};
@@ -207,6 +207,7 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     std::vector<uint8_t> padded((size_t)wm->distinct * row + 16, 0);
     for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);
     P.pat_sorted = padded.data();
+    P.gram_g7 = wm->gram_kind == SMH_GRAM_PAIR ? (const uint8_t *)wm->gram_table + SMH_GRAM_BYTES : nullptr;
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t) {

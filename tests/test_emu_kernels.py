@@ -121,3 +121,32 @@ def test_grid_size_does_not_change_the_count():
     for blocks in (1, 2, 5, 16):
         assert E.ac_scan(ac, text, 0, blocks) == vec["count_ac"]
         assert E.wm_scan(wm, text, 0, blocks) == vec["count_ac"]
+
+
+@pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 33, 50), (3, 4, 11, 200), (3, 4, 16, 2000),
+                                            (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
+                                            (2, 128, 7, 100)])
+def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
+    """The three q-gram shift-or forms (symbol pairs, 8-symbol grams, hashed byte grams), each forced with the
+    development knob so the test does not depend on the cost model: random text with planted occurrences,
+    including ones that straddle segment / wave-chunk boundaries and the text's first and last columns."""
+    monkeypatch.setenv("SMH_WM_TUNE", "gram=%d" % kind)
+    rng = np.random.RandomState(1000 * kind + m)
+    n = 3 * 4096 + 777
+    text = rng.randint(0, sigma, size=n).astype(np.uint8)
+    pat = rng.randint(0, sigma, size=(p, m)).astype(np.uint8)
+    for i, off in enumerate([0, 300, 640 - m // 2, 4096 - m // 2, 8191, 8192 + 2 * m + 64, n - m]):
+        if 0 <= off <= n - m:
+            text[off:off + m] = pat[(7 * i) % p]
+    pat[p // 2] = pat[0]  # a duplicate pattern: a column is counted once
+    wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
+    info = wm.info()
+    assert info.gram_planes == min(8, m - {1: 6, 3: 7, 2: 2}[kind])
+    if info.scan_engine != S.ALGO_WM:
+        wm.set_scan_engine(S.ALGO_WM)
+    want = O.count_bruteforce(pat.reshape(-1), m, p, text)
+    assert want >= 7
+    for blocks in (1, 3):
+        assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want
+    total, pos = E.wm_positions(wm, text, want + 8, 2)
+    assert total == want and len(set(pos.tolist())) == want

@@ -14,6 +14,8 @@ st = torch.cuda.current_stream().cuda_stream
 S.lib.smh_corpus_text_device(C.c_void_p(text.data_ptr()), n, 0, 42, sigma, C.c_void_p(st))
 pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
 wm = S.WmTables.from_patterns(pat, m, p, sigma)
+if "gram=" in os.environ.get("SMH_WM_TUNE", "") and wm.info().scan_engine != S.ALGO_WM:
+    wm.set_scan_engine(S.ALGO_WM)  # time this path's own kernels, not the automaton engine
 i = wm.info()
 cnt = torch.zeros(1, dtype=torch.int64, device=dev)
 for _ in range(2):
@@ -25,5 +27,5 @@ for _ in range(7):
     cnt.zero_(); a.record(); wm.scan_device(text.data_ptr(), n, cnt.data_ptr(), variant, st); b.record()
     torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 ts.sort()
-print("WM sigma=%d m=%d p=%d %d MiB variant=%d W=%d T=%d exact=%d hashed=%d: median %.4f ms %.0f GB/s  count %d"
-      % (sigma, m, p, mib, variant, i.block_symbols, i.filter_log2, i.filter_exact, i.filter_hashed, ts[3], n / ts[3] / 1e6, int(cnt.item())))
+print("WM sigma=%d m=%d p=%d %d MiB variant=%d W=%d T=%d exact=%d hashed=%d planes=%d engine=%d: median %.4f ms %.0f GB/s  count %d"
+      % (sigma, m, p, mib, variant, i.block_symbols, i.filter_log2, i.filter_exact, i.filter_hashed, i.gram_planes, i.scan_engine, ts[3], n / ts[3] / 1e6, int(cnt.item())))
