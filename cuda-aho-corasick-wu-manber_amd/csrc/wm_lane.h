@@ -76,17 +76,14 @@ SMH_LANE uint32_t smh_wm_mix(uint32_t h, uint32_t v)
     return h ^ (h >> 15);
 }
 
-/* device HASH/PREFIX stage: is text[e-m+1 .. e] one of the patterns?  Three dependent memory
- * phases (window dwords, one table slot, pattern dwords) instead of byte loops.  Kept small on
- * purpose: it is inlined into the scan kernel and must not raise its register pressure. */
-SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_params &P)
+/* second half of the device HASH/PREFIX stage: the bucket walk for a window whose hash `tag` is known.  The pattern
+ * bytes are compared with the text in HBM (reached by true matches and one false tag in ~1000 probes only). */
+SMH_LANE uint32_t smh_wm_probe(const uint8_t *text, uint64_t e, uint32_t tag, const smh_wm_params &P)
 {
     const uint64_t s0 = e + 1 - (uint64_t)P.m;
     const uint32_t *aligned = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
     const uint32_t shift_bits = (uint32_t)(s0 & 3u) * 8u;
     const int nd = (P.m + 3) >> 2;
-    uint32_t tag = 0x811C9DC5u;
-    for (int j = 0; j < nd; ++j) tag = smh_wm_mix(tag, smh_window_dword(aligned, shift_bits, j, P.m));
     uint32_t b = (tag * SMH_WM_HASH_MUL) >> (32 - (P.verify_log2 - 2)); /* bucket of four slots */
     const uint32_t bmask = (1u << (P.verify_log2 - 2)) - 1u;
     for (;;) {
@@ -104,6 +101,44 @@ SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_pa
         if (q4.v[3] == 0) return 0; /* slots fill in order: a bucket with a free slot ends the search */
         b = (b + 1) & bmask;
     }
+}
+
+/* device HASH/PREFIX stage: is text[e-m+1 .. e] one of the patterns?  Three dependent memory
+ * phases (window dwords, one table slot, pattern dwords) instead of byte loops.  Kept small on
+ * purpose: it is inlined into the scan kernel and must not raise its register pressure. */
+SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_params &P)
+{
+    const uint64_t s0 = e + 1 - (uint64_t)P.m;
+    const uint32_t *aligned = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
+    const uint32_t shift_bits = (uint32_t)(s0 & 3u) * 8u;
+    const int nd = (P.m + 3) >> 2;
+    uint32_t tag = 0x811C9DC5u;
+    for (int j = 0; j < nd; ++j) tag = smh_wm_mix(tag, smh_window_dword(aligned, shift_bits, j, P.m));
+    return smh_wm_probe(text, e, tag, P);
+}
+
+/* The same hash from a STAGED copy of the text (LDS on the GPU): `rd(off)` returns the aligned dword at byte offset
+ * `off` of a buffer that holds the bytes around the window, `s0` = offset of the window's first byte in it.  One
+ * aligned dword past the window's last is read (and shifted or masked away), so the buffer is padded. */
+template <typename RD>
+SMH_LANE uint32_t smh_wm_tag_staged(RD rd, uint32_t s0, int m)
+{
+    const uint32_t a0 = s0 & ~3u, sh = (s0 & 3u) * 8u;
+    const int nd = (m + 3) >> 2;
+    uint32_t tag = 0x811C9DC5u, lo = rd(a0);
+    for (int j = 0; j < nd; ++j) {
+        const uint32_t hi = rd(a0 + 4u * (uint32_t)(j + 1));
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        uint32_t v = __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+        uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+        const int rest = m - 4 * j;
+        if (rest < 4) v &= (1u << (8 * rest)) - 1u;
+        tag = smh_wm_mix(tag, v);
+        lo = hi;
+    }
+    return tag;
 }
 
 /* one length class of a mixed-length set: is text[e-m_c+1 .. e] one of the class's patterns? */
@@ -197,19 +232,14 @@ SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh
 /* Two windows at once: the stage is three DEPENDENT memory round trips (window dwords, table slot,
  * pattern dwords) and a wave has nothing else to do while it waits, so a second independent chain
  * per lane hides about half of that latency.  Same result as two smh_wm_verify calls. */
-SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, const smh_wm_params &P, uint32_t &r1)
+SMH_LANE uint32_t smh_wm_probe2(const uint8_t *text, uint64_t e0, uint64_t e1, uint32_t tag0, uint32_t tag1,
+                                const smh_wm_params &P, uint32_t &r1)
 {
     const uint64_t b0 = e0 + 1 - (uint64_t)P.m, b1 = e1 + 1 - (uint64_t)P.m;
     const uint32_t *al0 = reinterpret_cast<const uint32_t *>(text + (b0 & ~(uint64_t)3));
     const uint32_t *al1 = reinterpret_cast<const uint32_t *>(text + (b1 & ~(uint64_t)3));
     const uint32_t sh0 = (uint32_t)(b0 & 3u) * 8u, sh1 = (uint32_t)(b1 & 3u) * 8u;
     const int nd = (P.m + 3) >> 2;
-    uint32_t tag0 = 0x811C9DC5u, tag1 = 0x811C9DC5u;
-    for (int j = 0; j < nd; ++j) {
-        const uint32_t v0 = smh_window_dword(al0, sh0, j, P.m), v1 = smh_window_dword(al1, sh1, j, P.m);
-        tag0 = smh_wm_mix(tag0, v0);
-        tag1 = smh_wm_mix(tag1, v1);
-    }
     const uint32_t bshift = 32u - (uint32_t)(P.verify_log2 - 2), bmask = (1u << (P.verify_log2 - 2)) - 1u;
     uint32_t b0q = (tag0 * SMH_WM_HASH_MUL) >> bshift, b1q = (tag1 * SMH_WM_HASH_MUL) >> bshift;
     uint32_t r0 = 0;
@@ -252,13 +282,44 @@ SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, 
     return r0;
 }
 
+SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, const smh_wm_params &P, uint32_t &r1)
+{
+    const uint64_t b0 = e0 + 1 - (uint64_t)P.m, b1 = e1 + 1 - (uint64_t)P.m;
+    const uint32_t *al0 = reinterpret_cast<const uint32_t *>(text + (b0 & ~(uint64_t)3));
+    const uint32_t *al1 = reinterpret_cast<const uint32_t *>(text + (b1 & ~(uint64_t)3));
+    const uint32_t sh0 = (uint32_t)(b0 & 3u) * 8u, sh1 = (uint32_t)(b1 & 3u) * 8u;
+    const int nd = (P.m + 3) >> 2;
+    uint32_t tag0 = 0x811C9DC5u, tag1 = 0x811C9DC5u;
+    for (int j = 0; j < nd; ++j) {
+        const uint32_t v0 = smh_window_dword(al0, sh0, j, P.m), v1 = smh_window_dword(al1, sh1, j, P.m);
+        tag0 = smh_wm_mix(tag0, v0);
+        tag1 = smh_wm_mix(tag1, v1);
+    }
+    return smh_wm_probe2(text, e0, e1, tag0, tag1, P, r1);
+}
+
 #define SMH_WM_QCAP 128u /* END columns per wave, 1 KiB of LDS behind the filter */
 struct smh_wm_queue {
     uint64_t *slots; /* SMH_WM_QCAP entries, private to this wave (LDS on the GPU) */
     uint32_t count;  /* wave-uniform */
     uint32_t matches;
     const smh_pos_out *po; /* positions mode: verified columns are appended here; else NULL */
+    /* staged verify (gram kernels with STG > 0, below): LDS byte offsets of the lock words, the staging buffers and
+     * this wave's list of surviving columns; number of buffers; entries in the list */
+    uint32_t st_locks, st_bufs, st_list, st_nbufs, st_count;
 };
+
+/* ---- staged verify: the window hash of a surviving column is computed from an ON-CHIP copy of the wave-chunk.
+ * Re-reading the window from HBM costs one 128-byte line per surviving column -- with 100 000 byte patterns 0.75 %
+ * of the columns survive any filter that fits LDS, which was 2.2x the algorithmic HBM traffic and three dependent
+ * memory round trips per drain.  Here the wave copies its 4 KiB chunk (plus 16*STG bytes in front of it) from its
+ * registers into a staging buffer in LDS, every lane takes one surviving column (compacted list, 16-bit chunk
+ * offsets), reads the window's dwords from the buffer at a per-lane address -- the dynamic indexing registers do not
+ * offer -- and hashes them; only the bucket probe (L2-resident table) and, for a matching tag, the final compare
+ * leave the CU.  The table fills LDS, so the workgroup's 16 waves share SMH_STAGE_BUFS buffers through try-locks (a
+ * buffer is held for two LDS round trips; whoever holds one never waits for anything else). */
+#define SMH_STAGE_LIST 128u            /* surviving columns per wave between flushes (16-bit entries) */
+#define SMH_STAGE_BUF(STG) (16u * (STG) + 4096u + 16u)
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
@@ -824,15 +885,114 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
     return S & 0x7Fu;
 }
 
+/* ---- staged verify, wave level (description above smh_wm_queue's SMH_STAGE_* constants) ---- */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+typedef uint32_t smh_lds_v4 __attribute__((ext_vector_type(4)));
+SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    *reinterpret_cast<__attribute__((address_space(3))) smh_lds_v4 *>(byte_off) = smh_lds_v4{a, b, c, d};
+}
+SMH_LANE void smh_lds_store_u16(uint32_t byte_off, uint32_t v)
+{
+    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(byte_off) = (uint16_t)v;
+}
+
+/* append the chunk offset `c` (0 .. 4095) of one surviving column per lane with `cond`; the caller flushes first
+ * whenever fewer than 64 list entries are free */
+SMH_LANE void smh_wm_stage_emit(smh_wm_queue &Q, bool cond, uint32_t c)
+{
+    const uint64_t mask = __ballot(cond);
+    if (mask == 0) return;
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (cond) smh_lds_store_u16(Q.st_list + 2u * (Q.st_count + before), c);
+    Q.st_count += (uint32_t)__popcll(mask);
+}
+
+/* verify every listed column of the wave-chunk at `chunk_base` whose text the lanes hold in w (and the 16*STG
+ * bytes in front of it in `halo`, wave-uniform); all 64 lanes must call it */
+template <int STG>
+SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, const uint32_t (&w)[16],
+                                 const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
+{
+    if (Q.st_count == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr uint32_t HALO = 16u * STG, BUF = SMH_STAGE_BUF(STG);
+    /* take a staging buffer: lane 0 tries the lock words in turn, starting at a wave-dependent one */
+    uint32_t i = (threadIdx.x >> 6) % Q.st_nbufs;
+    for (;;) {
+        uint32_t got = 0;
+        if (lane == 0) {
+            uint32_t expected = 0u;
+            got = __hip_atomic_compare_exchange_strong(
+                      reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), &expected, 1u,
+                      __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+        }
+        if (__builtin_amdgcn_readfirstlane((int)got)) break;
+        i = i + 1u == Q.st_nbufs ? 0u : i + 1u;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const uint32_t buf = Q.st_bufs + i * BUF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) smh_lds_store16(buf + HALO + lane * 64u + 16u * q, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+#pragma unroll
+    for (int q = 0; q < STG; ++q)
+        if (lane == (uint32_t)q) smh_lds_store16(buf + 16u * q, halo[4 * q], halo[4 * q + 1], halo[4 * q + 2], halo[4 * q + 3]);
+    /* lane l hashes the windows of entries l and l + 64 (the list holds at most 128) */
+    const bool h0 = lane < Q.st_count, h1 = lane + 64u < Q.st_count;
+    const uint32_t c0 = smh_lds_u16(nullptr, Q.st_list + 2u * (h0 ? lane : 0u));
+    auto rd = [&](uint32_t off) { return smh_lds_u32(nullptr, buf + off); };
+    const uint32_t tag0 = smh_wm_tag_staged(rd, c0 + HALO + 1u - (uint32_t)P.m, P.m);
+    uint32_t c1 = c0, tag1 = tag0;
+    if (Q.st_count > 64u) { /* wave-uniform */
+        c1 = smh_lds_u16(nullptr, Q.st_list + 2u * (h1 ? lane + 64u : 0u));
+        tag1 = smh_wm_tag_staged(rd, c1 + HALO + 1u - (uint32_t)P.m, P.m);
+    }
+    /* hand the buffer back: the release waits for the window reads above, nothing else */
+    if (lane == 0)
+        __hip_atomic_store(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), 0u,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint64_t e0 = chunk_base + c0, e1 = chunk_base + c1;
+    uint32_t r0, r1 = 0;
+    if (Q.st_count > 64u)
+        r0 = smh_wm_probe2(text, e0, e1, tag0, tag1, P, r1);
+    else
+        r0 = smh_wm_probe(text, e0, tag0, P);
+    Q.matches += (h0 ? r0 : 0u) + (h1 ? r1 : 0u);
+    if (Q.po) {
+        smh_append_bits(h0 ? r0 : 0u, e0, *Q.po);
+        if (Q.st_count > 64u) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
+    }
+    Q.st_count = 0;
+}
+#else
+/* CPU emulation (one lane at a time): the same window hash over a private copy of the chunk laid out as the
+ * staging buffer, the same probe */
+template <int STG>
+SMH_LANE void smh_wm_stage_verify_emu(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint32_t c, const smh_wm_params &P)
+{
+    constexpr uint32_t HALO = 16u * STG;
+    uint8_t buf[SMH_STAGE_BUF(STG)];
+    memset(buf, 0xA5, sizeof buf); /* the pad is never part of a hash */
+    memcpy(buf, text + chunk_base - HALO, HALO + 4096u);
+    auto rd = [&](uint32_t off) { uint32_t v; memcpy(&v, buf + off, 4); return v; };
+    const uint32_t tag = smh_wm_tag_staged(rd, c + HALO + 1u - (uint32_t)P.m, P.m);
+    const uint32_t hit = smh_wm_probe(text, chunk_base + c, tag, P);
+    Q.matches += hit;
+    if (hit && Q.po) smh_append_bits(1u, chunk_base + c, *Q.po);
+}
+#endif
+
 /* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
  * `edge` = the 8 bytes in front of the wave-chunk (wave-uniform).  Returns nothing: candidates go to the queue. */
-template <int KIND, bool POS>
-SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&edge)[2],
+template <int KIND, bool POS, int STG = 0>
+SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&halo)[STG > 0 ? 4 * STG : 4],
                                     const void *tab, const smh_wm_params &P, smh_wm_queue &Q)
 {
+    /* halo = the 16 * max(STG, 1) bytes in front of the wave-chunk (wave-uniform); its last two dwords prime lane 0 */
+    constexpr int HD = STG > 0 ? 4 * STG : 4;
     uint32_t T = SMH_GRAM_S0, fl[3] = {0, 0, 0};
-    const uint32_t pre0 = smh_prev_lane_word(w[14], edge[0], text, a - 8u);
-    const uint32_t pre1 = smh_prev_lane_word(w[15], edge[1], text, a - 4u);
+    const uint32_t pre0 = smh_prev_lane_word(w[14], halo[HD - 2], text, a - 8u);
+    const uint32_t pre1 = smh_prev_lane_word(w[15], halo[HD - 1], text, a - 4u);
     if constexpr (KIND == 1) {
         /* rolling code * 2 (16-bit entries) of the last eight symbols; primed with the eight in front.  Per PAIR
          * of columns: v_bfe + v_lshl_or (code), v_and (address), ds_read_u16, v_lshl_or (both columns' steps). */
@@ -895,12 +1055,34 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
 #endif
     const uint32_t fix7 = smh_bitrev32(~prevT & 0x7Fu) >> 25; /* bit t SET = bit 6-t of the inherited state alive */
     uint64_t msk = (uint64_t)((fl[0] & (fix7 | ~0x7Fu)) | (fl[1] << 24)) | ((uint64_t)(fl[1] >> 8) << 32) | ((uint64_t)fl[2] << 48);
+    if constexpr (STG > 0) {
+        /* staged verify: list the surviving columns of this chunk, hash their windows from an LDS copy of it */
+        if (!SMH_WAVE_ANY(msk != 0)) return;
+        const uint64_t chunk_base = smh_uniform64(a & ~(uint64_t)4095);
+        const uint32_t in_chunk = (uint32_t)(a & 4095u);
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        do {
+            if (Q.st_count + 64u > SMH_STAGE_LIST) smh_wm_stage_flush<STG>(Q, text, chunk_base, w, halo, P);
+            const bool have = msk != 0;
+            const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
+            smh_wm_stage_emit(Q, have, in_chunk + b);
+            msk &= msk - 1u;
+        } while (SMH_WAVE_ANY(msk != 0));
+        smh_wm_stage_flush<STG>(Q, text, chunk_base, w, halo, P);
+#else
+        while (msk) {
+            smh_wm_stage_verify_emu<STG>(Q, text, chunk_base, in_chunk + (uint32_t)__builtin_ctzll(msk), P);
+            msk &= msk - 1u;
+        }
+#endif
+    } else {
     while (SMH_WAVE_ANY(msk != 0)) {
         if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
         const bool have = msk != 0;
         const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
         smh_wm_emit(Q, text, P, have, a + b);
         msk &= msk - 1u;
+    }
     }
 }
 
@@ -942,27 +1124,30 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     return cnt;
 }
 
-template <int KIND, bool POS = false>
+template <int KIND, bool POS = false, int STG = 0>
 SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n,
                                      const void *tab, const smh_wm_params &P, uint64_t *queue_base, const smh_pos_out *po = nullptr,
-                                     uint32_t smh_gram_drain_at = 64u)
+                                     uint32_t smh_gram_drain_at = 64u, const smh_wm_queue *stage = nullptr)
 {
     if (n < (uint64_t)P.m) return 0;
     const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
     const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
     const uint32_t lane = (uint32_t)(gthread & 63u);
-    smh_wm_queue Q;
+    smh_wm_queue Q = {};
+    if (stage) Q = *stage; /* staged verify (STG > 0): where the locks, buffers and this wave's list live */
     Q.slots = queue_base;
     Q.count = 0;
     Q.matches = 0;
+    Q.st_count = 0;
     Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
-    uint32_t cur[16], nxt[16], cur_edge[2], nxt_edge[2];
+    constexpr int HP = STG > 0 ? STG : 1, HD = 4 * HP; /* 16-byte pieces / dwords of text kept from in front of the chunk */
+    uint32_t cur[16], nxt[16], cur_halo[HD], nxt_halo[HD];
     uint64_t k = S.take(n_chunks);
     /* the fast path needs eight bytes in front of the chunk and, for the columns to have full windows, m - 1 of
      * them: chunk 0 is excluded (m - 1 <= 4095 is checked by the launcher); the last chunk only when partial */
     auto is_fast = [&](uint64_t kk) { return kk >= 1 && kk < n_chunks && (kk + 1) * chunk_bytes <= n; };
-    auto load = [&](uint64_t kk, uint32_t (&w)[16], uint32_t (&edge)[2]) {
+    auto load = [&](uint64_t kk, uint32_t (&w)[16], uint32_t (&halo)[HD]) {
         const uint64_t base = smh_uniform64(kk * chunk_bytes);
         const uint8_t *p = text + base + (uint64_t)lane * SMH_SEG;
 #pragma unroll
@@ -973,23 +1158,29 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
             w[4 * q + 2] = t.v[2];
             w[4 * q + 3] = t.v[3];
         }
-        const smh_u32x4 t = smh_load16(text + base - 16u);
-        edge[0] = t.v[2];
-        edge[1] = t.v[3];
+        /* the bytes in front of the wave-chunk, same address in every lane */
+#pragma unroll
+        for (int q = 0; q < HP; ++q) {
+            const smh_u32x4 t = smh_load16(text + base - 16u * (uint32_t)(HP - q));
+            halo[4 * q + 0] = t.v[0];
+            halo[4 * q + 1] = t.v[1];
+            halo[4 * q + 2] = t.v[2];
+            halo[4 * q + 3] = t.v[3];
+        }
     };
     bool cur_fast = is_fast(k);
-    if (cur_fast) load(k, cur, cur_edge);
+    if (cur_fast) load(k, cur, cur_halo);
     while (k < n_chunks) {
         const uint64_t kn = S.take(n_chunks);
         const bool nxt_fast = is_fast(kn);
         /* the verify stage runs HERE, between chunks and before the next chunk's text is requested: its loads
          * return in order behind everything the wave has in flight, so a drain entered while a prefetch is
          * outstanding also waits for that prefetch (measured: 2-3 x the cost per surviving column) */
-        if (Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
-        if (nxt_fast) load(kn, nxt, nxt_edge);
+        if (STG == 0 && Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
+        if (nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
-            smh_wm_gram_lane_fast<KIND, POS>(text, a, cur, cur_edge, tab, P, Q);
+            smh_wm_gram_lane_fast<KIND, POS, STG>(text, a, cur, cur_halo, tab, P, Q);
         } else if (POS) {
             uint64_t mm;
             smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P, &mm);
@@ -1000,13 +1191,13 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         if (nxt_fast) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
-            cur_edge[0] = nxt_edge[0];
-            cur_edge[1] = nxt_edge[1];
+#pragma unroll
+            for (int q = 0; q < HD; ++q) cur_halo[q] = nxt_halo[q];
         }
         cur_fast = nxt_fast;
         k = kn;
     }
-    smh_wm_drain(Q, text, P);
+    if (STG == 0) smh_wm_drain(Q, text, P);
     return cnt + Q.matches;
 }
 

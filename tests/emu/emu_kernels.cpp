@@ -210,17 +210,21 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     P.gram_g7 = wm->gram_kind == SMH_GRAM_PAIR ? (const uint8_t *)wm->gram_table + SMH_GRAM_BYTES : nullptr;
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
+    /* staged verify as launch_gram (wm_kernels.inc) picks it */
+    const int stg = wm->m - 1 <= 16 ? 1 : wm->m - 1 <= 32 ? 2 : 0;
     for (uint64_t t = 0; t < nthreads; ++t) {
         const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
+#define GRAM_CALL(KIND, STG) (po ? smh_wm_gram_thread<KIND, true, STG>(t, S, text, n, wm->gram_table, P, nullptr, po) \
+                                 : smh_wm_gram_thread<KIND, false, STG>(t, S, text, n, wm->gram_table, P, nullptr, po))
+#define GRAM_STG(KIND) (stg == 1 ? GRAM_CALL(KIND, 1) : stg == 2 ? GRAM_CALL(KIND, 2) : GRAM_CALL(KIND, 0))
         if (wm->gram_kind == SMH_GRAM_PAIR)
-            total += po ? smh_wm_gram_thread<1, true>(t, S, text, n, wm->gram_table, P, nullptr, po)
-                        : smh_wm_gram_thread<1, false>(t, S, text, n, wm->gram_table, P, nullptr, po);
+            total += GRAM_STG(1);
         else if (wm->gram_kind == SMH_GRAM_OCT)
-            total += po ? smh_wm_gram_thread<3, true>(t, S, text, n, wm->gram_table, P, nullptr, po)
-                        : smh_wm_gram_thread<3, false>(t, S, text, n, wm->gram_table, P, nullptr, po);
+            total += GRAM_STG(3);
         else
-            total += po ? smh_wm_gram_thread<2, true>(t, S, text, n, wm->gram_table, P, nullptr, po)
-                        : smh_wm_gram_thread<2, false>(t, S, text, n, wm->gram_table, P, nullptr, po);
+            total += GRAM_STG(2);
+#undef GRAM_STG
+#undef GRAM_CALL
     }
     return total;
 }

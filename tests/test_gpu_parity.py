@@ -314,3 +314,42 @@ def test_ascii_100k_patterns_against_bruteforce(m):
         ac = S.AcAutomaton.from_patterns(pat[:pa * m], m, pa, sigma)
         assert not ac.info().scan_exact
         assert ac.count_host(text[:1 << 20], S.VARIANT_TUNED)[0] == O.count_bruteforce(pat[:pa * m], m, pa, text[:1 << 20])
+
+
+@pytest.mark.parametrize("stage", ["", ",stage=0"], ids=["staged", "hbm_windows"])
+@pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 17, 6000), (1, 4, 33, 50), (1, 4, 40, 50),
+                                            (3, 4, 11, 200), (3, 4, 16, 20000), (3, 4, 32, 500), (2, 256, 5, 3000),
+                                            (2, 256, 12, 30000), (2, 256, 17, 100000), (2, 256, 18, 1000), (2, 256, 33, 2000),
+                                            (2, 256, 34, 2000), (2, 128, 7, 100)])
+def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, monkeypatch):
+    """Each q-gram shift-or form forced (development knob), with the staged verify (window hashes from the LDS copy
+    of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them) and with windows
+    re-read from HBM; texts with planted occurrences at chunk / segment boundaries and a stretch where EVERY column
+    survives the filter (a pattern repeated back to back), so lists overflow and are flushed mid-chunk."""
+    monkeypatch.setenv("SMH_WM_TUNE", "gram=%d%s" % (kind, stage))
+    rng = np.random.RandomState(1000 * kind + m)
+    n = 9 * 4096 + 777
+    text = rng.randint(0, sigma, size=n).astype(np.uint8)
+    pat = rng.randint(0, sigma, size=(p, m)).astype(np.uint8)
+    pat[1] = pat[0][0]  # a one-symbol run: every column inside a run of it matches
+    text[5 * 4096 - 700:5 * 4096 + 900] = pat[0][0]
+    rep = np.tile(pat[2], 3000 // m + 2)[:3000]  # pattern 2 back to back: one match every m columns, all grams in planes
+    text[7 * 4096 - 1500:7 * 4096 + 1500] = rep
+    for i, off in enumerate([0, 300, 640 - m // 2, 4096 - m // 2, 8191, 8192 + 2 * m + 64, 3 * 4096 - 1, 3 * 4096, n - m]):
+        text[off:off + m] = pat[(7 * i + 3) % p]
+    pat[p // 2] = pat[3]  # a duplicate pattern: a column is counted once
+    wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
+    assert wm.info().gram_planes == min(8, m - {1: 6, 3: 7, 2: 2}[kind])
+    if wm.info().scan_engine != S.ALGO_WM:
+        wm.set_scan_engine(S.ALGO_WM)
+    want = O.count_bruteforce(pat.reshape(-1), m, p, text)
+    assert want >= 1600
+    assert wm.count_host(text, S.VARIANT_TUNED)[0] == want
+    import torch
+    d_text = torch.from_numpy(text).cuda()
+    out = torch.zeros(want + 8, dtype=torch.int64, device="cuda")
+    cur = torch.zeros(1, dtype=torch.int64, device="cuda")
+    wm.positions_device(d_text.data_ptr(), n, out.data_ptr(), want + 8, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cur.item()) == want
+    assert sorted(out[:want].tolist()) == O.positions_bruteforce(pat.reshape(-1), m, p, text).tolist()
