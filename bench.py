@@ -422,6 +422,22 @@ def main():
                              block_symbols=wi.block_symbols, filter_log2=wi.filter_log2, filter_exact=wi.filter_exact,
                              shift_zero="%d/%d" % (wi.shift_zero, wi.shiftsize))
             verify.append(("wm", "wm", wpat, WM_LENGTH, WM_PATTERNS, SIGMA, text, we - wb, wlocal))
+        # the headline's longer pattern sets (m = 16, 32; the same 1000 patterns) through the Wu-Manber entry point
+        if rank == 0 and world == 1:
+            wl = {}
+            for m in AC_LENGTHS[1:]:
+                wml = S.WmTables.from_patterns(pats[m], m, AC_PATTERNS, SIGMA)
+                wcount.zero_()
+                mls = timed(lambda: wml.scan_device(text.data_ptr(), shard_len(m), wcount.data_ptr(), S.VARIANT_TUNED, stream), args.steps, wcount)
+                li = wml.info()
+                ms = sum(mls) / len(mls)
+                wl["m%d" % m] = dict(kernel_ms=round(ms, 4), min_ms=round(min(mls), 4), **rate(shard_len(m), ms), matches=int(wcount.item()),
+                                     scan_engine="automaton kernels" if li.scan_engine == S.ALGO_AC else "suffix-filter kernels",
+                                     gram_planes=li.gram_planes)
+                verify.append(("wm_long.m%d" % m, "wm", pats[m], m, AC_PATTERNS, SIGMA, text, shard_len(m), int(wcount.item())))
+                del wml
+            out["wm_long"] = dict(workload="WM: same text, the headline's %d-pattern sets of length %s through the Wu-Manber entry "
+                                           "point (q-gram shift-or filter in LDS + staged verify)" % (AC_PATTERNS, "/".join(str(m) for m in AC_LENGTHS[1:])), **wl)
 
     # ---- the 32 GB configurations, one GPU's shard of each (rank 0 of a single-GPU run only)
     side = not args.no_wm and world == 1

@@ -286,6 +286,7 @@ struct smh_wm {
     void *gram_table;
     uint32_t gram_bytes;
     double gram_density; /* fraction of columns expected to reach the verify stage on uniform text */
+    double scan_ms_est;  /* this path's own kernels, estimated ms per GiB (non-exact filters only; engine choice) */
     /* reference-layout tables */
     uint32_t shiftsize;
     uint32_t shift_zero;

@@ -181,10 +181,17 @@ static double gram_survivors(int kind, const void *tab, int alphabet)
 }
 
 /* scan time (ms per GiB on MI355X, profiles/r02_*) of each form + what a surviving column costs in the verify
- * stage; the form with the lowest estimate is kept, or none when the handle's block filter is estimated faster */
-/* verify stage: ms per GiB per unit of survivor fraction, growing with the window the stage has to fetch and hash
- * (fits to 8000 DNA patterns m = 16 / 32 and 100 000 byte patterns m = 5 / 12 / 20, profiles/r02_*) */
-#define SMH_GRAM_VERIFY_MS(m) (12.0 + 3.0 * (m))
+ * stage; the form with the lowest estimate is kept, or none when the handle's block filter is estimated faster.
+ * Shift-or steps (one v_lshl_or per column, per two columns in the pair form): pairs 0.178 (HBM-bound), 8-symbol
+ * grams 0.26 and byte grams 0.238 (one LDS lookup per column). */
+#define SMH_GRAM_PAIR_MS 0.178
+#define SMH_GRAM_OCT_MS 0.26
+#define SMH_GRAM_BYTE_MS 0.238
+/* verify stage: ms per GiB per unit of survivor fraction.  Staged (m <= 33: window hashes from the LDS copy of the
+ * chunk): 8000 DNA patterns m = 16 / 32 (0.41 % survive the pair form) 0.305 / 0.325, 100 000 byte patterns
+ * m = 12 / 20 (0.75 %) 0.367 / 0.406.  Windows re-read from HBM (longer patterns): grows with the window the stage
+ * has to fetch and hash (fits to the same sets before staging: 0.49 / 0.72, 0.63 / 0.82). */
+#define SMH_GRAM_VERIFY_MS(kind, m) ((m) <= 33 ? ((kind) == SMH_GRAM_PAIR ? 26.0 + 0.3 * (m) : 10.0 + 0.6 * (m)) : 12.0 + 3.0 * (m))
 #define SMH_HASHED_VERIFY_MS(m) (6.0 + 1.05 * (m))
 #define SMH_DIRECT_VERIFY_MS(m) ((m) > 4 ? 1.9 * (m) - 3.0 : 4.6)
 
@@ -223,7 +230,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
             }
         /* entry of eight symbols = (G of the older seven << 1) | G of the newer seven: one v_lshl_or does both columns */
         for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(((uint32_t)g7[x >> 2] << 1) | g7[x & 0x3FFFu]);
-        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4), ms = 0.205 + SMH_GRAM_VERIFY_MS(m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4), ms = SMH_GRAM_PAIR_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_PAIR, m) * dens;
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES + 16384; best_ms = ms; best_dens = dens;
@@ -244,7 +251,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
                 tab[code] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4), ms = 0.30 + SMH_GRAM_VERIFY_MS(m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4), ms = SMH_GRAM_OCT_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_OCT, m) * dens;
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_OCT; best_planes = J; best_bytes = 65536; best_ms = ms; best_dens = dens;
@@ -265,7 +272,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 const uint32_t idx = (uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15; /* low 32 bits of the product, top 17 */
                 tab[idx] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet), ms = 0.33 + SMH_GRAM_VERIFY_MS(m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet), ms = SMH_GRAM_BYTE_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_BYTE, m) * dens;
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_BYTE; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
@@ -282,6 +289,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
     wm->gram_table = best;
     wm->gram_bytes = best_bytes;
     wm->gram_density = best_dens;
+    wm->scan_ms_est = best_ms;
     return 0;
 }
 
@@ -532,6 +540,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
          * byte-block filter at 0.55, and their survivors cost the same verify stage */
         const double other_ms = wm->filter_hashed ? 0.55 + SMH_HASHED_VERIFY_MS(m) * wm->filter_density
                                                   : 0.40 + SMH_DIRECT_VERIFY_MS(m) * wm->filter_density;
+        wm->scan_ms_est = other_ms;
         if (build_gram_filter(wm, other_ms) != 0) goto oom;
     }
 
@@ -543,7 +552,8 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         ++smh_alt_engine_depth;
         struct smh_ac *ac = smh_ac_compile_patterns(wm->pat_sorted, m, d, alphabet);
         --smh_alt_engine_depth;
-        if (ac && ac->scan_cost <= SMH_WM_ALT_ENGINE_COST)
+        /* the automaton plan's cost is in units of the exact stride-1 scan, 0.289 ms/GiB */
+        if (ac && ac->scan_cost <= SMH_WM_ALT_ENGINE_COST && ac->scan_cost * 0.289 < wm->scan_ms_est)
             wm->alt_ac = ac;
         else
             smh_ac_free(ac);

@@ -384,6 +384,104 @@ SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_par
 }
 #endif
 
+/* ---- staged verify, wave level (description above smh_wm_queue's SMH_STAGE_* constants) ---- */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+typedef uint32_t smh_lds_v4 __attribute__((ext_vector_type(4)));
+SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    *reinterpret_cast<__attribute__((address_space(3))) smh_lds_v4 *>(byte_off) = smh_lds_v4{a, b, c, d};
+}
+SMH_LANE void smh_lds_store_u16(uint32_t byte_off, uint32_t v)
+{
+    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(byte_off) = (uint16_t)v;
+}
+
+/* append the chunk offset `c` (0 .. 4095) of one surviving column per lane with `cond`; the caller flushes first
+ * whenever fewer than 64 list entries are free */
+SMH_LANE void smh_wm_stage_emit(smh_wm_queue &Q, bool cond, uint32_t c)
+{
+    const uint64_t mask = __ballot(cond);
+    if (mask == 0) return;
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (cond) smh_lds_store_u16(Q.st_list + 2u * (Q.st_count + before), c);
+    Q.st_count += (uint32_t)__popcll(mask);
+}
+
+/* verify every listed column of the wave-chunk at `chunk_base` whose text the lanes hold in w (and the 16*STG
+ * bytes in front of it in `halo`, wave-uniform); all 64 lanes must call it */
+template <int STG>
+SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, const uint32_t (&w)[16],
+                                 const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
+{
+    if (Q.st_count == 0) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    constexpr uint32_t HALO = 16u * STG, BUF = SMH_STAGE_BUF(STG);
+    /* take a staging buffer: lane 0 tries the lock words in turn, starting at a wave-dependent one */
+    uint32_t i = (threadIdx.x >> 6) % Q.st_nbufs;
+    for (;;) {
+        uint32_t got = 0;
+        if (lane == 0) {
+            uint32_t expected = 0u;
+            got = __hip_atomic_compare_exchange_strong(
+                      reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), &expected, 1u,
+                      __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
+        }
+        if (__builtin_amdgcn_readfirstlane((int)got)) break;
+        i = i + 1u == Q.st_nbufs ? 0u : i + 1u;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    const uint32_t buf = Q.st_bufs + i * BUF;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) smh_lds_store16(buf + HALO + lane * 64u + 16u * q, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    if (lane == 0) { /* lane 0's view of the bytes in front of the chunk (wave-uniform in the gram kernels) */
+#pragma unroll
+        for (int q = 0; q < STG; ++q) smh_lds_store16(buf + 16u * q, halo[4 * q], halo[4 * q + 1], halo[4 * q + 2], halo[4 * q + 3]);
+    }
+    /* lane l hashes the windows of entries l and l + 64 (the list holds at most 128) */
+    const bool h0 = lane < Q.st_count, h1 = lane + 64u < Q.st_count;
+    const uint32_t c0 = smh_lds_u16(nullptr, Q.st_list + 2u * (h0 ? lane : 0u));
+    auto rd = [&](uint32_t off) { return smh_lds_u32(nullptr, buf + off); };
+    const uint32_t tag0 = smh_wm_tag_staged(rd, c0 + HALO + 1u - (uint32_t)P.m, P.m);
+    uint32_t c1 = c0, tag1 = tag0;
+    if (Q.st_count > 64u) { /* wave-uniform */
+        c1 = smh_lds_u16(nullptr, Q.st_list + 2u * (h1 ? lane + 64u : 0u));
+        tag1 = smh_wm_tag_staged(rd, c1 + HALO + 1u - (uint32_t)P.m, P.m);
+    }
+    /* hand the buffer back: the release waits for the window reads above, nothing else */
+    if (lane == 0)
+        __hip_atomic_store(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), 0u,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint64_t e0 = chunk_base + c0, e1 = chunk_base + c1;
+    uint32_t r0, r1 = 0;
+    if (Q.st_count > 64u)
+        r0 = smh_wm_probe2(text, e0, e1, tag0, tag1, P, r1);
+    else
+        r0 = smh_wm_probe(text, e0, tag0, P);
+    Q.matches += (h0 ? r0 : 0u) + (h1 ? r1 : 0u);
+    if (Q.po) {
+        smh_append_bits(h0 ? r0 : 0u, e0, *Q.po);
+        if (Q.st_count > 64u) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
+    }
+    Q.st_count = 0;
+}
+#else
+/* CPU emulation (one lane at a time): the same window hash over a private copy of the chunk laid out as the
+ * staging buffer, the same probe */
+template <int STG>
+SMH_LANE void smh_wm_stage_verify_emu(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint32_t c, const smh_wm_params &P)
+{
+    constexpr uint32_t HALO = 16u * STG;
+    uint8_t buf[SMH_STAGE_BUF(STG)];
+    memset(buf, 0xA5, sizeof buf); /* the pad is never part of a hash */
+    memcpy(buf, text + chunk_base - HALO, HALO + 4096u);
+    auto rd = [&](uint32_t off) { uint32_t v; memcpy(&v, buf + off, 4); return v; };
+    const uint32_t tag = smh_wm_tag_staged(rd, c + HALO + 1u - (uint32_t)P.m, P.m);
+    const uint32_t hit = smh_wm_probe(text, chunk_base + c, tag, P);
+    Q.matches += hit;
+    if (hit && Q.po) smh_append_bits(1u, chunk_base + c, *Q.po);
+}
+#endif
+
 /*
  * Fast path: the lane owns the 64 END columns of the segment at byte offset a
  * (a multiple of 64) and reads the 16*HC bytes in front of it to prime the
@@ -402,7 +500,7 @@ SMH_LANE uint32_t smh_alignbyte(uint32_t hi, uint32_t lo, uint32_t r)
 /* FK > 0: the byte-symbol tuned path -- the block is the column's last four bytes, read as one
  * unaligned little-endian dword out of the lane's registers (v_alignbyte), hashed filter with FK
  * bits per key.  FK == 0: any symbol width, rolling code. */
-template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false, bool STG = false>
 SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[4 * HC + 16],
                                    const uint32_t *filter, const smh_wm_params &P, smh_wm_queue &Q)
 {
@@ -438,12 +536,42 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
         /* compaction: one queue entry per surviving column, as many rounds as the busiest lane has;
          * the HASH/PREFIX stage (drain) is entered from this one place while the wave scans */
         uint64_t msk = ((uint64_t)surv[1] << 32) | surv[0];
+        if constexpr (STG) {
+            /* staged verify (see smh_wm_stage_flush): the 16 * HC bytes each lane loaded in front of its segment are,
+             * in lane 0, the bytes in front of the wave-chunk */
+            static_assert(!STG || (HC >= 1 && HC <= 2), "staged verify covers a halo of 16 or 32 bytes");
+            if (SMH_WAVE_ANY(msk != 0)) {
+                const uint64_t chunk_base = smh_uniform64(a & ~(uint64_t)4095);
+                const uint32_t in_chunk = (uint32_t)(a & 4095u);
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+                uint32_t own[16], halo[4 * HC];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) own[q] = w[4 * HC + q];
+#pragma unroll
+                for (int q = 0; q < 4 * HC; ++q) halo[q] = w[q];
+                do {
+                    if (Q.st_count + 64u > SMH_STAGE_LIST) smh_wm_stage_flush<HC>(Q, text, chunk_base, own, halo, P);
+                    const bool have = msk != 0;
+                    const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
+                    smh_wm_stage_emit(Q, have, in_chunk + b);
+                    msk &= msk - 1u;
+                } while (SMH_WAVE_ANY(msk != 0));
+                smh_wm_stage_flush<HC>(Q, text, chunk_base, own, halo, P);
+#else
+                while (msk) {
+                    smh_wm_stage_verify_emu<HC>(Q, text, chunk_base, in_chunk + (uint32_t)__builtin_ctzll(msk), P);
+                    msk &= msk - 1u;
+                }
+#endif
+            }
+        } else {
         while (SMH_WAVE_ANY(msk != 0)) {
             if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
             const bool have = msk != 0;
             const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
             smh_wm_emit(Q, text, P, have, a + b);
             msk &= msk - 1u;
+        }
         }
     }
     return cnt;
@@ -524,20 +652,22 @@ SMH_LANE uint32_t smh_wm_lane_table(const uint8_t *text, uint64_t n, uint64_t a,
 
 /* whole-grid work distribution for one lane; HC == 0: no fast path (m - 1 > 64).  The next chunk's
  * text is requested before the current chunk is scanned (software prefetch). */
-template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false, bool STG = false>
 SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n,
                                 const uint32_t *filter, const smh_wm_params &P, int block_symbols,
-                                uint64_t *queue_base, const smh_pos_out *po = nullptr)
+                                uint64_t *queue_base, const smh_pos_out *po = nullptr, const smh_wm_queue *stage = nullptr)
 {
     if (n < (uint64_t)P.m) return 0;
     constexpr int H = HC > 0 ? HC : 1;
     const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
     const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
     const uint32_t lane = (uint32_t)(gthread & 63u);
-    smh_wm_queue Q;
+    smh_wm_queue Q = {};
+    if (stage) Q = *stage; /* staged verify (STG): where the locks, buffers and this wave's list live */
     Q.slots = queue_base; /* this wave's slice (the kernel passes LDS) */
     Q.count = 0;
     Q.matches = 0;
+    Q.st_count = 0;
     Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
     uint32_t cur[4 * H + 16], nxt[4 * H + 16];
@@ -565,7 +695,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
         if (PREFETCH && nxt_fast) load(kn, nxt);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
-            cnt += smh_wm_lane_fast<HASHED, EXACT, H, FK, POS>(text, a, cur, filter, P, Q);
+            cnt += smh_wm_lane_fast<HASHED, EXACT, H, FK, POS, STG>(text, a, cur, filter, P, Q);
         } else if (POS) {
             /* first / last chunks: per-lane mask of matching END columns, then the wave-level append */
             uint64_t mm;
@@ -592,7 +722,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
         cur_fast = nxt_fast;
         k = kn;
     }
-    if (!EXACT) smh_wm_drain(Q, text, P);
+    if (!EXACT && !STG) smh_wm_drain(Q, text, P);
     return cnt + Q.matches;
 }
 
@@ -884,103 +1014,6 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
     }
     return S & 0x7Fu;
 }
-
-/* ---- staged verify, wave level (description above smh_wm_queue's SMH_STAGE_* constants) ---- */
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-typedef uint32_t smh_lds_v4 __attribute__((ext_vector_type(4)));
-SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    *reinterpret_cast<__attribute__((address_space(3))) smh_lds_v4 *>(byte_off) = smh_lds_v4{a, b, c, d};
-}
-SMH_LANE void smh_lds_store_u16(uint32_t byte_off, uint32_t v)
-{
-    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(byte_off) = (uint16_t)v;
-}
-
-/* append the chunk offset `c` (0 .. 4095) of one surviving column per lane with `cond`; the caller flushes first
- * whenever fewer than 64 list entries are free */
-SMH_LANE void smh_wm_stage_emit(smh_wm_queue &Q, bool cond, uint32_t c)
-{
-    const uint64_t mask = __ballot(cond);
-    if (mask == 0) return;
-    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (cond) smh_lds_store_u16(Q.st_list + 2u * (Q.st_count + before), c);
-    Q.st_count += (uint32_t)__popcll(mask);
-}
-
-/* verify every listed column of the wave-chunk at `chunk_base` whose text the lanes hold in w (and the 16*STG
- * bytes in front of it in `halo`, wave-uniform); all 64 lanes must call it */
-template <int STG>
-SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, const uint32_t (&w)[16],
-                                 const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
-{
-    if (Q.st_count == 0) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    constexpr uint32_t HALO = 16u * STG, BUF = SMH_STAGE_BUF(STG);
-    /* take a staging buffer: lane 0 tries the lock words in turn, starting at a wave-dependent one */
-    uint32_t i = (threadIdx.x >> 6) % Q.st_nbufs;
-    for (;;) {
-        uint32_t got = 0;
-        if (lane == 0) {
-            uint32_t expected = 0u;
-            got = __hip_atomic_compare_exchange_strong(
-                      reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), &expected, 1u,
-                      __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 1u : 0u;
-        }
-        if (__builtin_amdgcn_readfirstlane((int)got)) break;
-        i = i + 1u == Q.st_nbufs ? 0u : i + 1u;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    const uint32_t buf = Q.st_bufs + i * BUF;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) smh_lds_store16(buf + HALO + lane * 64u + 16u * q, w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-#pragma unroll
-    for (int q = 0; q < STG; ++q)
-        if (lane == (uint32_t)q) smh_lds_store16(buf + 16u * q, halo[4 * q], halo[4 * q + 1], halo[4 * q + 2], halo[4 * q + 3]);
-    /* lane l hashes the windows of entries l and l + 64 (the list holds at most 128) */
-    const bool h0 = lane < Q.st_count, h1 = lane + 64u < Q.st_count;
-    const uint32_t c0 = smh_lds_u16(nullptr, Q.st_list + 2u * (h0 ? lane : 0u));
-    auto rd = [&](uint32_t off) { return smh_lds_u32(nullptr, buf + off); };
-    const uint32_t tag0 = smh_wm_tag_staged(rd, c0 + HALO + 1u - (uint32_t)P.m, P.m);
-    uint32_t c1 = c0, tag1 = tag0;
-    if (Q.st_count > 64u) { /* wave-uniform */
-        c1 = smh_lds_u16(nullptr, Q.st_list + 2u * (h1 ? lane + 64u : 0u));
-        tag1 = smh_wm_tag_staged(rd, c1 + HALO + 1u - (uint32_t)P.m, P.m);
-    }
-    /* hand the buffer back: the release waits for the window reads above, nothing else */
-    if (lane == 0)
-        __hip_atomic_store(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), 0u,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint64_t e0 = chunk_base + c0, e1 = chunk_base + c1;
-    uint32_t r0, r1 = 0;
-    if (Q.st_count > 64u)
-        r0 = smh_wm_probe2(text, e0, e1, tag0, tag1, P, r1);
-    else
-        r0 = smh_wm_probe(text, e0, tag0, P);
-    Q.matches += (h0 ? r0 : 0u) + (h1 ? r1 : 0u);
-    if (Q.po) {
-        smh_append_bits(h0 ? r0 : 0u, e0, *Q.po);
-        if (Q.st_count > 64u) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
-    }
-    Q.st_count = 0;
-}
-#else
-/* CPU emulation (one lane at a time): the same window hash over a private copy of the chunk laid out as the
- * staging buffer, the same probe */
-template <int STG>
-SMH_LANE void smh_wm_stage_verify_emu(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint32_t c, const smh_wm_params &P)
-{
-    constexpr uint32_t HALO = 16u * STG;
-    uint8_t buf[SMH_STAGE_BUF(STG)];
-    memset(buf, 0xA5, sizeof buf); /* the pad is never part of a hash */
-    memcpy(buf, text + chunk_base - HALO, HALO + 4096u);
-    auto rd = [&](uint32_t off) { uint32_t v; memcpy(&v, buf + off, 4); return v; };
-    const uint32_t tag = smh_wm_tag_staged(rd, c + HALO + 1u - (uint32_t)P.m, P.m);
-    const uint32_t hit = smh_wm_probe(text, chunk_base + c, tag, P);
-    Q.matches += hit;
-    if (hit && Q.po) smh_append_bits(1u, chunk_base + c, *Q.po);
-}
-#endif
 
 /* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
  * `edge` = the 8 bytes in front of the wave-chunk (wave-uniform).  Returns nothing: candidates go to the queue. */

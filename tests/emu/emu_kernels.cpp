@@ -168,7 +168,7 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
 static const smh_wm_class *g_emu_classes = nullptr;
 static int g_emu_n_classes = 0;
 
-template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false>
+template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false, bool STG = false>
 static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint64_t blocks, const smh_pos_out *po = nullptr)
 {
     smh_wm_params P = {};
@@ -191,7 +191,7 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t)
-        total += smh_wm_thread<HASHED, EXACT, HC, FK, POS>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->filter, P, wm->block_symbols, nullptr, po);
+        total += smh_wm_thread<HASHED, EXACT, HC, FK, POS, STG>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->filter, P, wm->block_symbols, nullptr, po);
     return total;
 }
 
@@ -235,6 +235,15 @@ static uint64_t wm_halo(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     const int halo = wm->m - 1;
     if constexpr (HASHED && !EXACT) {
         if (wm->filter_le4 && halo <= 32) { /* as launch_halo in wm_kernels.hip */
+            if (g_emu_n_classes == 0) { /* single-length set: staged verify */
+                if (halo <= 16)
+                    return wm->filter_k == 2 ? wm_grid<true, false, 1, 2, POS, true>(wm, text, n, blocks, po)
+                         : wm->filter_k == 3 ? wm_grid<true, false, 1, 3, POS, true>(wm, text, n, blocks, po)
+                                             : wm_grid<true, false, 1, 4, POS, true>(wm, text, n, blocks, po);
+                return wm->filter_k == 2 ? wm_grid<true, false, 2, 2, POS, true>(wm, text, n, blocks, po)
+                     : wm->filter_k == 3 ? wm_grid<true, false, 2, 3, POS, true>(wm, text, n, blocks, po)
+                                         : wm_grid<true, false, 2, 4, POS, true>(wm, text, n, blocks, po);
+            }
             if (halo <= 16)
                 return wm->filter_k == 2 ? wm_grid<true, false, 1, 2, POS>(wm, text, n, blocks, po)
                      : wm->filter_k == 3 ? wm_grid<true, false, 1, 3, POS>(wm, text, n, blocks, po)
