@@ -304,22 +304,24 @@ struct smh_wm_queue {
     uint32_t count;  /* wave-uniform */
     uint32_t matches;
     const smh_pos_out *po; /* positions mode: verified columns are appended here; else NULL */
-    /* staged verify (gram kernels with STG > 0, below): LDS byte offsets of the lock words, the staging buffers and
-     * this wave's list of surviving columns; number of buffers; entries in the list */
-    uint32_t st_locks, st_bufs, st_list, st_nbufs, st_count;
+    /* staged verify (below): LDS byte offsets of the lock words and the staging buffers, number of buffers, and the
+     * number of surviving columns a wave-chunk must have for its windows to be hashed from the staged copy */
+    uint32_t st_locks, st_bufs, st_nbufs, st_min;
 };
 
 /* ---- staged verify: the window hash of a surviving column is computed from an ON-CHIP copy of the wave-chunk.
  * Re-reading the window from HBM costs one 128-byte line per surviving column -- with 100 000 byte patterns 0.75 %
  * of the columns survive any filter that fits LDS, which was 2.2x the algorithmic HBM traffic and three dependent
- * memory round trips per drain.  Here the wave copies its 4 KiB chunk (plus 16*STG bytes in front of it) from its
- * registers into a staging buffer in LDS, every lane takes one surviving column (compacted list, 16-bit chunk
- * offsets), reads the window's dwords from the buffer at a per-lane address -- the dynamic indexing registers do not
- * offer -- and hashes them; only the bucket probe (L2-resident table) and, for a matching tag, the final compare
- * leave the CU.  The table fills LDS, so the workgroup's 16 waves share SMH_STAGE_BUFS buffers through try-locks (a
- * buffer is held for two LDS round trips; whoever holds one never waits for anything else). */
-#define SMH_STAGE_LIST 128u            /* surviving columns per wave between flushes (16-bit entries) */
+ * memory round trips per drain.  A wave whose chunk has st_min or more surviving columns copies its 4 KiB chunk
+ * (plus 16*STG bytes in front of it) from its registers into a staging buffer in LDS, every lane takes one
+ * surviving column from the queue, reads the window's dwords from the buffer at a per-lane address -- the dynamic
+ * indexing registers do not offer -- and hashes them; only the bucket probe (L2-resident table) and, for a
+ * matching tag, the final compare leave the CU.  Chunks with FEWER survivors leave them in the queue, which is
+ * drained from HBM 64 columns at a time as before (a handful of survivors does not pay for the copy).  The table
+ * fills LDS, so the workgroup's 16 waves share a few buffers through try-locks (a buffer is held for two LDS round
+ * trips; whoever holds one never waits for anything else). */
 #define SMH_STAGE_BUF(STG) (16u * (STG) + 4096u + 16u)
+#define SMH_STAGE_MIN_DEFAULT 8u
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
@@ -384,37 +386,23 @@ SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_par
 }
 #endif
 
-/* ---- staged verify, wave level (description above smh_wm_queue's SMH_STAGE_* constants) ---- */
+/* ---- staged verify, wave level (description above SMH_STAGE_BUF) ---- */
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 typedef uint32_t smh_lds_v4 __attribute__((ext_vector_type(4)));
 SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
     *reinterpret_cast<__attribute__((address_space(3))) smh_lds_v4 *>(byte_off) = smh_lds_v4{a, b, c, d};
 }
-SMH_LANE void smh_lds_store_u16(uint32_t byte_off, uint32_t v)
-{
-    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>(byte_off) = (uint16_t)v;
-}
 
-/* append the chunk offset `c` (0 .. 4095) of one surviving column per lane with `cond`; the caller flushes first
- * whenever fewer than 64 list entries are free */
-SMH_LANE void smh_wm_stage_emit(smh_wm_queue &Q, bool cond, uint32_t c)
-{
-    const uint64_t mask = __ballot(cond);
-    if (mask == 0) return;
-    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    if (cond) smh_lds_store_u16(Q.st_list + 2u * (Q.st_count + before), c);
-    Q.st_count += (uint32_t)__popcll(mask);
-}
-
-/* verify every listed column of the wave-chunk at `chunk_base` whose text the lanes hold in w (and the 16*STG
- * bytes in front of it in `halo`, wave-uniform); all 64 lanes must call it */
+/* verify the queue entries [from, Q.count) -- all columns of the wave-chunk at `chunk_base`, whose text the lanes
+ * hold in w (and lane 0 the 16*STG bytes in front of it in `halo`) -- and remove them; at most 128 entries; all 64
+ * lanes must call it */
 template <int STG>
-SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, const uint32_t (&w)[16],
-                                 const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
+SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint32_t from,
+                                 const uint32_t (&w)[16], const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
 {
-    if (Q.st_count == 0) return;
-    const uint32_t lane = threadIdx.x & 63u;
+    if (Q.count <= from) return;
+    const uint32_t lane = threadIdx.x & 63u, cnt = Q.count - from;
     constexpr uint32_t HALO = 16u * STG, BUF = SMH_STAGE_BUF(STG);
     /* take a staging buffer: lane 0 tries the lock words in turn, starting at a wave-dependent one */
     uint32_t i = (threadIdx.x >> 6) % Q.st_nbufs;
@@ -437,32 +425,57 @@ SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t 
 #pragma unroll
         for (int q = 0; q < STG; ++q) smh_lds_store16(buf + 16u * q, halo[4 * q], halo[4 * q + 1], halo[4 * q + 2], halo[4 * q + 3]);
     }
-    /* lane l hashes the windows of entries l and l + 64 (the list holds at most 128) */
-    const bool h0 = lane < Q.st_count, h1 = lane + 64u < Q.st_count;
-    const uint32_t c0 = smh_lds_u16(nullptr, Q.st_list + 2u * (h0 ? lane : 0u));
+    /* lane l hashes the windows of entries l and l + 64 */
+    const bool h0 = lane < cnt, h1 = lane + 64u < cnt;
+    const uint64_t e0 = Q.slots[from + (h0 ? lane : 0u)];
     auto rd = [&](uint32_t off) { return smh_lds_u32(nullptr, buf + off); };
-    const uint32_t tag0 = smh_wm_tag_staged(rd, c0 + HALO + 1u - (uint32_t)P.m, P.m);
-    uint32_t c1 = c0, tag1 = tag0;
-    if (Q.st_count > 64u) { /* wave-uniform */
-        c1 = smh_lds_u16(nullptr, Q.st_list + 2u * (h1 ? lane + 64u : 0u));
-        tag1 = smh_wm_tag_staged(rd, c1 + HALO + 1u - (uint32_t)P.m, P.m);
+    const uint32_t tag0 = smh_wm_tag_staged(rd, (uint32_t)(e0 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
+    uint64_t e1 = e0;
+    uint32_t tag1 = tag0;
+    if (cnt > 64u) { /* wave-uniform */
+        e1 = Q.slots[from + (h1 ? lane + 64u : 0u)];
+        tag1 = smh_wm_tag_staged(rd, (uint32_t)(e1 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
     }
     /* hand the buffer back: the release waits for the window reads above, nothing else */
     if (lane == 0)
         __hip_atomic_store(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), 0u,
                            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint64_t e0 = chunk_base + c0, e1 = chunk_base + c1;
     uint32_t r0, r1 = 0;
-    if (Q.st_count > 64u)
+    if (cnt > 64u)
         r0 = smh_wm_probe2(text, e0, e1, tag0, tag1, P, r1);
     else
         r0 = smh_wm_probe(text, e0, tag0, P);
     Q.matches += (h0 ? r0 : 0u) + (h1 ? r1 : 0u);
     if (Q.po) {
         smh_append_bits(h0 ? r0 : 0u, e0, *Q.po);
-        if (Q.st_count > 64u) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
+        if (cnt > 64u) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
     }
-    Q.st_count = 0;
+    Q.count = from;
+}
+
+/* the surviving columns `msk` (bit b = column a + b) of a lane's segment in the wave-chunk at chunk_base: queue
+ * them; a chunk with st_min or more of them is verified from its staged copy at once, the others wait in the
+ * queue for the next drain from HBM */
+template <int STG>
+SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint64_t a, uint64_t msk,
+                                   const uint32_t (&w)[16], const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
+{
+    if (!SMH_WAVE_ANY(msk != 0)) return;
+    uint32_t from = Q.count; /* entries of earlier chunks */
+    do {
+        if (Q.count + 64u > SMH_WM_QCAP) {
+            smh_wm_stage_flush<STG>(Q, text, chunk_base, from, w, halo, P);
+            if (Q.count + 64u > SMH_WM_QCAP) { /* still full: the earlier chunks' entries, from HBM */
+                smh_wm_drain(Q, text, P);
+                from = 0;
+            }
+        }
+        const bool have = msk != 0;
+        const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
+        smh_wm_emit(Q, text, P, have, a + b);
+        msk &= msk - 1u;
+    } while (SMH_WAVE_ANY(msk != 0));
+    if (Q.count - from >= Q.st_min) smh_wm_stage_flush<STG>(Q, text, chunk_base, from, w, halo, P);
 }
 #else
 /* CPU emulation (one lane at a time): the same window hash over a private copy of the chunk laid out as the
@@ -479,6 +492,15 @@ SMH_LANE void smh_wm_stage_verify_emu(smh_wm_queue &Q, const uint8_t *text, uint
     const uint32_t hit = smh_wm_probe(text, chunk_base + c, tag, P);
     Q.matches += hit;
     if (hit && Q.po) smh_append_bits(1u, chunk_base + c, *Q.po);
+}
+template <int STG>
+SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint64_t a, uint64_t msk,
+                                   const uint32_t (&)[16], const uint32_t (&)[4 * STG], const smh_wm_params &P)
+{
+    while (msk) {
+        smh_wm_stage_verify_emu<STG>(Q, text, chunk_base, (uint32_t)(a - chunk_base) + (uint32_t)__builtin_ctzll(msk), P);
+        msk &= msk - 1u;
+    }
 }
 #endif
 
@@ -540,30 +562,12 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
             /* staged verify (see smh_wm_stage_flush): the 16 * HC bytes each lane loaded in front of its segment are,
              * in lane 0, the bytes in front of the wave-chunk */
             static_assert(!STG || (HC >= 1 && HC <= 2), "staged verify covers a halo of 16 or 32 bytes");
-            if (SMH_WAVE_ANY(msk != 0)) {
-                const uint64_t chunk_base = smh_uniform64(a & ~(uint64_t)4095);
-                const uint32_t in_chunk = (uint32_t)(a & 4095u);
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-                uint32_t own[16], halo[4 * HC];
+            uint32_t own[16], halo[4 * HC];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) own[q] = w[4 * HC + q];
+            for (int q = 0; q < 16; ++q) own[q] = w[4 * HC + q];
 #pragma unroll
-                for (int q = 0; q < 4 * HC; ++q) halo[q] = w[q];
-                do {
-                    if (Q.st_count + 64u > SMH_STAGE_LIST) smh_wm_stage_flush<HC>(Q, text, chunk_base, own, halo, P);
-                    const bool have = msk != 0;
-                    const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
-                    smh_wm_stage_emit(Q, have, in_chunk + b);
-                    msk &= msk - 1u;
-                } while (SMH_WAVE_ANY(msk != 0));
-                smh_wm_stage_flush<HC>(Q, text, chunk_base, own, halo, P);
-#else
-                while (msk) {
-                    smh_wm_stage_verify_emu<HC>(Q, text, chunk_base, in_chunk + (uint32_t)__builtin_ctzll(msk), P);
-                    msk &= msk - 1u;
-                }
-#endif
-            }
+            for (int q = 0; q < 4 * HC; ++q) halo[q] = w[q];
+            smh_wm_stage_columns<HC>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, own, halo, P);
         } else {
         while (SMH_WAVE_ANY(msk != 0)) {
             if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
@@ -667,7 +671,6 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
     Q.slots = queue_base; /* this wave's slice (the kernel passes LDS) */
     Q.count = 0;
     Q.matches = 0;
-    Q.st_count = 0;
     Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
     uint32_t cur[4 * H + 16], nxt[4 * H + 16];
@@ -692,6 +695,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
         const uint64_t kn = S.take(n_chunks);
         const bool nxt_fast = is_fast(kn);
         constexpr bool PREFETCH = EXACT && H == 1; /* only where registers allow: exact filter, short pre-halo */
+        if (STG && Q.count >= 64u) smh_wm_drain(Q, text, P); /* columns of sparse chunks, from HBM, 64 at a time */
         if (PREFETCH && nxt_fast) load(kn, nxt);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
@@ -722,7 +726,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
         cur_fast = nxt_fast;
         k = kn;
     }
-    if (!EXACT && !STG) smh_wm_drain(Q, text, P);
+    if (!EXACT) smh_wm_drain(Q, text, P);
     return cnt + Q.matches;
 }
 
@@ -1089,25 +1093,8 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     const uint32_t fix7 = smh_bitrev32(~prevT & 0x7Fu) >> 25; /* bit t SET = bit 6-t of the inherited state alive */
     uint64_t msk = (uint64_t)((fl[0] & (fix7 | ~0x7Fu)) | (fl[1] << 24)) | ((uint64_t)(fl[1] >> 8) << 32) | ((uint64_t)fl[2] << 48);
     if constexpr (STG > 0) {
-        /* staged verify: list the surviving columns of this chunk, hash their windows from an LDS copy of it */
-        if (!SMH_WAVE_ANY(msk != 0)) return;
-        const uint64_t chunk_base = smh_uniform64(a & ~(uint64_t)4095);
-        const uint32_t in_chunk = (uint32_t)(a & 4095u);
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        do {
-            if (Q.st_count + 64u > SMH_STAGE_LIST) smh_wm_stage_flush<STG>(Q, text, chunk_base, w, halo, P);
-            const bool have = msk != 0;
-            const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
-            smh_wm_stage_emit(Q, have, in_chunk + b);
-            msk &= msk - 1u;
-        } while (SMH_WAVE_ANY(msk != 0));
-        smh_wm_stage_flush<STG>(Q, text, chunk_base, w, halo, P);
-#else
-        while (msk) {
-            smh_wm_stage_verify_emu<STG>(Q, text, chunk_base, in_chunk + (uint32_t)__builtin_ctzll(msk), P);
-            msk &= msk - 1u;
-        }
-#endif
+        /* staged verify: chunks with many surviving columns hash their windows from an LDS copy of the chunk */
+        smh_wm_stage_columns<STG>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
     } else {
     while (SMH_WAVE_ANY(msk != 0)) {
         if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
@@ -1171,7 +1158,6 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
     Q.slots = queue_base;
     Q.count = 0;
     Q.matches = 0;
-    Q.st_count = 0;
     Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
     constexpr int HP = STG > 0 ? STG : 1, HD = 4 * HP; /* 16-byte pieces / dwords of text kept from in front of the chunk */
@@ -1209,7 +1195,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         /* the verify stage runs HERE, between chunks and before the next chunk's text is requested: its loads
          * return in order behind everything the wave has in flight, so a drain entered while a prefetch is
          * outstanding also waits for that prefetch (measured: 2-3 x the cost per surviving column) */
-        if (STG == 0 && Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
+        if (Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
         if (nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
@@ -1230,7 +1216,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         cur_fast = nxt_fast;
         k = kn;
     }
-    if (STG == 0) smh_wm_drain(Q, text, P);
+    smh_wm_drain(Q, text, P);
     return cnt + Q.matches;
 }
 
