@@ -439,6 +439,27 @@ def main():
             out["wm_long"] = dict(workload="WM: same text, the headline's %d-pattern sets of length %s through the Wu-Manber entry "
                                            "point (q-gram shift-or filter in LDS + staged verify)" % (AC_PATTERNS, "/".join(str(m) for m in AC_LENGTHS[1:])), **wl)
 
+    # ---- BASELINE configs[1] read literally: ONE set of 1000 patterns whose lengths run from 8 to 32 (40 per length),
+    #      through the pattern-set entry points (smh_pset_*: the reference API carries one length per run)
+    mixed = None
+    if not args.no_wm and rank == 0 and world == 1:
+        mlens, mpats = [], []
+        for L in range(8, 33):
+            mpats.append(S.corpus_patterns(L, 40, PAT_SEED + 100 + L, SIGMA, TEXT_SEED, n_total, 2))
+            mlens += [L] * 40
+        mixed = (np.concatenate(mpats), np.array(mlens, dtype=np.uint32))
+        mcount = torch.zeros(1, dtype=torch.int64, device=dev)
+        mobj = {}
+        for name, algo in (("ac", S.ALGO_AC), ("wm", S.ALGO_WM)):
+            ps = S.PatternSet(mixed[0], mixed[1], SIGMA, algo)
+            mls = timed(lambda: ps.scan_device(text.data_ptr(), per_gpu, mcount.data_ptr(), stream), args.steps, mcount)
+            ms = sum(mls) / len(mls)
+            mobj[name] = dict(kernel_ms=round(ms, 4), min_ms=round(min(mls), 4), **rate(per_gpu, ms), matches=int(mcount.item()),
+                              one_pass=int(ps.info().one_pass), classes=int(ps.info().classes))
+            ps.close()
+        out["mixed_8_32"] = dict(workload="BASELINE configs[1] read as ONE set: 1000 patterns, 40 of each length 8..32, same text, "
+                                          "scanned in one pass; count = sum over length classes of the reference's count", **mobj)
+
     # ---- the 32 GB configurations, one GPU's shard of each (rank 0 of a single-GPU run only)
     side = not args.no_wm and world == 1
     shard = args.shard_mib << 20
@@ -539,6 +560,15 @@ def main():
             want = cpu.ac_count(pat, m, p, sigma, h) if algo == "ac" else cpu.wm_count(pat, m, p, sigma, h)
             verified[name] = dict(gpu=got, cpu=int(want), equal=int(want) == got, text_bytes=n)
             parity_ok = parity_ok and int(want) == got
+        if mixed is not None:  # the mixed-length set: sum over its 25 length classes of the restated search_ac, full text
+            want = 0
+            for L in range(8, 33):
+                flat = mixed[0][sum(mixed[1][:(L - 8) * 40]):sum(mixed[1][:(L - 8) * 40]) + 40 * L]
+                want += cpu.ac_count(flat, L, 40, SIGMA, host_text)
+            for name in ("ac", "wm"):
+                got = out["mixed_8_32"][name]["matches"]
+                verified["mixed_8_32." + name] = dict(gpu=got, cpu=int(want), equal=int(want) == got, text_bytes=per_gpu)
+                parity_ok = parity_ok and int(want) == got
         out["verified"] = dict(checker="restated search_ac / search_wu2 (oracle/, pinned to the reference on the golden vectors) over "
                                        "byte-range shards with an m-1 halo on %d threads; full text of every configuration" % cpu.cores,
                                seconds=round(time.perf_counter() - t0, 1), all_equal=all(v["equal"] for v in verified.values()),

@@ -138,16 +138,26 @@ smh_pset *smh_pset_compile(const unsigned char *patterns, const uint32_t *length
         }
         set->suffix = smh_wm_compile(flat, (int)Lmin, p_size, alphabet);
         set->class_wm = (smh_wm **)malloc(n_classes * sizeof(smh_wm *));
+        /* 4-letter alphabet: the grouped pair-gram filter over the FULL patterns (smh_internal.h SMH_GRAM_PAIR2) --
+         * every pattern contributes all the planes its length allows, so candidates are rare even where the
+         * min-length suffix is not selective (1000 patterns of 8..32 symbols: one column in 5000) */
+        int grouped = 1;
+        if (set->suffix && set->class_wm && !(getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "nogram"))) {
+            grouped = smh_wm_build_gram_mixed(set->suffix, patterns, lengths, p_size);
+            if (grouped < 0) goto oom;
+        }
         /* worth it only while survivors are rare: each one costs a verify per class (~20 ps each), a scan
          * per class ~0.25 ms/GiB -- break-even near 1 % of the columns surviving the filter */
-        if (set->suffix && set->class_wm && set->suffix->filter_density < SMH_PSET_ONE_PASS_DENSITY) {
+        if (set->suffix && set->class_wm && (grouped == 0 || set->suffix->filter_density < SMH_PSET_ONE_PASS_DENSITY)) {
             for (uint32_t c = 0; c < n_classes; ++c) set->class_wm[c] = set->cls[c].wm;
         } else { /* stay with one scan per class */
             smh_wm_free(set->suffix);
             set->suffix = NULL;
         }
     }
-    if (algorithm == SMH_ALGO_AC && n_classes >= 2) {
+    /* SMH_ALGO_AC sets, and SMH_ALGO_WM sets neither one-pass filter serves (many short patterns: the candidates would
+     * mostly be real matches, which the automaton counts in line): the automaton with joined output counts */
+    if ((algorithm == SMH_ALGO_AC || !set->suffix) && n_classes >= 2) {
         set->acm = smh_acm_compile(patterns, lengths, p_size, alphabet); /* NULL: stay with one scan per class */
         if (getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "classes")) { smh_acm_free(set->acm); set->acm = NULL; }
     }

@@ -283,6 +283,7 @@ struct smh_wm {
      *                  number) * SMH_GRAM_MUL mod 2^32, 8-bit entries */
     int gram_kind;
     int gram_planes;
+    int gram_jb;         /* SMH_GRAM_PAIR2: planes of the short-pattern group (0 = no such group) */
     void *gram_table;
     uint32_t gram_bytes;
     double gram_density; /* fraction of columns expected to reach the verify stage on uniform text */
@@ -303,6 +304,9 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
                                    const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
                                    const int *PREFIX_size);
 void smh_wm_host_free(struct smh_wm *wm);
+/* grouped pair-gram filter over the FULL patterns of a mixed-length set, attached to the set's suffix handle;
+ * 0 = built (gram_kind == SMH_GRAM_PAIR2), 1 = not applicable / too many candidates, -1 = out of memory */
+int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns, const uint32_t *lengths, int p_size);
 void smh_wm_dev_free(struct smh_wm_dev *dev); /* smh_runtime.hip */
 
 /* hashes shared by host table build and device lookup -- keep in sync with wm_kernels.hip */
@@ -322,6 +326,16 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
 #define SMH_GRAM_PAIR 1
 #define SMH_GRAM_BYTE 2
 #define SMH_GRAM_OCT 3 /* alphabet 4: 8-symbol grams, table indexed by the gram (16 bits), 8-bit entries, one lookup per column */
+/* mixed-length sets on the 4-letter alphabet in ONE pass (pset_host.c): the pair form with TWO plane groups in one
+ * 16-bit entry -- group A = the patterns of 14 symbols and more (eight planes of 7-symbol grams over their last 14
+ * symbols, 9 entry bits), group B = the shorter ones (J_B = min length - 6 planes over their last J_B + 6 symbols,
+ * J_B + 1 entry bits, below A's) -- and two shift-or states per lane, one v_lshl_or each per lookup.  A column is a
+ * candidate when either state says so; candidates (rare: few patterns per group, all planes selective) are verified
+ * against every length class.  Behind the 128 KiB image: 32 KiB of per-gram values G_A | G_B << 8 for the
+ * bounds-checked path. */
+#define SMH_GRAM_PAIR2 4
+#define SMH_PSET_GROUPED_DENSITY 0.0005 /* candidates per column above which the grouped form is not used */
+#define SMH_GRAM_PAIR2_SPLIT 14 /* patterns at least this long have all eight planes */
 #define SMH_GRAM_BYTES (128u * 1024u)
 #define SMH_GRAM_MUL 0x9E3779u /* 24-bit multiplier of the byte-gram index (v_mul_u32_u24) */
 

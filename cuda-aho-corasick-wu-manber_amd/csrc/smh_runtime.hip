@@ -700,6 +700,9 @@ static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes
     L.d_filter = sdv->d_filter; L.d_pair = NULL; L.verify_log2 = 4; L.d_verify = NULL; L.d_pat_sorted = NULL;
     L.d_queue = sdv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
     L.n_classes = n_classes; L.d_classes = sdv->d_classes;
+    if (wm->gram_kind == SMH_GRAM_PAIR2) { /* grouped pair-gram filter over the full patterns (wm_host.c) */
+        L.d_gram = sdv->d_gram; L.gram_kind = wm->gram_kind; L.gram_jb = wm->gram_jb;
+    }
     if (po) {
         L.po = *po;
         HIP_TRY(smh_launch_wm_block_positions(L, (hipStream_t)stream));

@@ -293,6 +293,75 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
     return 0;
 }
 
+int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns, const uint32_t *lengths, int p_size)
+{
+    if (!suffix || suffix->alphabet != 4 || p_size < 1) return 1;
+    uint32_t minlen = UINT32_MAX;
+    int short_ones = 0;
+    for (int p = 0; p < p_size; ++p) {
+        if (lengths[p] < minlen) minlen = lengths[p];
+        if (lengths[p] < SMH_GRAM_PAIR2_SPLIT) ++short_ones;
+    }
+    if (minlen < 8) return 1; /* a pattern of 7 symbols has one plane: nothing to chain */
+    int JB = 0;
+    if (short_ones) {
+        JB = (int)minlen - 6;
+        if (JB > 5) JB = 5;
+    }
+    const int bsh = JB ? JB + 1 : 0;
+    uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES + 32768u);
+    uint8_t *gA = (uint8_t *)malloc(16384), *gB = (uint8_t *)malloc(16384);
+    if (!tab || !gA || !gB) { free(tab); free(gA); free(gB); return -1; }
+    memset(gA, 0xFF, 16384);                       /* bit 7-j SET = the gram is not in plane j of group A */
+    memset(gB, JB ? (1 << JB) - 1 : 0, 16384);     /* bit JB-1-j SET = not in plane j of group B */
+    uint64_t off = 0;
+    for (int p = 0; p < p_size; ++p) {
+        const uint32_t L = lengths[p];
+        const unsigned char *pat = patterns + off;
+        off += L;
+        const int isA = L >= SMH_GRAM_PAIR2_SPLIT, J = isA ? 8 : JB;
+        for (int j = 0; j < J; ++j) {
+            const unsigned char *g = pat + (L - 7 - (uint32_t)j);
+            uint32_t code = 0;
+            for (int i = 0; i < 7; ++i) code = (code << 2) | g[i];
+            if (isA) gA[code] &= (uint8_t)~(1u << (7 - j));
+            else gB[code] &= (uint8_t)~(1u << (JB - 1 - j));
+        }
+    }
+    for (uint32_t x = 0; x < 65536; ++x) {
+        const uint32_t eA = ((uint32_t)gA[x >> 2] << 1) | gA[x & 0x3FFFu], eB = ((uint32_t)gB[x >> 2] << 1) | gB[x & 0x3FFFu];
+        tab[x] = (uint16_t)((eA << bsh) | eB);
+    }
+    uint16_t *gx = (uint16_t *)((uint8_t *)tab + SMH_GRAM_BYTES);
+    for (uint32_t c = 0; c < 16384; ++c) gx[c] = (uint16_t)(gA[c] | ((uint32_t)gB[c] << 8));
+    /* candidates per column on pseudo-random text, both states */
+    enum { COLS = 1 << 18 };
+    uint64_t seed = 0x5EEDull, hits = 0;
+    uint32_t SA = ~0u, SB = ~0u, code = 0;
+    for (int x = 0; x < COLS; ++x) {
+        code = ((code << 2) | (uint32_t)(gram_rng(&seed) & 3u)) & 0x3FFFu;
+        SA = (SA << 1) | gA[code];
+        SB = (SB << 1) | gB[code];
+        if (x >= 16) hits += (((SA >> 7) & 1u) ^ 1u) | (JB ? ((SB >> (JB - 1)) & 1u) ^ 1u : 0u);
+    }
+    const double dens = (double)hits / (double)(COLS - 16);
+    free(gA); free(gB);
+    if (getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "debug"))
+        fprintf(stderr, "grouped pair-gram filter: %d short patterns with %d planes, candidates %.6f per column\n", short_ones, JB, dens);
+    /* every candidate is verified against each length class (windows from HBM), and a group's planes together are
+     * as selective as an exact match of its shortest pattern's length: with many SHORT patterns the candidates are
+     * mostly real matches of those classes and an automaton counts them in line, cheaper (pset_host.c falls back) */
+    if (dens > SMH_PSET_GROUPED_DENSITY && !(getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "grouped=force"))) { free(tab); return 1; }
+    free(suffix->gram_table);
+    suffix->gram_kind = SMH_GRAM_PAIR2;
+    suffix->gram_planes = 8;
+    suffix->gram_jb = JB;
+    suffix->gram_table = tab;
+    suffix->gram_bytes = SMH_GRAM_BYTES + 32768u;
+    suffix->gram_density = dens;
+    return 0;
+}
+
 struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int p_size, int alphabet,
                                    const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
                                    const int *PREFIX_size)

@@ -43,7 +43,9 @@ struct smh_wm_params {
      * patterns' last min-length symbols, and a surviving column is verified once per length class */
     int n_classes;                       /* 0 = a single-length set: verify / pat_sorted above */
     const struct smh_wm_class *classes;  /* HBM */
-    const uint8_t *gram_g7;              /* HBM: pair-gram filter only, the byte G of every 7-symbol gram (bounds-checked path) */
+    const uint8_t *gram_g7;              /* HBM: pair-gram filter only, the byte G of every 7-symbol gram (bounds-checked path);
+                                          * grouped pairs (KIND 4): 16-bit values G_A | G_B << 8 */
+    int gram_jb;                         /* grouped pairs: planes of the short-pattern group, 0 = none */
 };
 
 #define SMH_WM_MAX_CLASSES 32 /* distinct lengths of a mixed-length set scanned in one pass */
@@ -321,7 +323,7 @@ struct smh_wm_queue {
  * fills LDS, so the workgroup's 16 waves share a few buffers through try-locks (a buffer is held for two LDS round
  * trips; whoever holds one never waits for anything else). */
 #define SMH_STAGE_BUF(STG) (16u * (STG) + 4096u + 16u)
-#define SMH_STAGE_MIN_DEFAULT 8u
+#define SMH_STAGE_MIN_DEFAULT 8u /* gpurun_out/r02_u: 1..16 within 3 % on the dense sets, 16+ better on sparse ones, 32+ loses 10-30 % */
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
@@ -1019,6 +1021,55 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
     return S & 0x7Fu;
 }
 
+/* ---- grouped pairs (KIND 4, mixed-length sets; smh_internal.h SMH_GRAM_PAIR2): two shift-or states per lane.
+ * State A as in the pair form (candidate = bit 7 clear); state B has jb planes, candidate = bit jb-1 clear. */
+SMH_LANE void smh_gram2_state_before(const uint8_t *text, uint64_t a, const uint8_t *gx, uint32_t &SA, uint32_t &SB)
+{
+    SA = 0u;
+    SB = 0u;
+    if (a < 14) return; /* columns without seven symbols in front of them: keep the assumption (superset) */
+    for (uint64_t x = a - 7; x < a; ++x) {
+        uint32_t code = 0;
+        for (int i = 6; i >= 0; --i) code = (code << 2) | (text[x - (uint64_t)i] & 3u);
+        uint16_t g;
+        memcpy(&g, gx + 2u * code, 2);
+        SA = smh_gram_step(SA, g & 0xFFu);
+        SB = smh_gram_step(SB, g >> 8);
+    }
+}
+
+/* bounds-checked path of the grouped form; only_class >= 0: that class alone (positions mode appends per class) */
+SMH_LANE uint32_t smh_wm_gram2_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const smh_wm_params &P,
+                                         uint64_t *match_mask = nullptr, int only_class = -1)
+{
+    if (match_mask) *match_mask = 0;
+    if (a >= n) return 0;
+    uint64_t end = a + SMH_SEG;
+    if (end > n) end = n;
+    uint32_t SA, SB, cnt = 0;
+    smh_gram2_state_before(text, a, P.gram_g7, SA, SB);
+    for (uint64_t e = a; e < end; ++e) {
+        uint32_t GA = 0u, GB = 0u; /* a column without a whole gram in front of it cannot be ruled out */
+        if (e + 1 >= 7u) {
+            uint32_t code = 0;
+            for (int i = 6; i >= 0; --i) code = (code << 2) | (text[e - (uint64_t)i] & 3u);
+            uint16_t g;
+            memcpy(&g, P.gram_g7 + 2u * code, 2);
+            GA = g & 0xFFu;
+            GB = g >> 8;
+        }
+        SA = smh_gram_step(SA, GA);
+        SB = smh_gram_step(SB, GB);
+        const bool cand = !((SA >> 7) & 1u) || (P.gram_jb && !((SB >> (P.gram_jb - 1)) & 1u));
+        if (cand && e + 1 >= (uint64_t)P.m) {
+            const uint32_t hit = only_class >= 0 ? smh_wm_verify_class(text, e, P, only_class) : smh_wm_verify_any(text, e, P);
+            cnt += hit;
+            if (match_mask && hit) *match_mask |= 1ull << (e - a);
+        }
+    }
+    return cnt;
+}
+
 /* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
  * `edge` = the 8 bytes in front of the wave-chunk (wave-uniform).  Returns nothing: candidates go to the queue. */
 template <int KIND, bool POS, int STG = 0>
@@ -1028,6 +1079,10 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     /* halo = the 16 * max(STG, 1) bytes in front of the wave-chunk (wave-uniform); its last two dwords prime lane 0 */
     constexpr int HD = STG > 0 ? 4 * STG : 4;
     uint32_t T = SMH_GRAM_S0, fl[3] = {0, 0, 0};
+    /* grouped pairs: the short group's state (jb planes: the low jb-1 bits assumed alive), its flags, and the shift
+     * that brings its candidate bit (jb-1) to bit 7 */
+    [[maybe_unused]] const uint32_t bup = KIND == 4 && P.gram_jb ? 8u - (uint32_t)P.gram_jb : 0u;
+    [[maybe_unused]] uint32_t TB = KIND == 4 && P.gram_jb ? ~((1u << (P.gram_jb - 1)) - 1u) : ~0u, flb[3] = {0, 0, 0};
     const uint32_t pre0 = smh_prev_lane_word(w[14], halo[HD - 2], text, a - 8u);
     const uint32_t pre1 = smh_prev_lane_word(w[15], halo[HD - 1], text, a - 4u);
     if constexpr (KIND == 1) {
@@ -1053,6 +1108,31 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
             if (q == 5) fl[0] = smh_gram_flags(T, 24);
             if (q == 11) fl[1] = smh_gram_flags(T, 24);
             if (q == 15) fl[2] = smh_gram_flags(T, 16);
+        }
+    } else if constexpr (KIND == 4) {
+        /* grouped pairs: the pair form's lookup, two states (A above B in the entry) */
+        const uint32_t bsh = P.gram_jb ? (uint32_t)P.gram_jb + 1u : 0u, bmask = (1u << bsh) - 1u;
+        uint32_t code2 = 0;
+        {
+            const uint32_t x0 = (pre0 << 10) | pre0, x1 = (pre1 << 10) | pre1;
+            code2 = (code2 << 4) | smh_bfe(x0, 7, 5);
+            code2 = (code2 << 4) | smh_bfe(x0, 23, 5);
+            code2 = (code2 << 4) | smh_bfe(x1, 7, 5);
+            code2 = (code2 << 4) | smh_bfe(x1, 23, 5);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = (w[q] << 10) | w[q];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                code2 = ((code2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
+                const uint32_t e = smh_lds_u16(tab, code2);
+                T = smh_gram_step2(T, e >> bsh);
+                TB = smh_gram_step2(TB, e & bmask);
+            }
+            if (q == 5) { fl[0] = smh_gram_flags(T, 24); flb[0] = smh_gram_flags(TB << bup, 24); }
+            if (q == 11) { fl[1] = smh_gram_flags(T, 24); flb[1] = smh_gram_flags(TB << bup, 24); }
+            if (q == 15) { fl[2] = smh_gram_flags(T, 16); flb[2] = smh_gram_flags(TB << bup, 16); }
         }
     } else if constexpr (KIND == 3) {
         /* 8-symbol grams, one lookup per column: the rolling code takes a pair of symbols per update; the column
@@ -1085,13 +1165,24 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     }
     /* correct the first seven columns with the state the previous lane ended in */
     uint32_t prevT;
+    [[maybe_unused]] uint32_t prevB = 0;
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
     prevT = (uint32_t)__builtin_amdgcn_update_dpp((int)SMH_GRAM_S0, (int)T, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    if constexpr (KIND == 4) prevB = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)TB, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #else
-    prevT = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7);
+    if constexpr (KIND == 4) smh_gram2_state_before(text, a, P.gram_g7, prevT, prevB);
+    else prevT = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7);
 #endif
     const uint32_t fix7 = smh_bitrev32(~prevT & 0x7Fu) >> 25; /* bit t SET = bit 6-t of the inherited state alive */
     uint64_t msk = (uint64_t)((fl[0] & (fix7 | ~0x7Fu)) | (fl[1] << 24)) | ((uint64_t)(fl[1] >> 8) << 32) | ((uint64_t)fl[2] << 48);
+    if constexpr (KIND == 4) {
+        if (P.gram_jb) {
+            /* the short group's flags, its first jb-1 columns corrected the same way (lane 0 keeps the assumption) */
+            const uint32_t wb = (uint32_t)P.gram_jb - 1u, wmask = (1u << wb) - 1u;
+            const uint32_t fixb = wb ? smh_bitrev32(~prevB & wmask) >> (32u - wb) : 0u;
+            msk |= (uint64_t)((flb[0] & (fixb | ~wmask)) | (flb[1] << 24)) | ((uint64_t)(flb[1] >> 8) << 32) | ((uint64_t)flb[2] << 48);
+        }
+    }
     if constexpr (STG > 0) {
         /* staged verify: chunks with many surviving columns hash their windows from an LDS copy of the chunk */
         smh_wm_stage_columns<STG>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
@@ -1200,6 +1291,16 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
             smh_wm_gram_lane_fast<KIND, POS, STG>(text, a, cur, cur_halo, tab, P, Q);
+        } else if constexpr (KIND == 4) {
+            if (POS) { /* a column is appended once per length class that matches there */
+                uint64_t mm;
+                for (int c = 0; c < P.n_classes; ++c) {
+                    smh_wm_gram2_lane_slow(text, n, a, P, &mm, c);
+                    cnt += smh_append_bits(mm, a, *po);
+                }
+            } else {
+                cnt += smh_wm_gram2_lane_slow(text, n, a, P);
+            }
         } else if (POS) {
             uint64_t mm;
             smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P, &mm);

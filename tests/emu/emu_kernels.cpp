@@ -434,6 +434,26 @@ extern "C" uint64_t emu_wm_scan_multi(const smh_wm *suffix, const smh_wm *const 
     g_emu_n_classes = n_classes;
     uint64_t cursor = 0, total;
     smh_pos_out po{out, capacity, &cursor};
+    if (suffix->gram_kind == SMH_GRAM_PAIR2) { /* grouped pair-gram filter over the full patterns */
+        smh_wm_params P = {};
+        P.m = suffix->m;
+        P.bits = suffix->bits_per_symbol;
+        P.n_classes = n_classes;
+        P.classes = cls.data();
+        P.gram_g7 = (const uint8_t *)suffix->gram_table + SMH_GRAM_BYTES;
+        P.gram_jb = suffix->gram_jb;
+        const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
+        total = 0;
+        for (uint64_t t = 0; t < nthreads; ++t) {
+            const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
+            total += out ? smh_wm_gram_thread<4, true, 0>(t, S, text, n, suffix->gram_table, P, nullptr, &po)
+                         : smh_wm_gram_thread<4, false, 0>(t, S, text, n, suffix->gram_table, P, nullptr, &po);
+        }
+        if (out) total = cursor;
+        g_emu_classes = nullptr;
+        g_emu_n_classes = 0;
+        return total;
+    }
     if (out) {
         total = suffix->filter_hashed ? wm_halo<true, false, true>(suffix, text, n, blocks, &po)
                                       : wm_halo<false, false, true>(suffix, text, n, blocks, &po);

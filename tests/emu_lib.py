@@ -118,6 +118,19 @@ def wm_scan_multi(suffix, classes, text, capacity=None, blocks=0):
     return total, out[:min(total, capacity)]
 
 
+# ---- grouped pair-gram filter of a mixed-length set (csrc/wm_host.c): internal entry point, bound for the tests
+S.lib.smh_wm_build_gram_mixed.restype = C.c_int
+S.lib.smh_wm_build_gram_mixed.argtypes = [C.c_void_p, S.u8p, C.POINTER(C.c_uint32), C.c_int]
+
+
+def build_gram_mixed(suffix, patterns, lengths):
+    """attach the grouped pair-gram filter over the FULL patterns to the suffix handle; 0 = built, 1 = not applicable"""
+    patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    return int(S.lib.smh_wm_build_gram_mixed(suffix.h, patterns.ctypes.data_as(S.u8p),
+                                             lengths.ctypes.data_as(C.POINTER(C.c_uint32)), len(lengths)))
+
+
 # ---- mixed-length automaton (csrc/acm_host.c): internal entry points of the library, bound here for the tests
 S.lib.smh_acm_compile.restype = C.c_void_p
 S.lib.smh_acm_compile.argtypes = [S.u8p, C.POINTER(C.c_uint32), C.c_int, C.c_int]

@@ -22,7 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with open(os.path.join(ROOT, "tests", "golden", "ref_mixed_vectors.json")) as f:
     MIXED = json.load(f)
 IDS = [v["name"] for v in MIXED]
-ONE_PASS = {"mixed_ascii_5_20"}  # sets whose min-length suffix filter passes < 0.4 % of the columns
+# SMH_ALGO_WM sets whose min-length suffix filter passes < 0.4 % of the columns: one pass with that filter (the
+# others take the grouped pair-gram filter when their short patterns are few, else the automaton of ONE_PASS_AC)
+ONE_PASS = {"mixed_ascii_5_20"}
 # SMH_ALGO_AC sets: one automaton with joined output counts whenever a cut of it fits LDS with few candidates
 # (alphabet 256: a row costs 512 bytes, only depth 1 fits, every position would be a candidate: per class)
 ONE_PASS_AC = {"mixed_dna_8_32", "mixed_protein", "mixed_len_1_2", "mixed_prefix_hazard"}
@@ -51,7 +53,7 @@ def test_oracle_and_lane_code_reproduce_every_class(vec):
 
 @pytest.mark.parametrize("vec", [v for v in MIXED if min(c[0] for c in v["classes"]) >= 3],
                          ids=[v["name"] for v in MIXED if min(c[0] for c in v["classes"]) >= 3])
-def test_one_pass_lane_code_reproduces_the_decomposition(vec):
+def test_one_pass_lane_code_reproduces_the_decomposition(vec, monkeypatch):
     """SMH_ALGO_WM sets are scanned in ONE pass: a block filter over the patterns' last min-length symbols
     proposes END columns, every survivor is verified per length class.  Same total, same positions."""
     text, patterns, lengths = cases.build_mixed(vec)
@@ -68,8 +70,19 @@ def test_one_pass_lane_code_reproduces_the_decomposition(vec):
     want_pos = np.sort(np.concatenate([O.positions_bruteforce(classes[L], L, len(classes[L]) // L, text) for L in sorted(classes)]))
     total, got = E.wm_scan_multi(suffix, handles, text, vec["total"] + 3, 3)
     assert total == vec["total"] and np.array_equal(np.sort(got).astype(np.int64), want_pos)
+    if sigma == 4 and Lmin >= 8:
+        # grouped pair-gram filter over the FULL patterns (two shift-or states per lane), same total and positions;
+        # forced: with 200 patterns of 8 symbols the set itself takes the automaton (one column in 160 a candidate)
+        assert E.build_gram_mixed(suffix, patterns, lengths) == 1
+        monkeypatch.setenv("SMH_WM_TUNE", "grouped=force")
+        assert E.build_gram_mixed(suffix, patterns, lengths) == 0 and suffix.info().gram_planes == 8
+        for blocks in (1, 3):
+            assert E.wm_scan_multi(suffix, handles, text, None, blocks) == vec["total"]
+        total, got = E.wm_scan_multi(suffix, handles, text, vec["total"] + 3, 2)
+        assert total == vec["total"] and np.array_equal(np.sort(got).astype(np.int64), want_pos)
     # the handle takes the one-pass form only while the suffix filter lets few columns through
-    assert S.PatternSet(patterns, lengths, sigma, S.ALGO_WM).info().one_pass == (1 if vec["name"] in ONE_PASS else 0)
+    monkeypatch.delenv("SMH_WM_TUNE", raising=False)
+    assert S.PatternSet(patterns, lengths, sigma, S.ALGO_WM).info().one_pass == (1 if vec["name"] in ONE_PASS | ONE_PASS_AC else 0)
     assert S.PatternSet(patterns, lengths, sigma, S.ALGO_AC).info().one_pass == (1 if vec["name"] in ONE_PASS_AC else 0)
 
 
@@ -205,3 +218,82 @@ def test_gpu_set_at_baseline_shape():
     want = sum(O.oracle_ac(flat, L, len(flat) // L, sigma, sample)[0]
                for L, flat in cases.split_classes(patterns, lengths).items())
     assert ac.count_host(sample)[0] == want == wm.count_host(sample)[0]
+
+
+def _random_dna_set(seed):
+    """patterns of lo..hi symbols in two plane groups (shorter than 14 / 14 and more), suffixes of one another,
+    duplicates, occurrences planted across segment and wave-chunk boundaries and at both ends of the text"""
+    rng = np.random.RandomState(500 + seed)
+    n = int(rng.randint(3 * 4096 + 100, 6 * 4096))
+    text = rng.randint(0, 4, size=n).astype(np.uint8)
+    lo = [8, 8, 9, 10, 13, 14, 8, 11, 8, 16][seed]
+    hi = [32, 13, 40, 10, 33, 40, 9, 12, 20, 17][seed]
+    pats, lengths = [], []
+    for j in range(int(rng.randint(2, 400))):
+        L = int(rng.randint(lo, hi + 1))
+        if j % 5 == 4 and pats:  # a suffix of an earlier pattern (same end, shorter), or the pattern again
+            q = pats[rng.randint(0, len(pats))]
+            L = int(rng.randint(lo, len(q) + 1)) if len(q) >= lo else len(q)
+            pat = q[len(q) - L:]
+        else:
+            pat = rng.randint(0, 4, size=L).astype(np.uint8)
+        pats.append(np.array(pat, dtype=np.uint8))
+        lengths.append(len(pat))
+    if len(set(lengths)) < 2:
+        pats.append(rng.randint(0, 4, size=lo + 1).astype(np.uint8)); lengths.append(lo + 1)
+    for i, off in enumerate([0, 300, 640 - 5, 4096 - 7, 4096 - 1, 8191, 8192, 8192 + 100, n - 1]):
+        q = pats[(3 * i) % len(pats)]
+        off = min(max(off - (len(q) if off == n - 1 else 0) + (1 if off == n - 1 else 0), 0), n - len(q))
+        text[off:off + len(q)] = q
+    patterns, lengths = np.concatenate(pats), np.array(lengths, dtype=np.uint32)
+    classes = cases.split_classes(patterns, lengths)
+    want_pos = np.sort(np.concatenate([O.positions_bruteforce(classes[L], L, len(classes[L]) // L, text) for L in sorted(classes)]))
+    assert len(want_pos) >= 5
+    return text, patterns, lengths, classes, want_pos
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_grouped_pair_gram_filter_on_random_dna_sets(seed, monkeypatch):
+    """the one-pass form of SMH_ALGO_WM sets on the 4-letter alphabet (emulated lane code) against the definition
+    (sum over length classes)"""
+    text, patterns, lengths, classes, want_pos = _random_dna_set(seed)
+    want = len(want_pos)
+    Lmin = min(classes)
+    off, suf = 0, []
+    for L in lengths:
+        suf.append(patterns[off + int(L) - Lmin:off + int(L)])
+        off += int(L)
+    suffix = S.WmTables.from_patterns(np.concatenate(suf), Lmin, len(lengths), 4)
+    handles = [S.WmTables.from_patterns(classes[L], L, len(classes[L]) // L, 4) for L in sorted(classes)]
+    monkeypatch.setenv("SMH_WM_TUNE", "grouped=force")  # whatever the candidate rate: the count must not depend on it
+    assert E.build_gram_mixed(suffix, patterns, lengths) == 0
+    assert E.wm_scan_multi(suffix, handles, text, None, 2) == want
+    total, got = E.wm_scan_multi(suffix, handles, text, want + 3, 3)
+    assert total == want and np.array_equal(np.sort(got).astype(np.int64), want_pos)
+    monkeypatch.delenv("SMH_WM_TUNE")
+    assert S.PatternSet(patterns, lengths, 4, S.ALGO_WM).info().one_pass == 1  # grouped filter or automaton
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force", [True, False], ids=["grouped_forced", "as_chosen"])
+@pytest.mark.parametrize("seed", range(10))
+def test_gpu_grouped_pair_gram_filter_on_random_dna_sets(seed, force, monkeypatch):
+    """the same sets through smh_pset_* on the device: count and positions of SMH_ALGO_WM sets, with the grouped
+    pair-gram filter forced and with whatever one-pass form the set chose"""
+    import torch
+    text, patterns, lengths, classes, want_pos = _random_dna_set(seed)
+    want, n = len(want_pos), len(text)
+    if force:
+        monkeypatch.setenv("SMH_WM_TUNE", "grouped=force")
+    ps = S.PatternSet(patterns, lengths, 4, S.ALGO_WM)
+    assert ps.info().one_pass == 1
+    assert ps.count_host(text)[0] == want
+    dev = torch.device("cuda", 0)
+    d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    d_text[:n] = torch.from_numpy(text).to(dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    pos = torch.zeros(want + 3, dtype=torch.int64, device=dev)
+    ps.positions_device(d_text.data_ptr(), n, pos.data_ptr(), want + 3, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == want and np.array_equal(np.sort(pos[:want].cpu().numpy()), want_pos)
+    ps.close()
