@@ -458,18 +458,24 @@ SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t 
 /* the surviving columns `msk` (bit b = column a + b) of a lane's segment in the wave-chunk at chunk_base: queue
  * them; a chunk with st_min or more of them is verified from its staged copy at once, the others wait in the
  * queue for the next drain from HBM */
-template <int STG>
+/* QD = the kernel also has the drain from HBM (sparse chunks wait in the queue).  Without it every chunk with a
+ * surviving column is staged: the drain's code inside the chunk loop costs the scan 10 % even when it never runs
+ * (gpurun_out/r02_v: 0.175 -> 0.193 ms/GiB on a set without survivors), so the launcher picks it only for sets
+ * that expect a few survivors per chunk. */
+template <int STG, bool QD = true>
 SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint64_t a, uint64_t msk,
                                    const uint32_t (&w)[16], const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
 {
     if (!SMH_WAVE_ANY(msk != 0)) return;
-    uint32_t from = Q.count; /* entries of earlier chunks */
+    uint32_t from = QD ? Q.count : 0u; /* entries of earlier chunks */
     do {
         if (Q.count + 64u > SMH_WM_QCAP) {
             smh_wm_stage_flush<STG>(Q, text, chunk_base, from, w, halo, P);
-            if (Q.count + 64u > SMH_WM_QCAP) { /* still full: the earlier chunks' entries, from HBM */
-                smh_wm_drain(Q, text, P);
-                from = 0;
+            if constexpr (QD) {
+                if (Q.count + 64u > SMH_WM_QCAP) { /* still full: the earlier chunks' entries, from HBM */
+                    smh_wm_drain(Q, text, P);
+                    from = 0;
+                }
             }
         }
         const bool have = msk != 0;
@@ -477,7 +483,7 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
         smh_wm_emit(Q, text, P, have, a + b);
         msk &= msk - 1u;
     } while (SMH_WAVE_ANY(msk != 0));
-    if (Q.count - from >= Q.st_min) smh_wm_stage_flush<STG>(Q, text, chunk_base, from, w, halo, P);
+    if (!QD || Q.count - from >= Q.st_min) smh_wm_stage_flush<STG>(Q, text, chunk_base, from, w, halo, P);
 }
 #else
 /* CPU emulation (one lane at a time): the same window hash over a private copy of the chunk laid out as the
@@ -495,7 +501,7 @@ SMH_LANE void smh_wm_stage_verify_emu(smh_wm_queue &Q, const uint8_t *text, uint
     Q.matches += hit;
     if (hit && Q.po) smh_append_bits(1u, chunk_base + c, *Q.po);
 }
-template <int STG>
+template <int STG, bool QD = true>
 SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint64_t a, uint64_t msk,
                                    const uint32_t (&)[16], const uint32_t (&)[4 * STG], const smh_wm_params &P)
 {
@@ -1072,7 +1078,7 @@ SMH_LANE uint32_t smh_wm_gram2_lane_slow(const uint8_t *text, uint64_t n, uint64
 
 /* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
  * `edge` = the 8 bytes in front of the wave-chunk (wave-uniform).  Returns nothing: candidates go to the queue. */
-template <int KIND, bool POS, int STG = 0>
+template <int KIND, bool POS, int STG = 0, bool QD = true>
 SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&halo)[STG > 0 ? 4 * STG : 4],
                                     const void *tab, const smh_wm_params &P, smh_wm_queue &Q)
 {
@@ -1185,7 +1191,7 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     }
     if constexpr (STG > 0) {
         /* staged verify: chunks with many surviving columns hash their windows from an LDS copy of the chunk */
-        smh_wm_stage_columns<STG>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
+        smh_wm_stage_columns<STG, QD>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
     } else {
     while (SMH_WAVE_ANY(msk != 0)) {
         if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
@@ -1235,7 +1241,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     return cnt;
 }
 
-template <int KIND, bool POS = false, int STG = 0>
+template <int KIND, bool POS = false, int STG = 0, bool QD = true>
 SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n,
                                      const void *tab, const smh_wm_params &P, uint64_t *queue_base, const smh_pos_out *po = nullptr,
                                      uint32_t smh_gram_drain_at = 64u, const smh_wm_queue *stage = nullptr)
@@ -1286,11 +1292,11 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         /* the verify stage runs HERE, between chunks and before the next chunk's text is requested: its loads
          * return in order behind everything the wave has in flight, so a drain entered while a prefetch is
          * outstanding also waits for that prefetch (measured: 2-3 x the cost per surviving column) */
-        if (Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
+        if (QD && Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
         if (nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
-            smh_wm_gram_lane_fast<KIND, POS, STG>(text, a, cur, cur_halo, tab, P, Q);
+            smh_wm_gram_lane_fast<KIND, POS, STG, QD>(text, a, cur, cur_halo, tab, P, Q);
         } else if constexpr (KIND == 4) {
             if (POS) { /* a column is appended once per length class that matches there */
                 uint64_t mm;
@@ -1317,7 +1323,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         cur_fast = nxt_fast;
         k = kn;
     }
-    smh_wm_drain(Q, text, P);
+    if (QD) smh_wm_drain(Q, text, P);
     return cnt + Q.matches;
 }
 
