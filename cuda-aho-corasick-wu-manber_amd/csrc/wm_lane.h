@@ -399,7 +399,7 @@ SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_
 /* verify the queue entries [from, Q.count) -- all columns of the wave-chunk at `chunk_base`, whose text the lanes
  * hold in w (and lane 0 the 16*STG bytes in front of it in `halo`) -- and remove them; at most 128 entries; all 64
  * lanes must call it */
-template <int STG>
+template <int STG, bool QD = true>
 SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint32_t from,
                                  const uint32_t (&w)[16], const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
 {
@@ -429,13 +429,18 @@ SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t 
     }
     /* lane l hashes the windows of entries l and l + 64 */
     const bool h0 = lane < cnt, h1 = lane + 64u < cnt;
-    const uint64_t e0 = Q.slots[from + (h0 ? lane : 0u)];
+    /* QD: 64-bit END columns (entries of other chunks may wait in front of them); else 32-bit chunk offsets */
+    auto entry = [&](uint32_t i) -> uint64_t {
+        if constexpr (QD) return Q.slots[from + i];
+        else return chunk_base + reinterpret_cast<const uint32_t *>(Q.slots)[i];
+    };
+    const uint64_t e0 = entry(h0 ? lane : 0u);
     auto rd = [&](uint32_t off) { return smh_lds_u32(nullptr, buf + off); };
     const uint32_t tag0 = smh_wm_tag_staged(rd, (uint32_t)(e0 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
     uint64_t e1 = e0;
     uint32_t tag1 = tag0;
     if (cnt > 64u) { /* wave-uniform */
-        e1 = Q.slots[from + (h1 ? lane + 64u : 0u)];
+        e1 = entry(h1 ? lane + 64u : 0u);
         tag1 = smh_wm_tag_staged(rd, (uint32_t)(e1 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
     }
     /* hand the buffer back: the release waits for the window reads above, nothing else */
@@ -470,7 +475,7 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
     uint32_t from = QD ? Q.count : 0u; /* entries of earlier chunks */
     do {
         if (Q.count + 64u > SMH_WM_QCAP) {
-            smh_wm_stage_flush<STG>(Q, text, chunk_base, from, w, halo, P);
+            smh_wm_stage_flush<STG, QD>(Q, text, chunk_base, from, w, halo, P);
             if constexpr (QD) {
                 if (Q.count + 64u > SMH_WM_QCAP) { /* still full: the earlier chunks' entries, from HBM */
                     smh_wm_drain(Q, text, P);
@@ -480,10 +485,17 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
         }
         const bool have = msk != 0;
         const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
-        smh_wm_emit(Q, text, P, have, a + b);
+        if constexpr (QD) {
+            smh_wm_emit(Q, text, P, have, a + b);
+        } else { /* the queue only ever holds this chunk's columns: 32-bit offsets, half the LDS */
+            const uint64_t mask = __ballot(have);
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            if (have) reinterpret_cast<uint32_t *>(Q.slots)[Q.count + before] = (uint32_t)(a - chunk_base) + b;
+            Q.count += (uint32_t)__popcll(mask);
+        }
         msk &= msk - 1u;
     } while (SMH_WAVE_ANY(msk != 0));
-    if (!QD || Q.count - from >= Q.st_min) smh_wm_stage_flush<STG>(Q, text, chunk_base, from, w, halo, P);
+    if (!QD || Q.count - from >= Q.st_min) smh_wm_stage_flush<STG, QD>(Q, text, chunk_base, from, w, halo, P);
 }
 #else
 /* CPU emulation (one lane at a time): the same window hash over a private copy of the chunk laid out as the
