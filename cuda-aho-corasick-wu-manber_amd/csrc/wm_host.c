@@ -154,17 +154,18 @@ static uint64_t gram_rng(uint64_t *s)
     return z ^ (z >> 31);
 }
 
-static double gram_survivors(int kind, const void *tab, int alphabet)
+static double gram_survivors(int kind, const void *tab, int alphabet, int planes)
 {
     enum { COLS = 1 << 18 };
     uint64_t seed = 0x5EEDull, hits = 0;
     uint32_t S = ~0u, code = 0, k0 = 0, k1 = 0;
+    const int cand_bit = kind == SMH_GRAM_PAIR ? planes - 1 : 7; /* the pair form holds J-bit values, candidate = bit J-1 */
     for (int x = 0; x < COLS; ++x) {
         const uint32_t c = (uint32_t)(gram_rng(&seed) % (uint64_t)alphabet);
         uint32_t G;
         if (kind == SMH_GRAM_PAIR) {
             code = ((code << 2) | c) & 0x3FFFu;                     /* the 7 symbols ending here */
-            G = ((const uint8_t *)tab)[SMH_GRAM_BYTES + code];      /* the per-gram bytes behind the LDS image */
+            G = ((const uint16_t *)((const uint8_t *)tab + SMH_GRAM_BYTES))[code]; /* the per-gram values behind the LDS image */
         } else if (kind == SMH_GRAM_OCT) {
             code = ((code << 2) | c) & 0xFFFFu;
             G = ((const uint8_t *)tab)[code];
@@ -174,10 +175,10 @@ static double gram_survivors(int kind, const void *tab, int alphabet)
             k1 = c;
             G = ((const uint8_t *)tab)[(uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15];
         }
-        S = (S << 1) | G;                                           /* shift-or: bit 7 clear = candidate */
-        if (x >= 16) hits += ((S >> 7) & 1u) ^ 1u;
+        S = (S << 1) | G;                                           /* shift-or: candidate bit clear = candidate */
+        if (x >= 32) hits += ((S >> cand_bit) & 1u) ^ 1u;
     }
-    return (double)hits / (double)(COLS - 16);
+    return (double)hits / (double)(COLS - 32);
 }
 
 /* scan time (ms per GiB on MI355X, profiles/r02_*) of each form + what a surviving column costs in the verify
@@ -213,27 +214,30 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
     if (force > 0) best_ms = 1e30;
 #define GRAM_WANTED(kind) (force < 0 || force == (kind))
     if (wm->alphabet == 4 && m >= 9 && GRAM_WANTED(SMH_GRAM_PAIR)) {
-        /* 7-symbol grams; planes 0 .. J-1 need the gram that ends j before the end to start at >= 0 */
+        /* 7-symbol grams; planes 0 .. J-1 need the gram that ends j before the end to start at >= 0.  A 16-bit entry
+         * holds (G of the older seven << 1) | G of the newer seven, so up to FIFTEEN planes: with J = m - 6 the chain of
+         * overlapping grams covers the whole pattern and next to nothing but matches survives (8000 patterns of 16
+         * symbols: eight planes let 0.41 % of random columns through, ten planes 0.0002 %) */
         int J = m - 6;
-        if (J > 8) J = 8;
-        /* LDS image (128 KiB of 16-bit entries) + the per-gram bytes G (16 KiB, HBM only: bounds-checked path) */
-        uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES + 16384);
+        if (J > 15) J = 15;
+        /* LDS image (128 KiB of 16-bit entries) + the per-gram values G (32 KiB, HBM only: bounds-checked path) */
+        uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES + 32768);
         if (!tab) return -1;
-        uint8_t *g7 = (uint8_t *)tab + SMH_GRAM_BYTES;
-        memset(g7, 0xFF & ~((1 << (8 - J)) - 1), 16384); /* bit 7-j SET = the gram is NOT in plane j; unused planes clear */
+        uint16_t *g7 = (uint16_t *)((uint8_t *)tab + SMH_GRAM_BYTES);
+        for (uint32_t c = 0; c < 16384; ++c) g7[c] = (uint16_t)((1u << J) - 1u); /* bit J-1-j SET = the gram is NOT in plane j */
         for (int p = 0; p < d; ++p)
             for (int j = 0; j < J; ++j) {
                 const unsigned char *g = pats + (size_t)p * m + (m - 7 - j);
                 uint32_t code = 0;
                 for (int i = 0; i < 7; ++i) code = (code << 2) | g[i];
-                g7[code] &= (uint8_t)~(1u << (7 - j));
+                g7[code] &= (uint16_t)~(1u << (J - 1 - j));
             }
         /* entry of eight symbols = (G of the older seven << 1) | G of the newer seven: one v_lshl_or does both columns */
         for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(((uint32_t)g7[x >> 2] << 1) | g7[x & 0x3FFFu]);
-        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4), ms = SMH_GRAM_PAIR_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_PAIR, m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4, J), ms = SMH_GRAM_PAIR_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_PAIR, m) * dens;
         if (ms < best_ms) {
             free(best);
-            best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES + 16384; best_ms = ms; best_dens = dens;
+            best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES + 32768; best_ms = ms; best_dens = dens;
         } else {
             free(tab);
         }
@@ -251,7 +255,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
                 tab[code] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4), ms = SMH_GRAM_OCT_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_OCT, m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4, J), ms = SMH_GRAM_OCT_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_OCT, m) * dens;
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_OCT; best_planes = J; best_bytes = 65536; best_ms = ms; best_dens = dens;
@@ -272,7 +276,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 const uint32_t idx = (uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15; /* low 32 bits of the product, top 17 */
                 tab[idx] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet), ms = SMH_GRAM_BYTE_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_BYTE, m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet, J), ms = SMH_GRAM_BYTE_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_BYTE, m) * dens;
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_BYTE; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;

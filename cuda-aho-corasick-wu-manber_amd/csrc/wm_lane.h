@@ -46,6 +46,7 @@ struct smh_wm_params {
     const uint8_t *gram_g7;              /* HBM: pair-gram filter only, the byte G of every 7-symbol gram (bounds-checked path);
                                           * grouped pairs (KIND 4): 16-bit values G_A | G_B << 8 */
     int gram_jb;                         /* grouped pairs: planes of the short-pattern group, 0 = none */
+    int gram_planes;                     /* pair form (KIND 1): planes J (2..15), candidate = state bit J-1 clear */
 };
 
 #define SMH_WM_MAX_CLASSES 32 /* distinct lengths of a mixed-length set scanned in one pass */
@@ -949,7 +950,8 @@ SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, const smh_chunk_sched &S,
  * assumption: a few more columns reach the verify stage, which is exact, so the count does not change.
  * One column costs ONE v_lshl_or_b32: S = (S << 1) | G with G the table byte (zero-extended by ds_read_u8), so the
  * candidate bits just keep shifting up the register and 24 columns' flags are collected with one bit-reverse.  The
- * pair form does TWO columns with one v_lshl_or_b32: its 16-bit entry is (G_first << 1) | G_second. */
+ * pair form does TWO columns with one v_lshl_or_b32: its 16-bit entry is (G_first << 1) | G_second, with G up to 15 bits
+ * wide (J planes, candidate = bit J-1 clear; flags collected every 16 columns). */
 #define SMH_GRAM_S0 0xFFFFFF80u /* no candidates behind, all seven inherited terms alive */
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -980,6 +982,13 @@ SMH_LANE uint32_t smh_gram_flags(uint32_t S, int cols)
 {
     /* after the group's last column, bit 7 + t of S is the (inverted) flag of the column t before it */
     return (smh_bitrev32(~S) >> (25 - cols)) & ((1u << cols) - 1u);
+}
+
+/* pair form with J planes: candidate flags of the last 16 columns (bit c SET = the c-th of them, oldest first) */
+SMH_LANE uint32_t smh_gram_flags16(uint32_t S, int J)
+{
+    const uint32_t s = J >= 8 ? S >> (J - 8) : S << (8 - J); /* candidate bit J-1 -> bit 7 */
+    return (smh_bitrev32(~s) >> 9) & 0xFFFFu;
 }
 
 /* byte-gram key of column i of the segment: the three bytes that end there, as the low 24 bits of a dword.
@@ -1023,12 +1032,8 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
             S = smh_gram_step(S, smh_lds_u8(tab, code));
         }
     } else if (KIND == 1) {
-        if (a < 14) return S; /* columns without seven symbols in front of them: keep the assumption (superset) */
-        for (uint64_t x = a - 7; x < a; ++x) {
-            uint32_t code = 0;
-            for (int i = 6; i >= 0; --i) code = (code << 2) | (text[x - (uint64_t)i] & 3u);
-            S = smh_gram_step(S, g7[code]);
-        }
+        /* J - 1 columns of history (J = planes, handed over in place of a table pointer's companion: see callers) */
+        return 0u; /* the pair form has its own routine: smh_gram1_state_before */
     } else {
         if (a < 10) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
@@ -1037,6 +1042,21 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
         }
     }
     return S & 0x7Fu;
+}
+
+/* pair form (KIND 1): the low J-1 state bits a lane would have inherited, true value (0 = alive) */
+SMH_LANE uint32_t smh_gram1_state_before(const uint8_t *text, uint64_t a, const uint8_t *g7, int J)
+{
+    uint32_t S = 0u;
+    if (a < (uint64_t)(J - 1) + 6u) return S; /* columns without seven symbols in front of them: keep the assumption (superset) */
+    for (uint64_t x = a - (uint64_t)(J - 1); x < a; ++x) {
+        uint32_t code = 0;
+        for (int i = 6; i >= 0; --i) code = (code << 2) | (text[x - (uint64_t)i] & 3u);
+        uint16_t g;
+        memcpy(&g, g7 + 2u * code, 2);
+        S = smh_gram_step(S, g);
+    }
+    return S & ((1u << (J - 1)) - 1u);
 }
 
 /* ---- grouped pairs (KIND 4, mixed-length sets; smh_internal.h SMH_GRAM_PAIR2): two shift-or states per lane.
@@ -1096,7 +1116,10 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
 {
     /* halo = the 16 * max(STG, 1) bytes in front of the wave-chunk (wave-uniform); its last two dwords prime lane 0 */
     constexpr int HD = STG > 0 ? 4 * STG : 4;
-    uint32_t T = SMH_GRAM_S0, fl[3] = {0, 0, 0};
+    /* pair form: J planes (2..15), the low J-1 bits assumed alive */
+    [[maybe_unused]] const uint32_t jw = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u, jmask = (1u << jw) - 1u;
+    [[maybe_unused]] uint32_t fl16[4] = {0, 0, 0, 0};
+    uint32_t T = KIND == 1 ? ~jmask : SMH_GRAM_S0, fl[3] = {0, 0, 0};
     /* grouped pairs: the short group's state (jb planes: the low jb-1 bits assumed alive), its flags, and the shift
      * that brings its candidate bit (jb-1) to bit 7 */
     [[maybe_unused]] const uint32_t bup = KIND == 4 && P.gram_jb ? 8u - (uint32_t)P.gram_jb : 0u;
@@ -1123,9 +1146,7 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
                 code2 = ((code2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
                 T = smh_gram_step2(T, smh_lds_u16(tab, code2)); /* columns a + 4q + 2k and + 1 */
             }
-            if (q == 5) fl[0] = smh_gram_flags(T, 24);
-            if (q == 11) fl[1] = smh_gram_flags(T, 24);
-            if (q == 15) fl[2] = smh_gram_flags(T, 16);
+            if ((q & 3) == 3) fl16[q >> 2] = smh_gram_flags16(T, P.gram_planes); /* J planes: flags every 16 columns */
         }
     } else if constexpr (KIND == 4) {
         /* grouped pairs: the pair form's lookup, two states (A above B in the entry) */
@@ -1189,10 +1210,24 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     if constexpr (KIND == 4) prevB = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)TB, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #else
     if constexpr (KIND == 4) smh_gram2_state_before(text, a, P.gram_g7, prevT, prevB);
+    else if constexpr (KIND == 1) prevT = smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes);
     else prevT = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7);
 #endif
+    uint64_t msk;
+    if constexpr (KIND == 1) {
+        /* bit t (t < J-1) SET = bit J-2-t of the inherited state alive; lane 0's default (all of SMH_GRAM_S0's low
+         * seven bits clear) is the assumption for J <= 8 and merely a subset of it above: its bits 7.. read as dead,
+         * which would lose candidates, so lane 0 is given the assumption explicitly */
+        uint32_t pv = prevT;
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        if ((threadIdx.x & 63u) == 0) pv = 0u;
+#endif
+        const uint32_t fixj = jw ? smh_bitrev32(~pv & jmask) >> (32u - jw) : 0u;
+        msk = (uint64_t)((fl16[0] & (fixj | ~jmask)) | (fl16[1] << 16)) | ((uint64_t)(fl16[2] | (fl16[3] << 16)) << 32);
+    } else {
     const uint32_t fix7 = smh_bitrev32(~prevT & 0x7Fu) >> 25; /* bit t SET = bit 6-t of the inherited state alive */
-    uint64_t msk = (uint64_t)((fl[0] & (fix7 | ~0x7Fu)) | (fl[1] << 24)) | ((uint64_t)(fl[1] >> 8) << 32) | ((uint64_t)fl[2] << 48);
+    msk = (uint64_t)((fl[0] & (fix7 | ~0x7Fu)) | (fl[1] << 24)) | ((uint64_t)(fl[1] >> 8) << 32) | ((uint64_t)fl[2] << 48);
+    }
     if constexpr (KIND == 4) {
         if (P.gram_jb) {
             /* the short group's flags, its first jb-1 columns corrected the same way (lane 0 keeps the assumption) */
@@ -1226,7 +1261,8 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     uint64_t end = a + SMH_SEG;
     if (end > n) end = n;
     const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
-    uint32_t T = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7), cnt = 0;
+    const uint32_t cand_bit = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u;
+    uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes) : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7), cnt = 0;
     for (uint64_t e = a; e < end; ++e) {
         uint32_t G = 0u; /* a column without a whole gram in front of it cannot be ruled out */
         if (e + 1 >= q) {
@@ -1237,14 +1273,16 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
             } else if (KIND == 1) {
                 uint32_t code = 0;
                 for (int i = 6; i >= 0; --i) code = (code << 2) | (text[e - (uint64_t)i] & 3u);
-                G = P.gram_g7[code];
+                uint16_t g;
+                memcpy(&g, P.gram_g7 + 2u * code, 2);
+                G = g;
             } else {
                 const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
                 G = smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15);
             }
         }
         T = smh_gram_step(T, G);
-        if (!((T >> 7) & 1u) && e + 1 >= (uint64_t)P.m) {
+        if (!((T >> cand_bit) & 1u) && e + 1 >= (uint64_t)P.m) {
             const uint32_t hit = smh_wm_verify(text, e, P);
             cnt += hit;
             if (match_mask && hit) *match_mask |= 1ull << (e - a);

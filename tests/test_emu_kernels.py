@@ -123,7 +123,7 @@ def test_grid_size_does_not_change_the_count():
         assert E.wm_scan(wm, text, 0, blocks) == vec["count_ac"]
 
 
-@pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 33, 50), (3, 4, 11, 200), (3, 4, 16, 2000),
+@pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 14, 4000), (1, 4, 21, 9000), (1, 4, 33, 50), (3, 4, 11, 200), (3, 4, 16, 2000),
                                             (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
                                             (2, 128, 7, 100)])
 def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
@@ -141,7 +141,7 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
     pat[p // 2] = pat[0]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
     info = wm.info()
-    assert info.gram_planes == min(8, m - {1: 6, 3: 7, 2: 2}[kind])
+    assert info.gram_planes == min(15 if kind == 1 else 8, m - {1: 6, 3: 7, 2: 2}[kind])
     if info.scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)

@@ -339,7 +339,7 @@ def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, monkeypatch):
         text[off:off + m] = pat[(7 * i + 3) % p]
     pat[p // 2] = pat[3]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
-    assert wm.info().gram_planes == min(8, m - {1: 6, 3: 7, 2: 2}[kind])
+    assert wm.info().gram_planes == min(15 if kind == 1 else 8, m - {1: 6, 3: 7, 2: 2}[kind])
     if wm.info().scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)

@@ -200,7 +200,7 @@ def test_scan_engine_choice_is_made_on_the_host():
 def test_wm_scan_engine_choice_and_knob():
     long_dna = S.corpus_patterns(16, 1000, 7, 4, 42, 1 << 24, 2)
     own = S.WmTables.from_patterns(long_dna, 16, 1000, 4)
-    assert own.info().scan_engine == S.ALGO_WM and own.info().gram_planes == 8  # its pair-gram filter beats the automaton
+    assert own.info().scan_engine == S.ALGO_WM and own.info().gram_planes == 10  # its pair-gram filter beats the automaton
     long8 = S.corpus_patterns(16, 1000, 7, 8, 42, 1 << 24, 2)
     wm = S.WmTables.from_patterns(long8, 16, 1000, 8)   # 3-bit symbols: no gram form, non-exact direct filter
     assert wm.info().scan_engine == S.ALGO_AC          # its automaton fits LDS with next to no candidates
