@@ -81,16 +81,22 @@ SMH_LANE uint32_t smh_wm_mix(uint32_t h, uint32_t v)
 
 /* second half of the device HASH/PREFIX stage: the bucket walk for a window whose hash `tag` is known.  The pattern
  * bytes are compared with the text in HBM (reached by true matches and one false tag in ~1000 probes only). */
-SMH_LANE uint32_t smh_wm_probe(const uint8_t *text, uint64_t e, uint32_t tag, const smh_wm_params &P)
+SMH_LANE uint32_t smh_wm_first_bucket(uint32_t tag, const smh_wm_params &P) { return (tag * SMH_WM_HASH_MUL) >> (32 - (P.verify_log2 - 2)); }
+
+/* have_first: `first` holds the contents of the window's first bucket, loaded earlier (software pipelining, see
+ * smh_wm_pend_issue) */
+SMH_LANE uint32_t smh_wm_probe_from(const uint8_t *text, uint64_t e, uint32_t tag, const smh_wm_params &P, bool have_first,
+                                    smh_u32x4 first)
 {
     const uint64_t s0 = e + 1 - (uint64_t)P.m;
     const uint32_t *aligned = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
     const uint32_t shift_bits = (uint32_t)(s0 & 3u) * 8u;
     const int nd = (P.m + 3) >> 2;
-    uint32_t b = (tag * SMH_WM_HASH_MUL) >> (32 - (P.verify_log2 - 2)); /* bucket of four slots */
+    uint32_t b = smh_wm_first_bucket(tag, P); /* bucket of four slots */
     const uint32_t bmask = (1u << (P.verify_log2 - 2)) - 1u;
-    for (;;) {
-        const smh_u32x4 q4 = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)b);
+    for (bool preloaded = have_first;; preloaded = false) {
+        smh_u32x4 q4 = first;
+        if (!preloaded) q4 = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)b);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t slot = q4.v[k]; /* 12 tag bits | pattern + 1 (20 bits); 0 = empty */
@@ -104,6 +110,11 @@ SMH_LANE uint32_t smh_wm_probe(const uint8_t *text, uint64_t e, uint32_t tag, co
         if (q4.v[3] == 0) return 0; /* slots fill in order: a bucket with a free slot ends the search */
         b = (b + 1) & bmask;
     }
+}
+
+SMH_LANE uint32_t smh_wm_probe(const uint8_t *text, uint64_t e, uint32_t tag, const smh_wm_params &P)
+{
+    return smh_wm_probe_from(text, e, tag, P, false, smh_u32x4{{0, 0, 0, 0}});
 }
 
 /* device HASH/PREFIX stage: is text[e-m+1 .. e] one of the patterns?  Three dependent memory
@@ -121,25 +132,31 @@ SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_pa
 }
 
 /* The same hash from a STAGED copy of the text (LDS on the GPU): `rd(off)` returns the aligned dword at byte offset
- * `off` of a buffer that holds the bytes around the window, `s0` = offset of the window's first byte in it.  One
- * aligned dword past the window's last is read (and shifted or masked away), so the buffer is padded. */
-template <typename RD>
+ * `off` of a buffer that holds the bytes around the window, `s0` = offset of the window's first byte in it.  All
+ * MAXD + 1 aligned dwords a window of up to 4 * MAXD bytes can touch are requested up front (independent LDS reads,
+ * one round trip instead of one per dword; the buffer is padded for the ones past the window) and mixed in as far
+ * as the window reaches. */
+template <int MAXD, typename RD>
 SMH_LANE uint32_t smh_wm_tag_staged(RD rd, uint32_t s0, int m)
 {
     const uint32_t a0 = s0 & ~3u, sh = (s0 & 3u) * 8u;
     const int nd = (m + 3) >> 2;
-    uint32_t tag = 0x811C9DC5u, lo = rd(a0);
-    for (int j = 0; j < nd; ++j) {
-        const uint32_t hi = rd(a0 + 4u * (uint32_t)(j + 1));
+    uint32_t d[MAXD + 1];
+#pragma unroll
+    for (int j = 0; j <= MAXD; ++j) d[j] = rd(a0 + 4u * (uint32_t)j);
+    uint32_t tag = 0x811C9DC5u;
+#pragma unroll
+    for (int j = 0; j < MAXD; ++j) {
+        if (j < nd) {
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        uint32_t v = __builtin_amdgcn_alignbit(hi, lo, sh);
+            uint32_t v = __builtin_amdgcn_alignbit(d[j + 1], d[j], sh);
 #else
-        uint32_t v = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+            uint32_t v = (uint32_t)((((uint64_t)d[j + 1] << 32) | d[j]) >> sh);
 #endif
-        const int rest = m - 4 * j;
-        if (rest < 4) v &= (1u << (8 * rest)) - 1u;
-        tag = smh_wm_mix(tag, v);
-        lo = hi;
+            const int rest = m - 4 * j;
+            if (rest < 4) v &= (1u << (8 * rest)) - 1u;
+            tag = smh_wm_mix(tag, v);
+        }
     }
     return tag;
 }
@@ -310,6 +327,13 @@ struct smh_wm_queue {
     /* staged verify (below): LDS byte offsets of the lock words and the staging buffers, number of buffers, and the
      * number of surviving columns a wave-chunk must have for its windows to be hashed from the staged copy */
     uint32_t st_locks, st_bufs, st_nbufs, st_min;
+    /* software-pipelined probe (gram kernels): up to 64 hashed columns of the chunk staged last -- one per lane --
+     * wait here; their buckets are requested before the next chunk is scanned and looked at after it */
+    uint32_t pend_n;      /* wave-uniform: lanes below it hold a column */
+    uint32_t pend_loaded; /* wave-uniform: pend_q holds the first bucket */
+    uint32_t pend_tag;
+    uint64_t pend_e;
+    smh_u32x4 pend_q;
 };
 
 /* ---- staged verify: the window hash of a surviving column is computed from an ON-CHIP copy of the wave-chunk.
@@ -323,7 +347,8 @@ struct smh_wm_queue {
  * drained from HBM 64 columns at a time as before (a handful of survivors does not pay for the copy).  The table
  * fills LDS, so the workgroup's 16 waves share a few buffers through try-locks (a buffer is held for two LDS round
  * trips; whoever holds one never waits for anything else). */
-#define SMH_STAGE_BUF(STG) (16u * (STG) + 4096u + 16u)
+#define SMH_STAGE_BUF(STG) (16u * (STG) + 4096u + 48u) /* halo, chunk, pad for the dwords read past the last window */
+#define SMH_STAGE_MAXD(STG) ((STG) == 1 ? 5 : 9)         /* dwords of the longest window: m <= 17 / m <= 33 */
 #define SMH_STAGE_MIN_DEFAULT 8u /* gpurun_out/r02_u: 1..16 within 3 % on the dense sets, 16+ better on sparse ones, 32+ loses 10-30 % */
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -400,7 +425,27 @@ SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_
 /* verify the queue entries [from, Q.count) -- all columns of the wave-chunk at `chunk_base`, whose text the lanes
  * hold in w (and lane 0 the 16*STG bytes in front of it in `halo`) -- and remove them; at most 128 entries; all 64
  * lanes must call it */
-template <int STG, bool QD = true>
+/* request the first bucket of the pending columns (call between chunks, before the next chunk's text is requested) */
+SMH_LANE void smh_wm_pend_issue(smh_wm_queue &Q, const smh_wm_params &P)
+{
+    if (Q.pend_n == 0 || Q.pend_loaded) return;
+    Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
+    Q.pend_loaded = 1u;
+}
+/* decide the pending columns; all 64 lanes must call it */
+SMH_LANE void smh_wm_pend_finish(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
+{
+    if (Q.pend_n == 0) return;
+    const bool mine = (threadIdx.x & 63u) < Q.pend_n;
+    const uint32_t r = smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
+    Q.matches += mine ? r : 0u;
+    if (Q.po) smh_append_bits(mine ? r : 0u, Q.pend_e, *Q.po);
+    Q.pend_n = 0u;
+    Q.pend_loaded = 0u;
+}
+
+/* PIPE: the first 64 columns are left pending (smh_wm_pend_*) instead of being probed at once */
+template <int STG, bool QD = true, bool PIPE = false>
 SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint32_t from,
                                  const uint32_t (&w)[16], const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
 {
@@ -437,17 +482,28 @@ SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t 
     };
     const uint64_t e0 = entry(h0 ? lane : 0u);
     auto rd = [&](uint32_t off) { return smh_lds_u32(nullptr, buf + off); };
-    const uint32_t tag0 = smh_wm_tag_staged(rd, (uint32_t)(e0 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
+    const uint32_t tag0 = smh_wm_tag_staged<SMH_STAGE_MAXD(STG)>(rd, (uint32_t)(e0 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
     uint64_t e1 = e0;
     uint32_t tag1 = tag0;
     if (cnt > 64u) { /* wave-uniform */
         e1 = entry(h1 ? lane + 64u : 0u);
-        tag1 = smh_wm_tag_staged(rd, (uint32_t)(e1 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
+        tag1 = smh_wm_tag_staged<SMH_STAGE_MAXD(STG)>(rd, (uint32_t)(e1 - chunk_base) + HALO + 1u - (uint32_t)P.m, P.m);
     }
     /* hand the buffer back: the release waits for the window reads above, nothing else */
     if (lane == 0)
         __hip_atomic_store(reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.st_locks + 4u * i), 0u,
                            __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if constexpr (PIPE) {
+        smh_wm_pend_finish(Q, text, P); /* the chunk before: its bucket arrived while this one was scanned */
+        Q.pend_n = cnt < 64u ? cnt : 64u;
+        Q.pend_e = e0;
+        Q.pend_tag = tag0;
+        if (cnt > 64u) { /* the overflow of a dense chunk is decided at once */
+            const uint32_t r1 = smh_wm_probe(text, e1, tag1, P);
+            Q.matches += h1 ? r1 : 0u;
+            if (Q.po) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
+        }
+    } else {
     uint32_t r0, r1 = 0;
     if (cnt > 64u)
         r0 = smh_wm_probe2(text, e0, e1, tag0, tag1, P, r1);
@@ -457,6 +513,7 @@ SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t 
     if (Q.po) {
         smh_append_bits(h0 ? r0 : 0u, e0, *Q.po);
         if (cnt > 64u) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
+    }
     }
     Q.count = from;
 }
@@ -468,7 +525,7 @@ SMH_LANE void smh_wm_stage_flush(smh_wm_queue &Q, const uint8_t *text, uint64_t 
  * surviving column is staged: the drain's code inside the chunk loop costs the scan 10 % even when it never runs
  * (gpurun_out/r02_v: 0.175 -> 0.193 ms/GiB on a set without survivors), so the launcher picks it only for sets
  * that expect a few survivors per chunk. */
-template <int STG, bool QD = true>
+template <int STG, bool QD = true, bool PIPE = false>
 SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint64_t a, uint64_t msk,
                                    const uint32_t (&w)[16], const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
 {
@@ -476,7 +533,7 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
     uint32_t from = QD ? Q.count : 0u; /* entries of earlier chunks */
     do {
         if (Q.count + 64u > SMH_WM_QCAP) {
-            smh_wm_stage_flush<STG, QD>(Q, text, chunk_base, from, w, halo, P);
+            smh_wm_stage_flush<STG, QD, PIPE>(Q, text, chunk_base, from, w, halo, P);
             if constexpr (QD) {
                 if (Q.count + 64u > SMH_WM_QCAP) { /* still full: the earlier chunks' entries, from HBM */
                     smh_wm_drain(Q, text, P);
@@ -496,7 +553,7 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
         }
         msk &= msk - 1u;
     } while (SMH_WAVE_ANY(msk != 0));
-    if (!QD || Q.count - from >= Q.st_min) smh_wm_stage_flush<STG, QD>(Q, text, chunk_base, from, w, halo, P);
+    if (!QD || Q.count - from >= Q.st_min) smh_wm_stage_flush<STG, QD, PIPE>(Q, text, chunk_base, from, w, halo, P);
 }
 #else
 /* CPU emulation (one lane at a time): the same window hash over a private copy of the chunk laid out as the
@@ -509,12 +566,12 @@ SMH_LANE void smh_wm_stage_verify_emu(smh_wm_queue &Q, const uint8_t *text, uint
     memset(buf, 0xA5, sizeof buf); /* the pad is never part of a hash */
     memcpy(buf, text + chunk_base - HALO, HALO + 4096u);
     auto rd = [&](uint32_t off) { uint32_t v; memcpy(&v, buf + off, 4); return v; };
-    const uint32_t tag = smh_wm_tag_staged(rd, c + HALO + 1u - (uint32_t)P.m, P.m);
+    const uint32_t tag = smh_wm_tag_staged<SMH_STAGE_MAXD(STG)>(rd, c + HALO + 1u - (uint32_t)P.m, P.m);
     const uint32_t hit = smh_wm_probe(text, chunk_base + c, tag, P);
     Q.matches += hit;
     if (hit && Q.po) smh_append_bits(1u, chunk_base + c, *Q.po);
 }
-template <int STG, bool QD = true>
+template <int STG, bool QD = true, bool PIPE = false>
 SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint64_t a, uint64_t msk,
                                    const uint32_t (&)[16], const uint32_t (&)[4 * STG], const smh_wm_params &P)
 {
@@ -1238,7 +1295,7 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     }
     if constexpr (STG > 0) {
         /* staged verify: chunks with many surviving columns hash their windows from an LDS copy of the chunk */
-        smh_wm_stage_columns<STG, QD>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
+        smh_wm_stage_columns<STG, QD, true>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
     } else {
     while (SMH_WAVE_ANY(msk != 0)) {
         if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
@@ -1343,6 +1400,11 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
          * return in order behind everything the wave has in flight, so a drain entered while a prefetch is
          * outstanding also waits for that prefetch (measured: 2-3 x the cost per surviving column) */
         if (QD && Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        /* staged verify, pipelined: the buckets of the columns hashed at the end of the last chunk are requested now
+         * and looked at after this chunk's scan (by the next flush, or below) */
+        if (STG > 0) smh_wm_pend_issue(Q, P);
+#endif
         if (nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
@@ -1364,6 +1426,9 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         } else {
             cnt += smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P);
         }
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish(Q, text, P); /* a chunk without a flush of its own */
+#endif
         if (nxt_fast) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
@@ -1373,6 +1438,9 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         cur_fast = nxt_fast;
         k = kn;
     }
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    if (STG > 0) smh_wm_pend_finish(Q, text, P);
+#endif
     if (QD) smh_wm_drain(Q, text, P);
     return cnt + Q.matches;
 }
