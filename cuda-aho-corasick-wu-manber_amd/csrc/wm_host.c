@@ -582,7 +582,10 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
             smh_set_error("smh_wm_compile: more than 2^20 - 2 distinct patterns");
             goto bad;
         }
-        int lg = ceil_log2_u32((uint32_t)d * 2u);
+        /* four slots per pattern or more (2 MiB at 100 000 patterns): a bucket is then full -- and a probe needs a second,
+         * un-pipelined round trip -- for 1 % of the windows; at two per pattern it was 7-14 % of them, which showed as
+         * half of the verify stage's time once the first bucket's load was software-pipelined (gpurun_out/r02_aa) */
+        int lg = ceil_log2_u32((uint32_t)d * 4u);
         if (lg < 4) lg = 4;
         wm->verify_log2 = lg;
         size_t slots = (size_t)1 << lg;

@@ -1,0 +1,8 @@
+O=gpurun_out/r02_ac; mkdir -p $O
+run() { echo "== SMH_WM_TUNE=$1 :: $2"; SMH_WM_TUNE="$1" timeout 120 python tools/wmbench.py $2 2>&1 | grep -v amdgpu.ids; }
+( run "" "16 8000 64 4"; run "" "12 100000 64 256"; run "" "5 100000 64 256" ) > $O/small.log 2>&1; cat $O/small.log
+if grep -q "Memory access fault\|Traceback" $O/small.log; then echo FAULT; exit 1; fi
+timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?"; tail -4 $O/pytest.log
+if grep -q "Memory access fault" $O/pytest.log; then echo FAULT; exit 1; fi
+( for cfg in "16 1000 1024 4" "16 4000 1024 4" "16 8000 1024 4" "32 8000 1024 4" "12 100000 1024 256" "20 100000 1024 256" "8 100000 1024 256" "5 100000 1024 256" "12 10000 1024 256"; do run "" "$cfg"; done ) > $O/wmbench.log 2>&1
+grep -v "^==" $O/wmbench.log
