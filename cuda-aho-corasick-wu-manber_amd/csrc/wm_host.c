@@ -21,6 +21,7 @@
  */
 #include "smh_internal.h"
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -185,14 +186,22 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
  * stage; the form with the lowest estimate is kept, or none when the handle's block filter is estimated faster.
  * Shift-or steps (one v_lshl_or per column, per two columns in the pair form): pairs 0.178 (HBM-bound), 8-symbol
  * grams 0.26 and byte grams 0.238 (one LDS lookup per column). */
-#define SMH_GRAM_PAIR_MS 0.178
+#define SMH_GRAM_PAIR_MS 0.173
 #define SMH_GRAM_OCT_MS 0.26
 #define SMH_GRAM_BYTE_MS 0.238
-/* verify stage: ms per GiB per unit of survivor fraction.  Staged (m <= 33: window hashes from the LDS copy of the
- * chunk): 8000 DNA patterns m = 16 / 32 (0.41 % survive the pair form) 0.305 / 0.325, 100 000 byte patterns
- * m = 12 / 20 (0.75 %) 0.367 / 0.406.  Windows re-read from HBM (longer patterns): grows with the window the stage
- * has to fetch and hash (fits to the same sets before staging: 0.49 / 0.72, 0.63 / 0.82). */
-#define SMH_GRAM_VERIFY_MS(kind, m) ((m) <= 33 ? ((kind) == SMH_GRAM_PAIR ? 26.0 + 0.3 * (m) : 10.0 + 0.6 * (m)) : 12.0 + 3.0 * (m))
+/* verify stage, ms per GiB for a fraction `dens` of surviving columns.  Staged (m <= 33: window hashes from the LDS
+ * copy of the chunk, probe pipelined): the cost is mostly per wave-chunk that has any survivor -- lock, copy, hash
+ * round trips -- and grows slowly with their number (pair form, 16 symbols, survivors per 4 KiB chunk -> ms/GiB over the
+ * bare scan: 0.08 -> 0.002, 0.25 -> 0.02, 1.1 -> 0.05, 4.4 -> 0.09, 17 -> 0.13; byte grams, 100 000 patterns: 35 ->
+ * 0.11 / 0.15 at 12 / 20 symbols, 116 -> 0.28, 690 -> 1.28; gpurun_out/r02_s, r02_z .. r02_ac).  Windows re-read from HBM (longer patterns): linear in
+ * the survivors and the window the stage has to fetch and hash (fits to 8000 DNA patterns / 100 000 byte patterns
+ * before staging: 0.49 / 0.72, 0.63 / 0.82). */
+static double gram_verify_ms(int m, double dens)
+{
+    if (m > 33) return (12.0 + 3.0 * m) * dens;
+    const double pc = dens * 4096.0; /* survivors per wave-chunk; beyond a queue's worth several flushes per chunk */
+    return 0.04 * log(1.0 + 1.5 * pc) + (pc > 30.0 ? 0.0015 * (pc - 30.0) : 0.0);
+}
 #define SMH_HASHED_VERIFY_MS(m) (6.0 + 1.05 * (m))
 #define SMH_DIRECT_VERIFY_MS(m) ((m) > 4 ? 1.9 * (m) - 3.0 : 4.6)
 
@@ -234,7 +243,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
             }
         /* entry of eight symbols = (G of the older seven << 1) | G of the newer seven: one v_lshl_or does both columns */
         for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(((uint32_t)g7[x >> 2] << 1) | g7[x & 0x3FFFu]);
-        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4, J), ms = SMH_GRAM_PAIR_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_PAIR, m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4, J), ms = SMH_GRAM_PAIR_MS + gram_verify_ms(m, dens);
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES + 32768; best_ms = ms; best_dens = dens;
@@ -255,7 +264,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
                 tab[code] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4, J), ms = SMH_GRAM_OCT_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_OCT, m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4, J), ms = SMH_GRAM_OCT_MS + gram_verify_ms(m, dens);
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_OCT; best_planes = J; best_bytes = 65536; best_ms = ms; best_dens = dens;
@@ -276,7 +285,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 const uint32_t idx = (uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15; /* low 32 bits of the product, top 17 */
                 tab[idx] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet, J), ms = SMH_GRAM_BYTE_MS + SMH_GRAM_VERIFY_MS(SMH_GRAM_BYTE, m) * dens;
+        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet, J), ms = SMH_GRAM_BYTE_MS + gram_verify_ms(m, dens);
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_BYTE; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
