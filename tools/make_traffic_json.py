@@ -53,6 +53,17 @@ def main():
         rd, wr = int(round(fk * 1024 * 2)), int(round(wk * 1024))
         out[name] = dict(FETCH_SIZE_KB_mean=fk, dispatches=len(vals), WRITE_SIZE_KB_mean=wk,
                          hbm_read_bytes=rd, hbm_write_bytes=wr, hbm_bytes=rd + wr)
+        # one kernel instance may serve launches over different text sizes (1 GiB headline sets, 4 GiB shards):
+        # dispatches whose read volume differs by more than 1.5x are reported as separate groups
+        groups, cur = [], []
+        for v in sorted(vals):
+            if cur and v > 1.5 * cur[0]:
+                groups.append(cur)
+                cur = []
+            cur.append(v)
+        groups.append(cur)
+        if len(groups) > 1:
+            out[name]["by_text_size"] = [dict(dispatches=len(g), hbm_read_bytes=int(round(sum(g) / len(g) * 1024 * 2))) for g in groups]
     json.dump(dict(build_id=kernel_build_id(), profile=sys.argv[3] if len(sys.argv) > 3 else "",
                    source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
                           "--warmup 1 --no-cpu; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests "
