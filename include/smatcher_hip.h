@@ -294,11 +294,14 @@ typedef struct smh_pset_info {
     uint32_t patterns;     /* as given */
     uint32_t min_length;
     uint32_t max_length;
-    uint32_t one_pass;     /* 1: the text is read ONCE.  SMH_ALGO_WM sets with 2..32 lengths, all >= 3: a block filter
-                            * over the patterns' last min-length symbols proposes END columns, each survivor is
-                            * verified per length class.  SMH_ALGO_AC sets: one automaton whose states carry joined
+    uint32_t one_pass;     /* 1: the text is read ONCE.  SMH_ALGO_AC sets: one automaton whose states carry joined
                             * (suffix-closed) output counts, cut at the deepest level that fits LDS, longer patterns
-                            * verified along the goto trie.  0: one scan per class. */
+                            * verified along the goto trie.  SMH_ALGO_WM sets with 2..32 lengths, all >= 3: a filter
+                            * proposes END columns, each survivor is verified per length class -- on the 4-letter
+                            * alphabet a q-gram shift-or filter over the FULL patterns (two plane groups: patterns of
+                            * 14 symbols and more / the shorter ones) while candidates stay below one column in 2000,
+                            * else a block filter over the patterns' last min-length symbols while it passes < 0.4 %
+                            * of the columns; sets neither serves run the automaton above.  0: one scan per class. */
     uint32_t reserved;
 } smh_pset_info;
 
