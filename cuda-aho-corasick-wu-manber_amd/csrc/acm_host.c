@@ -163,7 +163,7 @@ struct smh_acm *smh_acm_compile(const unsigned char *patterns, const uint32_t *l
                 for (size_t cc = 0; cc < A && !has_child; ++cc) has_child = child[(size_t)t * A + cc] != 0;
             const uint32_t row = newid[t], cnt = out[t], cand = has_child ? 1u : 0u;
             if (eb == 2) ((uint16_t *)a->scan)[(size_t)r * A + c] = (uint16_t)(row | (cnt << 13) | (cand << 15));
-            else ((uint32_t *)a->scan)[(size_t)r * A + c] = row | (cnt << 24) | (cand << 31);
+            else ((uint32_t *)a->scan)[(size_t)r * A + c] = cand | (row * (uint32_t)A * 4u) | (cnt << 24); /* acm_lane.h smh_acm_entry<uint32_t> */
         }
     }
     /* 6. goto trie in BFS ids for the walk of the candidates */

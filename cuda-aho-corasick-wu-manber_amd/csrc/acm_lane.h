@@ -14,9 +14,27 @@
 
 #define SMH_ACM_QCAP 256u /* queue entries per wave (HBM workspace, 8 bytes each) */
 
+/* 16-bit entries: candidate << 15 | count << 13 | row.  32-bit entries are laid out for the instruction count of the
+ * scan (the kernel was VALU-bound at eight ops per byte): bit 0 = candidate (one v_alignbit shifts it into the
+ * lane's candidate mask), bits 3..23 = BYTE OFFSET of the next row in the table (the entry, masked, is the address:
+ * v_and_or with the symbol's offset), bits 24..30 = joined output count (added with a byte-select add). */
 template <typename E> struct smh_acm_entry;
 template <> struct smh_acm_entry<uint16_t> { static constexpr uint32_t ROW = 0x1FFFu, CNT_SHIFT = 13, CNT_BITS = 2, CAND_SHIFT = 15; };
-template <> struct smh_acm_entry<uint32_t> { static constexpr uint32_t ROW = 0xFFFFFFu, CNT_SHIFT = 24, CNT_BITS = 7, CAND_SHIFT = 31; };
+template <> struct smh_acm_entry<uint32_t> { static constexpr uint32_t ROW = 0x00FFFFF8u, CNT_SHIFT = 24, CNT_BITS = 7, CAND_SHIFT = 0; };
+
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+/* acc + byte 3 of e, one VALU op (SDWA byte select) */
+SMH_LANE uint32_t smh_add_byte3(uint32_t acc, uint32_t e)
+{
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(acc), "v"(e));
+    return r;
+}
+SMH_LANE uint32_t smh_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+#else
+SMH_LANE uint32_t smh_add_byte3(uint32_t acc, uint32_t e) { return acc + (e >> 24); }
+SMH_LANE uint32_t smh_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh); }
+#endif
 
 struct smh_acm_ctx { /* wave-uniform */
     const uint8_t *text;
@@ -88,18 +106,26 @@ template <typename E, int SIGMA>
 SMH_LANE uint32_t smh_acm_next(uint32_t e, uint32_t w, int k, const void *tab, int sigma_rt)
 {
     using X = smh_acm_entry<E>;
+    if (sizeof(E) == 4) {
+        /* the masked entry is the next row's byte offset; `w` is the text dword << 2 for SIGMA == 4 (smh_acm_prep) */
+        if (SIGMA == 4) return smh_lds_u32(tab, (e & X::ROW) | smh_bfe(w, 8 * k, 4));
+        uint32_t c = smh_byte_of(w, k);
+        if (c >= (uint32_t)sigma_rt) c = 0; /* never an out-of-range index (smatcher_hip.h: text symbols must be < alphabet) */
+        return smh_lds_u32(tab, (e & X::ROW) + 4u * c);
+    }
     if (SIGMA == 4) {
         const uint32_t c = smh_bfe(w, 8 * k, 2);
         const uint32_t addr = (((e & X::ROW) << 2) | c) * (uint32_t)sizeof(E);
-        return sizeof(E) == 2 ? smh_lds_u16(tab, addr) : smh_lds_u32(tab, addr);
+        return smh_lds_u16(tab, addr);
     } else {
         const uint32_t sigma = (uint32_t)sigma_rt;
         uint32_t c = smh_byte_of(w, k);
-        if (c >= sigma) c = 0; /* never an out-of-range index (smatcher_hip.h: text symbols must be < alphabet) */
+        if (c >= sigma) c = 0;
         const uint32_t addr = ((e & X::ROW) * sigma + c) * (uint32_t)sizeof(E);
-        return sizeof(E) == 2 ? smh_lds_u16(tab, addr) : smh_lds_u32(tab, addr);
+        return smh_lds_u16(tab, addr);
     }
 }
+template <typename E, int SIGMA> SMH_LANE uint32_t smh_acm_prep(uint32_t w) { return sizeof(E) == 4 && SIGMA == 4 ? w << 2 : w; }
 
 /* fast path: segment at a (a >= 16, a + 64 <= n); w[0..3] = the 16 bytes in front of it, w[4..19] = the segment */
 template <typename E, int SIGMA>
@@ -110,14 +136,30 @@ SMH_LANE uint32_t smh_acm_lane_fast(uint64_t a, const uint32_t (&w)[20], const v
     /* warm-up over the K-1 bytes in front of the segment (K - 1 <= 16): no counting, no candidates -- those
      * positions belong to the previous lane */
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
-        if (i >= 17 - C.K) e = smh_acm_next<E, SIGMA>(e, w[i >> 2], i & 3, tab, C.sigma);
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t x = smh_acm_prep<E, SIGMA>(w[q]);
 #pragma unroll
-    for (int i = 0; i < 64; ++i) {
-        e = smh_acm_next<E, SIGMA>(e, w[4 + (i >> 2)], i & 3, tab, C.sigma);
-        cnt += smh_bfe(e, X::CNT_SHIFT, X::CNT_BITS);
-        if (i < 32) clo |= (e >> X::CAND_SHIFT) << i;
-        else chi |= (e >> X::CAND_SHIFT) << (i - 32);
+        for (int k = 0; k < 4; ++k)
+            if (4 * q + k >= 17 - C.K) e = smh_acm_next<E, SIGMA>(e, x, k, tab, C.sigma);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t x = smh_acm_prep<E, SIGMA>(w[4 + q]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * q + k;
+            e = smh_acm_next<E, SIGMA>(e, x, k, tab, C.sigma);
+            if (sizeof(E) == 4) {
+                /* per byte: v_bfe + v_and_or (address), ds_read_b32, one add (count), one v_alignbit (candidate) */
+                cnt = smh_add_byte3(cnt, e);
+                if (i < 32) clo = smh_alignbit(e, clo, 1u);
+                else chi = smh_alignbit(e, chi, 1u);
+            } else {
+                cnt += smh_bfe(e, X::CNT_SHIFT, X::CNT_BITS);
+                if (i < 32) clo |= (e >> X::CAND_SHIFT) << i;
+                else chi |= (e >> X::CAND_SHIFT) << (i - 32);
+            }
+        }
     }
     uint64_t msk = ((uint64_t)chi << 32) | clo;
     while (SMH_WAVE_ANY(msk != 0)) {
@@ -142,10 +184,11 @@ SMH_LANE uint32_t smh_acm_lane_slow(uint64_t a, const void *tab_g, const smh_acm
     for (uint64_t i = warm; i < end; ++i) {
         uint32_t c = C.text[i];
         if (c >= (uint32_t)C.sigma) c = 0;
-        e = ((const E *)tab_g)[(uint64_t)(e & X::ROW) * (uint32_t)C.sigma + c];
+        if (sizeof(E) == 4) memcpy(&e, (const uint8_t *)tab_g + (e & X::ROW) + 4u * c, 4); /* the masked entry is a byte offset */
+        else e = ((const E *)tab_g)[(uint64_t)(e & X::ROW) * (uint32_t)C.sigma + c];
         if (i >= a) {
             cnt += (e >> X::CNT_SHIFT) & ((1u << X::CNT_BITS) - 1u);
-            if (e >> X::CAND_SHIFT) cnt += smh_acm_walk(C, i);
+            if ((e >> X::CAND_SHIFT) & 1u) cnt += smh_acm_walk(C, i);
         }
     }
     return cnt;
