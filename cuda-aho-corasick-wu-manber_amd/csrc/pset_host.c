@@ -46,6 +46,11 @@ struct smh_pset {
     /* SMH_ALGO_AC sets with 2 or more lengths: ONE pass with one automaton whose states carry joined output
      * counts (acm_host.c); NULL when no cut of it fits LDS, then one scan per class */
     struct smh_acm *acm;
+    /* split form (SMH_ALGO_WM, 4-letter alphabet, TWO passes): `suffix` / `class_wm` cover the classes from index
+     * split_first on (patterns of SMH_GRAM_PAIR2_SPLIT symbols and more: grouped pair-gram filter, next to no
+     * candidates), `acm` the shorter patterns (whose matches are frequent and which the automaton counts in line).
+     * 0 when suffix / acm cover the whole set. */
+    uint32_t split_first;
 };
 
 static int cmp_u32(const void *a, const void *b)
@@ -128,7 +133,13 @@ smh_pset *smh_pset_compile(const unsigned char *patterns, const uint32_t *length
             return NULL;
         }
     }
-    /* one-pass form */
+    /* ---- fewer passes than one per class.  SMH_ALGO_WM sets, in this order: (A) grouped pair-gram filter over the
+     * full patterns, (B) the automaton with joined output counts, (C) block filter over the patterns' last min-length
+     * symbols while it is sparse, (D) split form: (A) for the long patterns + (B) for the short ones.  SMH_ALGO_AC
+     * sets: (B). ---- */
+    const int no_gram = getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "nogram");
+    const int no_acm = getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "classes");
+    int grouped = 1;
     if (algorithm == SMH_ALGO_WM && n_classes >= 2 && n_classes <= SMH_PSET_MAX_ONE_PASS_CLASSES && set->cls[0].length >= 3) {
         const uint32_t Lmin = set->cls[0].length;
         uint64_t off = 0;
@@ -138,28 +149,76 @@ smh_pset *smh_pset_compile(const unsigned char *patterns, const uint32_t *length
         }
         set->suffix = smh_wm_compile(flat, (int)Lmin, p_size, alphabet);
         set->class_wm = (smh_wm **)malloc(n_classes * sizeof(smh_wm *));
-        /* 4-letter alphabet: the grouped pair-gram filter over the FULL patterns (smh_internal.h SMH_GRAM_PAIR2) --
-         * every pattern contributes all the planes its length allows, so candidates are rare even where the
-         * min-length suffix is not selective (1000 patterns of 8..32 symbols: one column in 5000) */
-        int grouped = 1;
-        if (set->suffix && set->class_wm && !(getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "nogram"))) {
+        if (set->class_wm)
+            for (uint32_t c = 0; c < n_classes; ++c) set->class_wm[c] = set->cls[c].wm;
+        /* (A) 4-letter alphabet: every pattern contributes all the planes its length allows, so candidates are rare even
+         * where the min-length suffix is not selective -- as long as the SHORT patterns are few (smh_internal.h) */
+        if (set->suffix && set->class_wm && !no_gram) {
             grouped = smh_wm_build_gram_mixed(set->suffix, patterns, lengths, p_size);
             if (grouped < 0) goto oom;
         }
-        /* worth it only while survivors are rare: each one costs a verify per class (~20 ps each), a scan
-         * per class ~0.25 ms/GiB -- break-even near 1 % of the columns surviving the filter */
-        if (set->suffix && set->class_wm && (grouped == 0 || set->suffix->filter_density < SMH_PSET_ONE_PASS_DENSITY)) {
-            for (uint32_t c = 0; c < n_classes; ++c) set->class_wm[c] = set->cls[c].wm;
-        } else { /* stay with one scan per class */
+    }
+    if (n_classes >= 2 && grouped != 0 && !no_acm) /* (B); NULL: no cut of the automaton fits LDS with few candidates */
+        set->acm = smh_acm_compile(patterns, lengths, p_size, alphabet);
+    if (set->suffix && grouped != 0) {
+        /* (C) worth it only while survivors are rare: each one costs a verify per class, a scan per class ~0.25 ms/GiB;
+         * the automaton, where it exists, is the better single pass (0.29-0.38 ms/GiB whatever the set) */
+        if (set->acm || !set->class_wm || set->suffix->filter_density >= SMH_PSET_ONE_PASS_DENSITY) {
             smh_wm_free(set->suffix);
             set->suffix = NULL;
         }
     }
-    /* SMH_ALGO_AC sets, and SMH_ALGO_WM sets neither one-pass filter serves (many short patterns: the candidates would
-     * mostly be real matches, which the automaton counts in line): the automaton with joined output counts */
-    if ((algorithm == SMH_ALGO_AC || !set->suffix) && n_classes >= 2) {
-        set->acm = smh_acm_compile(patterns, lengths, p_size, alphabet); /* NULL: stay with one scan per class */
-        if (getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "classes")) { smh_acm_free(set->acm); set->acm = NULL; }
+    if (algorithm == SMH_ALGO_WM && !set->suffix && !set->acm && alphabet == 4 && n_classes >= 2 && !no_gram && !no_acm &&
+        set->cls[0].length < SMH_GRAM_PAIR2_SPLIT && set->cls[n_classes - 1].length >= SMH_GRAM_PAIR2_SPLIT) {
+        /* (D) thousands of patterns over a wide range of lengths: neither filter is selective (many short patterns) and
+         * the whole automaton does not fit.  Two passes: long patterns through (A), short ones through (B). */
+        uint32_t first_long = 0;
+        while (set->cls[first_long].length < SMH_GRAM_PAIR2_SPLIT) ++first_long;
+        const uint32_t n_long = n_classes - first_long, Lmin = set->cls[first_long].length;
+        unsigned char *part = (unsigned char *)malloc(total ? total : 1);
+        uint32_t *plen = (uint32_t *)malloc((size_t)p_size * sizeof(uint32_t));
+        if (!part || !plen) { free(part); free(plen); goto oom; }
+        if (n_long <= SMH_PSET_MAX_ONE_PASS_CLASSES) {
+            int np = 0;
+            uint64_t off = 0, fill = 0;
+            for (int j = 0; j < p_size; ++j) { /* the long patterns, and their last Lmin symbols */
+                if (lengths[j] >= SMH_GRAM_PAIR2_SPLIT) {
+                    memcpy(part + fill, patterns + off, lengths[j]);
+                    memcpy(flat + (size_t)np * Lmin, patterns + off + lengths[j] - Lmin, Lmin);
+                    fill += lengths[j];
+                    plen[np++] = lengths[j];
+                }
+                off += lengths[j];
+            }
+            set->suffix = smh_wm_compile(flat, (int)Lmin, np, alphabet);
+            free(set->class_wm);
+            set->class_wm = (smh_wm **)malloc(n_long * sizeof(smh_wm *));
+            int ok = set->suffix && set->class_wm && smh_wm_build_gram_mixed(set->suffix, part, plen, np) == 0;
+            if (ok) {
+                for (uint32_t c = 0; c < n_long; ++c) set->class_wm[c] = set->cls[first_long + c].wm;
+                np = 0; off = 0; fill = 0;
+                for (int j = 0; j < p_size; ++j) { /* the short patterns */
+                    if (lengths[j] < SMH_GRAM_PAIR2_SPLIT) {
+                        memcpy(part + fill, patterns + off, lengths[j]);
+                        fill += lengths[j];
+                        plen[np++] = lengths[j];
+                    }
+                    off += lengths[j];
+                }
+                set->acm = smh_acm_compile(part, plen, np, alphabet);
+                ok = set->acm != NULL;
+            }
+            if (ok) {
+                set->split_first = first_long;
+            } else { /* one scan per class */
+                smh_wm_free(set->suffix);
+                set->suffix = NULL;
+                smh_acm_free(set->acm);
+                set->acm = NULL;
+            }
+        }
+        free(part);
+        free(plen);
     }
     free(sorted);
     free(flat);
@@ -188,7 +247,8 @@ int smh_pset_get_info(const smh_pset *set, smh_pset_info *out)
     out->patterns = set->patterns;
     out->min_length = set->cls[0].length;
     out->max_length = set->cls[set->n_classes - 1].length;
-    out->one_pass = set->suffix != NULL || set->acm != NULL;
+    out->one_pass = (set->suffix != NULL || set->acm != NULL) && set->split_first == 0;
+    out->passes = set->split_first ? 2u : (out->one_pass ? 1u : set->n_classes);
     return SMH_OK;
 }
 
@@ -207,9 +267,14 @@ int smh_pset_get_class(const smh_pset *set, uint32_t i, uint32_t *length, uint32
 int smh_pset_scan(smh_pset *set, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream)
 {
     if (!pset_ok(set, "smh_pset_scan")) return SMH_EINVAL;
-    if (set->suffix && ((uintptr_t)d_text & 15u) == 0)
-        return smh_wm_scan_multi(set->suffix, set->class_wm, (int)set->n_classes, d_text, n, d_count, stream);
-    if (set->acm && ((uintptr_t)d_text & 15u) == 0) return smh_acm_scan(set->acm, d_text, n, d_count, stream);
+    if (((uintptr_t)d_text & 15u) == 0 && (set->suffix || set->acm)) {
+        /* one pass, or (split form) the long patterns' filter pass and the short patterns' automaton pass */
+        int rc = SMH_OK;
+        if (set->suffix)
+            rc = smh_wm_scan_multi(set->suffix, set->class_wm, (int)(set->n_classes - set->split_first), d_text, n, d_count, stream);
+        if (rc == SMH_OK && set->acm) rc = smh_acm_scan(set->acm, d_text, n, d_count, stream);
+        return rc;
+    }
     for (uint32_t c = 0; c < set->n_classes; ++c) {
         struct smh_pset_class *k = &set->cls[c];
         const int rc = k->wm ? smh_wm_scan(k->wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream)
@@ -223,10 +288,14 @@ int smh_pset_positions(smh_pset *set, const unsigned char *d_text, uint64_t n, u
                        uint64_t capacity, uint64_t *d_cursor, void *stream)
 {
     if (!pset_ok(set, "smh_pset_positions")) return SMH_EINVAL;
-    if (set->suffix && ((uintptr_t)d_text & 15u) == 0)
-        return smh_wm_positions_multi(set->suffix, set->class_wm, (int)set->n_classes, d_text, n, d_positions, capacity,
-                                      d_cursor, stream);
-    for (uint32_t c = 0; c < set->n_classes; ++c) {
+    uint32_t per_class_end = set->n_classes;
+    if (set->suffix && ((uintptr_t)d_text & 15u) == 0) {
+        const int rc = smh_wm_positions_multi(set->suffix, set->class_wm, (int)(set->n_classes - set->split_first), d_text, n,
+                                              d_positions, capacity, d_cursor, stream);
+        if (rc != SMH_OK || set->split_first == 0) return rc;
+        per_class_end = set->split_first; /* split form: the short classes one by one (the automaton only counts) */
+    }
+    for (uint32_t c = 0; c < per_class_end; ++c) {
         struct smh_pset_class *k = &set->cls[c];
         const int rc = k->wm ? smh_wm_positions(k->wm, d_text, n, d_positions, capacity, d_cursor, stream)
                              : smh_ac_positions(k->ac, d_text, n, d_positions, capacity, d_cursor, stream);

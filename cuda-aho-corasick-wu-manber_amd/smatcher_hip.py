@@ -55,7 +55,7 @@ class WmInfo(C.Structure):
 class PsetInfo(C.Structure):
     _fields_ = [("alphabet", C.c_uint32), ("algorithm", C.c_uint32), ("classes", C.c_uint32),
                 ("patterns", C.c_uint32), ("min_length", C.c_uint32), ("max_length", C.c_uint32),
-                ("one_pass", C.c_uint32), ("reserved", C.c_uint32)]
+                ("one_pass", C.c_uint32), ("passes", C.c_uint32)]
 
 
 class ShInfo(C.Structure):

@@ -302,7 +302,9 @@ typedef struct smh_pset_info {
                             * 14 symbols and more / the shorter ones) while candidates stay below one column in 2000,
                             * else a block filter over the patterns' last min-length symbols while it passes < 0.4 %
                             * of the columns; sets neither serves run the automaton above.  0: one scan per class. */
-    uint32_t reserved;
+    uint32_t passes;       /* scans of the text one smh_pset_scan makes: 1 (one_pass), 2 (SMH_ALGO_WM sets on the 4-letter
+                            * alphabet that neither single pass serves: the patterns of 14 symbols and more through the
+                            * q-gram filter, the shorter ones through the automaton), else the number of classes */
 } smh_pset_info;
 
 /* patterns: the p_size patterns back to back (pattern j has lengths[j] symbols, each < alphabet) */

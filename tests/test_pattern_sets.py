@@ -297,3 +297,53 @@ def test_gpu_grouped_pair_gram_filter_on_random_dna_sets(seed, force, monkeypatc
     torch.cuda.synchronize()
     assert int(cnt.item()) == want and np.array_equal(np.sort(pos[:want].cpu().numpy()), want_pos)
     ps.close()
+
+
+def _wide_dna_set(p=2400, lo=8, hi=40, n=1 << 20, seed=77):
+    """thousands of DNA patterns over a wide range of lengths: too many short ones for the grouped filter, too many
+    nodes for one automaton in LDS"""
+    rng = np.random.RandomState(seed)
+    text = rng.randint(0, 4, size=n).astype(np.uint8)
+    lengths = rng.randint(lo, hi + 1, size=p).astype(np.uint32)
+    pats = []
+    for j, L in enumerate(lengths):
+        if j % 3 == 0:
+            off = int(rng.randint(0, n - L))
+            pats.append(text[off:off + L])
+        else:
+            pats.append(rng.randint(0, 4, size=L).astype(np.uint8))
+    return text, np.concatenate(pats), lengths
+
+
+def test_split_form_is_chosen_for_large_wide_sets():
+    text, patterns, lengths = _wide_dna_set()
+    wm = S.PatternSet(patterns, lengths, 4, S.ALGO_WM)
+    info = wm.info()
+    assert info.one_pass == 0 and info.passes == 2 and info.classes == 33   # long patterns: filter pass; short: automaton pass
+    ac = S.PatternSet(patterns, lengths, 4, S.ALGO_AC)
+    assert ac.info().one_pass == 0 and ac.info().passes == 33
+    small = S.PatternSet(patterns[:int(lengths[:50].sum())], lengths[:50], 4, S.ALGO_WM)
+    assert small.info().one_pass == 1 and small.info().passes == 1
+
+
+@pytest.mark.gpu
+def test_gpu_split_form_counts_and_positions():
+    import torch
+    text, patterns, lengths = _wide_dna_set()
+    n = len(text)
+    classes = cases.split_classes(patterns, lengths)
+    want_pos = np.sort(np.concatenate([O.positions_bruteforce(classes[L], L, len(classes[L]) // L, text) for L in sorted(classes)]))
+    want = len(want_pos)
+    assert want > 1000
+    ps = S.PatternSet(patterns, lengths, 4, S.ALGO_WM)
+    assert ps.info().passes == 2
+    assert ps.count_host(text)[0] == want
+    dev = torch.device("cuda", 0)
+    d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    d_text[:n] = torch.from_numpy(text).to(dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    pos = torch.zeros(want + 3, dtype=torch.int64, device=dev)
+    ps.positions_device(d_text.data_ptr(), n, pos.data_ptr(), want + 3, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == want and np.array_equal(np.sort(pos[:want].cpu().numpy()), want_pos)
+    ps.close()
