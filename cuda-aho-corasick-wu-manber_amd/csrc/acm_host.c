@@ -122,8 +122,9 @@ struct smh_acm *smh_acm_compile(const unsigned char *patterns, const uint32_t *l
         uint32_t maxout = 0;
         for (uint32_t r = 0; r < rows; ++r)
             if (out[order[r]] > maxout) maxout = out[order[r]];
-        if (rows <= 8192u && maxout <= 3u && (uint64_t)rows * A * 2u <= SMH_ACM_LDS_BUDGET) { K = k; eb = 2; }
-        else if (maxout <= 127u && (uint64_t)rows * A * 4u <= SMH_ACM_LDS_BUDGET) { K = k; eb = 4; }
+        /* 32-bit entries wherever they fit: their layout makes the scan 3.5 VALU per byte against 8 (acm_lane.h) */
+        if (maxout <= 127u && (uint64_t)rows * A * 4u <= SMH_ACM_LDS_BUDGET) { K = k; eb = 4; }
+        else if (rows <= 8192u && maxout <= 3u && (uint64_t)rows * A * 2u <= SMH_ACM_LDS_BUDGET) { K = k; eb = 2; }
     }
     if (!K) {
         smh_set_error("smh_acm_compile: no cut of the automaton fits %u bytes of LDS (alphabet %d)", SMH_ACM_LDS_BUDGET, alphabet);
