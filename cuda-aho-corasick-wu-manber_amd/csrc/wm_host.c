@@ -521,6 +521,17 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
             for (int j = 0; j < d; ++j) {
                 uint32_t key = block_code(wm->pat_sorted + (size_t)j * m + (m - 1), Wh, bits) & kmask;
                 if (le4) key = __builtin_bswap32(key); /* rolling code = big-endian; the scan reads the dword */
+                if (le4) {
+                    /* the byte-block form's own hash and bit layout: smh_wm_filter_key_v2 in wm_lane.h */
+                    const uint32_t lo24 = key & 0xFFFFFFu;
+                    const uint32_t h = (uint32_t)((uint64_t)lo24 * 0x9E3779u) + (key >> 24) * 0x85EBCBu;
+                    const uint32_t g = (uint32_t)((uint64_t)lo24 * 0xC2B2AFu);
+                    const uint32_t blk = (h >> 3) & 0x3FFFu;
+                    hashed[2u * blk] |= (1u << ((g >> 8) & 31u)) | (1u << ((g >> 16) & 31u));
+                    if (k >= 3) hashed[2u * blk + 1u] |= 1u << ((g >> 24) & 31u);
+                    if (k >= 4) hashed[2u * blk + 1u] |= 1u << (g & 31u);
+                    continue;
+                }
                 uint32_t h = smh_wm_block_hash(key);
                 /* 64-bit blocks, bit positions: smh_wm_filter_key in wm_lane.h */
                 uint32_t blk = h >> (32 - (Th - 6));

@@ -234,13 +234,69 @@ SMH_LANE uint32_t smh_wm_filter_key(uint32_t key, const uint32_t *filter, const 
     return hit;
 }
 
+/* The byte-block form (filter_le4: key = the column's last four bytes as a little-endian dword, 2^20 filter bits) has its
+ * own hash and bit layout, chosen for the instruction count of the scan (it was VALU-bound at 16.5 ops per column):
+ *   h = key[23:0] * 0x9E3779 + key[31:24] * 0x85EBCB      block = bits 3..16 of h: (h & 0x1FFF8) IS its LDS byte address
+ *   g = key[23:0] * 0xC2B2AF                              bit positions = the low five bits of g's BYTES 1, 2 (low dword
+ *                                                         of the block), 3 and 0 (high dword; K >= 3, K == 4)
+ * so a column costs: v_alignbyte (key), v_mul_u32_u24 with a byte-3 select + v_mad_u32_u24 (h), v_mul_u32_u24 (g),
+ * v_and (address), ds_read_b64, K shifts whose amount is a byte select of g (SDWA), one three-input AND, one
+ * v_alignbit that shifts the answer into the survivor mask: 10 VALU at K = 3, 12 at K = 4.  Mirrored by wm_host.c. */
+#define SMH_BLK_MUL_A 0x9E3779u
+#define SMH_BLK_MUL_B 0x85EBCBu
+#define SMH_BLK_MUL_G 0xC2B2AFu
+template <int K>
+SMH_LANE uint32_t smh_wm_filter_key_v2(uint32_t key, const uint32_t *filter, const smh_wm_params &P)
+{
+    const uint32_t lo24 = key & 0xFFFFFFu;
+    const uint32_t h = (uint32_t)((uint64_t)lo24 * SMH_BLK_MUL_A) + (key >> 24) * SMH_BLK_MUL_B;
+    const uint32_t g = (uint32_t)((uint64_t)lo24 * SMH_BLK_MUL_G);
+    const smh_u32x2 w = smh_filter_block(filter, (h >> 3) & 0x3FFFu);
+    const int k = K ? K : P.filter_k;
+    uint32_t hit = smh_bit_at(w.lo, g >> 8) & smh_bit_at(w.lo, g >> 16);
+    if (k >= 3) hit &= smh_bit_at(w.hi, g >> 24);
+    if (k >= 4) hit &= smh_bit_at(w.hi, g);
+    return hit;
+}
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+/* the same test as the instruction sequence above, in two halves so that the caller can keep several blocks' reads in
+ * flight: LDS byte address of the key's block (and g), then the test (bit 0 of the result is the answer) */
+SMH_LANE uint32_t smh_wm_v2_addr(uint32_t key, uint32_t &g)
+{
+    uint32_t t, h;
+    const uint32_t mulb = SMH_BLK_MUL_B;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(t) : "v"(key), "v"(mulb));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(key), "s"(SMH_BLK_MUL_A), "v"(t));
+    g = __umul24(key, SMH_BLK_MUL_G);
+    return h & 0x1FFF8u;
+}
+template <int K>
+SMH_LANE uint32_t smh_wm_v2_test(uint32_t g, uint32_t lo, uint32_t hi)
+{
+    uint32_t a, b, c;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(g), "v"(lo));
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(b) : "v"(g), "v"(lo));
+    uint32_t r = a & b;
+    if (K >= 3) {
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(c) : "v"(g), "v"(hi));
+        r &= c;
+    }
+    if (K >= 4) {
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(c) : "v"(g), "v"(hi));
+        r &= c;
+    }
+    return r;
+}
+#endif
+
 /* SHIFT stage for one column: returns 1 when the block's filter bit(s) are set */
 template <bool HASHED>
 SMH_LANE uint32_t smh_wm_filter(uint32_t code, const uint32_t *filter, const smh_wm_params &P)
 {
     const uint32_t key = code & P.code_mask;
     if (HASHED) {
-        return smh_wm_filter_key<0>(P.filter_le4 ? smh_bswap32(key) : key, filter, P);
+        if (P.filter_le4) return smh_wm_filter_key_v2<0>(smh_bswap32(key), filter, P); /* rolling code = big-endian */
+        return smh_wm_filter_key<0>(key, filter, P);
     } else {
         return (filter[key >> 5] >> (key & 31u)) & 1u;
     }
@@ -608,13 +664,32 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
     uint32_t surv[2] = {0, 0};
     if constexpr (FK > 0) {
         static_assert(HASHED && !EXACT, "the byte-block path is the hashed, verified one");
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
+        auto key_of = [&](int i) {
             const int first = 16 * HC + i - 3; /* register byte index of the block's first byte */
             const int d = first >> 2, r = first & 3;
-            const uint32_t key = r == 0 ? w[d] : smh_alignbyte(w[d + 1], w[d], (uint32_t)r);
-            surv[i >> 5] |= smh_wm_filter_key<FK>(key, filter, P) << (i & 31);
+            return r == 0 ? w[d] : smh_alignbyte(w[d + 1], w[d], (uint32_t)r);
+        };
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        /* four columns at a time: addresses, then the four block reads in flight together, then the tests.  Bit 0 of a
+         * test's result goes into the survivor mask at the top and the earlier columns move down (v_alignbit): after 32
+         * columns bit i is column i's */
+        typedef uint32_t smh_v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i0 = 0; i0 < 64; i0 += 4) {
+            uint32_t g[4], addr[4];
+            smh_v2u blk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) addr[j] = smh_wm_v2_addr(key_of(i0 + j), g[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) blk[j] = *reinterpret_cast<const __attribute__((address_space(3))) smh_v2u *>(addr[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                surv[i0 >> 5] = __builtin_amdgcn_alignbit(smh_wm_v2_test<FK>(g[j], blk[j].x, blk[j].y), surv[i0 >> 5], 1u);
         }
+#else
+#pragma unroll
+        for (int i = 0; i < 64; ++i) surv[i >> 5] |= smh_wm_filter_key_v2<FK>(key_of(i), filter, P) << (i & 31);
+#endif
     } else {
 #pragma unroll
     for (int i = 0; i < 16 * HC; ++i) code = (code << P.bits) | smh_byte_of(w[i >> 2], i & 3);
