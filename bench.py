@@ -296,15 +296,20 @@ def main():
         b, e = shard_ends[m]
         return e - b
 
-    def step(events=None):
-        counts.zero_()
+    # every step has its own count buffer: its all-reduce is started behind its three scans and runs on RCCL's stream
+    # while the next step's scans run on ours; all of them are waited for inside the timed region
+    step_counts = torch.zeros((args.warmup + args.steps + 1, len(AC_LENGTHS)), dtype=torch.int64, device=dev)
+
+    def step(k, events=None):
+        c = step_counts[k]
+        c.zero_()
         for i, m in enumerate(AC_LENGTHS):
             if events is not None:
                 events[i][0].record()
-            acs[m].scan_device(text.data_ptr(), shard_len(m), counts.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
+            acs[m].scan_device(text.data_ptr(), shard_len(m), c.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
             if events is not None:
                 events[i][1].record()
-        sharded.reduce_count(counts)
+        return sharded.reduce_count_async(c)
 
     def barrier():
         torch.cuda.synchronize()
@@ -312,21 +317,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    sharded.finish([step(k) for k in range(args.warmup)])
     evs = [[(ev(), ev()) for _ in AC_LENGTHS] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(evs[k])
+    sharded.finish([step(args.warmup + k, evs[k]) for k in range(args.steps)])
     barrier()
     elapsed = time.perf_counter() - t0
+    counts = step_counts[args.warmup + args.steps - 1] if args.steps else step_counts[0]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_counts = [int(x) for x in counts.tolist()]
     # per-GPU counts for the report: one untimed pass without the reduce, then one small all-gather
+    counts = step_counts[-1]
     counts.zero_()
     for i, m in enumerate(AC_LENGTHS):
         acs[m].scan_device(text.data_ptr(), shard_len(m), counts.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)

@@ -28,6 +28,22 @@ def reduce_count(local_count):
     return local_count
 
 
+def reduce_count_async(local_count):
+    """The same sum, not waited for: returns a work handle (None with one rank).  Under RCCL the all-reduce runs on
+    the communicator's own stream behind the kernels that produced `local_count`, so the NEXT scans of the caller's
+    stream overlap it; the caller keeps `local_count` untouched until `finish(handle)`."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.all_reduce(local_count, op=dist.ReduceOp.SUM, async_op=True)
+    return None
+
+
+def finish(handles):
+    """Wait for the reductions started with reduce_count_async (makes the current stream wait for them)."""
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
 def gather_counts(local_counts):
     """Every rank's per-shard counts, for the report (and as a parity check against per-shard CPU counts):
     `local_counts` is an int64 tensor of the same shape on every rank; returns a [world, ...] int64 CPU

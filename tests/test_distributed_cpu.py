@@ -48,8 +48,11 @@ def _worker(rank, world, port, name, out_dir):
     mine = local.clone()
     everyone = sharded.gather_counts(local)  # [world, 2]: what bench.py reports as per-GPU counts
     assert everyone.shape == (world, 2) and torch.equal(everyone[rank], mine)
+    # the overlapped form bench.py times: every step reduces its own buffer, all are waited for at the end
+    steps = [local.clone() for _ in range(3)]
+    sharded.finish([sharded.reduce_count_async(c) for c in steps])
     sharded.reduce_count(local)
-    assert torch.equal(everyone.sum(dim=0), local)
+    assert torch.equal(everyone.sum(dim=0), local) and all(torch.equal(c, local) for c in steps)
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([mine[0], mine[1], local[0], local[1], b, e]))
     dist.destroy_process_group()
 
