@@ -22,6 +22,11 @@ for it in range(600):
     ln=np.random.randint(3,12,size=20).astype(np.uint32)
     ps=S.PatternSet(np.random.randint(0,4,size=int(ln.sum())).astype(np.uint8), ln, 4, it%2)
     ps.count_host(text); ps.close()
+    # wide DNA sets: grouped pair-gram filter / automaton / (every 50th: thousands of patterns) the split form
+    npat = 2400 if it % 50 == 49 else 120
+    ln=np.random.randint(8 if it % 3 else 14,41,size=npat).astype(np.uint32)
+    ps=S.PatternSet(np.random.randint(0,4,size=int(ln.sum())).astype(np.uint8), ln, 4, S.ALGO_WM)
+    ps.count_host(text); ps.close()
 torch.cuda.synchronize()
 free1,_=torch.cuda.mem_get_info()
 r1=resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
