@@ -127,50 +127,40 @@ SMH_LANE uint32_t smh_acm_next(uint32_t e, uint32_t w, int k, const void *tab, i
 }
 template <typename E, int SIGMA> SMH_LANE uint32_t smh_acm_prep(uint32_t w) { return sizeof(E) == 4 && SIGMA == 4 ? w << 2 : w; }
 
-/* fast path: segment at a (a >= 16, a + 64 <= n); w[0..3] = the 16 bytes in front of it, w[4..19] = the segment.
- * TWO automata per lane: one owns the segment's first 32 positions (warmed up over the bytes in front of the segment),
- * the other its last 32 (warmed up over the K-1 bytes in front of THEM, which are the lane's own) -- the scan is one
- * dependent LDS lookup per byte, so a second independent chain hides half of the lookup latency for 2(K-1) instead
- * of K-1 warm-up lookups per segment (1000 DNA patterns of 8..32 symbols, K = 14: 0.290 -> see DESIGN.md). */
+/* fast path: segment at a (a >= 16, a + 64 <= n); w[0..3] = the 16 bytes in front of it, w[4..19] = the segment */
 template <typename E, int SIGMA>
 SMH_LANE uint32_t smh_acm_lane_fast(uint64_t a, const uint32_t (&w)[20], const void *tab, const smh_acm_ctx &C, smh_acm_queue &Q)
 {
     using X = smh_acm_entry<E>;
-    uint32_t e0 = 0, e1 = 0, cnt = 0, cnt1 = 0, clo = 0, chi = 0;
-    /* warm-up over K-1 <= 16 bytes: no counting, no candidates -- those positions belong to the previous lane / to the
-     * other automaton */
+    uint32_t e = 0, cnt = 0, clo = 0, chi = 0;
+    /* warm-up over the K-1 bytes in front of the segment (K - 1 <= 16): no counting, no candidates -- those
+     * positions belong to the previous lane */
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t x0 = smh_acm_prep<E, SIGMA>(w[q]), x1 = smh_acm_prep<E, SIGMA>(w[8 + q]); /* bytes -16.., bytes 16.. */
+        const uint32_t x = smh_acm_prep<E, SIGMA>(w[q]);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (4 * q + k >= 17 - C.K) {
-                e0 = smh_acm_next<E, SIGMA>(e0, x0, k, tab, C.sigma);
-                e1 = smh_acm_next<E, SIGMA>(e1, x1, k, tab, C.sigma);
-            }
+            if (4 * q + k >= 17 - C.K) e = smh_acm_next<E, SIGMA>(e, x, k, tab, C.sigma);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const uint32_t x0 = smh_acm_prep<E, SIGMA>(w[4 + q]), x1 = smh_acm_prep<E, SIGMA>(w[12 + q]);
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t x = smh_acm_prep<E, SIGMA>(w[4 + q]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int i = 4 * q + k; /* positions i and 32 + i */
-            e0 = smh_acm_next<E, SIGMA>(e0, x0, k, tab, C.sigma);
-            e1 = smh_acm_next<E, SIGMA>(e1, x1, k, tab, C.sigma);
+            const int i = 4 * q + k;
+            e = smh_acm_next<E, SIGMA>(e, x, k, tab, C.sigma);
             if (sizeof(E) == 4) {
                 /* per byte: v_bfe + v_and_or (address), ds_read_b32, one add (count), one v_alignbit (candidate) */
-                cnt = smh_add_byte3(cnt, e0);
-                cnt1 = smh_add_byte3(cnt1, e1);
-                clo = smh_alignbit(e0, clo, 1u);
-                chi = smh_alignbit(e1, chi, 1u);
+                cnt = smh_add_byte3(cnt, e);
+                if (i < 32) clo = smh_alignbit(e, clo, 1u);
+                else chi = smh_alignbit(e, chi, 1u);
             } else {
-                cnt += smh_bfe(e0, X::CNT_SHIFT, X::CNT_BITS) + smh_bfe(e1, X::CNT_SHIFT, X::CNT_BITS);
-                clo |= (e0 >> X::CAND_SHIFT) << i;
-                chi |= (e1 >> X::CAND_SHIFT) << i;
+                cnt += smh_bfe(e, X::CNT_SHIFT, X::CNT_BITS);
+                if (i < 32) clo |= (e >> X::CAND_SHIFT) << i;
+                else chi |= (e >> X::CAND_SHIFT) << (i - 32);
             }
         }
     }
-    cnt += cnt1;
     uint64_t msk = ((uint64_t)chi << 32) | clo;
     while (SMH_WAVE_ANY(msk != 0)) {
         const bool have = msk != 0;
