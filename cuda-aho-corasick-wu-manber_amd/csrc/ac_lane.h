@@ -113,13 +113,6 @@ struct smh_ac_queue {
     uint64_t *slots; /* SMH_AC_QCAP entries in HBM, private to this wave */
     uint32_t count;  /* wave-uniform */
     uint32_t matches;
-    /* position-only candidates (SMH_CAND_ROOT) of texts up to 4 GiB wait in a small LDS queue instead: the HBM queue's
-     * store shares the vector-memory counter with the text prefetch, and the wave sat out its acknowledgement (~0.8 us) at
-     * the end of every chunk that had a candidate -- 0.6 us per 8 KiB on the headline sets, 11 % of the scan
-     * (tools/wavetrace.py: median wave 193 us against 173 us for the same image with K = m) */
-    uint32_t lds_off;   /* byte offset of this wave's 32-bit slots */
-    uint32_t lds_cap;   /* slots; 0 = no LDS queue */
-    uint32_t lds_count; /* wave-uniform */
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -171,48 +164,8 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
     }
     Q.count += np;
 }
-/* the LDS queue of position-only candidates: walk them (all at once, one per lane) */
-SMH_LANE void smh_ac_drain_lds(smh_ac_queue &Q, const smh_ac_verify_ctx &V)
-{
-    if (Q.lds_count == 0) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t base = 0; base < Q.lds_count; base += 64u) {
-        const uint32_t i = base + lane;
-        uint64_t hit = 0, q = 0;
-        if (i < Q.lds_count) {
-            q = smh_lds_u32(nullptr, Q.lds_off + 4u * i);
-            hit = smh_ac_deep_walk(V, q, 0u, SMH_CAND_ROOT);
-        }
-        if (V.pos.cursor) Q.matches += smh_append_bits(hit, q + (uint64_t)(V.m - V.K), V.pos);
-        else Q.matches += (uint32_t)hit;
-    }
-    Q.lds_count = 0;
-}
-/* lanes with `cond` queue the position-only candidate `pos`; wave-uniform control flow */
-SMH_LANE void smh_ac_emit_root(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos)
-{
-    const uint64_t mask = __ballot(cond);
-    if (mask == 0) return;
-    const uint32_t np = (uint32_t)__popcll(mask);
-    if (Q.lds_cap) {
-        if (Q.lds_count + np > Q.lds_cap) smh_ac_drain_lds(Q, V);
-        if (np <= Q.lds_cap) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            if (cond) *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(Q.lds_off + 4u * (Q.lds_count + before)) = (uint32_t)pos;
-            Q.lds_count += np;
-            return;
-        }
-    }
-    smh_ac_emit(Q, V, cond, pos, 0u, SMH_CAND_ROOT); /* a burst larger than the LDS queue, or a text beyond 4 GiB */
-}
 #else
 SMH_LANE void smh_ac_drain(smh_ac_queue &, const smh_ac_verify_ctx &) {}
-SMH_LANE void smh_ac_drain_lds(smh_ac_queue &, const smh_ac_verify_ctx &) {}
-SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, uint32_t kind);
-SMH_LANE void smh_ac_emit_root(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos)
-{
-    smh_ac_emit(Q, V, cond, pos, 0u, SMH_CAND_ROOT);
-}
 SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, uint32_t kind)
 {
     if (!cond) return;
@@ -594,7 +547,7 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
                 while (SMH_WAVE_ANY(msk != 0)) {
                     const bool have = msk != 0;
                     const uint32_t b = have ? (uint32_t)__builtin_ctz(msk) : 0u;
-                    smh_ac_emit_root(Q, V, have, a[j] + 32u * g + b);
+                    smh_ac_emit(Q, V, have, a[j] + 32u * g + b, 0u, SMH_CAND_ROOT);
                     msk &= msk - 1u;
                 }
             }
@@ -664,8 +617,7 @@ SMH_LANE uint64_t smh_ac_segment_match_mask(const smh_ac_verify_ctx &V, uint64_t
  * value is then the number of matches this lane appended; the kernels ignore it). */
 template <typename FMT, int HC, int NCH, bool EXACT, bool PREFETCH = true, int SW = 16, bool POS = false>
 SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chunk_sched &S, const void *tab,
-                                const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base,
-                                uint32_t lds_queue_off = 0, uint32_t lds_queue_cap = 0)
+                                const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base)
 {
     if (V.n < (uint64_t)V.m) return 0;
     const uint64_t n_starts = V.n - (uint64_t)V.m + 1;
@@ -678,9 +630,6 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chun
     Q.slots = queue_base ? queue_base + smh_uniform64(wave) * SMH_AC_QCAP : nullptr;
     Q.count = 0;
     Q.matches = 0;
-    Q.lds_off = lds_queue_off;
-    Q.lds_cap = V.n <= 0xFFFFFFFFull ? lds_queue_cap : 0u; /* 32-bit positions */
-    Q.lds_count = 0;
     uint32_t cnt = 0;
     /* software pipeline: the segments of the wave's NEXT chunk are requested before the current
      * chunk is scanned, so the HBM latency of a chunk hides behind a whole chunk of lookups */
@@ -745,10 +694,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chun
         cur_fast = nxt_fast;
         k = kn;
     }
-    if (!EXACT) {
-        smh_ac_drain_lds(Q, V);
-        smh_ac_drain(Q, V);
-    }
+    if (!EXACT) smh_ac_drain(Q, V);
     return cnt + Q.matches;
 }
 
