@@ -543,7 +543,13 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
         }
     }
     if (BITS) {
-        /* compaction: one queue entry per set bit, as many rounds as the busiest lane has bits */
+        /* compaction: one queue entry per set bit, as many rounds as the busiest lane has bits.  ONE vote decides the
+         * common case (no candidate anywhere in the wave's chunk): the six loops below each start with a vote of
+         * their own, and their code -- the drain with its walk is inlined six times -- sat in the way of every chunk */
+        uint32_t any_bits = 0;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) any_bits |= mlo[j] | mhi[j] | mhalo[j];
+        if (SMH_UNLIKELY(SMH_WAVE_ANY(any_bits != 0))) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             uint32_t *const masks[3] = {&mlo[j], &mhi[j], &mhalo[j]};
@@ -557,6 +563,7 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
                     msk &= msk - 1u;
                 }
             }
+        }
         }
     }
     return cnt;
