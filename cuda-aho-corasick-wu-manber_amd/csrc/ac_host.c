@@ -176,6 +176,7 @@ void smh_ac_host_free(struct smh_ac *ac)
     free(ac->g_supply);
     free(ac->g_final);
     smh_wm_free(ac->alt_wm);
+    smh_wm_free(ac->hv_wm);
     ac->magic = 0;
     free(ac);
 }
@@ -428,16 +429,21 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
      * position in nine) the same count is obtained much faster by the suffix-filter kernels, which
      * hash W symbols instead of walking K levels.  The patterns are read back from the goto trie and
      * compiled for that engine; smh_ac_scan / smh_ac_positions use it unless a plan is forced. */
-    if (ac->fixed_length_ok && ac->scan_cost > SMH_AC_ALT_ENGINE_COST && m >= 3 && smh_wu_shiftsize_for(alphabet) &&
-        smh_alt_engine_depth == 0) {
+    /* The same Wu-Manber handle also serves the automaton kernels' own verify stage (`hv_wm`): a candidate of a depth-cut
+     * plan (K < m) used to be walked down the full DFA -- up to m DEPENDENT loads, ~1 us each beside the streaming text,
+     * and every wave ends with such a walk: 20-30 us at the end of a 200 us launch (tools/wavetrace.py).  Hashing the
+     * window and probing the handle's verify table decides it in three. */
+    if (ac->fixed_length_ok && m >= 3 && smh_wu_shiftsize_for(alphabet) && smh_alt_engine_depth == 0) {
         ++smh_alt_engine_depth;
         /* the caller's arrays may have been adopted (and shrunk in place) in step 6: read the handle's copy */
         const int *tsrc = ac->g_transition ? ac->g_transition : trans;
         const unsigned int *fsrc = ac->g_final ? ac->g_final : final;
         unsigned char *pats = ac_extract_patterns(tsrc, fsrc, ac->g_transition ? ac->states : R, alphabet, m, ac->finals);
         if (pats) {
-            ac->alt_wm = smh_wm_compile(pats, m, (int)ac->finals, alphabet); /* NULL: stay with the automaton */
+            struct smh_wm *w = smh_wm_compile(pats, m, (int)ac->finals, alphabet); /* NULL: stay with the automaton / the walk */
             free(pats);
+            if (w && ac->scan_cost > SMH_AC_ALT_ENGINE_COST) ac->alt_wm = w;
+            else ac->hv_wm = w;
         }
         --smh_alt_engine_depth;
     }

@@ -25,6 +25,7 @@
 #define SMH_AC_LANE_H
 
 #include "lane_common.h"
+#include "wm_lane.h" /* smh_wm_verify: the verify stage hashes the window when the handle carries a verify table */
 #include <utility>
 
 template <typename E> struct smh_ac_entry;
@@ -50,6 +51,10 @@ struct smh_ac_verify_ctx {
     const void *trunc1;          /* stride-1 depth-K table in HBM */
     int trunc1_entry_bytes;
     smh_pos_out pos;             /* positions mode: where match END columns go (cursor == NULL: counting) */
+    /* hash verify (ac_host.c hv_wm): the Wu-Manber verify table and the zero-padded patterns, or NULL: walk the DFA */
+    const uint32_t *hv_verify;
+    const uint8_t *hv_pats;
+    int hv_log2;
 };
 
 /* depth_first[0..71] BY VALUE: as a kernel argument it is read with scalar loads from the kernarg
@@ -85,6 +90,16 @@ SMH_LANE uint32_t smh_ac_deep_walk(const smh_ac_verify_ctx &V, uint64_t q, uint3
 {
     int t0 = V.K;
     uint64_t start = q + 1 - (uint64_t)V.K; /* text position of the pattern's first symbol */
+    if (V.hv_verify && (kind == SMH_CAND_ROOT || V.m - V.K > 3)) {
+        /* three dependent loads (window, bucket, pattern) instead of one per remaining symbol */
+        if (start + (uint64_t)V.m > V.n) return 0;
+        smh_wm_params P = {};
+        P.m = V.m;
+        P.verify_log2 = V.hv_log2;
+        P.verify = V.hv_verify;
+        P.pat_sorted = V.hv_pats;
+        return smh_wm_verify(V.text, start + (uint64_t)V.m - 1u, P);
+    }
     if (kind == SMH_CAND_LAZY) {
         uint32_t c0 = V.text[q];
         if (c0 >= (uint32_t)V.sigma) c0 = 0;

@@ -75,6 +75,7 @@ struct smh_ac {
     double scan_cost;     /* plan cost model's estimate, 1.0 = an exact stride-1 scan (ac_host.c) */
     struct smh_wm *alt_wm; /* suffix-filter engine for sets whose best automaton plan is verify-bound, else NULL */
     int alt_off;          /* a scan plan was forced: scans use the automaton kernels regardless */
+    struct smh_wm *hv_wm; /* verify table + patterns for the automaton kernels' verify stage (hash the window, probe), else NULL */
     /* stride-1 depth-K table in HBM: the slow path and the resolution of stride-2 "first symbol"
      * candidates read it; identical to scan_table when scan_stride == 1 */
     void *trunc1_table;

@@ -315,12 +315,28 @@ static int ac_ensure_reference_tables(struct smh_ac *ac, smh_ac_dev *d)
  * wrappers call it BEFORE their first event so that the reported kernel time is the kernel's
  * (cuda/cuda_wm.cu:271-283 brackets the launch only) */
 static int wm_prepare(struct smh_wm *wm, int variant);
+static int wm_ensure_device(struct smh_wm *wm, smh_wm_dev **out);
+/* the automaton kernels' verify stage hashes the window when the handle carries a verify table (ac_host.c hv_wm) */
+static int ac_fill_hash_verify(struct smh_ac *ac, smh_ac_verify_ctx &V)
+{
+    V.hv_verify = NULL; V.hv_pats = NULL; V.hv_log2 = 0;
+    if (!ac->hv_wm || !ac->hv_wm->verify) return SMH_OK;
+    smh_wm_dev *hd = NULL;
+    const int rc = wm_ensure_device(ac->hv_wm, &hd);
+    if (rc != SMH_OK) return rc;
+    V.hv_verify = hd->d_verify; V.hv_pats = hd->d_pat_sorted; V.hv_log2 = ac->hv_wm->verify_log2;
+    return SMH_OK;
+}
 static int ac_prepare(struct smh_ac *ac, int variant)
 {
     if (variant == SMH_VARIANT_TUNED && ac->alt_wm && !ac->alt_off) return wm_prepare(ac->alt_wm, variant);
     smh_ac_dev *d = NULL;
     int rc = ac_ensure_device(ac, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = ac_ensure_reference_tables(ac, d);
+    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && ac->hv_wm) {
+        smh_wm_dev *hd = NULL;
+        rc = wm_ensure_device(ac->hv_wm, &hd);
+    }
     return rc;
 }
 
@@ -361,6 +377,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
         L.V.full = dv->d_table; L.V.full_entry_bytes = ac->entry_bytes; L.V.depth_first = dv->d_depth_first;
         L.V.trunc1 = dv->d_trunc1; L.V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+        if ((rc = ac_fill_hash_verify(ac, L.V)) != SMH_OK) return rc;
         L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
         L.d_scan_table = dv->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = dv->d_queue;
         for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
@@ -402,6 +419,7 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
     V.text = d_text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
     V.full = dv->d_table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = dv->d_depth_first;
     V.trunc1 = dv->d_trunc1; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    if ((rc = ac_fill_hash_verify(ac, V)) != SMH_OK) return rc;
     /* the tuned scan kernels in positions mode: matches are recorded as bits and appended per wave */
     smh_ac_launch L = {};
     L.V = V;

@@ -20,6 +20,22 @@
 #include "ac_lane.h"
 #include "wm_lane.h"
 
+/* hash verify of the automaton kernels (ac_host.c hv_wm): host pointers, patterns zero-padded to whole dwords */
+struct emu_hv {
+    std::vector<uint8_t> padded;
+    void fill(const smh_ac *ac, smh_ac_verify_ctx &V)
+    {
+        V.hv_verify = nullptr; V.hv_pats = nullptr; V.hv_log2 = 0;
+        const smh_wm *w = ac->hv_wm;
+        if (!w || !w->verify) return;
+        const size_t row = (size_t)((w->m + 3) / 4) * 4;
+        padded.assign((size_t)w->distinct * row + 16, 0);
+        for (int j = 0; j < w->distinct; ++j) memcpy(padded.data() + (size_t)j * row, w->pat_sorted + (size_t)j * w->m, (size_t)w->m);
+        V.hv_verify = w->verify; V.hv_pats = padded.data(); V.hv_log2 = w->verify_log2;
+    }
+};
+
+
 #define EMU_BLOCK_THREADS 1024
 #define EMU_AC_NCH 1 /* == SMH_AC_NCH in ac_kernels.hip */
 
@@ -110,6 +126,8 @@ extern "C" uint64_t emu_ac_positions_tuned(const smh_ac *ac, const uint8_t *text
     V.text = padded.data(); V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
     V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df.data();
     V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    emu_hv hv;
+    hv.fill(ac, V);
     uint64_t cursor = 0;
     V.pos = smh_pos_out{out, capacity, &cursor};
     uint64_t r;
@@ -147,6 +165,8 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
             V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
             V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
             V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+            emu_hv hv;
+            hv.fill(ac, V);
             if (ac->scan_stride == 2 && ac->scan_full_rows)
                 total = ac_halo<uint16_t, 4, 3>(ac, V, blocks);
             else if (ac->scan_stride == 2)
@@ -308,6 +328,8 @@ extern "C" uint64_t emu_ac_positions(const smh_ac *ac, const uint8_t *text, uint
     V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
     V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
     V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    emu_hv hv;
+    hv.fill(ac, V);
     uint64_t cursor = 0;
     const uint64_t nthreads = (uint64_t)blocks * 256;
     for (uint64_t t = 0; t < nthreads; ++t) smh_ac_positions_thread(t, nthreads, V, out, capacity, &cursor);
