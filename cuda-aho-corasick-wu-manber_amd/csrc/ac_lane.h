@@ -348,6 +348,21 @@ SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c
                                const uint64_t (&pos)[NCH], bool second_valid, uint32_t (&e)[NCH], uint32_t &cnt,
                                int hbit = 0)
 {
+    if constexpr (FMT::SPARSE) {
+        /* hybrid image: the state stays the plain row id and flags arrive through the callback, from the rare
+         * compact-row resolution only -- the common halo step carries no flag arithmetic either (packing row | flags
+         * << 16 and taking it apart again was 5 VALU per chain and halo step) */
+        if (c.hmask || EXACT) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+                e[j] = c.fmt.next_f(c.fmt.row(e[j]), x[j], k, c.tab, [&](uint32_t f) {
+                    if (!second_valid) f &= 1u;
+                    if (c.hmask) c.hmask[j] |= f << hbit;
+                    else cnt += (uint32_t)__builtin_popcount(f);
+                });
+            return;
+        }
+    }
     uint32_t f[NCH], prev[NCH];
     uint32_t anyf = 0;
 #pragma unroll
