@@ -303,12 +303,12 @@ def main():
     def step(k, events=None):
         c = step_counts[k]
         c.zero_()
+        if events is not None:
+            events[0].record()  # one event between consecutive launches: the end of one is the start of the next
         for i, m in enumerate(AC_LENGTHS):
-            if events is not None:
-                events[i][0].record()
             acs[m].scan_device(text.data_ptr(), shard_len(m), c.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
             if events is not None:
-                events[i][1].record()
+                events[i + 1].record()
         return sharded.reduce_count_async(c)
 
     def barrier():
@@ -318,7 +318,7 @@ def main():
         torch.cuda.synchronize()
 
     sharded.finish([step(k) for k in range(args.warmup)])
-    evs = [[(ev(), ev()) for _ in AC_LENGTHS] for _ in range(args.steps)]
+    evs = [[ev() for _ in range(len(AC_LENGTHS) + 1)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     sharded.finish([step(args.warmup + k, evs[k]) for k in range(args.steps)])
@@ -340,7 +340,7 @@ def main():
     local_counts = [int(x) for x in counts.tolist()]
 
     # per-launch durations (ms) from the events on the launch stream
-    kern_ms = {m: [evs[k][i][0].elapsed_time(evs[k][i][1]) for k in range(args.steps)] for i, m in enumerate(AC_LENGTHS)}
+    kern_ms = {m: [evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)] for i, m in enumerate(AC_LENGTHS)}
     bits_per_step = 8.0 * sum(shard_len(m) for m in AC_LENGTHS)
     if world > 1:
         t = torch.tensor([bits_per_step], dtype=torch.float64, device=dev)

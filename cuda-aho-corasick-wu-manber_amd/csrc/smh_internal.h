@@ -274,7 +274,8 @@ struct smh_wm {
      * (3-gram bit table T8, smatcher.h:77-80, shift-or state) with positional planes over the patterns' tail.
      *   SMH_GRAM_PAIR  alphabet 4: 7-symbol grams, table indexed by EIGHT consecutive symbols (16 bits), 16-bit
      *                  entries (G of the older seven symbols' column << 1) | G of the next column -- one lookup
-     *                  and ONE v_lshl_or serve two columns; behind the 128 KiB image, 16 KiB of per-gram bytes G for
+     *                  and ONE v_lshl_or serve two columns, G up to 15 bits wide (planes); behind the 128 KiB image, 32 KiB
+     *                  of per-gram values G for
      *                  the bounds-checked path (never staged in LDS)
      *   SMH_GRAM_OCT   alphabet 4: 8-symbol grams, 8-bit entries indexed by the gram, one lookup per column: for
      *                  pattern counts at which the 7-symbol planes fill up (8000 patterns: 39 % full, and

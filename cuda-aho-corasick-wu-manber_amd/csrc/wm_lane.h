@@ -43,8 +43,8 @@ struct smh_wm_params {
      * patterns' last min-length symbols, and a surviving column is verified once per length class */
     int n_classes;                       /* 0 = a single-length set: verify / pat_sorted above */
     const struct smh_wm_class *classes;  /* HBM */
-    const uint8_t *gram_g7;              /* HBM: pair-gram filter only, the byte G of every 7-symbol gram (bounds-checked path);
-                                          * grouped pairs (KIND 4): 16-bit values G_A | G_B << 8 */
+    const uint8_t *gram_g7;              /* HBM: pair-gram forms only, 16-bit per 7-symbol gram for the bounds-checked path: the
+                                          * value G (KIND 1, up to 15 planes); grouped pairs (KIND 4): G_A | G_B << 8 */
     int gram_jb;                         /* grouped pairs: planes of the short-pattern group, 0 = none */
     int gram_planes;                     /* pair form (KIND 1): planes J (2..15), candidate = state bit J-1 clear */
 };

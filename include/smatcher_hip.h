@@ -158,7 +158,7 @@ typedef struct smh_wm_info {
     uint32_t scan_engine;     /* SMH_ALGO_WM: this path's kernels scan; SMH_ALGO_AC: a small-alphabet set of long
                                * patterns whose automaton fits LDS is scanned by the automaton kernels (faster
                                * than a non-exact direct filter; same count) -- see smh_wm_set_scan_engine */
-    uint32_t gram_planes;     /* > 0: the scan runs the q-gram shift-and filter with this many positional planes
+    uint32_t gram_planes;     /* > 0: the scan runs the q-gram shift-or filter with this many positional planes
                                * (one lookup per column, or per two columns on the 4-letter alphabet) */
 } smh_wm_info;
 
