@@ -170,14 +170,23 @@ SMH_LANE void smh_ac_drain(smh_ac_queue &Q, const smh_ac_verify_ctx &V)
     Q.count = 0;
 }
 
+/* the same drain as a real function: the emit sites of the vote-and-replay plans (one per halo step and replayed
+ * lookup, hundreds per kernel) call it instead of inlining the walk -- their code size and compile time, not their
+ * speed, are what matters (a full queue is rare); the one emit site of the bit-recording plans keeps the inline form */
+__device__ __noinline__ static void smh_ac_drain_call(smh_ac_queue *Q, const smh_ac_verify_ctx *V) { smh_ac_drain(*Q, *V); }
+
 /* wavefront-level compaction: lanes with `cond` append {position, row} to the wave's queue.
  * Must be called in wave-uniform control flow. */
+template <bool INLINE_DRAIN = true>
 SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, uint32_t kind)
 {
     const uint64_t mask = __ballot(cond);
     if (mask == 0) return;
     const uint32_t np = (uint32_t)__popcll(mask);
-    if (Q.count + np > SMH_AC_QCAP) smh_ac_drain(Q, V);
+    if (Q.count + np > SMH_AC_QCAP) {
+        if constexpr (INLINE_DRAIN) smh_ac_drain(Q, V);
+        else smh_ac_drain_call(&Q, &V);
+    }
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (cond) {
         const uint64_t ent = pos | ((uint64_t)(row | (kind << 22)) << 40);
@@ -187,6 +196,7 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
 }
 #else
 SMH_LANE void smh_ac_drain(smh_ac_queue &, const smh_ac_verify_ctx &) {}
+template <bool INLINE_DRAIN = true>
 SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond, uint64_t pos, uint32_t row, uint32_t kind)
 {
     if (!cond) return;
@@ -334,11 +344,11 @@ SMH_LANE void smh_ac_emit_flags(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &
                                 uint64_t pos)
 {
     if (FMT::STRIDE == 1) {
-        smh_ac_emit(*c.Q, *c.V, f != 0, pos, c.fmt.row(e), SMH_CAND_ROW);
+        smh_ac_emit<false>(*c.Q, *c.V, f != 0, pos, c.fmt.row(e), SMH_CAND_ROW);
     } else {
         /* first symbol of the pair: the depth-K row is not in the entry -> resolved lazily */
-        smh_ac_emit(*c.Q, *c.V, (f & 1u) != 0, pos, c.fmt.row(prev), SMH_CAND_LAZY);
-        smh_ac_emit(*c.Q, *c.V, (f & 2u) != 0, pos + 1u, c.fmt.row(e), SMH_CAND_ROW);
+        smh_ac_emit<false>(*c.Q, *c.V, (f & 1u) != 0, pos, c.fmt.row(prev), SMH_CAND_LAZY);
+        smh_ac_emit<false>(*c.Q, *c.V, (f & 2u) != 0, pos + 1u, c.fmt.row(e), SMH_CAND_ROW);
     }
 }
 
@@ -580,20 +590,26 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
 #pragma unroll
         for (int j = 0; j < NCH; ++j) any_bits |= mlo[j] | mhi[j] | mhalo[j];
         if (SMH_UNLIKELY(SMH_WAVE_ANY(any_bits != 0))) {
+            /* ONE emit site (a rolled loop over the 3 * NCH masks): the drain, with its verify, is inlined wherever
+             * smh_ac_emit is -- six copies of it doubled the kernels' code and their compile time */
+            uint32_t mm[3 * NCH];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            uint32_t *const masks[3] = {&mlo[j], &mhi[j], &mhalo[j]};
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                uint32_t msk = *masks[g];
+            for (int j = 0; j < NCH; ++j) {
+                mm[3 * j] = mlo[j];
+                mm[3 * j + 1] = mhi[j];
+                mm[3 * j + 2] = mhalo[j];
+            }
+#pragma unroll 1
+            for (int g = 0; g < 3 * NCH; ++g) {
+                uint32_t msk = mm[g];
+                const uint64_t base = a[g / 3] + 32u * (uint32_t)(g % 3);
                 while (SMH_WAVE_ANY(msk != 0)) {
                     const bool have = msk != 0;
                     const uint32_t b = have ? (uint32_t)__builtin_ctz(msk) : 0u;
-                    smh_ac_emit(Q, V, have, a[j] + 32u * g + b, 0u, SMH_CAND_ROOT);
+                    smh_ac_emit(Q, V, have, base + b, 0u, SMH_CAND_ROOT);
                     msk &= msk - 1u;
                 }
             }
-        }
         }
     }
     return cnt;
