@@ -515,7 +515,8 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         const int le4 = bits == 8 && Wh == 4;
         /* try 2, 3 and 4 bits per key (all inside one word, so the scan still costs one LDS lookup
          * per column) and keep the one that lets the fewest random keys through */
-        for (int k = 2; k <= 4; ++k) {
+        double best_score = 1e30;
+        for (int k = 2; k <= (le4 ? 5 : 4); ++k) {
             uint32_t *hashed = (uint32_t *)calloc(nwords, sizeof(uint32_t));
             if (!hashed) { free(direct); free(best); goto oom; }
             for (int j = 0; j < d; ++j) {
@@ -530,6 +531,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
                     hashed[2u * blk] |= (1u << ((g >> 8) & 31u)) | (1u << ((g >> 16) & 31u));
                     if (k >= 3) hashed[2u * blk + 1u] |= 1u << ((g >> 24) & 31u);
                     if (k >= 4) hashed[2u * blk + 1u] |= 1u << (g & 31u);
+                    if (k >= 5) hashed[2u * blk] |= 1u << ((h >> 24) & 31u);
                     continue;
                 }
                 uint32_t h = smh_wm_block_hash(key);
@@ -545,14 +547,19 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
                 const double fl = (double)__builtin_popcount(hashed[2 * b]) / 32.0;
                 const double fh = (double)__builtin_popcount(hashed[2 * b + 1]) / 32.0;
                 double pk = fl * fl;
-                for (int i = 2; i < k; ++i) pk *= fh;
+                for (int i = 2; i < k && i < 4; ++i) pk *= fh;
+                if (k >= 5) pk *= fl; /* the byte-block form's fifth bit is in the low dword again */
                 acc += pk;
             }
             const double density = acc / (double)(nwords / 2);
-            if (density < best_density) {
+            /* the byte-block form pays two VALU per bit and column (0.03 ms/GiB) and the staged verify per survivor:
+             * the cheapest total wins, not the sparsest filter; the other forms keep the sparsest */
+            const double score = le4 && m <= 33 ? 0.27 + 0.032 * k + gram_verify_ms(m, density) : density;
+            if (score < best_score) {
                 free(best);
                 best = hashed;
                 best_density = density;
+                best_score = score;
                 best_k = k;
             } else {
                 free(hashed);
@@ -638,7 +645,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         /* this path's block filter, same units: a non-exact direct filter scans at 0.40 ms/GiB, the hashed
          * byte-block filter at 0.55, and their survivors cost the same verify stage */
         /* the byte-block form (12 VALU per column, staged verify): 0.65 ms/GiB at 100 000 patterns of 5 bytes, 1.8 % passing */
-        const double other_ms = wm->filter_hashed && wm->filter_le4 && m <= 33 ? 0.40 + gram_verify_ms(m, wm->filter_density)
+        const double other_ms = wm->filter_hashed && wm->filter_le4 && m <= 33 ? 0.27 + 0.032 * wm->filter_k + gram_verify_ms(m, wm->filter_density)
                               : wm->filter_hashed ? 0.55 + SMH_HASHED_VERIFY_MS(m) * wm->filter_density
                                                   : 0.40 + SMH_DIRECT_VERIFY_MS(m) * wm->filter_density;
         wm->scan_ms_est = other_ms;

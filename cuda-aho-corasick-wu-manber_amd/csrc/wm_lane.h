@@ -238,7 +238,8 @@ SMH_LANE uint32_t smh_wm_filter_key(uint32_t key, const uint32_t *filter, const 
  * own hash and bit layout, chosen for the instruction count of the scan (it was VALU-bound at 16.5 ops per column):
  *   h = key[23:0] * 0x9E3779 + key[31:24] * 0x85EBCB      block = bits 3..16 of h: (h & 0x1FFF8) IS its LDS byte address
  *   g = key[23:0] * 0xC2B2AF                              bit positions = the low five bits of g's BYTES 1, 2 (low dword
- *                                                         of the block), 3 and 0 (high dword; K >= 3, K == 4)
+ *                                                         of the block), 3 and 0 (high dword; K >= 3, K >= 4) and of h's
+ *                                                         byte 3 (low dword; K == 5)
  * so a column costs: v_alignbyte (key), v_mul_u32_u24 with a byte-3 select + v_mad_u32_u24 (h), v_mul_u32_u24 (g),
  * v_and (address), ds_read_b64, K shifts whose amount is a byte select of g (SDWA), one three-input AND, one
  * v_alignbit that shifts the answer into the survivor mask: 10 VALU at K = 3, 12 at K = 4.  Mirrored by wm_host.c. */
@@ -256,14 +257,15 @@ SMH_LANE uint32_t smh_wm_filter_key_v2(uint32_t key, const uint32_t *filter, con
     uint32_t hit = smh_bit_at(w.lo, g >> 8) & smh_bit_at(w.lo, g >> 16);
     if (k >= 3) hit &= smh_bit_at(w.hi, g >> 24);
     if (k >= 4) hit &= smh_bit_at(w.hi, g);
+    if (k >= 5) hit &= smh_bit_at(w.lo, h >> 24);
     return hit;
 }
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 /* the same test as the instruction sequence above, in two halves so that the caller can keep several blocks' reads in
  * flight: LDS byte address of the key's block (and g), then the test (bit 0 of the result is the answer) */
-SMH_LANE uint32_t smh_wm_v2_addr(uint32_t key, uint32_t &g)
+SMH_LANE uint32_t smh_wm_v2_addr(uint32_t key, uint32_t &g, uint32_t &h)
 {
-    uint32_t t, h;
+    uint32_t t;
     const uint32_t mulb = SMH_BLK_MUL_B;
     asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(t) : "v"(key), "v"(mulb));
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(h) : "v"(key), "s"(SMH_BLK_MUL_A), "v"(t));
@@ -271,7 +273,7 @@ SMH_LANE uint32_t smh_wm_v2_addr(uint32_t key, uint32_t &g)
     return h & 0x1FFF8u;
 }
 template <int K>
-SMH_LANE uint32_t smh_wm_v2_test(uint32_t g, uint32_t lo, uint32_t hi)
+SMH_LANE uint32_t smh_wm_v2_test(uint32_t g, uint32_t h, uint32_t lo, uint32_t hi)
 {
     uint32_t a, b, c;
     asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(g), "v"(lo));
@@ -283,6 +285,10 @@ SMH_LANE uint32_t smh_wm_v2_test(uint32_t g, uint32_t lo, uint32_t hi)
     }
     if (K >= 4) {
         asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(c) : "v"(g), "v"(hi));
+        r &= c;
+    }
+    if (K >= 5) {
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(c) : "v"(h), "v"(lo));
         r &= c;
     }
     return r;
@@ -676,15 +682,15 @@ SMH_LANE uint32_t smh_wm_lane_fast(const uint8_t *text, uint64_t a, const uint32
         typedef uint32_t smh_v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int i0 = 0; i0 < 64; i0 += 4) {
-            uint32_t g[4], addr[4];
+            uint32_t g[4], hh[4], addr[4];
             smh_v2u blk[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) addr[j] = smh_wm_v2_addr(key_of(i0 + j), g[j]);
+            for (int j = 0; j < 4; ++j) addr[j] = smh_wm_v2_addr(key_of(i0 + j), g[j], hh[j]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) blk[j] = *reinterpret_cast<const __attribute__((address_space(3))) smh_v2u *>(addr[j]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                surv[i0 >> 5] = __builtin_amdgcn_alignbit(smh_wm_v2_test<FK>(g[j], blk[j].x, blk[j].y), surv[i0 >> 5], 1u);
+                surv[i0 >> 5] = __builtin_amdgcn_alignbit(smh_wm_v2_test<FK>(g[j], hh[j], blk[j].x, blk[j].y), surv[i0 >> 5], 1u);
         }
 #else
 #pragma unroll

@@ -256,22 +256,20 @@ static uint64_t wm_halo(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     const int halo = wm->m - 1;
     if constexpr (HASHED && !EXACT) {
         if (wm->filter_le4 && halo <= 32) { /* as launch_halo in wm_kernels.hip */
-            if (g_emu_n_classes == 0) { /* single-length set: staged verify */
-                if (halo <= 16)
-                    return wm->filter_k == 2 ? wm_grid<true, false, 1, 2, POS, true>(wm, text, n, blocks, po)
-                         : wm->filter_k == 3 ? wm_grid<true, false, 1, 3, POS, true>(wm, text, n, blocks, po)
-                                             : wm_grid<true, false, 1, 4, POS, true>(wm, text, n, blocks, po);
-                return wm->filter_k == 2 ? wm_grid<true, false, 2, 2, POS, true>(wm, text, n, blocks, po)
-                     : wm->filter_k == 3 ? wm_grid<true, false, 2, 3, POS, true>(wm, text, n, blocks, po)
-                                         : wm_grid<true, false, 2, 4, POS, true>(wm, text, n, blocks, po);
+#define EMU_BYTE_BLOCK(HCV, STGV)                                                                                   \
+            switch (wm->filter_k) {                                                                                   \
+            case 2: return wm_grid<true, false, HCV, 2, POS, STGV>(wm, text, n, blocks, po);                           \
+            case 3: return wm_grid<true, false, HCV, 3, POS, STGV>(wm, text, n, blocks, po);                           \
+            case 5: return wm_grid<true, false, HCV, 5, POS, STGV>(wm, text, n, blocks, po);                           \
+            default: return wm_grid<true, false, HCV, 4, POS, STGV>(wm, text, n, blocks, po);                          \
             }
-            if (halo <= 16)
-                return wm->filter_k == 2 ? wm_grid<true, false, 1, 2, POS>(wm, text, n, blocks, po)
-                     : wm->filter_k == 3 ? wm_grid<true, false, 1, 3, POS>(wm, text, n, blocks, po)
-                                         : wm_grid<true, false, 1, 4, POS>(wm, text, n, blocks, po);
-            return wm->filter_k == 2 ? wm_grid<true, false, 2, 2, POS>(wm, text, n, blocks, po)
-                 : wm->filter_k == 3 ? wm_grid<true, false, 2, 3, POS>(wm, text, n, blocks, po)
-                                     : wm_grid<true, false, 2, 4, POS>(wm, text, n, blocks, po);
+            if (g_emu_n_classes == 0) { /* single-length set: staged verify */
+                if (halo <= 16) { EMU_BYTE_BLOCK(1, true) }
+                EMU_BYTE_BLOCK(2, true)
+            }
+            if (halo <= 16) { EMU_BYTE_BLOCK(1, false) }
+            EMU_BYTE_BLOCK(2, false)
+#undef EMU_BYTE_BLOCK
         }
     }
     if (halo <= 16) return wm_grid<HASHED, EXACT, 1, 0, POS>(wm, text, n, blocks, po);
