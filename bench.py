@@ -301,8 +301,7 @@ def main():
     step_counts = torch.zeros((args.warmup + args.steps + 1, len(AC_LENGTHS)), dtype=torch.int64, device=dev)
 
     def step(k, events=None):
-        c = step_counts[k]
-        c.zero_()
+        c = step_counts[k]  # zero since its allocation: every step accumulates into a row of its own
         if events is not None:
             events[0].record()  # one event between consecutive launches: the end of one is the start of the next
         for i, m in enumerate(AC_LENGTHS):
