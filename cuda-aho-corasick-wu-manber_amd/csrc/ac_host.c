@@ -476,7 +476,7 @@ bad:
  * very rare (it measured 2.0 TB/s at one candidate per 260 bytes).  Relative cost per text byte:
  *     stride 1:  1 + 0.08 [K < m] + 3 * P(a 16-byte piece of a wave holds a candidate)
  *     stride 2:  0.62 + 300 * r [K < m]                       r = candidates per text byte
- *     hybrid  :  0.55 (two chains per lane: halo <= 16 bytes; else 0.67) + 2.0 * P(a wave holds a lane deeper
+ *     hybrid  :  0.51 (three chains per lane: halo <= 16 bytes; else 0.67) + 2.0 * P(a wave holds a lane deeper
  *                than D) + (0.07 + 300 * r) [K < m]
  *                (round 1 fit: K16D8 1.25, K16D7 2.26, K12D9 exact 0.91 / cut 0.98 of the stride-1 time; round 2
  *                refit of the constant terms after the leaner step and the dynamic chunk scheduling) */
@@ -717,9 +717,9 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 const uint64_t nc = rk - nf;
                 if (nf * 32u + nc * 4u + nc / 4u + 64u > lds_budget || rk + nc / 8u > 65000u) continue;
                 const double r = candidate_rate(ac, K), q = deep_rate(ac, D);
-                /* round 2 refit (leaner step, dynamic chunk scheduling): K12D9 cut 0.220 ms/GiB with two chains per
-                 * lane (halo <= 16 bytes), 0.255 with one, against 0.289 for the exact stride-1 scan */
-                const double base = K - 1 <= 16 ? 0.55 : 0.67;
+                /* round 2 refit (leaner step, dynamic chunk scheduling): K12D9 cut 0.205 ms/GiB with three chains per
+                 * lane (halo <= 16 bytes; 0.220 with two), 0.255 with one, against 0.289 for the exact stride-1 scan */
+                const double base = K - 1 <= 16 ? 0.51 : 0.67;
                 const double cost = base + 2.0 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.07 + 300.0 * r : 0.0);
                 if (cost < best_cost) { best_cost = cost; best_s = 3; best_k[3] = K; best_d = D; }
                 break;
