@@ -1359,6 +1359,27 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
         uint32_t pv = prevT;
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         if ((threadIdx.x & 63u) == 0) pv = 0u;
+        if constexpr (STG > 0) {
+            /* ... which lets column c of lane 0 through on c + 1 planes only: 0.06 surviving columns per wave-chunk at 1000
+             * patterns, 0.6 at 8000 (one chunk in two staged for nothing: 8000 patterns of 32 symbols scanned at 0.226
+             * ms/GiB with 0.2 real survivors per chunk).  So when lane 0 has such a flag, the state the chunk inherits is
+             * computed from the halo -- the last NP pairs of columns in front of the chunk decide its low J-1 bits; same
+             * values in every lane, the lookups are broadcasts -- and lane 0 is corrected like the others. */
+            if (P.gram_jb >= 0 /* development knob SMH_WM_TUNE="lane0=0" */ && __builtin_amdgcn_readfirstlane((int)(fl16[0] & jmask)) != 0) {
+                constexpr int NP = STG == 1 ? 5 : 7, ND = (2 * NP + 6) / 4; /* pairs of columns (>= J-1 columns), dwords of halo */
+                uint32_t c2 = 0, Th = 0;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const uint32_t hw = halo[HD - ND + d], x = (hw << 10) | hw;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        c2 = ((c2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
+                        if (2 * d + k >= 3) Th = smh_gram_step2(Th, smh_lds_u16(tab, c2));
+                    }
+                }
+                if ((threadIdx.x & 63u) == 0) pv = Th;
+            }
+        }
 #endif
         const uint32_t fixj = jw ? smh_bitrev32(~pv & jmask) >> (32u - jw) : 0u;
         msk = (uint64_t)((fl16[0] & (fixj | ~jmask)) | (fl16[1] << 16)) | ((uint64_t)(fl16[2] | (fl16[3] << 16)) << 32);
