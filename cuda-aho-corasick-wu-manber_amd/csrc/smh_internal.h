@@ -289,6 +289,7 @@ struct smh_wm {
     void *gram_table;
     uint32_t gram_bytes;
     double gram_density; /* fraction of columns expected to reach the verify stage on uniform text */
+    double gram_lane0;   /* pair form: columns per wave-chunk that only the assumption made for lane 0 lets through (wm_lane.h) */
     double scan_ms_est;  /* this path's own kernels, estimated ms per GiB (non-exact filters only; engine choice) */
     /* reference-layout tables */
     uint32_t shiftsize;

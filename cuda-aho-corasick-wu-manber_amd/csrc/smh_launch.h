@@ -167,6 +167,7 @@ struct smh_wm_launch {
     const uint32_t *d_gram; /* gram filter (128 KiB), else NULL; gram_kind 1 = symbol pairs (alphabet 4), 2 = byte grams */
     int gram_kind;
     float gram_density;     /* surviving columns per text column the compile measured on random text */
+    float gram_lane0;       /* pair form: columns per wave-chunk let through by the assumption made for lane 0 alone */
     int gram_planes;        /* pair form: planes J (2..15) */
     int gram_jb;            /* gram_kind 4 (grouped pairs, mixed-length sets): planes of the short-pattern group */
     int verify_log2;

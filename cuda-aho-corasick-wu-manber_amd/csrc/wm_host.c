@@ -244,9 +244,18 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
         /* entry of eight symbols = (G of the older seven << 1) | G of the newer seven: one v_lshl_or does both columns */
         for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(((uint32_t)g7[x >> 2] << 1) | g7[x & 0x3FFFu]);
         const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4, J), ms = SMH_GRAM_PAIR_MS + gram_verify_ms(m, dens);
+        /* lane 0 of a wave-chunk starts from "every plane still alive": its column c passes on planes 0..c alone */
+        double lane0 = 0.0, run = 1.0;
+        for (int j = 0; j < J - 1; ++j) {
+            uint32_t in = 0;
+            for (uint32_t c = 0; c < 16384; ++c) in += !((g7[c] >> (J - 1 - j)) & 1u);
+            run *= (double)in / 16384.0;
+            lane0 += run;
+        }
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_PAIR; best_planes = J; best_bytes = SMH_GRAM_BYTES + 32768; best_ms = ms; best_dens = dens;
+            wm->gram_lane0 = lane0;
         } else {
             free(tab);
         }

@@ -45,7 +45,7 @@ struct smh_wm_params {
     const struct smh_wm_class *classes;  /* HBM */
     const uint8_t *gram_g7;              /* HBM: pair-gram forms only, 16-bit per 7-symbol gram for the bounds-checked path: the
                                           * value G (KIND 1, up to 15 planes); grouped pairs (KIND 4): G_A | G_B << 8 */
-    int gram_jb;                         /* grouped pairs: planes of the short-pattern group, 0 = none */
+    int gram_jb;                         /* grouped pairs: planes of the short-pattern group, 0 = none; pair form: -1 = lane 0 keeps its assumption */
     int gram_planes;                     /* pair form (KIND 1): planes J (2..15), candidate = state bit J-1 clear */
 };
 
@@ -1365,7 +1365,7 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
              * ms/GiB with 0.2 real survivors per chunk).  So when lane 0 has such a flag, the state the chunk inherits is
              * computed from the halo -- the last NP pairs of columns in front of the chunk decide its low J-1 bits; same
              * values in every lane, the lookups are broadcasts -- and lane 0 is corrected like the others. */
-            if (P.gram_jb >= 0 /* development knob SMH_WM_TUNE="lane0=0" */ && __builtin_amdgcn_readfirstlane((int)(fl16[0] & jmask)) != 0) {
+            if (P.gram_jb >= 0 /* the launcher's choice: wm_kernels.inc launch_gram_stg */ && __builtin_amdgcn_readfirstlane((int)(fl16[0] & jmask)) != 0) {
                 constexpr int NP = STG == 1 ? 5 : 7, ND = (2 * NP + 6) / 4; /* pairs of columns (>= J-1 columns), dwords of halo */
                 uint32_t c2 = 0, Th = 0;
 #pragma unroll
