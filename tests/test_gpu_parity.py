@@ -316,6 +316,38 @@ def test_ascii_100k_patterns_against_bruteforce(m):
         assert ac.count_host(text[:1 << 20], S.VARIANT_TUNED)[0] == O.count_bruteforce(pat[:pa * m], m, pa, text[:1 << 20])
 
 
+@pytest.mark.parametrize("lane0", [0, 1])
+@pytest.mark.parametrize("m,p", [(11, 3000), (13, 500), (16, 3000), (17, 8000), (18, 3000), (21, 200), (27, 5000), (32, 8000), (33, 3000)])
+def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, monkeypatch):
+    """Pair-gram filter: the shift-or state that lane 0 of a wave-chunk inherits is either assumed (every plane alive)
+    or worked out from the 16 / 32 bytes in front of the chunk (wm_lane.h; the launcher's choice, forced both ways
+    here).  Occurrences END in each of the first 15 columns of a chunk -- the columns that state decides -- in every
+    chunk of the text, with enough patterns that lane 0 has early flags in most chunks."""
+    monkeypatch.setenv("SMH_WM_TUNE", "gram=1,lane0=%d" % lane0)
+    rng = np.random.RandomState(77 * m + p)
+    n = 48 * 4096 + 123
+    text = rng.randint(0, 4, size=n).astype(np.uint8)
+    pat = rng.randint(0, 4, size=(p, m)).astype(np.uint8)
+    for k in range(1, 48):
+        end = k * 4096 + (k % 15)
+        text[end - m + 1:end + 1] = pat[(7 * k) % p]
+    wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, 4)
+    assert wm.info().gram_planes == min(15, m - 6)
+    if wm.info().scan_engine != S.ALGO_WM:
+        wm.set_scan_engine(S.ALGO_WM)
+    want = O.count_bruteforce(pat.reshape(-1), m, p, text)
+    assert want >= 47
+    assert wm.count_host(text, S.VARIANT_TUNED)[0] == want
+    import torch
+    d_text = torch.from_numpy(text).cuda()
+    out = torch.zeros(want + 8, dtype=torch.int64, device="cuda")
+    cur = torch.zeros(1, dtype=torch.int64, device="cuda")
+    wm.positions_device(d_text.data_ptr(), n, out.data_ptr(), want + 8, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cur.item()) == want
+    assert sorted(out[:want].tolist()) == O.positions_bruteforce(pat.reshape(-1), m, p, text).tolist()
+
+
 @pytest.mark.parametrize("stage", ["", ",stage=0"], ids=["staged", "hbm_windows"])
 @pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 17, 6000), (1, 4, 33, 50), (1, 4, 40, 50),
                                             (3, 4, 11, 200), (3, 4, 16, 20000), (3, 4, 32, 500), (2, 256, 5, 3000),
