@@ -274,15 +274,10 @@ struct smh_fmt_s2h {
     uint32_t nf;    /* ids >= nf are compact */
     uint32_t cbase; /* nf * 28: byte address of item slot i is i * 4 + cbase */
     SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 10) | w; } /* as smh_fmt_s2 */
+    /* the lanes that sit in a compact row: `t` is the full-row lookup already issued for the clamped row */
     template <typename F>
-    SMH_MEMBER uint32_t next_f(uint32_t row, uint32_t x, int k, const void *tab, F &&on_flags) const
+    SMH_MEMBER uint32_t resolve(uint32_t row, uint32_t c, uint32_t t, const void *tab, F &&on_flags) const
     {
-        const uint32_t c = smh_bfe(x, k == 0 ? 7 : 23, 5); /* pair code * 2 */
-        /* the full-row lookup is issued for every lane before the vote (a compact row id is clamped
-         * to a harmless full row), so the common path is as short as the plain stride-2 one:
-         * min, shift-or, read */
-        const uint32_t rc = smh_umin_uniform(nf - 1u, row);
-        uint32_t t = smh_lds_u16(tab, (rc << 5) | c);
         bool deep = row >= nf;
         if (SMH_UNLIKELY(SMH_WAVE_ANY(deep))) {
             const uint32_t code = c >> 1;
@@ -311,6 +306,37 @@ struct smh_fmt_s2h {
             if (done) t = r;
         }
         return t;
+    }
+    template <typename F>
+    SMH_MEMBER uint32_t next_f(uint32_t row, uint32_t x, int k, const void *tab, F &&on_flags) const
+    {
+        const uint32_t c = smh_bfe(x, k == 0 ? 7 : 23, 5); /* pair code * 2 */
+        /* the full-row lookup is issued for every lane before the vote (a compact row id is clamped
+         * to a harmless full row), so the common path is as short as the plain stride-2 one:
+         * min, shift-or, read */
+        const uint32_t rc = smh_umin_uniform(nf - 1u, row);
+        const uint32_t t = smh_lds_u16(tab, (rc << 5) | c);
+        return resolve(row, c, t, tab, on_flags);
+    }
+    /* the same step for the N chains of a lane with ONE vote in the common path (the deepest of the N rows decides;
+     * per chain it was a compare, a mask move and a branch each: 173 scalar instructions per 4 KiB of text against 39
+     * in the plain stride-2 kernel); on_flags(j, flags) */
+    template <int N, typename F>
+    SMH_MEMBER void next_fn(uint32_t (&row)[N], const uint32_t (&x)[N], int k, const void *tab, F &&on_flags) const
+    {
+        uint32_t c[N], t[N], deepest = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            c[j] = smh_bfe(x[j], k == 0 ? 7 : 23, 5);
+            t[j] = smh_lds_u16(tab, (smh_umin_uniform(nf - 1u, row[j]) << 5) | c[j]);
+            deepest = deepest > row[j] ? deepest : row[j];
+        }
+        if (SMH_UNLIKELY(SMH_WAVE_ANY(deepest >= nf))) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) t[j] = resolve(row[j], c[j], t[j], tab, [&](uint32_t f) { on_flags(j, f); });
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) row[j] = t[j];
     }
     /* generic form for the halo steps: row | flags << 16 */
     SMH_MEMBER uint32_t next(uint32_t e, uint32_t x, int k, const void *tab) const
@@ -363,6 +389,14 @@ SMH_LANE void smh_ac_step_full(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c
          * compact-row resolution only -- the common halo step carries no flag arithmetic either (packing row | flags
          * << 16 and taking it apart again was 5 VALU per chain and halo step) */
         if (c.hmask || EXACT) {
+            if constexpr (NCH > 1) {
+                c.fmt.next_fn(e, x, k, c.tab, [&](int j, uint32_t f) {
+                    if (!second_valid) f &= 1u;
+                    if (c.hmask) c.hmask[j] |= f << hbit;
+                    else cnt += (uint32_t)__builtin_popcount(f);
+                });
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < NCH; ++j)
                 e[j] = c.fmt.next_f(c.fmt.row(e[j]), x[j], k, c.tab, [&](uint32_t f) {
@@ -519,7 +553,21 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
 #pragma unroll
             for (int j = 0; j < NCH; ++j) x[j] = fmt.prep(w[j][q]);
 #pragma unroll
-            for (int k = 0; k < SPD; ++k)
+            for (int k = 0; k < SPD; ++k) {
+                if constexpr (FMT::SPARSE && NCH > 1) {
+                    /* all chains of the lane in one step: one vote in the common path */
+                    static_assert(EXACT || BITS, "the hybrid image records candidates as bits");
+                    const int bit = 4 * q + 2 * k;
+                    fmt.next_fn(e, x, k, tab, [&](int j, uint32_t f) {
+                        if (EXACT && !REC)
+                            cnt += (uint32_t)__builtin_popcount(f);
+                        else if (bit < 32)
+                            mlo[j] |= f << bit;
+                        else
+                            mhi[j] |= f << (bit - 32);
+                    });
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
                     if constexpr (FMT::SPARSE) {
@@ -549,6 +597,7 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
                         anyf |= e[j];
                     }
                 }
+            }
         }
         if (!EXACT && !BITS) {
             if (SMH_WAVE_ANY(fmt.any(anyf) != 0)) {
