@@ -723,7 +723,7 @@ SMH_LANE uint64_t smh_ac_segment_match_mask(const smh_ac_verify_ctx &V, uint64_t
 
 /* POS: positions mode -- instead of counting, every match appends its END column to V.pos (the return
  * value is then the number of matches this lane appended; the kernels ignore it). */
-template <typename FMT, int HC, int NCH, bool EXACT, int PREFETCH = 1, int SW = 16, bool POS = false>
+template <typename FMT, int HC, int NCH, bool EXACT, int PREFETCH = SMH_PREFETCH, int SW = 16, bool POS = false>
 SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chunk_sched &S, const void *tab,
                                 const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base)
 {

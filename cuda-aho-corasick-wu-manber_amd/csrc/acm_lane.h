@@ -226,13 +226,17 @@ SMH_LANE uint32_t smh_acm_thread(uint64_t gthread, const smh_chunk_sched &S, con
     while (k < n_chunks) {
         const uint64_t kn = S.take(n_chunks);
         const bool nxt_fast = is_fast(kn) && C.K <= 17;
-        if (nxt_fast) load(kn, nxt);
+        if (SMH_PREFETCH && nxt_fast) load(kn, nxt);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) cnt += smh_acm_lane_fast<E, SIGMA>(a, cur, tab, C, Q);
         else cnt += smh_acm_lane_slow<E>(a, tab_g, C);
         if (nxt_fast) {
+            if (SMH_PREFETCH) {
 #pragma unroll
-            for (int q = 0; q < 20; ++q) cur[q] = nxt[q];
+                for (int q = 0; q < 20; ++q) cur[q] = nxt[q];
+            } else {
+                load(kn, cur);
+            }
         }
         cur_fast = nxt_fast;
         k = kn;

@@ -28,6 +28,14 @@
 #include <string.h>
 
 #define SMH_SEG 64u /* bytes per lane segment */
+/* Register prefetch of a wave's NEXT chunk while the current one is scanned (a second set of text registers, copied over
+ * after the scan).  Off: with the table in LDS a CU runs 16 waves, which cover a chunk's load latency by themselves, and the
+ * copy (16-20 v_mov per chunk, 7 % of the stride-2 automaton kernel's VALU work) and the registers cost more than the
+ * prefetch hides -- stride-2 automaton m = 8: 0.184 -> 0.170 ms/GiB, stride-1 8000 patterns 0.310 -> 0.285, K = 10
+ * 0.187 -> 0.171 (gpurun_out/r02_az; profiles/r02_h/notes).  -DSMH_PREFETCH=1 builds the round-2 kernels up to r02_g. */
+#ifndef SMH_PREFETCH
+#define SMH_PREFETCH 0
+#endif
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 #define SMH_LANE __device__ __forceinline__

@@ -853,7 +853,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
     while (k < n_chunks) {
         const uint64_t kn = S.take(n_chunks);
         const bool nxt_fast = is_fast(kn);
-        constexpr bool PREFETCH = EXACT && H == 1; /* only where registers allow: exact filter, short pre-halo */
+        constexpr bool PREFETCH = SMH_PREFETCH && EXACT && H == 1; /* lane_common.h; only where registers allow: exact filter, short pre-halo */
         if (STG && Q.count >= 64u) smh_wm_drain(Q, text, P); /* columns of sparse chunks, from HBM, 64 at a time */
         if (PREFETCH && nxt_fast) load(kn, nxt);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
@@ -1507,7 +1507,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
          * and looked at after this chunk's scan (by the next flush, or below) */
         if (STG > 0) smh_wm_pend_issue(Q, P);
 #endif
-        if (nxt_fast) load(kn, nxt, nxt_halo);
+        if (SMH_PREFETCH && nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (cur_fast) {
             smh_wm_gram_lane_fast<KIND, POS, STG, QD>(text, a, cur, cur_halo, tab, P, Q);
@@ -1532,10 +1532,14 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish(Q, text, P); /* a chunk without a flush of its own */
 #endif
         if (nxt_fast) {
+            if (SMH_PREFETCH) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
+                for (int q = 0; q < 16; ++q) cur[q] = nxt[q];
 #pragma unroll
-            for (int q = 0; q < HD; ++q) cur_halo[q] = nxt_halo[q];
+                for (int q = 0; q < HD; ++q) cur_halo[q] = nxt_halo[q];
+            } else {
+                load(kn, cur, cur_halo);
+            }
         }
         cur_fast = nxt_fast;
         k = kn;

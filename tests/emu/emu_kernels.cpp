@@ -83,12 +83,12 @@ static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t b
             if constexpr (HC == 1) /* as launch_two_chains<3> (ac_kernels.inc): three chains per lane, no register prefetch */
                 total += smh_ac_thread<smh_fmt_s2h, 1, 3, EXACT, 0, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
             else if constexpr (EXACT || HC <= 2)
-                total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT, 1, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
+                total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT, SMH_PREFETCH, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
         } else if constexpr (STRIDE == 2) {
-            total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT, 1, 16, POS>(smh_fmt_s2{}, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
+            total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT, SMH_PREFETCH, 16, POS>(smh_fmt_s2{}, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
         } else {
             const smh_fmt_s1<E, SIGMA> fmt{V.sigma};
-            total += smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, EMU_AC_NCH, EXACT, 1, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
+            total += smh_ac_thread<smh_fmt_s1<E, SIGMA>, HC, EMU_AC_NCH, EXACT, SMH_PREFETCH, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
         }
     }
     return total;
@@ -300,7 +300,7 @@ extern "C" uint64_t emu_wm_scan(const smh_wm *wm, const uint8_t *text_in, uint64
         } else if (wm->pair_table) {
             const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
             for (uint64_t t = 0; t < nthreads; ++t)
-                total += smh_wm_pair_thread<true>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->m, wm->pair_table, wm->filter);
+                total += smh_wm_pair_thread<SMH_PREFETCH != 0>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, wm->m, wm->pair_table, wm->filter);
         } else if (wm->gram_kind != SMH_GRAM_NONE) {
             total = wm_gram_grid(wm, text, n, blocks, nullptr);
         } else if (wm->filter_hashed) {
