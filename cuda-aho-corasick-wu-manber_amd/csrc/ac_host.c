@@ -530,7 +530,8 @@ static double candidate_rate(const struct smh_ac *ac, int K)
  * to compare c1 only), [24..25] flags to raise on a hit (1: prefix ends at the first symbol, 2: at
  * the second), [26] hit => the step ends in row (this id + 1), [27] hit => the step ends in the row
  * whose id is in the next 4-byte slot.  Compact rows are numbered along their chains so that [26]
- * covers all but the branching states.  Row ids are 16 bits; ids >= scan_full_rows are compact. */
+ * covers all but the branching states.  Row ids are 16 bits; full rows are 0 .. scan_full_rows - 1, the item slots of the
+ * compact part SMH_HYB_COMPACT0 (0x8000) upwards. */
 struct hyb_item { uint8_t code, c1only, flags; uint32_t target; /* old row id, or UINT32_MAX */ };
 
 static uint32_t hyb_step(const struct smh_ac *ac, int K, uint32_t r, int c, int *flag)
@@ -605,7 +606,7 @@ static int hyb_build(const struct smh_ac *ac, int K, int D, uint32_t budget, voi
             const int own = n > 0 && (it[0].target == UINT32_MAX || hid[it[0].target - nf] == hid[cur - nf] + 1u);
             for (int i = own ? 1 : 0; i < n; ++i) cursor += it[i].target == UINT32_MAX ? 1u : 2u;
         }
-        if (cursor > 65535u) goto out;
+        if (cursor - nf > 0x7FFFu) goto out; /* compact ids are SMH_HYB_COMPACT0 + slot, 16 bits */
     }
     {
         const uint64_t total = (uint64_t)nf * 32u + (uint64_t)(cursor - nf) * 4u;
@@ -614,7 +615,10 @@ static int hyb_build(const struct smh_ac *ac, int K, int D, uint32_t budget, voi
     }
     img = calloc(*bytes + 16u, 1);
     if (!img) { rc = SMH_ENOMEM; goto out; }
-#define HYB_ID(r) ((r) < nf ? (r) : hid[(r) - nf])
+    /* ids as the image holds them: full rows keep theirs, item slot s of the compact part is SMH_HYB_COMPACT0 + s (so that
+     * the scan's unclamped full-row lookup of a compact id falls outside LDS: ac_lane.h smh_fmt_s2h) */
+#define HYB_OUT(id) ((id) < nf ? (id) : (id) - nf + SMH_HYB_COMPACT0)
+#define HYB_ID(r) HYB_OUT((r) < nf ? (r) : hid[(r) - nf])
     uint16_t *t16 = (uint16_t *)img;
     for (uint32_t r = 0; r < nf; ++r)
         for (int c1 = 0; c1 < 4; ++c1)
@@ -638,9 +642,9 @@ static int hyb_build(const struct smh_ac *ac, int K, int D, uint32_t budget, voi
         }
         /* own slot without an item: a pass-through (mask 0 always "hits", but with no flags and no
          * end-of-step bits a hit just follows the link) */
-        if (!own) rec[id - nf] = n > 0 ? item_slot[0] : fail;
+        if (!own) rec[id - nf] = n > 0 ? HYB_OUT(item_slot[0]) : fail;
         for (int i = 0; i < n; ++i) {
-            const uint32_t link = i == n - 1 ? fail : item_slot[i + 1];
+            const uint32_t link = i == n - 1 ? fail : HYB_OUT(item_slot[i + 1]);
             uint32_t v = link | ((uint32_t)it[i].code << 16) | ((it[i].c1only ? 12u : 15u) << 20) |
                          ((uint32_t)it[i].flags << 24);
             if (it[i].target != UINT32_MAX) {
@@ -648,13 +652,14 @@ static int hyb_build(const struct smh_ac *ac, int K, int D, uint32_t budget, voi
                     v |= 1u << 26;
                 } else {
                     v |= 1u << 27;
-                    rec[item_slot[i] + 1u - nf] = hid[it[i].target - nf];
+                    rec[item_slot[i] + 1u - nf] = HYB_OUT(hid[it[i].target - nf]);
                 }
             }
             rec[item_slot[i] - nf] = v;
         }
     }
 #undef HYB_ID
+#undef HYB_OUT
     *image = img;
     img = NULL;
     *nf_out = nf;

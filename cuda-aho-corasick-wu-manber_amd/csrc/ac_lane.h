@@ -271,8 +271,23 @@ struct smh_fmt_s2 { /* stride 2, alphabet 4: entry = row | F1 << 14 | F2 << 15, 
 struct smh_fmt_s2h {
     static constexpr int STRIDE = 2;
     static constexpr bool SPARSE = true;
-    uint32_t nf;    /* ids >= nf are compact */
-    uint32_t cbase; /* nf * 28: byte address of item slot i is i * 4 + cbase */
+    /* Full rows have the ids [0, full_rows); item slot s of the compact part has the id SMH_HYB_COMPACT0 + s.  A lane that
+     * sits in a compact row therefore issues the common path's full-row lookup at (id << 5) >= 1 MiB, beyond the
+     * workgroup's LDS: a ds_read out of range returns 0 and raises nothing (tools/lds_oob.hip on gfx950), and the value is
+     * replaced by the resolution below anyway -- so the common path needs no clamp: v_lshl_or, ds_read_u16 per step and
+     * chain (the v_min that kept the id inside the table was 14 % of the kernel's VALU work).  The CPU emulation reads
+     * row 0 instead. */
+    uint32_t nf;    /* ids >= nf are compact: SMH_HYB_COMPACT0 */
+    uint32_t cbase; /* byte address of the item slot with id i is i * 4 + cbase (mod 2^32) */
+    static SMH_MEMBER smh_fmt_s2h make(uint32_t full_rows) { return smh_fmt_s2h{SMH_HYB_COMPACT0, full_rows * 32u - 4u * SMH_HYB_COMPACT0}; }
+    SMH_MEMBER uint32_t full_addr(uint32_t row, uint32_t c) const
+    {
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        return (row << 5) | c;
+#else
+        return ((row < nf ? row : 0u) << 5) | c;
+#endif
+    }
     SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 10) | w; } /* as smh_fmt_s2 */
     /* the lanes that sit in a compact row: `t` is the full-row lookup already issued for the clamped row */
     template <typename F>
@@ -311,11 +326,9 @@ struct smh_fmt_s2h {
     SMH_MEMBER uint32_t next_f(uint32_t row, uint32_t x, int k, const void *tab, F &&on_flags) const
     {
         const uint32_t c = smh_bfe(x, k == 0 ? 7 : 23, 5); /* pair code * 2 */
-        /* the full-row lookup is issued for every lane before the vote (a compact row id is clamped
-         * to a harmless full row), so the common path is as short as the plain stride-2 one:
-         * min, shift-or, read */
-        const uint32_t rc = smh_umin_uniform(nf - 1u, row);
-        const uint32_t t = smh_lds_u16(tab, (rc << 5) | c);
+        /* the full-row lookup is issued for every lane before the vote (harmless for a compact row id: see above),
+         * so the common path is the plain stride-2 one: shift-or, read */
+        const uint32_t t = smh_lds_u16(tab, full_addr(row, c));
         return resolve(row, c, t, tab, on_flags);
     }
     /* the same step for the N chains of a lane with ONE vote in the common path (the deepest of the N rows decides;
@@ -328,7 +341,7 @@ struct smh_fmt_s2h {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             c[j] = smh_bfe(x[j], k == 0 ? 7 : 23, 5);
-            t[j] = smh_lds_u16(tab, (smh_umin_uniform(nf - 1u, row[j]) << 5) | c[j]);
+            t[j] = smh_lds_u16(tab, full_addr(row[j], c[j]));
             deepest = deepest > row[j] ? deepest : row[j];
         }
         if (SMH_UNLIKELY(SMH_WAVE_ANY(deepest >= nf))) {

@@ -33,6 +33,9 @@
  * copy (16-20 v_mov per chunk, 7 % of the stride-2 automaton kernel's VALU work) and the registers cost more than the
  * prefetch hides -- stride-2 automaton m = 8: 0.184 -> 0.170 ms/GiB, stride-1 8000 patterns 0.310 -> 0.285, K = 10
  * 0.187 -> 0.171 (gpurun_out/r02_az; profiles/r02_h/notes).  -DSMH_PREFETCH=1 builds the round-2 kernels up to r02_g. */
+#ifndef SMH_HYB_COMPACT0
+#define SMH_HYB_COMPACT0 0x8000u /* hybrid stride-2 image: id of the first item slot of the compact part (== smh_internal.h; ac_host.c hyb_build, ac_lane.h) */
+#endif
 #ifndef SMH_PREFETCH
 #define SMH_PREFETCH 0
 #endif

@@ -114,6 +114,9 @@ extern thread_local int smh_alt_engine_depth;
 extern _Thread_local int smh_alt_engine_depth;
 #endif
 #define SMH_WM_ALT_ENGINE_COST 1.15 /* automaton plan cost (1.0 = 3.5 TB/s) below which it beats the non-exact direct filter */
+#ifndef SMH_HYB_COMPACT0
+#define SMH_HYB_COMPACT0 0x8000u /* hybrid stride-2 image: id of the first item slot of the compact part (== lane_common.h) */
+#endif
 #define SMH_AC_ALT_ENGINE_COST 2.5 /* above this plan cost (< ~1.4 TB/s) the suffix-filter engine scans the set */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
