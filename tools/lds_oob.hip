@@ -1,4 +1,4 @@
-// Development probe: what does a ds_read beyond the workgroup's LDS allocation return on gfx950?
+// Development probe (hipcc -O2 --offload-arch=gfx950 -o tools/lds_oob tools/lds_oob.hip): what does a ds_read beyond the workgroup's LDS allocation return on gfx950?
 // (the hybrid AC image lets lanes that sit in a compact row issue the full-row lookup with their raw id)
 #include <hip/hip_runtime.h>
 #include <cstdio>
