@@ -462,10 +462,10 @@ SMH_LANE bool smh_ac_halo_step(const smh_ac_scan_ctx<FMT, HC, NCH, EXACT, SW> &c
     if (H % FMT::STRIDE != 0) return true; /* stride 2 consumes bytes H and H+1 at even H */
     if (H >= c.halo) return false;
     const uint32_t need = c.df->v[H + 1];
-    bool any = false;
+    uint32_t deepest = 0; /* one compare for the lane's chains: v_max3 on three */
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) any |= c.fmt.row(e[j]) >= need;
-    if (!SMH_WAVE_ANY(any)) return false;
+    for (int j = 0; j < NCH; ++j) deepest = deepest > c.fmt.row(e[j]) ? deepest : c.fmt.row(e[j]);
+    if (!SMH_WAVE_ANY(deepest >= need)) return false;
     if ((H & 3) == 0) {
         /* next halo dword: the neighbour lane's segment word H/4 (all lanes active here: every
          * branch above is wave-uniform); lane 63 takes the next chain's lane 0, or the tail */

@@ -80,7 +80,7 @@ static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t b
     for (uint64_t t = 0; t < nthreads; ++t) {
         if constexpr (STRIDE == 3) {
             const smh_fmt_s2h fmt = smh_fmt_s2h::make(ac->scan_full_rows);
-            if constexpr (HC == 1) /* as launch_two_chains<3> (ac_kernels.inc): three chains per lane, no register prefetch */
+            if constexpr (HC == 1) /* as launch_chains<3> (ac_kernels.inc): three chains per lane, no register prefetch */
                 total += smh_ac_thread<smh_fmt_s2h, 1, 3, EXACT, 0, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
             else if constexpr (EXACT || HC <= 2)
                 total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT, SMH_PREFETCH, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
