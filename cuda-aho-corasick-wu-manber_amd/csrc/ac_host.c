@@ -433,7 +433,12 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
      * plan (K < m) used to be walked down the full DFA -- up to m DEPENDENT loads, ~1 us each beside the streaming text,
      * and every wave ends with such a walk: 20-30 us at the end of a 200 us launch (tools/wavetrace.py).  Hashing the
      * window and probing the handle's verify table decides it in three. */
-    if (ac->fixed_length_ok && m >= 3 && smh_wu_shiftsize_for(alphabet) && smh_alt_engine_depth == 0) {
+    /* Only plans that need it pay for it: an exact plan (K == m) never verifies a candidate and a cheap plan never hands
+     * the scan over, so for those the patterns are not extracted and no second handle is compiled (it doubled the compile
+     * time and the host memory of the common exact plans).  A depth-cut plan forced later on such a handle
+     * (smh_ac_set_scan_plan) walks its candidates down the full DFA instead -- same count. */
+    if (ac->fixed_length_ok && m >= 3 && smh_wu_shiftsize_for(alphabet) && smh_alt_engine_depth == 0 &&
+        (!ac->scan_exact || ac->scan_cost > SMH_AC_ALT_ENGINE_COST)) {
         ++smh_alt_engine_depth;
         /* the caller's arrays may have been adopted (and shrunk in place) in step 6: read the handle's copy */
         const int *tsrc = ac->g_transition ? ac->g_transition : trans;
@@ -571,7 +576,9 @@ static int hyb_items(const struct smh_ac *ac, int K, uint32_t s, struct hyb_item
     return n;
 }
 
-/* returns SMH_OK and the image, SMH_EUNSUP when (K, D) does not fit or is not representable */
+/* returns SMH_OK and the image, SMH_EUNSUP when (K, D) does not fit or is not representable, HYB_ESLOTS when the
+ * compact part needs more than 0x7FFF item slots (a smaller D only adds compact rows: the caller stops trying) */
+#define HYB_ESLOTS (-100)
 static int hyb_build(const struct smh_ac *ac, int K, int D, uint32_t budget, void **image, uint32_t *bytes, uint32_t *nf_out)
 {
     if (ac->alphabet != 4 || K > ac->m || D < 1 || D > K - 3) return SMH_EUNSUP;
@@ -606,7 +613,7 @@ static int hyb_build(const struct smh_ac *ac, int K, int D, uint32_t budget, voi
             const int own = n > 0 && (it[0].target == UINT32_MAX || hid[it[0].target - nf] == hid[cur - nf] + 1u);
             for (int i = own ? 1 : 0; i < n; ++i) cursor += it[i].target == UINT32_MAX ? 1u : 2u;
         }
-        if (cursor - nf > 0x7FFFu) goto out; /* compact ids are SMH_HYB_COMPACT0 + slot, 16 bits */
+        if (cursor - nf > 0x7FFFu) { rc = HYB_ESLOTS; goto out; } /* compact ids are SMH_HYB_COMPACT0 + slot, 16 bits */
     }
     {
         const uint64_t total = (uint64_t)nf * 32u + (uint64_t)(cursor - nf) * 4u;
@@ -720,7 +727,8 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 const uint64_t nf = ac->depth_first[D + 1], rk = ac->depth_first[K];
                 if (nf >= rk) continue;
                 const uint64_t nc = rk - nf;
-                if (nf * 32u + nc * 4u + nc / 4u + 64u > lds_budget || rk + nc / 8u > 65000u) continue;
+                /* nc + nc/8 estimates the item slots (one per chain state, two more per branch): ids are 15 bits */
+                if (nf * 32u + nc * 4u + nc / 4u + 64u > lds_budget || nc + nc / 8u > 0x7FFFu) continue;
                 const double r = candidate_rate(ac, K), q = deep_rate(ac, D);
                 /* round 2 refit (leaner step, dynamic chunk scheduling): K12D9 cut 0.205 ms/GiB with three chains per
                  * lane (halo <= 16 bytes; 0.220 with two), 0.255 with one, against 0.289 for the exact stride-1 scan */
@@ -742,7 +750,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
         for (int D = best_d; D >= 1 && rc != SMH_OK; --D) {
             rc = hyb_build(ac, best_k[3], D, lds_budget, &hyb_image, &hyb_bytes, &hyb_nf);
             if (rc == SMH_ENOMEM) { smh_set_error("smh_ac_plan_scan: out of memory"); return rc; }
-            if (force_d) break;
+            if (force_d || rc == HYB_ESLOTS) break; /* too many item slots: a smaller D has more of them */
         }
         if (rc != SMH_OK) {
             if (force_stride == 3) {

@@ -55,6 +55,7 @@ static void usage(void)
     printf("-pattern <file>\t\t pattern file (default <dir>/pattern/<n>/<m>/<alphabet>/pattern)\n");
     printf("-coding <raw|dna|protein|ascii>\t how the text file encodes symbols (default raw)\n");
     printf("-ranks <R>\t\t split the text into R byte ranges as the reference's MPI ranks do\n");
+    printf("-multi\t\t\t also run the ranks side by side, one device each, counts added by RCCL (default for R > 1)\n");
     printf("-dry\t\t\t load / create the data and build the tables, then stop (no GPU needed)\n");
     exit(0);
 }
@@ -168,7 +169,7 @@ static void create_patterns(unsigned char *pattern2, int m, int p_size, int alph
 
 int main(int argc, char **argv)
 {
-    int m = 0, p_size = 0, nFull = 0, alphabet = 0, B = 3, create_data = 0, ranks = 1, dry = 0, coding = 0;
+    int m = 0, p_size = 0, nFull = 0, alphabet = 0, B = 3, create_data = 0, ranks = 1, dry = 0, coding = 0, force_multi = 0;
     const char *data_dir = "./data-cuda-multi", *text_arg = NULL, *pattern_arg = NULL;
     int i, j;
 
@@ -177,6 +178,7 @@ int main(int argc, char **argv)
         if (strcmp(argv[i], "--help") == 0 || strcmp(argv[i], "-h") == 0) usage();
         if (strcmp(argv[i], "-c") == 0) create_data = 1;
         if (strcmp(argv[i], "-dry") == 0) dry = 1;
+        if (strcmp(argv[i], "-multi") == 0) force_multi = 1;
         if (i + 1 >= argc) continue;
         if (strcmp(argv[i], "-m") == 0) m = atoi(argv[i + 1]);
         if (strcmp(argv[i], "-n") == 0) nFull = atoi(argv[i + 1]);
@@ -425,32 +427,42 @@ int main(int argc, char **argv)
 
     /* The same R byte ranges once more, this time the way the reference's MPI job runs them: all at once, one
      * device per rank, text shards resident, ONE all-reduce of the 64-bit counts (main.c:464-489, 654-657 with
-     * RCCL for MPI).  Needs R devices; with fewer the ranks above have run one after the other. */
-    if (devices >= ranks && (run_ac || run_wm)) {
+     * RCCL for MPI).  Only for R > 1 (or `-multi`, which also runs it with one rank) and only when R devices are
+     * visible.  The per-rank results above are complete without it: when the multi-device layer cannot be set up
+     * (no RCCL and no host-sum, out of memory) that is a warning; a count that DIFFERS is an error. */
+    if ((ranks > 1 || force_multi) && devices >= ranks && (run_ac || run_wm)) {
         smh_multi *mg = NULL;
-        if (smh_multi_create(&mg, NULL, ranks, 0) != SMH_OK || smh_multi_load_text(mg, textFull, (uint64_t)nFull, m - 1) != SMH_OK) {
-            fprintf(stderr, "multi-device run: %s\n", smh_last_error());
-            exit(1);
+        if (smh_multi_create(&mg, NULL, ranks, SMH_MULTI_HOST_SUM) != SMH_OK ||
+            smh_multi_load_text(mg, textFull, (uint64_t)nFull, m - 1) != SMH_OK) {
+            fprintf(stderr, "multi-device run skipped: %s\n", smh_last_error());
+            if (mg) smh_multi_free(mg);
+            mg = NULL;
         }
         uint64_t total = 0, per[SMH_MULTI_MAX_DEVICES];
         double secs = 0;
-        if (run_ac) {
+        if (mg && run_ac) {
             smh_ac *h = smh_ac_compile_patterns(pattern2, m, p_size, alphabet);
-            if (!h || smh_multi_ac_count(mg, h, &total, per, &secs) != SMH_OK) { fprintf(stderr, "multi-device ac: %s\n", smh_last_error()); exit(1); }
-            printf("multi-device ac (%d devices, %s) matches \t%llu\t time \t%f\n", ranks, smh_multi_uses_rccl(mg) ? "RCCL all-reduce" : "host sum",
-                   (unsigned long long)total, secs);
-            if ((long long)total != ac_sum) { fprintf(stderr, "multi-device ac counted %llu, the ranks one by one %lld\n", (unsigned long long)total, ac_sum); exit(1); }
-            smh_ac_free(h);
+            if (!h || smh_multi_ac_count(mg, h, &total, per, &secs) != SMH_OK) {
+                fprintf(stderr, "multi-device ac skipped: %s\n", smh_last_error());
+            } else {
+                printf("multi-device ac (%d devices, %s) matches \t%llu\t time \t%f\n", ranks,
+                       smh_multi_uses_rccl(mg) ? "RCCL all-reduce" : "host sum", (unsigned long long)total, secs);
+                if ((long long)total != ac_sum) { fprintf(stderr, "multi-device ac counted %llu, the ranks one by one %lld\n", (unsigned long long)total, ac_sum); exit(1); }
+            }
+            if (h) smh_ac_free(h);
         }
-        if (run_wm) {
+        if (mg && run_wm) {
             smh_wm *h = smh_wm_compile(pattern2, m, p_size, alphabet);
-            if (!h || smh_multi_wm_count(mg, h, &total, per, &secs) != SMH_OK) { fprintf(stderr, "multi-device wm: %s\n", smh_last_error()); exit(1); }
-            printf("multi-device wm (%d devices, %s) matches \t%llu\t time \t%f\n", ranks, smh_multi_uses_rccl(mg) ? "RCCL all-reduce" : "host sum",
-                   (unsigned long long)total, secs);
-            if ((long long)total != wm_sum) { fprintf(stderr, "multi-device wm counted %llu, the ranks one by one %lld\n", (unsigned long long)total, wm_sum); exit(1); }
-            smh_wm_free(h);
+            if (!h || smh_multi_wm_count(mg, h, &total, per, &secs) != SMH_OK) {
+                fprintf(stderr, "multi-device wm skipped: %s\n", smh_last_error());
+            } else {
+                printf("multi-device wm (%d devices, %s) matches \t%llu\t time \t%f\n", ranks,
+                       smh_multi_uses_rccl(mg) ? "RCCL all-reduce" : "host sum", (unsigned long long)total, secs);
+                if ((long long)total != wm_sum) { fprintf(stderr, "multi-device wm counted %llu, the ranks one by one %lld\n", (unsigned long long)total, wm_sum); exit(1); }
+            }
+            if (h) smh_wm_free(h);
         }
-        smh_multi_free(mg);
+        if (mg) smh_multi_free(mg);
         fflush(stdout);
     }
 

@@ -120,6 +120,7 @@ extern _Thread_local int smh_alt_engine_depth;
 #define SMH_AC_ALT_ENGINE_COST 2.5 /* above this plan cost (< ~1.4 TB/s) the suffix-filter engine scans the set */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
+int smh_ac_prepare_device(struct smh_ac *ac); /* smh_runtime.hip: table set of the current device, no launch */
 
 /* ------------------------------------------------------------------ mixed-length automaton (acm_host.c)
  * One Aho-Corasick automaton with joined (suffix-closed) output COUNTS for a set of patterns of different
@@ -314,6 +315,8 @@ void smh_wm_host_free(struct smh_wm *wm);
  * 0 = built (gram_kind == SMH_GRAM_PAIR2), 1 = not applicable / too many candidates, -1 = out of memory */
 int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns, const uint32_t *lengths, int p_size);
 void smh_wm_dev_free(struct smh_wm_dev *dev); /* smh_runtime.hip */
+int smh_wm_prepare_device(struct smh_wm *wm); /* smh_runtime.hip */
+int smh_dev_build_peak(int reset);            /* test hook: most table-set builds in flight together */
 
 /* hashes shared by host table build and device lookup -- keep in sync with wm_kernels.hip */
 #define SMH_HASH_MUL 0x9E3779B1u

@@ -23,6 +23,8 @@
 #include <string.h>
 #include <chrono>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 #include "smh_internal.h"
 
@@ -103,6 +105,7 @@ struct smh_multi {
     uint64_t per;     /* ceil(n_total / n): main.c:375-378 */
     int halo;         /* bytes kept beyond every range: scans with m - 1 <= halo are possible */
     std::vector<smh_multi_dev> dev;
+    std::vector<const void *> warmed; /* handles whose kernels have run once on every device (prepare_all) */
 };
 #define SMH_MAGIC_MULTI 0x4d554c54u /* "MULT" */
 
@@ -208,6 +211,7 @@ static int place(smh_multi *mg, uint64_t n_total, int halo)
     mg->n_total = n_total;
     mg->per = (n_total + (uint64_t)mg->n - 1) / (uint64_t)mg->n;
     mg->halo = halo;
+    mg->warmed.clear();
     for (int i = 0; i < mg->n; ++i) {
         smh_multi_dev &d = mg->dev[i];
         HIP_TRY(hipSetDevice(d.device));
@@ -264,14 +268,75 @@ extern "C" int smh_multi_generate_text(smh_multi *mg, uint64_t n_total, uint64_t
     return rc;
 }
 
+/* Everything the first scan of a handle would otherwise do inside the timed region, on every device AT ONCE: one
+ * host thread per device builds the handle's table set there (smh_runtime.hip ensure_device_set: hipMalloc +
+ * synchronous copies, outside the process-wide mutex) and runs one scan of the first few KiB of the shard into a
+ * scratch counter, which loads the kernel's code object on that device and fills the per-device launch-attribute
+ * cache.  After it *seconds of a count call is launches + reduce only (the reference times the kernel alone,
+ * cuda/cuda_wm.cu:271-283).  The count calls run it themselves before their clock starts; calling it ahead of time
+ * makes the first count call as fast as the tenth. */
+template <typename Prep, typename Scan>
+static int prepare_all(smh_multi *mg, const void *key, int m, Prep prep, Scan scan)
+{
+    if (m - 1 > mg->halo && mg->n_total) {
+        smh_set_error("smh_multi: pattern length %d needs a halo of %d bytes, the text was placed with %d", m, m - 1, mg->halo);
+        return SMH_EINVAL;
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    bool warm = false; /* the table sets are looked up every time (a list walk); the warm-up scan runs once per handle */
+    for (const void *k : mg->warmed) warm = warm || k == key;
+    std::vector<int> rcs((size_t)mg->n, SMH_OK);
+    std::vector<std::string> errs((size_t)mg->n);
+    auto work = [&](int i) {
+        smh_multi_dev &d = mg->dev[i];
+        int rc = SMH_OK;
+        if (hipSetDevice(d.device) != hipSuccess) {
+            smh_set_error("smh_multi: hipSetDevice(%d) failed", d.device);
+            rc = SMH_ENODEV;
+        }
+        if (rc == SMH_OK) rc = prep();
+        if (rc == SMH_OK && !warm && d.d_text && d.bytes >= (uint64_t)m) {
+            const uint64_t len = d.bytes < 16384u ? d.bytes : 16384u;
+            rc = scan(d.d_text, len, d.d_count + 2, (void *)d.stream); /* slot 2: scratch, never read */
+            if (rc == SMH_OK && hipStreamSynchronize(d.stream) != hipSuccess) {
+                smh_set_error("smh_multi: device %d: warm-up scan failed: %s", d.device, hipGetErrorString(hipGetLastError()));
+                rc = SMH_ENODEV;
+            }
+        }
+        rcs[(size_t)i] = rc;
+        if (rc != SMH_OK) errs[(size_t)i] = smh_last_error(); /* the message is thread-local: carry it over */
+    };
+    if (mg->n == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < mg->n; ++i) th.emplace_back(work, i);
+        for (auto &t : th) t.join();
+    }
+    (void)hipSetDevice(prev);
+    for (int i = 0; i < mg->n; ++i)
+        if (rcs[(size_t)i] != SMH_OK) {
+            smh_set_error("%s", errs[(size_t)i].c_str());
+            return rcs[(size_t)i];
+        }
+    if (!warm && mg->n_total) mg->warmed.push_back(key);
+    return SMH_OK;
+}
+
 /* launch `scan(device text, shard length, device counter, stream)` on every device, reduce, read back */
-template <typename Scan>
-static int count_all(smh_multi *mg, int m, uint64_t *total, uint64_t *per_device, double *seconds, Scan scan)
+template <typename Prep, typename Scan>
+static int count_all(smh_multi *mg, const void *key, int m, uint64_t *total, uint64_t *per_device, double *seconds, Prep prep, Scan scan)
 {
     if (!total) { smh_set_error("smh_multi: NULL result"); return SMH_EINVAL; }
     if (m - 1 > mg->halo) {
         smh_set_error("smh_multi: pattern length %d needs a halo of %d bytes, the text was placed with %d", m, m - 1, mg->halo);
         return SMH_EINVAL;
+    }
+    {
+        /* table sets that are already there cost a list walk per device; missing ones go up now, before the clock */
+        const int prc = prepare_all(mg, key, m, prep, scan);
+        if (prc != SMH_OK) return prc;
     }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -340,9 +405,10 @@ extern "C" int smh_multi_ac_count(smh_multi *mg, smh_ac *ac, uint64_t *total, ui
     if (rc != SMH_OK) return rc;
     smh_ac_info info;
     if ((rc = smh_ac_get_info(ac, &info)) != SMH_OK) return rc;
-    return count_all(mg, (int)info.m, total, per_device, seconds, [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
-        return smh_ac_scan(ac, t, len, c, SMH_VARIANT_TUNED, s);
-    });
+    return count_all(mg, ac, (int)info.m, total, per_device, seconds, [&]() { return smh_ac_prepare_device(ac); },
+                     [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
+                         return smh_ac_scan(ac, t, len, c, SMH_VARIANT_TUNED, s);
+                     });
 }
 
 extern "C" int smh_multi_wm_count(smh_multi *mg, smh_wm *wm, uint64_t *total, uint64_t *per_device, double *seconds)
@@ -351,7 +417,32 @@ extern "C" int smh_multi_wm_count(smh_multi *mg, smh_wm *wm, uint64_t *total, ui
     if (rc != SMH_OK) return rc;
     smh_wm_info info;
     if ((rc = smh_wm_get_info(wm, &info)) != SMH_OK) return rc;
-    return count_all(mg, (int)info.m, total, per_device, seconds, [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
-        return smh_wm_scan(wm, t, len, c, SMH_VARIANT_TUNED, s);
-    });
+    return count_all(mg, wm, (int)info.m, total, per_device, seconds, [&]() { return smh_wm_prepare_device(wm); },
+                     [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
+                         return smh_wm_scan(wm, t, len, c, SMH_VARIANT_TUNED, s);
+                     });
+}
+
+extern "C" int smh_multi_ac_prepare(smh_multi *mg, smh_ac *ac)
+{
+    int rc = check(mg, "smh_multi_ac_prepare");
+    if (rc != SMH_OK) return rc;
+    smh_ac_info info;
+    if ((rc = smh_ac_get_info(ac, &info)) != SMH_OK) return rc;
+    return prepare_all(mg, ac, (int)info.m, [&]() { return smh_ac_prepare_device(ac); },
+                       [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
+                           return smh_ac_scan(ac, t, len, c, SMH_VARIANT_TUNED, s);
+                       });
+}
+
+extern "C" int smh_multi_wm_prepare(smh_multi *mg, smh_wm *wm)
+{
+    int rc = check(mg, "smh_multi_wm_prepare");
+    if (rc != SMH_OK) return rc;
+    smh_wm_info info;
+    if ((rc = smh_wm_get_info(wm, &info)) != SMH_OK) return rc;
+    return prepare_all(mg, wm, (int)info.m, [&]() { return smh_wm_prepare_device(wm); },
+                       [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
+                           return smh_wm_scan(wm, t, len, c, SMH_VARIANT_TUNED, s);
+                       });
 }

@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include "smh_internal.h"
@@ -82,22 +83,47 @@ static int current_cus(int *n_cus)
 }
 
 /* find the table set of the current device in a handle's list, or build one with `build` and publish it
- * only when every upload succeeded (a half-built set is freed, so the next call retries cleanly) */
+ * only when every upload succeeded (a half-built set is freed, so the next call retries cleanly).  The build
+ * -- synchronous hipMalloc + hipMemcpy of the tables -- runs OUTSIDE the mutex: a process that drives every
+ * GPU of a node prepares its devices from one thread each (smh_multi_*_prepare) and those uploads must run
+ * side by side; the list is only searched and extended under the lock.  Two threads that build a set for the
+ * same handle on the same device at once both succeed, and the loser's set is freed. */
+static std::atomic<int> g_builds_now{0}, g_builds_peak{0};
+extern "C" int smh_dev_build_peak(int reset) /* test hook: most table-set builds ever in flight together */
+{
+    const int v = g_builds_peak.load();
+    if (reset) g_builds_peak.store(0);
+    return v;
+}
 template <typename D, typename Build>
 static int ensure_device_set(D **head, void (*free_one)(D *), Build build, D **out)
 {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(g_dev_mu);
-    for (D *d = *head; d; d = d->next)
-        if (d->device == dev) { *out = d; return SMH_OK; }
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        for (D *d = *head; d; d = d->next)
+            if (d->device == dev) { *out = d; return SMH_OK; }
+    }
     D *d = new D();
     memset(d, 0, sizeof *d);
     d->device = dev;
+    const int now = ++g_builds_now;
+    for (int peak = g_builds_peak.load(); now > peak && !g_builds_peak.compare_exchange_weak(peak, now);) {}
     const int rc = build(d);
+    --g_builds_now;
     if (rc != SMH_OK) { free_one(d); return rc; }
-    d->next = *head;
-    *head = d;
+    D *mine = d;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        for (D *o = *head; o; o = o->next)
+            if (o->device == dev) { d = o; break; }
+        if (d == mine) {
+            d->next = *head;
+            *head = d;
+        }
+    }
+    if (d != mine) free_one(mine); /* another thread published a set for this device meanwhile */
     *out = d;
     return SMH_OK;
 }
@@ -338,6 +364,19 @@ static int ac_prepare(struct smh_ac *ac, int variant)
         rc = wm_ensure_device(ac->hv_wm, &hd);
     }
     return rc;
+}
+
+/* everything the tuned scans of a handle need on the CURRENT device, without launching (smh_multi.hip prepares
+ * every device of a node from a thread of its own before the first timed scan) */
+extern "C" int smh_ac_prepare_device(struct smh_ac *ac)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC) { smh_set_error("smh_ac_prepare_device: bad handle"); return SMH_EINVAL; }
+    return ac_prepare(ac, SMH_VARIANT_TUNED);
+}
+extern "C" int smh_wm_prepare_device(struct smh_wm *wm)
+{
+    if (!wm || wm->magic != SMH_MAGIC_WM) { smh_set_error("smh_wm_prepare_device: bad handle"); return SMH_EINVAL; }
+    return wm_prepare(wm, SMH_VARIANT_TUNED);
 }
 
 extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,

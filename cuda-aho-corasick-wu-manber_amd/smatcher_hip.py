@@ -100,7 +100,8 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_sbom_compile_patterns", "smh_sbom_get_info", "smh_sbom_scan", "smh_sbom_count_host", "smh_sbom_free",
                "smh_sog_compile_tables", "smh_sog_scan", "smh_sog_count_host", "smh_sog_free",
                "smh_multi_create", "smh_multi_device_count", "smh_multi_uses_rccl", "smh_multi_load_text",
-               "smh_multi_generate_text", "smh_multi_ac_count", "smh_multi_wm_count", "smh_multi_free"]
+               "smh_multi_generate_text", "smh_multi_ac_count", "smh_multi_wm_count", "smh_multi_ac_prepare",
+               "smh_multi_wm_prepare", "smh_multi_free"]
 
 
 def _load():
@@ -247,6 +248,9 @@ def _load():
     lib.smh_multi_generate_text.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     lib.smh_multi_ac_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), dblp]
     lib.smh_multi_wm_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), dblp]
+    lib.smh_multi_ac_prepare.argtypes = [C.c_void_p, C.c_void_p]
+    lib.smh_multi_wm_prepare.argtypes = [C.c_void_p, C.c_void_p]
+    lib.smh_dev_build_peak.argtypes = [C.c_int]
     lib.smh_multi_free.restype = None
     lib.smh_multi_free.argtypes = [C.c_void_p]
     return lib
@@ -537,6 +541,13 @@ class MultiGpu:
 
     def wm_count(self, wm):
         return self._count(lib.smh_multi_wm_count, wm, "smh_multi_wm_count")
+
+    def prepare(self, handle):
+        """table sets + one warm-up launch on every device, side by side (smh_multi_*_prepare)"""
+        if isinstance(handle, AcAutomaton):
+            _check(lib.smh_multi_ac_prepare(self.h, handle.h), "smh_multi_ac_prepare")
+        else:
+            _check(lib.smh_multi_wm_prepare(self.h, handle.h), "smh_multi_wm_prepare")
 
     def close(self):
         if self.h:

@@ -200,7 +200,11 @@ void smh_sog_free(smh_sog *sg);
  * (main.c:467-477; every scan uses the TRUE length of its range); a count call launches the tuned kernel on
  * every device side by side and adds the 64-bit counts with ONE ncclAllReduce(ncclUint64, ncclSum) over an
  * RCCL communicator of the devices (ncclCommInitAll) -- the MPI_Reduce of main.c:656 over xGMI.  Handles are
- * shared: a compiled automaton keeps one table set per device.  Call from one host thread. */
+ * shared: a compiled automaton keeps one table set per device.
+ * Threading contract of the whole library: a compiled handle (smh_ac, smh_wm, ...) may be scanned from several
+ * host threads at once, each with its own current device -- the per-device table sets are published under a
+ * mutex and built outside it; compiling, re-planning and freeing a handle must not run beside a scan of it.  An
+ * smh_multi object is driven from ONE host thread (it starts one thread per device itself where that pays). */
 typedef struct smh_multi smh_multi;
 #define SMH_MULTI_MAX_DEVICES 16
 #define SMH_MULTI_HOST_SUM 1 /* smh_multi_create: when RCCL cannot be loaded, add the counts on the host instead of failing */
@@ -217,6 +221,11 @@ int smh_multi_generate_text(smh_multi *mg, uint64_t n_total, uint64_t seed, int 
  * smh_multi_device_count entries) = device i's own count, *seconds (optional) = wall time of launches + reduce */
 int smh_multi_ac_count(smh_multi *mg, smh_ac *ac, uint64_t *total, uint64_t *per_device, double *seconds);
 int smh_multi_wm_count(smh_multi *mg, smh_wm *wm, uint64_t *total, uint64_t *per_device, double *seconds);
+/* build the handle's table set on every device of `mg` side by side (one host thread per device) and run its kernel
+ * once per device on a few KiB, so that the first count call measures what the tenth does: launches + reduce.  The
+ * count calls do the same before their clock starts; this only moves it out of the first call. */
+int smh_multi_ac_prepare(smh_multi *mg, smh_ac *ac);
+int smh_multi_wm_prepare(smh_multi *mg, smh_wm *wm);
 void smh_multi_free(smh_multi *mg);
 
 /* ---- Set-Horspool (sh/sh.c, cuda/cuda_sh.cu) ----

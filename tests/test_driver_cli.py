@@ -111,8 +111,8 @@ def test_fasta_decoding(tmp_path, coding, sigma, letters):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [1, 3])
-def test_driver_totals_match_oracle_on_a_fasta_text(tmp_path, capfd, ranks):
+@pytest.mark.parametrize("ranks,multi", [(1, False), (3, False), (1, True)])
+def test_driver_totals_match_oracle_on_a_fasta_text(tmp_path, capfd, ranks, multi):
     if not os.path.exists(DSO):
         pytest.fail("smatcher_main.so missing: `make -C cuda-aho-corasick-wu-manber_amd` builds it")
     n, m, p, sigma = 1500007, 12, 400, 4
@@ -123,7 +123,7 @@ def test_driver_totals_match_oracle_on_a_fasta_text(tmp_path, capfd, ranks):
     drv = C.CDLL(DSO)
     args = [b"smatcher", b"all", b"-m", str(m).encode(), b"-p_size", str(p).encode(), b"-n", str(n).encode(),
             b"-alphabet", str(sigma).encode(), b"-text", str(fasta).encode(), b"-coding", b"dna",
-            b"-pattern", str(pfile).encode(), b"-c", b"-ranks", str(ranks).encode()]
+            b"-pattern", str(pfile).encode(), b"-c", b"-ranks", str(ranks).encode()] + ([b"-multi"] if multi else [])
     argv = (C.c_char_p * len(args))(*args)
     capfd.readouterr()
     assert drv.smatcher_main(len(args), argv) == 0
@@ -132,6 +132,11 @@ def test_driver_totals_match_oracle_on_a_fasta_text(tmp_path, capfd, ranks):
     want, _ = O.oracle_ac(pat, m, p, sigma, sym)
     assert want >= p // 2
     assert "Total results (ac): %d.\n" % want in out and "Total results: %d.\n" % want in out
+    # the side-by-side multi-device pass (smh_multi_*) runs for R > 1 when R devices are visible, or on request
+    assert ("multi-device ac (%d devices" % ranks in out) == (multi or (ranks > 1 and S.device_count() >= ranks))
+    if multi:
+        assert "multi-device ac (1 devices, RCCL all-reduce) matches \t%d\t" % want in out
+        assert "multi-device wm (1 devices, RCCL all-reduce) matches \t%d\t" % want in out
     assert "Total results (sh): %d.\n" % want in out and out.count("search_sh matches") == ranks
     assert "Total results (sbom): %d.\n" % want in out and out.count("search_sbom matches") == ranks
     assert out.count("search_ac matches") == ranks and out.count("search_wm2 matches") == ranks
