@@ -18,21 +18,31 @@ MPI_Reduce, main.c:656).  value = bits scanned by all ranks / wall time of the K
 N > 1 is weak scaling: every rank holds its own 1 GiB byte range (+ m-1 halo) of one N GiB text
 (shard formula main.c:467-477); there is no data-path collective.
 
-Extra objects on the JSON line:
+Extra objects on the JSON line (every one of them at every N unless it says otherwise):
   roofline               HBM bound; achieved = algorithmic bytes per launch (1 byte per text symbol) / mean
                          launch duration from events on the launch stream; traffic from the committed
                          rocprofv3 --pmc passes when they were taken on THIS build of the kernels
-  cpu_baseline           the reference's own compiled search_ac (oracle/_ref; the oracle port when absent),
-                         one thread, on a bounded prefix of the same text
-  cpu_baseline_wm        the same for search_wu2 (wu/wu.c:151-209) beside the WM configuration
-  cpu_baseline_all_cores both, fanned out over the host's cores by byte range (main.c:467-477)
   ac / wm                per-configuration rates (WM = BASELINE configs[2]: same text, 10 000 x m=8)
-  ac_8000_patterns       BASELINE configs[3] shape on one GPU (a 4 GiB shard, 8 000 patterns, m = 8/16/32)
-  wm_ascii               BASELINE configs[4] shape on one GPU (a 4 GiB shard of 256-symbol text, 100 000
-                         patterns, m = 5/12/20)
+  ac_8000_patterns       BASELINE configs[3]: AC, 8 000 patterns, m = 8/16/32, a 4 GiB byte range (+ halo) of
+                         one (N x 4 GiB) DNA text PER GPU, generated on its device; 64-bit counts all-reduced;
+                         aggregate Gbit/s = all bytes / the slowest device's kernel time, per-GPU hbm_frac
+  wm_ascii               BASELINE configs[4]: WM, 256-symbol text, 100 000 patterns, m = 5/8/12/20, same sharding
+  smh_multi              the same three workloads driven by ONE process through the native C path
+                         (csrc/smh_multi.hip: one thread per device for the uploads, kernels side by side,
+                         ncclAllReduce(uint64) over an ncclCommInitAll communicator); totals must equal the
+                         per-rank path's
   verified               EVERY `matches` above against a CPU count of the same text in the same run: the
-                         restated search_ac / search_wu2 (oracle/, pinned to the reference) over byte-range
-                         shards on all host cores
+                         restated search_ac / search_wu2 (oracle/, pinned to the reference) on the host threads
+                         of the rank that owns the shard (cores / N each).  N = 1: the full text of every
+                         configuration.  N > 1: the full 1 GiB shard of the headline sets; for the 4 GiB shards
+                         a stated slice (--verify-mib: head + the last 64 MiB with the halo).  N per-GPU
+                         entries per name; any mismatch fails the run on rank 0.
+  cpu_baseline*          N = 1 only (rank 0): the reference's own compiled search_ac / search_wu2 (oracle/_ref;
+                         the oracle port when absent), one thread and all cores, on bounded prefixes
+  stream_read            what a pure streaming read of the same 1 GiB reaches in this run (best of five variants)
+  table_kernels          N = 1 only: the table-walking kernels behind cuda_ac1/2, cuda_wm1/2, cuda_sh1/2,
+                         cuda_sbom1/2, cuda_sog1/2 on a 64 MiB prefix (latency-bound by design: the reference's
+                         tables walked as given)
 """
 import argparse
 import ctypes as C
@@ -54,7 +64,7 @@ AC_LENGTHS = (8, 16, 32)
 AC_PATTERNS = 1000
 WM_PATTERNS, WM_LENGTH = 10000, 8
 C4_PATTERNS = 8000
-C5_PATTERNS, C5_LENGTHS, C5_SIGMA = 100000, (5, 12, 20), 256
+C5_PATTERNS, C5_LENGTHS, C5_SIGMA = 100000, (5, 8, 12, 20), 256
 
 
 def kernel_build_id():
@@ -107,12 +117,15 @@ def cpu_model():
 # ---------------------------------------------------------------------------------------------------------
 # CPU side: the checker.  The only place bench.py touches oracle/ (through tests/oracle_lib.py).
 class Cpu:
-    def __init__(self):
+    def __init__(self, world=1):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         from concurrent.futures import ThreadPoolExecutor
         self.O = O
-        self.cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+        self.host_threads = len(os.sched_getaffinity(0))   # what this process may run on
+        self.host_cpus = os.cpu_count()                    # what the machine has
+        # every rank of an N-rank job checks its own shard: an equal share of the threads each, at most 64
+        self.cores = max(1, min(self.host_threads // max(world, 1), 64))
         self.pool = ThreadPoolExecutor(self.cores)
         self.kind = "reference" if O.have_ref() else "port"
         self.model = cpu_model()
@@ -162,20 +175,23 @@ class Cpu:
         parts = list(self.pool.map(lambda be: O.ref_wu(pat, m, p, sigma, text[be[0]:be[1]], flat=True), ranges))
         return max(q[3] for q in parts), sum(q[0] for q in parts) == want
 
-    # --- full-text verification (restated search, tables built once and shared by the threads) ---
-    def ac_count(self, pat, m, p, sigma, text):
-        O, n = self.O, len(text)
-        _, tabs = O.oracle_ac(pat, m, p, sigma)
-        pieces = max(self.cores * 4, 1)
-        ranges = [O.shard_range(n, pieces, r, m) for r in range(pieces)]
-        return sum(self.pool.map(lambda be: O.oracle_ac_search_tables(text[be[0]:be[1]], sigma, tabs), ranges))
+    # --- verification (restated search, tables built once and shared by the threads) ---
+    def counter(self, algo, pat, m, p, sigma):
+        """-> count(host text) over byte-range pieces with an m-1 halo on this rank's threads"""
+        O = self.O
+        if algo == "ac":
+            _, tabs = O.oracle_ac(pat, m, p, sigma)
+            one = lambda t: O.oracle_ac_search_tables(t, sigma, tabs)
+        else:
+            csr = O.WMTablesCSR(pat, m, p, sigma)
+            one = csr.search
 
-    def wm_count(self, pat, m, p, sigma, text):
-        O, n = self.O, len(text)
-        csr = O.WMTablesCSR(pat, m, p, sigma)
-        pieces = max(self.cores * 4, 1)
-        ranges = [O.shard_range(n, pieces, r, m) for r in range(pieces)]
-        return sum(self.pool.map(lambda be: csr.search(text[be[0]:be[1]]), ranges))
+        def count(text):
+            n = len(text)
+            pieces = max(self.cores * 4, 1)
+            ranges = [O.shard_range(n, pieces, r, m) for r in range(pieces)]
+            return int(sum(self.pool.map(lambda be: one(text[be[0]:be[1]]), ranges)))
+        return count
 
 
 def spawn_ranks(n):
@@ -210,6 +226,55 @@ def spawn_ranks(n):
     sys.exit(rc)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# The native one-process leg: `bench.py --multi-leg N ...` is started by rank 0 as a CHILD process (torch-free:
+# ctypes over libsmatcher_hip.so only) while the ranks keep their GPUs idle, and prints one JSON object.
+def multi_leg(args):
+    import smatcher_hip as S
+    n_dev = args.multi_leg
+    if S.device_count() < n_dev:
+        print(json.dumps({"error": "%d device(s) visible to the one-process leg, %d wanted" % (S.device_count(), n_dev)}))
+        return
+    mg = S.MultiGpu(n_dev)
+    per_gpu, shard = args.mib_per_gpu << 20, args.shard_mib << 20
+    out = {"devices": n_dev, "reduce": "ncclAllReduce(uint64, sum) over ncclCommInitAll" if mg.uses_rccl else "host sum",
+           "what": "ONE process drives all devices through smh_multi_* (csrc/smh_multi.hip); seconds = launches on every "
+                   "device + the count all-reduce + read-back, table sets prepared before the clock"}
+
+    def run(name, algo, sigma, lengths, p, seed, n_each, workload):
+        n_total = n_each * n_dev
+        mg.generate_text(n_total, TEXT_SEED, sigma, max(lengths) - 1)
+        obj = {"workload": workload}
+        for m in lengths:
+            pat = S.corpus_patterns(m, p, seed, sigma, TEXT_SEED, n_total, 2)
+            h = (S.AcAutomaton if algo == "ac" else S.WmTables).from_patterns(pat, m, p, sigma)
+            count = mg.ac_count if algo == "ac" else mg.wm_count
+            t0 = time.perf_counter()
+            mg.prepare(h)
+            prep = time.perf_counter() - t0
+            runs = [count(h) for _ in range(args.steps)]
+            secs = sorted(r[2] for r in runs)
+            total, per = runs[-1][0], runs[-1][1]
+            assert all(r[0] == total for r in runs)
+            med = secs[len(secs) // 2]
+            gbs = n_total / med / 1e9
+            obj["m%d" % m] = dict(seconds=round(med, 6), first_call_seconds=round(runs[0][2], 6), min_seconds=round(secs[0], 6),
+                                  prepare_seconds=round(prep, 4), GBps=round(gbs, 1), Gbit_s=round(8 * gbs, 1),
+                                  hbm_frac_per_gpu=round(gbs / n_dev / HBM_PEAK_GBS, 4), matches=total, per_gpu_matches=per)
+            h.close()
+        out[name] = obj
+
+    run("ac", "ac", SIGMA, AC_LENGTHS, AC_PATTERNS, PAT_SEED, per_gpu,
+        "BASELINE configs[1] shape: %d MiB of DNA per device, %d patterns, m=8/16/32" % (args.mib_per_gpu, AC_PATTERNS))
+    if not args.no_wm:
+        run("ac_8000_patterns", "ac", SIGMA, AC_LENGTHS, C4_PATTERNS, PAT_SEED + 3, shard,
+            "BASELINE configs[3]: %d MiB of DNA per device, 8000 patterns" % args.shard_mib)
+        run("wm_ascii", "wm", C5_SIGMA, C5_LENGTHS, C5_PATTERNS, PAT_SEED + 2, shard,
+            "BASELINE configs[4]: %d MiB of 256-symbol text per device, 100000 patterns" % args.shard_mib)
+    mg.close()
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -219,10 +284,18 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=96, help="prefix the serial search_ac baseline runs on")
     ap.add_argument("--cpu-wm-sample-mib", type=int, default=16, help="prefix the serial search_wu2 baseline runs on")
     ap.add_argument("--shard-mib", type=int, default=4096, help="per-GPU shard of the 32 GB configurations (configs[3], [4])")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines and the full-text verification")
+    ap.add_argument("--verify-mib", type=int, default=-1,
+                    help="MiB of every 4 GiB shard the CPU recounts (head + last 64 MiB); 0 = all of it; default: all at N = 1, 512 at N > 1")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines and the verification")
     ap.add_argument("--no-wm", action="store_true", help="skip the side configurations (WM, configs[3], configs[4])")
+    ap.add_argument("--no-multi", action="store_true", help="skip the one-process smh_multi leg")
+    ap.add_argument("--multi-leg", type=int, default=0, help=argparse.SUPPRESS)  # internal: the child of the smh_multi leg
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal of the N > 1 control flow on ONE card: every rank uses device 0, process group over gloo")
     args = ap.parse_args()
 
+    if args.multi_leg:
+        return multi_leg(args)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         spawn_ranks(args.gpus)  # does not return
@@ -235,7 +308,7 @@ def main():
 
     world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available() or S.device_count() < 1:
@@ -246,10 +319,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_device:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     per_gpu = args.mib_per_gpu << 20
     n_total = per_gpu * world
+    shard = args.shard_mib << 20
+    verify_budget = (args.verify_mib << 20) if args.verify_mib >= 0 else (0 if world == 1 else 512 << 20)
     stream = torch.cuda.current_stream().cuda_stream
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
@@ -259,6 +338,12 @@ def main():
         if rc != 0:
             raise SystemExit("corpus generation failed: " + S.lib.smh_last_error().decode())
         return t
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     def timed(launch, reps, counter):
         """`reps` launches bracketed by events on the launch stream -> list of ms"""
@@ -280,21 +365,12 @@ def main():
     # ---- pattern sets (host) and compiled automata
     pats = {m: S.corpus_patterns(m, AC_PATTERNS, PAT_SEED, SIGMA, TEXT_SEED, n_total, 2) for m in AC_LENGTHS}
     acs = {m: S.AcAutomaton.from_patterns(pats[m], m, AC_PATTERNS, SIGMA) for m in AC_LENGTHS}
-    halo = max(AC_LENGTHS) - 1
 
     # ---- this rank's byte range of the N GiB text, generated in HBM (never crosses PCIe)
-    begin = rank * per_gpu
-    shard_ends = {m: sharded.shard_for_rank(n_total, world, rank, m) for m in AC_LENGTHS}
-    for m in AC_LENGTHS:
-        assert shard_ends[m][0] == begin
-    n_alloc = min(per_gpu + halo, n_total - begin)
+    begin, n_alloc, shard_len = sharded.shard_plan(n_total, world, rank, AC_LENGTHS)
+    assert begin == rank * per_gpu
     text = corpus(n_alloc, begin, SIGMA)
-    counts = torch.zeros(len(AC_LENGTHS), dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
-
-    def shard_len(m):
-        b, e = shard_ends[m]
-        return e - b
 
     # every step has its own count buffer: its all-reduce is started behind its three scans and runs on RCCL's stream
     # while the next step's scans run on ours; all of them are waited for inside the timed region
@@ -305,16 +381,10 @@ def main():
         if events is not None:
             events[0].record()  # one event between consecutive launches: the end of one is the start of the next
         for i, m in enumerate(AC_LENGTHS):
-            acs[m].scan_device(text.data_ptr(), shard_len(m), c.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
+            acs[m].scan_device(text.data_ptr(), shard_len[m], c.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
             if events is not None:
                 events[i + 1].record()
         return sharded.reduce_count_async(c)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     sharded.finish([step(k) for k in range(args.warmup)])
     evs = [[ev() for _ in range(len(AC_LENGTHS) + 1)] for _ in range(args.steps)]
@@ -324,53 +394,61 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     counts = step_counts[args.warmup + args.steps - 1] if args.steps else step_counts[0]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max(sharded.gather_objects(elapsed))  # the job's time is the slowest rank's
     total_counts = [int(x) for x in counts.tolist()]
     # per-GPU counts for the report: one untimed pass without the reduce, then one small all-gather
     counts = step_counts[-1]
     counts.zero_()
     for i, m in enumerate(AC_LENGTHS):
-        acs[m].scan_device(text.data_ptr(), shard_len(m), counts.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
+        acs[m].scan_device(text.data_ptr(), shard_len[m], counts.data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
     torch.cuda.synchronize()
     per_gpu_counts = sharded.gather_counts(counts).tolist()
     local_counts = [int(x) for x in counts.tolist()]
 
     # per-launch durations (ms) from the events on the launch stream
     kern_ms = {m: [evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)] for i, m in enumerate(AC_LENGTHS)}
-    bits_per_step = 8.0 * sum(shard_len(m) for m in AC_LENGTHS)
-    if world > 1:
-        t = torch.tensor([bits_per_step], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        bits_per_step = float(t.item())
+    bits_per_step = 8.0 * sum(sum(sl.values()) for sl in sharded.gather_objects(shard_len))
     value = bits_per_step * args.steps / elapsed / 1e9
+    mean = lambda xs: sum(xs) / len(xs)
+    all_kern_ms = sharded.gather_objects({m: mean(kern_ms[m]) for m in AC_LENGTHS})  # [rank][m]
 
     out = None
-    verify = []  # (name, algorithm, patterns, m, p, sigma, device text tensor, n, gpu count): checked at the end
+    # every rank: (name, algorithm, patterns, m, p, sigma, device text, shard length, gpu count, scan(ptr, n) -> count)
+    verify = []
+    one = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def scan_with(handle):
+        def scan(ptr, n):
+            one.zero_()
+            handle.scan_device(ptr, n, one.data_ptr(), S.VARIANT_TUNED, stream)
+            torch.cuda.synchronize()
+            return int(one.item())
+        return scan
+
+    for i, m in enumerate(AC_LENGTHS):
+        verify.append(("ac.m%d" % m, "ac", pats[m], m, AC_PATTERNS, SIGMA, text, shard_len[m], local_counts[i], scan_with(acs[m])))
+
     if rank == 0:
-        mean = lambda xs: sum(xs) / len(xs)
         ac_detail = {}
         for i, m in enumerate(AC_LENGTHS):
             info = acs[m].info()
             ms = mean(kern_ms[m])
             ac_detail["m%d" % m] = dict(kernel_ms=round(ms, 4), median_ms=round(sorted(kern_ms[m])[len(kern_ms[m]) // 2], 4),
-                                        min_ms=round(min(kern_ms[m]), 4), **rate(shard_len(m), ms),
+                                        min_ms=round(min(kern_ms[m]), 4), **rate(shard_len[m], ms),
+                                        per_gpu_ms=[round(r[m], 4) for r in all_kern_ms],
                                         dfa_rows=info.rows, lds_rows=info.lds_rows, lds_bytes=info.lds_bytes,
                                         scan_stride=info.scan_stride, scan_depth=info.scan_depth,
                                         scan_exact=info.scan_exact, scan_full_rows=info.scan_full_rows,
                                         scan_engine="suffix-filter kernels" if info.scan_engine == S.ALGO_WM else "automaton kernels",
                                         matches=total_counts[i])
-            verify.append(("ac.m%d" % m, "ac", pats[m], m, AC_PATTERNS, SIGMA, text, shard_len(m), local_counts[i]))
         dom = max(AC_LENGTHS, key=lambda m: mean(kern_ms[m]))
         dom_ms = mean(kern_ms[dom])
-        achieved = shard_len(dom) / (dom_ms * 1e-3) / 1e9
+        achieved = shard_len[dom] / (dom_ms * 1e-3) / 1e9
         traffic, traffic_source = measured_traffic(acs[dom].info())
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
                         kernel="ac_dfa_kernel (m=%d set)" % dom, launch_ms=round(dom_ms, 4),
-                        algorithmic_bytes_per_launch=shard_len(dom))
+                        algorithmic_bytes_per_launch=shard_len[dom])
         out = {
             "metric": "Gbit/s text scanned (AC and WM) at 1/2/4/8 MI355X; % HBM roofline",
             "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -385,14 +463,28 @@ def main():
             "roofline": roofline, "ac": ac_detail, "device": S.device_name(), "kernel_build_id": kernel_build_id(),
             "per_gpu_matches": {"m%d" % m: [int(r[i]) for r in per_gpu_counts] for i, m in enumerate(AC_LENGTHS)},
         }
+        if args.share_device:
+            out["rehearsal"] = "--share-device: every rank on device 0, process group over gloo; rates are not N-GPU rates"
 
-    # ---- what a pure streaming read of the same 1 GiB reaches on this device, same run
+    # ---- what a pure streaming read of the same 1 GiB reaches on this device, same run: the best of the
+    #      grid-stride probe and four scan-shaped ones (wave-chunks from the LDS counter, 16 / 32 waves per CU, plain /
+    #      non-temporal loads)
     if rank == 0:
         probe = torch.zeros(1, dtype=torch.int64, device=dev)
-        pms = sorted(timed(lambda: S.lib.smh_stream_read_probe(C.c_void_p(text.data_ptr()), per_gpu, C.c_void_p(probe.data_ptr()),
-                                                               C.c_void_p(stream)), 6, probe))[2]
-        out["stream_read"] = dict(kernel="smh_stream_read_kernel (16-byte loads, XOR, no table work)", ms=round(pms, 4),
-                                  **{k: v for k, v in rate(per_gpu, pms).items() if k != "Gbit_s"})
+        names = ["grid-stride, 16-byte loads", "4 KiB wave-chunks, 16 waves/CU", "4 KiB wave-chunks, 32 waves/CU",
+                 "4 KiB wave-chunks, 16 waves/CU, non-temporal loads", "4 KiB wave-chunks, 32 waves/CU, non-temporal loads"]
+        variants = {}
+        for v, nm in enumerate(names):
+            def launch(v=v):
+                rc = S.lib.smh_stream_read_probe_variant(C.c_void_p(text.data_ptr()), per_gpu, C.c_void_p(probe.data_ptr()), C.c_void_p(stream), v)
+                if rc != 0:
+                    raise SystemExit("stream probe %d: %s" % (v, S.lib.smh_last_error().decode()))
+            pms = sorted(timed(launch, 6, probe))[2]
+            variants[nm] = dict(ms=round(pms, 4), GBps=rate(per_gpu, pms)["GBps"])
+        best = min(variants, key=lambda k: variants[k]["ms"])
+        out["stream_read"] = dict(kernel="smh_stream_read_probe_variant: best of %d read-only kernels (no table work)" % len(names),
+                                  best=best, ms=variants[best]["ms"],
+                                  **{k: v for k, v in rate(per_gpu, variants[best]["ms"]).items() if k != "Gbit_s"}, variants=variants)
         out["roofline"]["of_stream_read"] = round(out["roofline"]["achieved"] / out["stream_read"]["GBps"], 4)
 
     # ---- match positions: the m=16 set's END columns into a device buffer, same text
@@ -401,50 +493,52 @@ def main():
         cap = max(1024, 2 * int(local_counts[AC_LENGTHS.index(m_pos)]))
         pbuf = torch.zeros(cap, dtype=torch.int64, device=dev)
         pcur = torch.zeros(1, dtype=torch.int64, device=dev)
-        pms = sorted(timed(lambda: acs[m_pos].positions_device(text.data_ptr(), shard_len(m_pos), pbuf.data_ptr(), cap,
+        pms = sorted(timed(lambda: acs[m_pos].positions_device(text.data_ptr(), shard_len[m_pos], pbuf.data_ptr(), cap,
                                                                pcur.data_ptr(), stream), 6, pcur))[2]
         out["positions"] = dict(workload="smh_ac_positions, m=%d set, same text: END columns of all matches" % m_pos,
-                                kernel_ms=round(pms, 4), GBps=rate(shard_len(m_pos), pms)["GBps"], matches=int(pcur.item()),
+                                kernel_ms=round(pms, 4), GBps=rate(shard_len[m_pos], pms)["GBps"], matches=int(pcur.item()),
                                 equals_count=int(pcur.item()) == local_counts[AC_LENGTHS.index(m_pos)])
 
+    # ---- one pattern set over every rank's shard of a sharded text: per-rank kernel time (events), counts all-reduced
+    def sharded_set(name, algo, pat, m, p, sigma, dtext, n_m, reps):
+        handle = (S.AcAutomaton if algo == "ac" else S.WmTables).from_patterns(pat, m, p, sigma)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        handle.scan_device(dtext.data_ptr(), n_m, cnt.data_ptr(), S.VARIANT_TUNED, stream)  # tables up, code loaded
+        barrier()  # the ranks' launches run side by side, as in the job
+        ms = sorted(timed(lambda: handle.scan_device(dtext.data_ptr(), n_m, cnt.data_ptr(), S.VARIANT_TUNED, stream), reps, cnt))
+        local = int(cnt.item())
+        sharded.reduce_count(cnt)  # the MPI_Reduce of main.c:656
+        recs = sharded.gather_objects(dict(n=n_m, ms=ms[len(ms) // 2], matches=local))
+        verify.append((name, algo, pat, m, p, sigma, dtext, n_m, local, scan_with(handle)))
+        obj = sharded.summarize_shard_runs(recs, HBM_PEAK_GBS)
+        assert obj["matches"] == int(cnt.item()), "all-reduced count differs from the sum of the gathered shard counts"
+        return obj, handle
+
     # ---- WM side measurement (BASELINE configs[2]: same text, 10 000 patterns of length 8)
-    wpat = None
+    wpat = wm = None
     if not args.no_wm:
         wpat = S.corpus_patterns(WM_LENGTH, WM_PATTERNS, PAT_SEED + 1, SIGMA, TEXT_SEED, n_total, 2)
-        wm = S.WmTables.from_patterns(wpat, WM_LENGTH, WM_PATTERNS, SIGMA)
         wb, we = sharded.shard_for_rank(n_total, world, rank, WM_LENGTH)
-        wcount = torch.zeros(1, dtype=torch.int64, device=dev)
-        wms = timed(lambda: wm.scan_device(text.data_ptr(), we - wb, wcount.data_ptr(), S.VARIANT_TUNED, stream), args.steps, wcount)
-        wlocal = int(wcount.item())
-        sharded.reduce_count(wcount)
+        obj, wm = sharded_set("wm", "wm", wpat, WM_LENGTH, WM_PATTERNS, SIGMA, text, we - wb, args.steps)
         if rank == 0:
             wi = wm.info()
-            ms = sum(wms) / len(wms)
-            out["wm"] = dict(workload="WM: same text, %d patterns of length %d (BASELINE configs[2]); per-GPU kernel rate"
-                                      % (WM_PATTERNS, WM_LENGTH),
-                             kernel_ms=round(ms, 4), min_ms=round(min(wms), 4), **rate(we - wb, ms), matches=int(wcount.item()),
+            out["wm"] = dict(workload="WM: same text, %d patterns of length %d (BASELINE configs[2]); rate = all ranks' bytes / "
+                                      "slowest device's kernel time" % (WM_PATTERNS, WM_LENGTH), **obj,
                              block_symbols=wi.block_symbols, filter_log2=wi.filter_log2, filter_exact=wi.filter_exact,
                              shift_zero="%d/%d" % (wi.shift_zero, wi.shiftsize))
-            verify.append(("wm", "wm", wpat, WM_LENGTH, WM_PATTERNS, SIGMA, text, we - wb, wlocal))
         # the headline's longer pattern sets (m = 16, 32; the same 1000 patterns) through the Wu-Manber entry point
-        if rank == 0 and world == 1:
-            wl = {}
-            for m in AC_LENGTHS[1:]:
-                wml = S.WmTables.from_patterns(pats[m], m, AC_PATTERNS, SIGMA)
-                wcount.zero_()
-                mls = timed(lambda: wml.scan_device(text.data_ptr(), shard_len(m), wcount.data_ptr(), S.VARIANT_TUNED, stream), args.steps, wcount)
-                li = wml.info()
-                ms = sum(mls) / len(mls)
-                wl["m%d" % m] = dict(kernel_ms=round(ms, 4), min_ms=round(min(mls), 4), **rate(shard_len(m), ms), matches=int(wcount.item()),
-                                     scan_engine="automaton kernels" if li.scan_engine == S.ALGO_AC else "suffix-filter kernels",
-                                     gram_planes=li.gram_planes)
-                verify.append(("wm_long.m%d" % m, "wm", pats[m], m, AC_PATTERNS, SIGMA, text, shard_len(m), int(wcount.item())))
-                del wml
+        wl = {}
+        for m in AC_LENGTHS[1:]:
+            obj, wml = sharded_set("wm_long.m%d" % m, "wm", pats[m], m, AC_PATTERNS, SIGMA, text, shard_len[m], args.steps)
+            li = wml.info()
+            wl["m%d" % m] = dict(**obj, scan_engine="automaton kernels" if li.scan_engine == S.ALGO_AC else "suffix-filter kernels",
+                                 gram_planes=li.gram_planes)
+        if rank == 0:
             out["wm_long"] = dict(workload="WM: same text, the headline's %d-pattern sets of length %s through the Wu-Manber entry "
                                            "point (q-gram shift-or filter in LDS + staged verify)" % (AC_PATTERNS, "/".join(str(m) for m in AC_LENGTHS[1:])), **wl)
 
     # ---- BASELINE configs[1] read literally: ONE set of 1000 patterns whose lengths run from 8 to 32 (40 per length),
-    #      through the pattern-set entry points (smh_pset_*: the reference API carries one length per run)
+    #      through the pattern-set entry points (smh_pset_*: the reference API carries one length per run); N = 1
     mixed = None
     if not args.no_wm and rank == 0 and world == 1:
         mlens, mpats = [], []
@@ -464,42 +558,140 @@ def main():
         out["mixed_8_32"] = dict(workload="BASELINE configs[1] read as ONE set: 1000 patterns, 40 of each length 8..32, same text, "
                                           "scanned in one pass; count = sum over length classes of the reference's count", **mobj)
 
-    # ---- the 32 GB configurations, one GPU's shard of each (rank 0 of a single-GPU run only)
-    side = not args.no_wm and world == 1
-    shard = args.shard_mib << 20
-    if side:
-        # BASELINE configs[3]: AC, 8000 patterns; 32 GB over 8 GPUs = a 4 GiB byte range per GPU
-        text4 = text if shard == per_gpu else corpus(shard, 0, SIGMA)
-        c4, c4cnt = {}, torch.zeros(1, dtype=torch.int64, device=dev)
-        for m4 in AC_LENGTHS:
-            p4 = S.corpus_patterns(m4, C4_PATTERNS, PAT_SEED + 3, SIGMA, TEXT_SEED, shard, 2)
-            ac4 = S.AcAutomaton.from_patterns(p4, m4, C4_PATTERNS, SIGMA)
-            ms4 = sorted(timed(lambda: ac4.scan_device(text4.data_ptr(), shard, c4cnt.data_ptr(), S.VARIANT_TUNED, stream), 5, c4cnt))[2]
-            i4 = ac4.info()
-            c4["m%d" % m4] = dict(kernel_ms=round(ms4, 4), **rate(shard, ms4), matches=int(c4cnt.item()),
-                                  scan_engine="suffix-filter kernels" if i4.scan_engine == S.ALGO_WM else "automaton kernels",
-                                  scan_stride=i4.scan_stride, scan_depth=i4.scan_depth)
-            verify.append(("ac_8000_patterns.m%d" % m4, "ac", p4, m4, C4_PATTERNS, SIGMA, text4, shard, int(c4cnt.item())))
-            del ac4
-        out["ac_8000_patterns"] = dict(workload="AC: %d MiB of DNA text (one GPU's byte range of BASELINE configs[3]: 32 GB over 8 "
-                                                "GPUs), 8000 patterns per set, m=8/16/32; scan_engine says which kernels served "
-                                                "the Aho-Corasick entry point" % args.shard_mib, **c4)
-        # BASELINE configs[4]: WM, 256-symbol alphabet, 100 000 patterns, lengths 5-20 as fixed-length sets
-        text5 = corpus(shard, 0, C5_SIGMA)
-        c5, cnt5 = {}, torch.zeros(1, dtype=torch.int64, device=dev)
-        for m5 in C5_LENGTHS:
-            p5 = S.corpus_patterns(m5, C5_PATTERNS, PAT_SEED + 2, C5_SIGMA, TEXT_SEED, shard, 2)
-            wm5 = S.WmTables.from_patterns(p5, m5, C5_PATTERNS, C5_SIGMA)
-            ms5 = sorted(timed(lambda: wm5.scan_device(text5.data_ptr(), shard, cnt5.data_ptr(), S.VARIANT_TUNED, stream), 5, cnt5))[2]
-            c5["m%d" % m5] = dict(kernel_ms=round(ms5, 4), **rate(shard, ms5), matches=int(cnt5.item()))
-            verify.append(("wm_ascii.m%d" % m5, "wm", p5, m5, C5_PATTERNS, C5_SIGMA, text5, shard, int(cnt5.item())))
-            del wm5
-        out["wm_ascii"] = dict(workload="WM: %d MiB of 256-symbol text (one GPU's byte range of BASELINE configs[4]), 100000 "
-                                        "patterns per set, m=5/12/20" % args.shard_mib, **c5)
+    # ---- the 32 GB configurations: every rank scans ITS 4 GiB byte range (+ halo) of one (N x 4 GiB) text
+    if not args.no_wm:
+        def shard_config(label, algo, sigma, lengths, p, seed, workload):
+            n_tot = shard * world
+            b0, resident, lens = sharded.shard_plan(n_tot, world, rank, lengths)
+            reuse = sigma == SIGMA and world == 1 and shard == per_gpu
+            t = text if reuse else corpus(resident, b0, sigma)
+            objs = {}
+            for m in lengths:
+                pat = S.corpus_patterns(m, p, seed, sigma, TEXT_SEED, n_tot, 2)
+                obj, h = sharded_set("%s.m%d" % (label, m), algo, pat, m, p, sigma, t, lens[m], 5)
+                if algo == "ac":
+                    i4 = h.info()
+                    obj.update(scan_engine="suffix-filter kernels" if i4.scan_engine == S.ALGO_WM else "automaton kernels",
+                               scan_stride=i4.scan_stride, scan_depth=i4.scan_depth)
+                objs["m%d" % m] = obj
+            if rank == 0:
+                out[label] = dict(workload=workload, text_bytes_total=n_tot, sharding="byte-range x%d, m-1 halo, counts all-reduced" % world, **objs)
 
-    # ---- CPU baselines + bit-exact verification of every count above (rank 0, N = 1 only)
+        # BASELINE configs[3]: AC, 8000 patterns; 32 GB over 8 GPUs = a 4 GiB byte range per GPU
+        shard_config("ac_8000_patterns", "ac", SIGMA, AC_LENGTHS, C4_PATTERNS, PAT_SEED + 3,
+                     "AC: %d MiB of DNA text per GPU (BASELINE configs[3]: 32 GB over 8 GPUs), 8000 patterns per set, m=8/16/32; "
+                     "scan_engine says which kernels served the Aho-Corasick entry point" % args.shard_mib)
+        # BASELINE configs[4]: WM, 256-symbol alphabet, 100 000 patterns, lengths 5-20 as fixed-length sets
+        shard_config("wm_ascii", "wm", C5_SIGMA, C5_LENGTHS, C5_PATTERNS, PAT_SEED + 2,
+                     "WM: %d MiB of 256-symbol text per GPU (BASELINE configs[4]), 100000 patterns per set, m=%s"
+                     % (args.shard_mib, "/".join(str(m) for m in C5_LENGTHS)))
+
+    # ---- the table-walking kernels (cuda_*1/2: the reference's tables walked as given) on a 64 MiB prefix, N = 1
+    if not args.no_wm and rank == 0 and world == 1:
+        tn = min(64 << 20, per_gpu)
+        tk, tcnt = {}, torch.zeros(1, dtype=torch.int64, device=dev)
+        tpat = pats[8]
+        sets = [("ac_table_kernel (cuda_ac1/2)", acs[8], lambda h: h.scan_device(text.data_ptr(), tn, tcnt.data_ptr(), S.VARIANT_TABLE, stream)),
+                ("wm_table_kernel (cuda_wm1/2)", S.WmTables.from_patterns(tpat, 8, AC_PATTERNS, SIGMA),
+                 lambda h: h.scan_device(text.data_ptr(), tn, tcnt.data_ptr(), S.VARIANT_TABLE, stream)),
+                ("sh_table_kernel (cuda_sh1/2)", S.ShTrie.from_patterns(tpat, 8, AC_PATTERNS, SIGMA),
+                 lambda h: h.scan_device(text.data_ptr(), tn, tcnt.data_ptr(), None, S.VARIANT_TABLE, stream)),
+                ("sbom_table_kernel (cuda_sbom1/2)", S.SbomOracle.from_patterns(tpat, 8, AC_PATTERNS, SIGMA),
+                 lambda h: h.scan_device(text.data_ptr(), tn, tcnt.data_ptr(), S.VARIANT_TABLE, stream)),
+                ("sog_table_kernel (cuda_sog1/2)", S.SogTables(tpat, AC_PATTERNS),
+                 lambda h: h.scan_device(text.data_ptr(), tn, tcnt.data_ptr(), S.VARIANT_TABLE, stream))]
+        want = None
+        for nm, h, launch in sets:
+            tms = sorted(timed(lambda: launch(h), 3, tcnt))[1]
+            tk[nm] = dict(kernel_ms=round(tms, 4), **rate(tn, tms), matches=int(tcnt.item()))
+            want = int(tcnt.item()) if want is None else want
+            if int(tcnt.item()) != want:
+                raise SystemExit("PARITY FAILURE: %s counted %d, ac_table_kernel %d" % (nm, int(tcnt.item()), want))
+        verify.append(("table_kernels", "ac", tpat, 8, AC_PATTERNS, SIGMA, text, tn, want, None))
+        out["table_kernels"] = dict(workload="the reference-layout tables walked as given (latency-bound by design), m=8 set of %d "
+                                             "patterns, first %d MiB of the same text; all five counts equal" % (AC_PATTERNS, tn >> 20), **tk)
+
+    # ---- the same workloads through the native one-process path (smh_multi_*): a CHILD process of rank 0 drives all N
+    #      devices while the ranks wait in the c10d store with their GPUs idle
+    if not args.no_multi and not args.share_device:
+        torch.cuda.synchronize()
+        sharded.host_barrier("smh_multi_before")
+        if rank == 0:
+            cmd = [sys.executable, os.path.abspath(__file__), "--multi-leg", str(world), "--steps", "5", "--mib-per-gpu", str(args.mib_per_gpu),
+                   "--shard-mib", str(args.shard_mib)] + (["--no-wm"] if args.no_wm else [])
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                leg = json.loads(line[-1]) if r.returncode == 0 and line else {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+            except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+                leg = {"error": repr(e)[:400]}
+            # same text, same patterns, same byte ranges: the totals must be the per-rank path's
+            agree = {}
+            for key, mine in (("ac", out.get("ac")), ("ac_8000_patterns", out.get("ac_8000_patterns")), ("wm_ascii", out.get("wm_ascii"))):
+                for mk, v in (leg.get(key) or {}).items():
+                    if mk.startswith("m") and mine and mk in mine:
+                        agree["%s.%s" % (key, mk)] = v["matches"] == mine[mk]["matches"]
+            leg["totals_equal_per_rank_path"] = agree
+            out["smh_multi"] = leg
+            if agree and not all(agree.values()):
+                print(json.dumps(out))
+                raise SystemExit("PARITY FAILURE: smh_multi totals differ from the per-rank totals: %r" % agree)
+        sharded.host_barrier("smh_multi_after")
+
+    # ---- bit-exact verification of every count above, every rank its own shards; CPU baselines at N = 1
+    parity_ok = True
+    if not args.no_cpu:
+        cpu = Cpu(world)
+        t0 = time.perf_counter()
+        mine, host_cache = {}, {}
+
+        longest = {}  # (text, offset) -> the longest slice any entry wants from there: copied once, sliced per entry
+
+        def host_slice(dtext, off, ln):
+            key = (id(dtext), off)
+            if key not in host_cache or len(host_cache[key]) < ln:
+                host_cache.clear()  # one (up to 4 GiB) host copy at a time
+                host_cache[key] = dtext[off:off + max(ln, longest.get(key, 0))].cpu().numpy()
+            return host_cache[key][:ln]
+
+        def slices_of(n, m):
+            # the headline's 1 GiB shards are recounted whole at every N; the 4 GiB shards within the budget
+            return sharded.verify_slices(n, m, 0 if n <= per_gpu + 64 else verify_budget)
+
+        for v in verify:
+            for off, ln in slices_of(v[7], v[3]):
+                longest[(id(v[6]), off)] = max(longest.get((id(v[6]), off), 0), ln)
+        verify.sort(key=lambda v: id(v[6]))  # shards of the same text together: fewer device-to-host copies
+        for name, algo, pat, m, p, sigma, dtext, n, got, scan in verify:
+            slices = slices_of(n, m)
+            count = cpu.counter(algo, pat, m, p, sigma)
+            g, c = [], []
+            for off, ln in slices:
+                g.append(got if (off == 0 and ln == n) or scan is None else scan(dtext.data_ptr() + off, ln))
+                c.append(count(host_slice(dtext, off, ln)))
+            mine[name] = dict(gpu=g, cpu=c, slices=[[o, l] for o, l in slices], shard_bytes=n)
+        if mixed is not None:  # the mixed-length set: sum over its 25 length classes of the restated search_ac, full text
+            want, host_text = 0, host_slice(text, 0, per_gpu)
+            for L in range(8, 33):
+                flat = mixed[0][sum(mixed[1][:(L - 8) * 40]):sum(mixed[1][:(L - 8) * 40]) + 40 * L]
+                want += cpu.counter("ac", flat, L, 40, SIGMA)(host_text)
+            for name in ("ac", "wm"):
+                mine["mixed_8_32." + name] = dict(gpu=[out["mixed_8_32"][name]["matches"]], cpu=[int(want)], slices=[[0, per_gpu]], shard_bytes=per_gpu)
+        my_secs = time.perf_counter() - t0
+        merged, all_equal = sharded.merge_verified(sharded.gather_objects(mine))
+        secs = max(sharded.gather_objects(my_secs))
+        parity_ok = all_equal
+        if rank == 0:
+            out["verified"] = dict(checker="restated search_ac / search_wu2 (oracle/, pinned to the reference on the golden vectors) over "
+                                           "byte-range pieces with an m-1 halo, every rank its own shards on %d of the host's %d threads "
+                                           "(%d CPUs); %s" % (cpu.cores, cpu.host_threads, cpu.host_cpus,
+                                                              "full text of every configuration" if verify_budget == 0 else
+                                                              "1 GiB shards whole, 4 GiB shards: first %d MiB + last 64 MiB (with the halo)"
+                                                              % ((verify_budget >> 20) - 64)),
+                                   seconds=round(secs, 1), all_equal=all_equal, counts=merged)
+
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = Cpu()
         sample = min(args.cpu_sample_mib << 20, per_gpu)
         host_text = text[:per_gpu].cpu().numpy()
         prefix = S.corpus_text(4096, TEXT_SEED, SIGMA, offset=0)
@@ -508,27 +700,20 @@ def main():
         # serial search_ac on the prefix
         secs, cpu_counts = cpu.ac_serial(pats, AC_PATTERNS, SIGMA, prefix)
         out["cpu_baseline"] = dict(value=round(8.0 * sample * len(pats) / secs / 1e9, 4), unit="Gbit/s", cores=1, kind=cpu.kind,
-                                   cpu=cpu.model,
+                                   cpu=cpu.model, host_cpus=cpu.host_cpus,
                                    sample="search_ac (ac/ac.c:198-222) over the first %d MiB of the same text, m=%s, %d patterns "
                                           "each, 1 thread, %.1f s" % (sample >> 20, "/".join(str(m) for m in pats), AC_PATTERNS, secs))
-        gpu_counts, c1 = {}, torch.zeros(1, dtype=torch.int64, device=dev)
-        for m in AC_LENGTHS:
-            c1.zero_()
-            acs[m].scan_device(text.data_ptr(), sample, c1.data_ptr(), S.VARIANT_TUNED, stream)
-            torch.cuda.synchronize()
-            gpu_counts[m] = int(c1.item())
-        parity_ok = all(gpu_counts[m] == cpu_counts[m] for m in AC_LENGTHS)
-        out["parity"] = dict(bit_exact=parity_ok, gpu_counts=gpu_counts, cpu_counts=cpu_counts, sample_bytes=sample)
+        gpu_counts = {m: verify_scan(text.data_ptr(), sample) for m, verify_scan in ((m, scan_with(acs[m])) for m in AC_LENGTHS)}
+        ok = all(gpu_counts[m] == cpu_counts[m] for m in AC_LENGTHS)
+        out["parity"] = dict(bit_exact=ok, gpu_counts=gpu_counts, cpu_counts=cpu_counts, sample_bytes=sample)
+        parity_ok = parity_ok and ok
         # serial search_wu2 on its (smaller) prefix: the 3-symbol SHIFT table is all zero on DNA from ~1000 patterns up,
         # so every column scans a bucket (0.036 Gbit/s on one thread)
         if wpat is not None:
             wsample = min(args.cpu_wm_sample_mib << 20, per_gpu)
             wsecs, wcnt = cpu.wm_serial(wpat, WM_LENGTH, WM_PATTERNS, SIGMA, host_text[:wsample])
-            c1.zero_()
-            wm.scan_device(text.data_ptr(), wsample, c1.data_ptr(), S.VARIANT_TUNED, stream)
-            torch.cuda.synchronize()
             out["cpu_baseline_wm"] = dict(value=round(8.0 * wsample / wsecs / 1e9, 4), unit="Gbit/s", cores=1, kind=cpu.kind,
-                                          cpu=cpu.model, counts_match=int(c1.item()) == wcnt,
+                                          cpu=cpu.model, counts_match=scan_with(wm)(text.data_ptr(), wsample) == wcnt,
                                           sample="search_wu2 (wu/wu.c:151-209) over the first %d MiB of the same text, %d patterns of "
                                                  "length %d, 1 thread, %.1f s" % (wsample >> 20, WM_PATTERNS, WM_LENGTH, wsecs))
             parity_ok = parity_ok and out["cpu_baseline_wm"]["counts_match"]
@@ -543,7 +728,7 @@ def main():
         if cpu.kind == "reference":
             secs, ok, wall = cpu.ac_all_cores_reference(pats, AC_PATTERNS, SIGMA, prefix, cpu_counts)
             allc = dict(value=round(8.0 * sample * len(pats) / secs / 1e9, 3), unit="Gbit/s", cores=cpu.cores, kind="reference",
-                        cpu=cpu.model, counts_match=ok,
+                        cpu=cpu.model, host_cpus=cpu.host_cpus, counts_match=ok,
                         sample="same sample as byte-range shards (main.c:467-477) on %d threads; time = slowest shard's search_ac "
                                "per set, summed (%.2f s; %.1f s wall with preproc_ac repeated per shard as every MPI rank of the "
                                "reference does)" % (cpu.cores, secs, wall))
@@ -554,38 +739,14 @@ def main():
                 ok = ok and wok
             out["cpu_baseline_all_cores"] = allc
             parity_ok = parity_ok and ok
-        # every `matches` on this line against a CPU count of the SAME text (full length), all cores
-        t0 = time.perf_counter()
-        verified, host_cache = {}, {id(text): host_text}
-        for name, algo, pat, m, p, sigma, dtext, n, got in verify:
-            if id(dtext) not in host_cache:
-                host_cache = {id(text): host_text, id(dtext): dtext[:n].cpu().numpy()}  # one 4 GiB copy at a time
-            h = host_cache[id(dtext)][:n]
-            want = cpu.ac_count(pat, m, p, sigma, h) if algo == "ac" else cpu.wm_count(pat, m, p, sigma, h)
-            verified[name] = dict(gpu=got, cpu=int(want), equal=int(want) == got, text_bytes=n)
-            parity_ok = parity_ok and int(want) == got
-        if mixed is not None:  # the mixed-length set: sum over its 25 length classes of the restated search_ac, full text
-            want = 0
-            for L in range(8, 33):
-                flat = mixed[0][sum(mixed[1][:(L - 8) * 40]):sum(mixed[1][:(L - 8) * 40]) + 40 * L]
-                want += cpu.ac_count(flat, L, 40, SIGMA, host_text)
-            for name in ("ac", "wm"):
-                got = out["mixed_8_32"][name]["matches"]
-                verified["mixed_8_32." + name] = dict(gpu=got, cpu=int(want), equal=int(want) == got, text_bytes=per_gpu)
-                parity_ok = parity_ok and int(want) == got
-        out["verified"] = dict(checker="restated search_ac / search_wu2 (oracle/, pinned to the reference on the golden vectors) over "
-                                       "byte-range shards with an m-1 halo on %d threads; full text of every configuration" % cpu.cores,
-                               seconds=round(time.perf_counter() - t0, 1), all_equal=all(v["equal"] for v in verified.values()),
-                               counts=verified)
-        if not parity_ok:
-            print(json.dumps(out))
-            raise SystemExit("PARITY FAILURE: GPU counts differ from the CPU reference")
 
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if not parity_ok:
+        raise SystemExit("PARITY FAILURE: GPU counts differ from the CPU reference")
 
 
 if __name__ == "__main__":

@@ -242,6 +242,59 @@ extern "C" int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t
     return SMH_OK;
 }
 
+/* The same measurement with the scan kernels' access shape: contiguous 4 KiB wave-chunks taken from the workgroup's
+ * LDS counter (lane_common.h smh_chunk_sched), a lane's 64-byte segment as four 16-byte loads, 16 or 32 waves per
+ * CU (dynamic LDS sized so that one or two workgroups fit), plain or non-temporal loads.  The grid-stride probe
+ * above was beaten by a real scan kernel (5.8 against 6.3 TB/s): a probe that is to serve as "what streaming
+ * reaches here" must at least stream the way the fastest scan does.  smh_stream_read_probe_variant(v):
+ *   0 grid-stride (above)   1 chunks, 16 waves/CU   2 chunks, 32 waves/CU   3 = 1 non-temporal   4 = 2 non-temporal */
+template <bool NT>
+__global__ __launch_bounds__(1024) void smh_stream_chunk_kernel(const uint8_t *__restrict__ text, uint64_t n_chunks,
+                                                                unsigned long long *out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char probe_lds[];
+    const smh_chunk_sched S = smh_sched_init(probe_lds, 0);
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t acc = 0;
+    for (uint64_t k = S.take(n_chunks); k < n_chunks; k = S.take(n_chunks)) {
+        typedef uint32_t smh_v4u __attribute__((ext_vector_type(4)));
+        const smh_v4u *p = reinterpret_cast<const smh_v4u *>(text + k * 4096u + (uint64_t)lane * 64u);
+        smh_v4u v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = NT ? __builtin_nontemporal_load(p + q) : p[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_down(acc, off, 64);
+    if (lane == 0 && acc) atomicXor(out, (unsigned long long)acc);
+}
+
+extern "C" int smh_stream_read_probe_variant(const void *d_buf, uint64_t bytes, uint64_t *d_out, void *stream, int variant)
+{
+    if (variant == 0) return smh_stream_read_probe(d_buf, bytes, d_out, stream);
+    if (!d_buf || !d_out || ((uintptr_t)d_buf & 15u) != 0 || variant < 0 || variant > 4) {
+        smh_set_error("smh_stream_read_probe_variant: bad arguments");
+        return SMH_EINVAL;
+    }
+    int n_cus = 0, rc;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    const bool nt = variant >= 3;
+    const int per_cu = (variant == 1 || variant == 3) ? 1 : 2;
+    const uint32_t lds = per_cu == 1 ? 96u * 1024u : 48u * 1024u; /* what limits the scan kernels too: their table */
+    static smh_attr_cache cache_plain, cache_nt;
+    int q = 0;
+    if (nt) HIP_TRY(cache_nt.get(smh_stream_chunk_kernel<true>, lds, 1024, &q));
+    else HIP_TRY(cache_plain.get(smh_stream_chunk_kernel<false>, lds, 1024, &q));
+    if (q < per_cu) { smh_set_error("smh_stream_read_probe_variant: %d workgroup(s) per CU fit, %d wanted", q, per_cu); return SMH_EUNSUP; }
+    const dim3 grid((unsigned)(n_cus * per_cu));
+    if (nt) hipLaunchKernelGGL(smh_stream_chunk_kernel<true>, grid, dim3(1024), lds, (hipStream_t)stream, (const uint8_t *)d_buf, bytes / 4096u, (unsigned long long *)d_out);
+    else hipLaunchKernelGGL(smh_stream_chunk_kernel<false>, grid, dim3(1024), lds, (hipStream_t)stream, (const uint8_t *)d_buf, bytes / 4096u, (unsigned long long *)d_out);
+    HIP_TRY(hipGetLastError());
+    return SMH_OK;
+}
+
 extern "C" int smh_corpus_text_device(unsigned char *d_out, uint64_t n, uint64_t offset, uint64_t seed,
                                       int alphabet, void *stream)
 {

@@ -89,6 +89,7 @@ LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_s
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
                "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
+               "smh_stream_read_probe_variant",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
                "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
@@ -121,6 +122,7 @@ def _load():
     lib.smh_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     lib.smh_stream_synchronize.argtypes = [C.c_void_p]
     lib.smh_stream_read_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    lib.smh_stream_read_probe_variant.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
     lib.smh_splitmix64_at.restype = C.c_uint64
     lib.smh_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
     lib.smh_corpus_text_host.restype = None
@@ -484,6 +486,10 @@ class SogTables:
     def tables(self):
         return (self.T8.ctypes.data_as(u8p), self.scanner_hs.ctypes.data_as(u32p), self.scanner_index.ctypes.data_as(i32p),
                 self.scanner_hs2.ctypes.data_as(u8p))
+
+    def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
+        _check(lib.smh_sog_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant, C.c_void_p(stream or 0)),
+               "smh_sog_scan")
 
     def count_host(self, text, variant=VARIANT_TUNED):
         a, p = _u8(text)

@@ -136,6 +136,23 @@ def test_device_resident_text_and_streams():
         ac.scan_device(text.data_ptr() + 4, n - 4, cnt.data_ptr(), S.VARIANT_TUNED, stream)
 
 
+def test_stream_read_probe_variants_read_every_byte():
+    """the five read-only probes (bench.py `stream_read`) XOR all dwords of the buffer: same value, the host's"""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = 96 << 20  # a multiple of the 4 KiB wave-chunk
+    buf = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev)
+    want = int(np.bitwise_xor.reduce(buf.cpu().numpy().view(np.uint32)))
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for v in range(5):
+        out.zero_()
+        assert S.lib.smh_stream_read_probe_variant(C.c_void_p(buf.data_ptr()), n, C.c_void_p(out.data_ptr()), C.c_void_p(stream), v) == 0
+        torch.cuda.synchronize()
+        assert int(out.item()) == want, v
+    assert S.lib.smh_stream_read_probe_variant(C.c_void_p(buf.data_ptr()), n, C.c_void_p(out.data_ptr()), C.c_void_p(stream), 5) != 0
+
+
 @pytest.mark.parametrize("name", ["big_dfa", "ascii_5_20", "mx_s256_m32_p1000"])
 def test_dfa_larger_than_lds(name):
     """Automata that do not fit LDS are cut at depth K; candidates are verified in HBM -- same counts."""
