@@ -38,23 +38,35 @@ template <> struct smh_ac_entry<uint32_t> {
 
 #define SMH_AC_QCAP 256u /* queue entries per wave (HBM workspace, 8 bytes each) */
 
-/* everything the verify stage needs; wave-uniform */
+/* What only the RARE paths read -- the verify stage (a candidate of a depth-cut plan), the bounds-checked walk over the
+ * text's last piece, the per-segment positions kernel: the full DFA, the stride-1 depth-K table, the hash-verify tables.
+ * It lives in device memory (one copy per handle and device, uploaded with the table set) and the kernels receive a
+ * POINTER to it: passed by value these eleven fields were 20 scalar registers that the compiler loaded in the kernel's
+ * prologue and kept alive -- or spilled to VGPR lanes and read back with v_readlane inside the halo steps -- across the
+ * whole scan loop; the depth-cut kernels carried four times the scalar spill code of the exact ones and ran 0.02-0.03
+ * ms/GiB behind them (round 3: the same kernel with the verify stage compiled out, 0.200 -> 0.182). */
+struct smh_ac_cold_ctx {
+    const void *full;            /* full DFA in HBM */
+    const uint32_t *depth_first; /* [d] = first row with depth >= d; padded with `rows` */
+    const void *trunc1;          /* stride-1 depth-K table in HBM */
+    /* hash verify (ac_host.c hv_wm): the Wu-Manber verify table and the zero-padded patterns, or NULL: walk the DFA */
+    const uint32_t *hv_verify;
+    const uint8_t *hv_pats;
+    int full_entry_bytes;
+    int trunc1_entry_bytes;
+    int hv_log2;
+    int reserved;
+};
+
+/* what a scan needs from its caller; wave-uniform */
 struct smh_ac_verify_ctx {
     const uint8_t *text;
     uint64_t n;
     int m;
     int K;
     int sigma;
-    const void *full;            /* full DFA in HBM */
-    int full_entry_bytes;
-    const uint32_t *depth_first; /* [d] = first row with depth >= d; padded with `rows` */
-    const void *trunc1;          /* stride-1 depth-K table in HBM */
-    int trunc1_entry_bytes;
+    const smh_ac_cold_ctx *cold; /* device memory (the emulator: host memory) */
     smh_pos_out pos;             /* positions mode: where match END columns go (cursor == NULL: counting) */
-    /* hash verify (ac_host.c hv_wm): the Wu-Manber verify table and the zero-padded patterns, or NULL: walk the DFA */
-    const uint32_t *hv_verify;
-    const uint8_t *hv_pats;
-    int hv_log2;
 };
 
 /* depth_first[0..71] BY VALUE: as a kernel argument it is read with scalar loads from the kernarg
@@ -88,39 +100,40 @@ SMH_LANE uint32_t smh_entry_at(const void *t, int eb, uint64_t i)
 
 SMH_LANE uint32_t smh_ac_deep_walk(const smh_ac_verify_ctx &V, uint64_t q, uint32_t row, uint32_t kind)
 {
+    const smh_ac_cold_ctx &C = *V.cold;
     int t0 = V.K;
     uint64_t start = q + 1 - (uint64_t)V.K; /* text position of the pattern's first symbol */
-    if (V.hv_verify && (kind == SMH_CAND_ROOT || V.m - V.K > 3)) {
+    if (C.hv_verify && (kind == SMH_CAND_ROOT || V.m - V.K > 3)) {
         /* three dependent loads (window, bucket, pattern) instead of one per remaining symbol */
         if (start + (uint64_t)V.m > V.n) return 0;
         smh_wm_params P = {};
         P.m = V.m;
-        P.verify_log2 = V.hv_log2;
-        P.verify = V.hv_verify;
-        P.pat_sorted = V.hv_pats;
+        P.verify_log2 = C.hv_log2;
+        P.verify = C.hv_verify;
+        P.pat_sorted = C.hv_pats;
         return smh_wm_verify(V.text, start + (uint64_t)V.m - 1u, P);
     }
     if (kind == SMH_CAND_LAZY) {
         uint32_t c0 = V.text[q];
         if (c0 >= (uint32_t)V.sigma) c0 = 0;
-        const uint32_t e = smh_entry_at(V.trunc1, V.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c0);
-        row = e & (V.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu);
+        const uint32_t e = smh_entry_at(C.trunc1, C.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c0);
+        row = e & (C.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu);
     } else if (kind == SMH_CAND_ROOT) {
         row = 0;
         t0 = 0;
     }
     if (start + (uint64_t)V.m > V.n) return 0;
-    const uint32_t fshift = V.full_entry_bytes == 2 ? 15u : 31u;
+    const uint32_t fshift = C.full_entry_bytes == 2 ? 15u : 31u;
     const uint32_t fmask = (1u << fshift) - 1u;
     /* one DEPENDENT load per step (the DFA entry); the next text byte and the depth bound do not depend on it and are
      * requested beside it -- three loads in sequence per step made the walk that ends every wave of a depth-cut plan
      * 20 us long (tools/wavetrace.py: median wave 193 us against 173 us for the same image with K = m) */
     uint32_t c = V.text[start + (uint64_t)t0];
     for (int t = t0; t < V.m; ++t) {
-        const uint32_t need = V.depth_first[t + 1];
+        const uint32_t need = C.depth_first[t + 1];
         const uint32_t cn = t + 1 < V.m ? V.text[start + (uint64_t)t + 1u] : 0u;
         if (c >= (uint32_t)V.sigma) return 0;
-        const uint32_t e = smh_entry_at(V.full, V.full_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
+        const uint32_t e = smh_entry_at(C.full, C.full_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
         if (e >> fshift) return 1;
         row = e & fmask;
         if (row < need) return 0;
@@ -268,24 +281,39 @@ struct smh_fmt_s2 { /* stride 2, alphabet 4: entry = row | F1 << 14 | F2 << 15, 
  * Flags are raised only inside that resolution, so the common path carries no flag arithmetic:
  * next_f hands them to a callback.  The lane state is the row id (16 bits).
  */
-struct smh_fmt_s2h {
+template <bool CLAMP> struct smh_fmt_s2h_t {
     static constexpr int STRIDE = 2;
     static constexpr bool SPARSE = true;
     /* Full rows have the ids [0, full_rows); item slot s of the compact part has the id SMH_HYB_COMPACT0 + s.  A lane that
-     * sits in a compact row therefore issues the common path's full-row lookup at (id << 5) >= 1 MiB, beyond the
-     * workgroup's LDS: a ds_read out of range returns 0 and raises nothing (tools/lds_oob.hip on gfx950), and the value is
-     * replaced by the resolution below anyway -- so the common path needs no clamp: v_lshl_or, ds_read_u16 per step and
-     * chain (the v_min that kept the id inside the table was 14 % of the kernel's VALU work).  The CPU emulation reads
-     * row 0 instead. */
+     * sits in a compact row issues the common path's full-row lookup like every other lane, and the value is replaced by
+     * the resolution below.  Two forms of that lookup's address:
+     *   CLAMP = false  (row << 5) | c as it is: for a compact id that is >= 1 MiB, beyond the workgroup's LDS, where a
+     *                  ds_read returns 0 and raises nothing -- the architected behaviour of an out-of-range LDS read
+     *                  on GCN / CDNA, which the library nevertheless CHECKS once per device before it relies on it
+     *                  (smh_lds_oob_reads_zero in ac_kernels.inc: a probe kernel reads the very addresses this path
+     *                  can produce).  The common step is v_bfe, v_lshl_or, ds_read_u16 per chain.
+     *   CLAMP = true   the id is clamped to row 0 first (one v_cndmask more per step and chain: +14 % VALU work):
+     *                  what runs on a device whose probe did not read zeros, and in the one-chain instantiations.
+     * The CPU emulation executes the SAME addressing and models the out-of-range read as 0 (`limit` = image bytes). */
     uint32_t nf;    /* ids >= nf are compact: SMH_HYB_COMPACT0 */
     uint32_t cbase; /* byte address of the item slot with id i is i * 4 + cbase (mod 2^32) */
-    static SMH_MEMBER smh_fmt_s2h make(uint32_t full_rows) { return smh_fmt_s2h{SMH_HYB_COMPACT0, full_rows * 32u - 4u * SMH_HYB_COMPACT0}; }
+    uint32_t limit; /* bytes of the image in LDS (emulation of the out-of-range read only) */
+    static SMH_MEMBER smh_fmt_s2h_t make(uint32_t full_rows, uint32_t image_bytes)
+    {
+        return smh_fmt_s2h_t{SMH_HYB_COMPACT0, full_rows * 32u - 4u * SMH_HYB_COMPACT0, image_bytes};
+    }
     SMH_MEMBER uint32_t full_addr(uint32_t row, uint32_t c) const
     {
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        if (CLAMP) return ((row < nf ? row : 0u) << 5) | c;
         return (row << 5) | c;
+    }
+    /* the full-row lookup: on the GPU a plain ds_read_u16 (out of range: 0); emulated with that rule spelled out */
+    SMH_MEMBER uint32_t read_full(const void *tab, uint32_t addr) const
+    {
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        return smh_lds_u16(tab, addr);
 #else
-        return ((row < nf ? row : 0u) << 5) | c;
+        return addr + 2u <= limit ? smh_lds_u16(tab, addr) : 0u;
 #endif
     }
     SMH_MEMBER uint32_t prep(uint32_t w) const { return (w << 10) | w; } /* as smh_fmt_s2 */
@@ -328,7 +356,7 @@ struct smh_fmt_s2h {
         const uint32_t c = smh_bfe(x, k == 0 ? 7 : 23, 5); /* pair code * 2 */
         /* the full-row lookup is issued for every lane before the vote (harmless for a compact row id: see above),
          * so the common path is the plain stride-2 one: shift-or, read */
-        const uint32_t t = smh_lds_u16(tab, full_addr(row, c));
+        const uint32_t t = read_full(tab, full_addr(row, c));
         return resolve(row, c, t, tab, on_flags);
     }
     /* the same step for the N chains of a lane with ONE vote in the common path (the deepest of the N rows decides;
@@ -341,7 +369,7 @@ struct smh_fmt_s2h {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             c[j] = smh_bfe(x[j], k == 0 ? 7 : 23, 5);
-            t[j] = smh_lds_u16(tab, full_addr(row[j], c[j]));
+            t[j] = read_full(tab, full_addr(row[j], c[j]));
             deepest = deepest > row[j] ? deepest : row[j];
         }
         if (SMH_UNLIKELY(SMH_WAVE_ANY(deepest >= nf))) {
@@ -362,6 +390,8 @@ struct smh_fmt_s2h {
     SMH_MEMBER uint32_t row(uint32_t e) const { return e & 0xFFFFu; }
     SMH_MEMBER uint32_t any(uint32_t e) const { return e >> 16; }
 };
+typedef smh_fmt_s2h_t<true> smh_fmt_s2h;       /* safe everywhere */
+typedef smh_fmt_s2h_t<false> smh_fmt_s2h_oob;  /* needs smh_lds_oob_reads_zero() on the device */
 
 template <typename FMT, int HC, int NCH, bool EXACT, int SW = 16> struct smh_ac_scan_ctx {
     FMT fmt;
@@ -522,6 +552,52 @@ SMH_LANE void smh_ac_load_segments(const uint8_t *text, const uint64_t (&a)[NCH]
         }
 }
 
+/* What a segment's recorded bits become once its halo is done (shared by the byte-text and the packed-text fast paths):
+ * REC  positions mode with K == m: bit = match END column, appended to the output (returns the matches appended);
+ * BITS depth-cut stride-2 plans: bit = END of a K-symbol prefix, queued for the verify stage by position only. */
+template <int NCH, bool REC, bool BITS>
+SMH_LANE uint32_t smh_ac_finish_masks(const uint64_t (&a)[NCH], const uint32_t (&mlo)[NCH], const uint32_t (&mhi)[NCH],
+                                      const uint32_t (&mhalo)[NCH], const smh_ac_verify_ctx &V, smh_ac_queue &Q)
+{
+    uint32_t cnt = 0;
+    if (REC) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            cnt += smh_append_bits2(((uint64_t)mhi[j] << 32) | mlo[j], a[j], mhalo[j], a[j] + SMH_SEG, V.pos);
+        }
+    }
+    if (BITS) {
+        /* compaction: one queue entry per set bit, as many rounds as the busiest lane has bits.  ONE vote decides the
+         * common case (no candidate anywhere in the wave's chunk): the loops below each start with a vote of
+         * their own, and their code sat in the way of every chunk */
+        uint32_t any_bits = 0;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) any_bits |= mlo[j] | mhi[j] | mhalo[j];
+        if (SMH_UNLIKELY(SMH_WAVE_ANY(any_bits != 0))) {
+            /* ONE emit site (a rolled loop over the 3 * NCH masks) */
+            uint32_t mm[3 * NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                mm[3 * j] = mlo[j];
+                mm[3 * j + 1] = mhi[j];
+                mm[3 * j + 2] = mhalo[j];
+            }
+#pragma unroll 1
+            for (int g = 0; g < 3 * NCH; ++g) {
+                uint32_t msk = mm[g];
+                const uint64_t base = a[g / 3] + 32u * (uint32_t)(g % 3);
+                while (SMH_WAVE_ANY(msk != 0)) {
+                    const bool have = msk != 0;
+                    const uint32_t b = have ? (uint32_t)__builtin_ctz(msk) : 0u;
+                    smh_ac_emit(Q, V, have, base + b, 0u, SMH_CAND_ROOT);
+                    msk &= msk - 1u;
+                }
+            }
+        }
+    }
+    return cnt;
+}
+
 /*
  * Fast path: NCH segments per lane (already in registers), each fully inside the text together
  * with 16*HC bytes after it (the caller guarantees a[j] + 64 + 16*HC <= n and 16*HC >= K-1).
@@ -638,43 +714,7 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
         }
     }
     smh_ac_halo_all(ctx, w, e, cnt, std::make_integer_sequence<int, 16 * HC>{});
-    if (REC) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            cnt += smh_append_bits2(((uint64_t)mhi[j] << 32) | mlo[j], a[j], mhalo[j], a[j] + SMH_SEG, V.pos);
-        }
-    }
-    if (BITS) {
-        /* compaction: one queue entry per set bit, as many rounds as the busiest lane has bits.  ONE vote decides the
-         * common case (no candidate anywhere in the wave's chunk): the six loops below each start with a vote of
-         * their own, and their code -- the drain with its walk is inlined six times -- sat in the way of every chunk */
-        uint32_t any_bits = 0;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) any_bits |= mlo[j] | mhi[j] | mhalo[j];
-        if (SMH_UNLIKELY(SMH_WAVE_ANY(any_bits != 0))) {
-            /* ONE emit site (a rolled loop over the 3 * NCH masks): the drain, with its verify, is inlined wherever
-             * smh_ac_emit is -- six copies of it doubled the kernels' code and their compile time */
-            uint32_t mm[3 * NCH];
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                mm[3 * j] = mlo[j];
-                mm[3 * j + 1] = mhi[j];
-                mm[3 * j + 2] = mhalo[j];
-            }
-#pragma unroll 1
-            for (int g = 0; g < 3 * NCH; ++g) {
-                uint32_t msk = mm[g];
-                const uint64_t base = a[g / 3] + 32u * (uint32_t)(g % 3);
-                while (SMH_WAVE_ANY(msk != 0)) {
-                    const bool have = msk != 0;
-                    const uint32_t b = have ? (uint32_t)__builtin_ctz(msk) : 0u;
-                    smh_ac_emit(Q, V, have, base + b, 0u, SMH_CAND_ROOT);
-                    msk &= msk - 1u;
-                }
-            }
-        }
-    }
-    return cnt;
+    return cnt + smh_ac_finish_masks<NCH, REC, BITS>(a, mlo, mhi, mhalo, V, Q);
 }
 
 /* Slow path: any segment, byte loads with bounds checks, stride-1 depth-K table from HBM,
@@ -683,18 +723,19 @@ SMH_LANE uint32_t smh_ac_lane_fast(const FMT &fmt, const uint8_t *text, const ui
 SMH_LANE uint32_t smh_ac_lane_slow(const smh_ac_verify_ctx &V, uint64_t n_starts, uint64_t a, uint32_t seg_bytes = SMH_SEG)
 {
     if (a >= n_starts) return 0;
+    const smh_ac_cold_ctx &C = *V.cold;
     uint64_t own_end = a + seg_bytes;
     if (own_end > n_starts) own_end = n_starts;
     /* K-symbol prefixes that START in [a, own_end) END before own_end + K - 1 */
     uint64_t stop = own_end + (uint64_t)(V.K - 1);
     if (stop > V.n) stop = V.n;
-    const uint32_t tmask = V.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu;
-    const uint32_t tshift = V.trunc1_entry_bytes == 2 ? 15u : 31u;
+    const uint32_t tmask = C.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu;
+    const uint32_t tshift = C.trunc1_entry_bytes == 2 ? 15u : 31u;
     uint32_t row = 0, cnt = 0;
     for (uint64_t i = a; i < stop; ++i) {
         uint32_t c = V.text[i];
         if (c >= (uint32_t)V.sigma) c = 0;
-        const uint32_t e = smh_entry_at(V.trunc1, V.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
+        const uint32_t e = smh_entry_at(C.trunc1, C.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
         row = e & tmask;
         if (e >> tshift) cnt += V.K >= V.m ? 1u : smh_ac_deep_walk(V, i, row, SMH_CAND_ROW);
     }
@@ -733,6 +774,28 @@ SMH_LANE uint32_t smh_ac_lane_table(const uint8_t *text, uint64_t n, uint64_t n_
  * so at any moment the resident waves stream one contiguous window of text.
  */
 SMH_LANE uint64_t smh_ac_segment_match_mask(const smh_ac_verify_ctx &V, uint64_t n_starts, uint64_t a);
+
+/* One 4 KiB piece (64 lanes x one segment) of a wave-chunk that did not qualify for the multi-segment fast path -- the
+ * text's last chunk, in practice.  A piece that still lies inside the text with its halo takes the one-segment fast path;
+ * only the piece that holds the text's end walks byte by byte with bounds checks (~30 us for its 64 bytes per lane: every
+ * step is a dependent load from HBM/L2).  Without this split a lane of an N-segment kernel walked all N segments of the
+ * last chunk that way, one after the other: 90 us with three segments per lane, 180 us with six -- the whole launch. */
+template <typename FMT, int HC, bool EXACT, int SW, bool POS>
+SMH_LANE uint32_t smh_ac_piece(const FMT &fmt, const smh_ac_verify_ctx &V, uint64_t piece_base, uint32_t lane, uint64_t n_starts,
+                               const void *tab, const smh_ac_df &df, smh_ac_queue &Q)
+{
+    constexpr uint32_t SEGB = 4u * SW;
+    const uint64_t as = piece_base + (uint64_t)lane * SEGB;
+    if (piece_base + 64u * SEGB + 16u * HC <= V.n) { /* wave-uniform */
+        uint64_t a[1] = {as};
+        uint32_t w[1][SW], tail[4 * HC];
+        smh_ac_load_segments<1, SW>(V.text, a, w);
+        smh_ac_load_tail<HC>(V.text + piece_base + 64u * SEGB, tail);
+        return smh_ac_lane_fast<FMT, HC, 1, EXACT, SW, POS>(fmt, V.text, a, w, tail, tab, V.K, df, V, Q);
+    }
+    if (POS) return smh_append_bits(smh_ac_segment_match_mask(V, n_starts, as), as + (uint64_t)(V.m - 1), V.pos);
+    return smh_ac_lane_slow(V, n_starts, as, SEGB);
+}
 
 /* POS: positions mode -- instead of counting, every match appends its END column to V.pos (the return
  * value is then the number of matches this lane appended; the kernels ignore it). */
@@ -773,7 +836,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chun
         const uint64_t kn = S.take(n_chunks); /* taken before this chunk is scanned: its text is prefetched below */
         const uint64_t base_n = smh_uniform64(kn * chunk_bytes);
         const bool nxt_fast = kn < n_chunks && base_n + chunk_bytes + 16u * HC <= V.n;
-        if (PREFETCH && nxt_fast) {
+        if (PREFETCH == 1 && nxt_fast) {
             uint64_t an[NCH];
 #pragma unroll
             for (int j = 0; j < NCH; ++j) an[j] = base_n + ((uint64_t)j * 64u + lane) * SEGB;
@@ -785,19 +848,22 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chun
 #pragma unroll
             for (int j = 0; j < NCH; ++j) a[j] = base + ((uint64_t)j * 64u + lane) * SEGB;
             cnt += smh_ac_lane_fast<FMT, HC, NCH, EXACT, SW, POS>(fmt, V.text, a, cur, cur_tail, tab, V.K, df, V, Q);
+        } else if (NCH > 1) {
+            /* the text's last chunk: piece by piece, fast where a piece still has its halo inside the text */
+            static_assert(!POS || SW == 16, "positions mode uses 64-byte segments");
+#pragma unroll 1
+            for (int j = 0; j < NCH; ++j)
+                cnt += smh_ac_piece<FMT, HC, EXACT, SW, POS>(fmt, V, base + (uint64_t)j * 64u * SEGB, lane, n_starts, tab, df, Q);
         } else if (POS) {
             /* the text's last chunk(s): per-lane mask of matching STARTS, then the wave-level append */
             static_assert(!POS || SW == 16, "positions mode uses 64-byte segments");
-            for (int j = 0; j < NCH; ++j) {
-                const uint64_t as = base + ((uint64_t)j * 64u + lane) * SEGB;
-                cnt += smh_append_bits(smh_ac_segment_match_mask(V, n_starts, as), as + (uint64_t)(V.m - 1), V.pos);
-            }
+            const uint64_t as = base + (uint64_t)lane * SEGB;
+            cnt += smh_append_bits(smh_ac_segment_match_mask(V, n_starts, as), as + (uint64_t)(V.m - 1), V.pos);
         } else {
-            for (int j = 0; j < NCH; ++j)
-                cnt += smh_ac_lane_slow(V, n_starts, base + ((uint64_t)j * 64u + lane) * SEGB, SEGB);
+            cnt += smh_ac_lane_slow(V, n_starts, base + (uint64_t)lane * SEGB, SEGB);
         }
         if (nxt_fast) {
-            if (PREFETCH) {
+            if (PREFETCH == 1) {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j)
 #pragma unroll
@@ -845,18 +911,19 @@ SMH_LANE uint32_t smh_ac_table_thread(uint64_t gthread, uint64_t nthreads, const
 SMH_LANE uint64_t smh_ac_segment_match_mask(const smh_ac_verify_ctx &V, uint64_t n_starts, uint64_t a)
 {
     if (a >= n_starts) return 0;
+    const smh_ac_cold_ctx &C = *V.cold;
     uint64_t own_end = a + SMH_SEG;
     if (own_end > n_starts) own_end = n_starts;
     uint64_t stop = own_end + (uint64_t)(V.K - 1);
     if (stop > V.n) stop = V.n;
-    const uint32_t tmask = V.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu;
-    const uint32_t tshift = V.trunc1_entry_bytes == 2 ? 15u : 31u;
+    const uint32_t tmask = C.trunc1_entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu;
+    const uint32_t tshift = C.trunc1_entry_bytes == 2 ? 15u : 31u;
     uint32_t row = 0;
     uint64_t mask = 0;
     for (uint64_t i = a; i < stop; ++i) {
         uint32_t c = V.text[i];
         if (c >= (uint32_t)V.sigma) c = 0;
-        const uint32_t e = smh_entry_at(V.trunc1, V.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
+        const uint32_t e = smh_entry_at(C.trunc1, C.trunc1_entry_bytes, (uint64_t)row * (uint32_t)V.sigma + c);
         row = e & tmask;
         if (e >> tshift) {
             const uint32_t hit = V.K >= V.m ? 1u : smh_ac_deep_walk(V, i, row, SMH_CAND_ROW);

@@ -81,7 +81,8 @@ struct smh_ac_launch {
 uint32_t smh_ac_max_blocks(int n_cus);
 hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream);
 hipError_t smh_launch_ac_dfa_positions(const smh_ac_launch &L, hipStream_t stream);
-hipError_t smh_launch_ac_dfa_wide(const smh_ac_launch &L, hipStream_t stream); /* 32-bit entries; called by smh_launch_ac_dfa */
+hipError_t smh_launch_ac_dfa_wide(const smh_ac_launch &L, hipStream_t stream);
+bool smh_lds_oob_reads_zero(hipStream_t stream); /* ac_kernels.inc: per-device probe behind the unclamped hybrid kernels */ /* 32-bit entries; called by smh_launch_ac_dfa */
 
 struct smh_ac_table_launch {
     const uint8_t *d_text;

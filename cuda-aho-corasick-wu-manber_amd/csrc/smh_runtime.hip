@@ -38,6 +38,7 @@ struct smh_ac_dev {
     void *d_trunc1;
     uint64_t *d_queue;
     uint32_t *d_depth_first;
+    smh_ac_cold_ctx *d_cold; /* what the kernels' rare paths read (ac_lane.h), pointers into this set and the hv handle's */
     int32_t *d_transition;
     uint32_t *d_supply;
     uint32_t *d_final;
@@ -323,6 +324,7 @@ static void ac_dev_free_one(smh_ac_dev *dev)
     (void)hipFree(dev->d_scan);
     (void)hipFree(dev->d_queue);
     (void)hipFree(dev->d_depth_first);
+    (void)hipFree(dev->d_cold);
     (void)hipFree(dev->d_transition);
     (void)hipFree(dev->d_supply);
     (void)hipFree(dev->d_final);
@@ -396,14 +398,34 @@ static int ac_ensure_reference_tables(struct smh_ac *ac, smh_ac_dev *d)
 static int wm_prepare(struct smh_wm *wm, int variant);
 static int wm_ensure_device(struct smh_wm *wm, smh_wm_dev **out);
 /* the automaton kernels' verify stage hashes the window when the handle carries a verify table (ac_host.c hv_wm) */
-static int ac_fill_hash_verify(struct smh_ac *ac, smh_ac_verify_ctx &V)
+static int ac_fill_cold(struct smh_ac *ac, smh_ac_dev *dv, smh_ac_verify_ctx &V)
 {
-    V.hv_verify = NULL; V.hv_pats = NULL; V.hv_log2 = 0;
-    if (!ac->hv_wm || !ac->hv_wm->verify) return SMH_OK;
-    smh_wm_dev *hd = NULL;
-    const int rc = wm_ensure_device(ac->hv_wm, &hd);
-    if (rc != SMH_OK) return rc;
-    V.hv_verify = hd->d_verify; V.hv_pats = hd->d_pat_sorted; V.hv_log2 = ac->hv_wm->verify_log2;
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        if (dv->d_cold) { V.cold = dv->d_cold; return SMH_OK; }
+    }
+    smh_ac_cold_ctx C = {};
+    C.full = dv->d_table; C.full_entry_bytes = ac->entry_bytes; C.depth_first = dv->d_depth_first;
+    C.trunc1 = dv->d_trunc1; C.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+    if (ac->hv_wm && ac->hv_wm->verify) {
+        smh_wm_dev *hd = NULL;
+        const int rc = wm_ensure_device(ac->hv_wm, &hd);
+        if (rc != SMH_OK) return rc;
+        C.hv_verify = hd->d_verify; C.hv_pats = hd->d_pat_sorted; C.hv_log2 = ac->hv_wm->verify_log2;
+    }
+    smh_ac_cold_ctx *d = NULL;
+    HIP_TRY(hipMalloc((void **)&d, sizeof C));
+    if (hipMemcpy(d, &C, sizeof C, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        smh_set_error("smh_ac_scan: upload of the verify context failed");
+        return SMH_ENODEV;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_dev_mu);
+        if (!dv->d_cold) { dv->d_cold = d; d = NULL; }
+    }
+    if (d) (void)hipFree(d); /* another thread published one meanwhile */
+    V.cold = dv->d_cold;
     return SMH_OK;
 }
 static int ac_prepare(struct smh_ac *ac, int variant)
@@ -412,9 +434,9 @@ static int ac_prepare(struct smh_ac *ac, int variant)
     smh_ac_dev *d = NULL;
     int rc = ac_ensure_device(ac, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = ac_ensure_reference_tables(ac, d);
-    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && ac->hv_wm) {
-        smh_wm_dev *hd = NULL;
-        rc = wm_ensure_device(ac->hv_wm, &hd);
+    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED) {
+        smh_ac_verify_ctx V = {};
+        rc = ac_fill_cold(ac, d, V); /* the hash-verify handle's tables and the kernels' cold context */
     }
     return rc;
 }
@@ -467,9 +489,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
     } else if (variant == SMH_VARIANT_TUNED) {
         smh_ac_launch L = {};
         L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
-        L.V.full = dv->d_table; L.V.full_entry_bytes = ac->entry_bytes; L.V.depth_first = dv->d_depth_first;
-        L.V.trunc1 = dv->d_trunc1; L.V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
-        if ((rc = ac_fill_hash_verify(ac, L.V)) != SMH_OK) return rc;
+        if ((rc = ac_fill_cold(ac, dv, L.V)) != SMH_OK) return rc;
         L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
         L.d_scan_table = dv->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = dv->d_queue;
         for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
@@ -509,9 +529,7 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     smh_ac_verify_ctx V = {};
     V.text = d_text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
-    V.full = dv->d_table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = dv->d_depth_first;
-    V.trunc1 = dv->d_trunc1; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
-    if ((rc = ac_fill_hash_verify(ac, V)) != SMH_OK) return rc;
+    if ((rc = ac_fill_cold(ac, dv, V)) != SMH_OK) return rc;
     /* the tuned scan kernels in positions mode: matches are recorded as bits and appended per wave */
     smh_ac_launch L = {};
     L.V = V;

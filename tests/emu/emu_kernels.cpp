@@ -20,23 +20,36 @@
 #include "ac_lane.h"
 #include "wm_lane.h"
 
-/* hash verify of the automaton kernels (ac_host.c hv_wm): host pointers, patterns zero-padded to whole dwords */
+/* the kernels' cold context (ac_lane.h smh_ac_cold_ctx) with host pointers: full DFA, stride-1 table, depth_first, and the hash
+ * verify of the automaton kernels (ac_host.c hv_wm; patterns zero-padded to whole dwords) */
 struct emu_hv {
     std::vector<uint8_t> padded;
-    void fill(const smh_ac *ac, smh_ac_verify_ctx &V)
+    smh_ac_cold_ctx C;
+    void fill(const smh_ac *ac, smh_ac_verify_ctx &V, const uint32_t *depth_first)
     {
-        V.hv_verify = nullptr; V.hv_pats = nullptr; V.hv_log2 = 0;
+        C = smh_ac_cold_ctx{};
+        C.full = ac->table; C.full_entry_bytes = ac->entry_bytes; C.depth_first = depth_first;
+        C.trunc1 = ac->trunc1_table; C.trunc1_entry_bytes = ac->trunc1_entry_bytes;
+        V.cold = &C;
         const smh_wm *w = ac->hv_wm;
         if (!w || !w->verify) return;
         const size_t row = (size_t)((w->m + 3) / 4) * 4;
         padded.assign((size_t)w->distinct * row + 16, 0);
         for (int j = 0; j < w->distinct; ++j) memcpy(padded.data() + (size_t)j * row, w->pat_sorted + (size_t)j * w->m, (size_t)w->m);
-        V.hv_verify = w->verify; V.hv_pats = padded.data(); V.hv_log2 = w->verify_log2;
+        C.hv_verify = w->verify; C.hv_pats = padded.data(); C.hv_log2 = w->verify_log2;
     }
 };
 
 
 #define EMU_BLOCK_THREADS 1024
+static int emu_tune(const char *key, int dflt)
+{
+    const char *t = getenv("SMH_AC_TUNE");
+    if (!t) return dflt;
+    const char *p = strstr(t, key);
+    if (!p) return dflt;
+    return atoi(p + strlen(key) + 1);
+}
 #define EMU_AC_NCH 1 /* == SMH_AC_NCH in ac_kernels.hip */
 
 struct guarded {
@@ -79,11 +92,25 @@ static uint64_t ac_grid(const smh_ac *ac, const smh_ac_verify_ctx &V, uint64_t b
     uint64_t total = 0;
     for (uint64_t t = 0; t < nthreads; ++t) {
         if constexpr (STRIDE == 3) {
-            const smh_fmt_s2h fmt = smh_fmt_s2h::make(ac->scan_full_rows);
-            if constexpr (HC == 1) /* as launch_chains<3> (ac_kernels.inc): three chains per lane, no register prefetch */
-                total += smh_ac_thread<smh_fmt_s2h, 1, 3, EXACT, 0, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
-            else if constexpr (EXACT || HC <= 2)
+            /* as launch_chains<3> / launch_hybrid_chains (ac_kernels.inc): the multi-chain instantiations run the UNCLAMPED
+             * format (the out-of-range full-row read modelled as 0, what the device probe guarantees), exact plans with two
+             * chains and the register prefetch, depth-cut plans and positions mode with three; SMH_AC_TUNE="clamp=1" and
+             * the one-chain instantiations (halo beyond 16 bytes) the clamped one */
+            if constexpr (HC == 1) {
+                const bool two = EXACT && !POS && emu_tune("nch", 2) == 2;
+                if (emu_tune("clamp", 0) == 0) {
+                    const smh_fmt_s2h_oob fmt = smh_fmt_s2h_oob::make(ac->scan_full_rows, ac->scan_bytes);
+                    total += two ? smh_ac_thread<smh_fmt_s2h_oob, 1, 2, EXACT, 1, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr)
+                                 : smh_ac_thread<smh_fmt_s2h_oob, 1, 3, EXACT, 0, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
+                } else {
+                    const smh_fmt_s2h fmt = smh_fmt_s2h::make(ac->scan_full_rows, ac->scan_bytes);
+                    total += two ? smh_ac_thread<smh_fmt_s2h, 1, 2, EXACT, 1, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr)
+                                 : smh_ac_thread<smh_fmt_s2h, 1, 3, EXACT, 0, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
+                }
+            } else if constexpr (EXACT || HC <= 2) {
+                const smh_fmt_s2h fmt = smh_fmt_s2h::make(ac->scan_full_rows, ac->scan_bytes);
                 total += smh_ac_thread<smh_fmt_s2h, HC, EMU_AC_NCH, EXACT, SMH_PREFETCH, 16, POS>(fmt, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
+            }
         } else if constexpr (STRIDE == 2) {
             total += smh_ac_thread<smh_fmt_s2, HC, EMU_AC_NCH, EXACT, SMH_PREFETCH, 16, POS>(smh_fmt_s2{}, t, smh_sched_static(t >> 6, nthreads >> 6), ac->scan_table, V, df, nullptr);
         } else {
@@ -126,10 +153,8 @@ extern "C" uint64_t emu_ac_positions_tuned(const smh_ac *ac, const uint8_t *text
     memcpy(padded.data(), text, n);
     smh_ac_verify_ctx V = {};
     V.text = padded.data(); V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
-    V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df.data();
-    V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
     emu_hv hv;
-    hv.fill(ac, V);
+    hv.fill(ac, V, df.data());
     uint64_t cursor = 0;
     V.pos = smh_pos_out{out, capacity, &cursor};
     uint64_t r;
@@ -165,10 +190,8 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
         } else {
             smh_ac_verify_ctx V = {};
             V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
-            V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
-            V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
             emu_hv hv;
-            hv.fill(ac, V);
+            hv.fill(ac, V, df);
             if (ac->scan_stride == 2 && ac->scan_full_rows)
                 total = ac_halo<uint16_t, 4, 3>(ac, V, blocks);
             else if (ac->scan_stride == 2)
@@ -326,10 +349,8 @@ extern "C" uint64_t emu_ac_positions(const smh_ac *ac, const uint8_t *text, uint
     for (size_t i = 0; i < dflen; ++i) df[i] = (int)i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
     smh_ac_verify_ctx V = {};
     V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
-    V.full = ac->table; V.full_entry_bytes = ac->entry_bytes; V.depth_first = df;
-    V.trunc1 = ac->trunc1_table; V.trunc1_entry_bytes = ac->trunc1_entry_bytes;
     emu_hv hv;
-    hv.fill(ac, V);
+    hv.fill(ac, V, df);
     uint64_t cursor = 0;
     const uint64_t nthreads = (uint64_t)blocks * 256;
     for (uint64_t t = 0; t < nthreads; ++t) smh_ac_positions_thread(t, nthreads, V, out, capacity, &cursor);

@@ -150,3 +150,4 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
         assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want
     total, pos = E.wm_positions(wm, text, want + 8, 2)
     assert total == want and len(set(pos.tolist())) == want
+

@@ -237,6 +237,34 @@ def test_every_scan_plan_gives_the_same_count(name):
     assert tried >= (3 if sigma <= 20 else 1)  # alphabet 128 / 256: only K = 1 fits LDS
 
 
+@pytest.mark.parametrize("tune", ["clamp=0", "clamp=1", "clamp=0,nch=3", "clamp=1,nch=3", "clamp=0,nch=2", "clamp=1,nch=2", "nch=1"])
+def test_hybrid_kernel_instantiations_agree(tune, monkeypatch):
+    """Every instantiation of the hybrid-image kernels gives the reference's count: the unclamped full-row lookup (run only
+    after the per-device probe smh_lds_oob_reads_zero has seen out-of-range LDS reads return 0) and its clamped twin, two
+    chains with the register prefetch and three without, exact and depth-cut plans, 4 MiB of text with planted matches."""
+    monkeypatch.setenv("SMH_AC_TUNE", tune)
+    sigma, n = 4, (4 << 20) + 12345
+    text = O.gen_text(n, 77, sigma)
+    for m, p, plans in ((12, 1000, [(3, 12 | (9 << 8)), (3, 12 | (6 << 8)), (3, 9 | (5 << 8))]),
+                        (16, 1000, [(0, 0), (3, 12 | (9 << 8)), (3, 16 | (8 << 8)), (3, 13 | (7 << 8))]),
+                        (32, 600, [(0, 0), (3, 12 | (8 << 8)), (3, 17 | (9 << 8))])):
+        pat = O.gen_patterns_mixed(m, p, 300 + m, sigma, 77, n, 2)
+        want, _ = O.oracle_ac(pat, m, p, sigma, text)
+        assert want > p // 4
+        ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+        ran = 0
+        for stride, depth in plans:
+            try:
+                ac.set_scan_plan(stride, depth)
+            except S.SmhError:
+                continue
+            if stride == 3:
+                assert ac.info().scan_full_rows > 0
+            assert ac.count_host(text, S.VARIANT_TUNED)[0] == want, (tune, m, stride, depth)
+            ran += 1
+        assert ran >= 2
+
+
 def test_baseline_size_properties():
     """BASELINE configs[1]/[2] size: 1 GiB DNA text in HBM.  The oracle cannot scan that in seconds,
     so: (a) oracle on a 32 MiB slice, (b) AC == WM on the full text, (c) sum over the 8 byte-range
