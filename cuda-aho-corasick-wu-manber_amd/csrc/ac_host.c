@@ -175,6 +175,8 @@ void smh_ac_host_free(struct smh_ac *ac)
     free(ac->g_transition);
     free(ac->g_supply);
     free(ac->g_final);
+    free(ac->dense_pair);
+    free(ac->dense_filter);
     smh_wm_free(ac->alt_wm);
     smh_wm_free(ac->hv_wm);
     ac->magic = 0;
@@ -438,7 +440,7 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
      * time and the host memory of the common exact plans).  A depth-cut plan forced later on such a handle
      * (smh_ac_set_scan_plan) walks its candidates down the full DFA instead -- same count. */
     if (ac->fixed_length_ok && m >= 3 && smh_wu_shiftsize_for(alphabet) && smh_alt_engine_depth == 0 &&
-        (!ac->scan_exact || ac->scan_cost > SMH_AC_ALT_ENGINE_COST)) {
+        !ac->scan_dense && (!ac->scan_exact || ac->scan_cost > SMH_AC_ALT_ENGINE_COST)) {
         ++smh_alt_engine_depth;
         /* the caller's arrays may have been adopted (and shrunk in place) in step 6: read the handle's copy */
         const int *tsrc = ac->g_transition ? ac->g_transition : trans;
@@ -685,17 +687,50 @@ static double deep_rate(const struct smh_ac *ac, int D)
     return r > 1.0 ? 1.0 : r;
 }
 
+/* dense plan tables: walk the full DFA over every m-symbol string (4^m <= 65536 of them) and note the accepting ones */
+#define SMH_AC_DENSE_COST 0.70 /* 0.20 ms/GiB measured for the pair lookup, against 0.289 for the exact stride-1 scan */
+static int dense_build(struct smh_ac *ac)
+{
+    const int m = ac->m;
+    if (ac->alphabet != 4 || m < 3 || m > 8 || !ac->fixed_length_ok) return SMH_EUNSUP;
+    if (ac->dense_pair) return SMH_OK;
+    const uint32_t n_codes = 1u << (2 * m), mask = ac->entry_bytes == 2 ? 0x7FFFu : 0x7FFFFFFFu;
+    uint32_t *filter = (uint32_t *)calloc(n_codes / 32u ? n_codes / 32u : 1u, sizeof(uint32_t));
+    uint32_t *pair = (uint32_t *)calloc(16384u, sizeof(uint32_t));
+    if (!filter || !pair) { free(filter); free(pair); return SMH_ENOMEM; }
+    for (uint32_t code = 0; code < n_codes; ++code) { /* oldest symbol in the highest bits */
+        uint32_t row = 0, e = 0;
+        for (int i = m - 1; i >= 0; --i) {
+            e = entry_get(ac->table, ac->entry_bytes, (size_t)row * 4u + ((code >> (2 * i)) & 3u));
+            row = e & mask;
+        }
+        if (e >> (ac->entry_bytes == 2 ? 15 : 31)) filter[code >> 5] |= 1u << (code & 31u);
+    }
+    /* the same bits indexed by the code i of NINE symbols: the seven oldest select the dword, the newest pair two adjacent
+     * bits in it -- "the m symbols ending at the 8th / at the 9th symbol are accepted" (smh_internal.h smh_wm.pair_table) */
+    for (uint32_t i = 0; i < (1u << 18); ++i) {
+        const uint32_t c1 = (i >> 2) & (n_codes - 1u), c2 = i & (n_codes - 1u), pr = i & 15u;
+        if ((filter[c1 >> 5] >> (c1 & 31u)) & 1u) pair[i >> 4] |= 1u << (2u * pr);
+        if ((filter[c2 >> 5] >> (c2 & 31u)) & 1u) pair[i >> 4] |= 1u << (2u * pr + 1u);
+    }
+    ac->dense_filter = filter;
+    ac->dense_pair = pair;
+    return SMH_OK;
+}
+
 static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth, int allow_hybrid)
 {
     const int A = ac->alphabet;
     const int kmax = ac->m < SMH_AC_MAX_SCAN_DEPTH ? ac->m : SMH_AC_MAX_SCAN_DEPTH;
+    const int no_dense = force_depth == -1; /* internal: the ordinary plan beside a dense one */
+    if (no_dense) force_depth = 0;
     const int force_k = force_depth & 0xFF, force_d = (force_depth >> 8) & 0xFF;
     int best_k[4] = {0, 0, 0, 0}, best_d = 0;
     double best_cost = 1e30;
     int best_s = 0;
     for (int s = 1; s <= 2; ++s) {
         if (s == 2 && A != 4) continue;
-        if (force_stride && s != force_stride) continue;
+        if (force_stride && force_stride != 4 && s != force_stride) continue;
         for (int K = kmax; K >= 1; --K) {
             if (force_k && K != force_k) continue;
             uint64_t rk = ac->depth_first[K + 1 <= ac->max_depth + 1 ? K + 1 : ac->max_depth + 1];
@@ -718,7 +753,7 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
      * (1000 patterns, m = 16 / 32, 1 GiB): the common step costs what a plain stride-2 step costs
      * (0.21 ms/GiB), a step in which ANY lane of the wave sits in a compact row 3.2-3.5 x that (two more
      * dependent LDS round trips and the item arithmetic), recording candidates as bits 0.04 ms/GiB */
-    if (allow_hybrid && A == 4 && (!force_stride || force_stride == 3)) {
+    if (allow_hybrid && A == 4 && (!force_stride || force_stride == 3 || force_stride == 4)) {
         for (int K = kmax; K >= 4; --K) {
             if (force_k && K != force_k) continue;
             if (K < ac->m && K - 1 > 32) continue; /* the candidate-bit recording covers a 32-byte halo */
@@ -738,6 +773,24 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 break;
             }
         }
+    }
+    /* dense plan: the complete 4^m-state automaton as a bit set (see smh_internal.h); stride code 4 forces it */
+    int dense = 0;
+    if (!no_dense && A == 4 && ac->m >= 3 && ac->m <= 8 && (force_stride == 4 || (!force_stride && !force_k && SMH_AC_DENSE_COST < best_cost))) {
+        const int rc = dense_build(ac);
+        if (rc == SMH_ENOMEM) { smh_set_error("smh_ac_plan_scan: out of memory"); return rc; }
+        if (rc == SMH_OK) dense = 1;
+    }
+    if (force_stride == 4 && !dense) {
+        smh_set_error("smh_ac_plan_scan: the dense plan needs alphabet 4 and 3 <= m <= 8");
+        return SMH_EUNSUP;
+    }
+    if (dense && force_stride == 4) { /* the tables of an ordinary plan are still built: slow paths and positions fall back on them */
+        const int rc = plan_scan(ac, lds_budget, 0, -1, allow_hybrid);
+        if (rc != SMH_OK) return rc;
+        ac->scan_dense = 1;
+        ac->scan_cost = SMH_AC_DENSE_COST;
+        return SMH_OK;
     }
     if (!best_s) {
         smh_set_error("smh_ac_plan_scan: no depth-K automaton fits %u bytes of LDS (alphabet %d)", lds_budget, A);
@@ -797,7 +850,8 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
     ac->scan_exact = K >= ac->m;
     ac->scan_rows = rk;
     ac->scan_candidate_rate = candidate_rate(ac, K);
-    ac->scan_cost = best_cost;
+    ac->scan_cost = dense ? SMH_AC_DENSE_COST : best_cost;
+    ac->scan_dense = dense;
     ac->trunc1_table = t1;
     ac->trunc1_entry_bytes = eb1;
     ac->trunc1_bytes = (uint64_t)n1 * eb1;
@@ -883,12 +937,13 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_exact = (uint32_t)ac->scan_exact;
     out->scan_full_rows = ac->scan_full_rows;
     out->scan_engine = ac->alt_wm && !ac->alt_off ? SMH_ALGO_WM : SMH_ALGO_AC;
+    out->scan_dense = (uint32_t)ac->scan_dense;
     return SMH_OK;
 }
 
 int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
 {
-    if (!ac || ac->magic != SMH_MAGIC_AC || stride < 0 || stride > 3 || depth < 0) {
+    if (!ac || ac->magic != SMH_MAGIC_AC || stride < 0 || stride > 4 || depth < 0) {
         smh_set_error("smh_ac_set_scan_plan: bad arguments");
         return SMH_EINVAL;
     }

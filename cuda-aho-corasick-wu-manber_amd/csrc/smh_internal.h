@@ -73,6 +73,16 @@ struct smh_ac {
     uint32_t scan_bytes;  /* padded to 16 */
     double scan_candidate_rate; /* expected candidates per text byte on uniform text (0 when exact) */
     double scan_cost;     /* plan cost model's estimate, 1.0 = an exact stride-1 scan (ac_host.c) */
+    /* dense plan (alphabet 4, 3 <= m <= 8; stride code 4): the automaton completed to EVERY string of up to m symbols -- its
+     * state is then the last m text symbols themselves, kept as a rolling code in a register, and the transition
+     * function degenerates to "is this code accepting?" -- one bit per m-symbol string.  dense_pair is that bit set laid
+     * out for two END columns per lookup (index = the code of nine symbols; as smh_wm.pair_table), dense_filter the plain
+     * one (2^(2m) bits) for the bounds-checked path.  Chosen when the stride-2 image of the ordinary automaton does not
+     * fit LDS: every level the patterns fill completely (8000 random 8-mers: all 4^d states down to d = 6) costs rows
+     * there and nothing here. */
+    int scan_dense;
+    uint32_t *dense_pair;   /* 16384 dwords = 64 KiB */
+    uint32_t *dense_filter; /* max(1, 4^m / 32) dwords */
     struct smh_wm *alt_wm; /* suffix-filter engine for sets whose best automaton plan is verify-bound, else NULL */
     int alt_off;          /* a scan plan was forced: scans use the automaton kernels regardless */
     struct smh_wm *hv_wm; /* verify table + patterns for the automaton kernels' verify stage (hash the window, probe), else NULL */

@@ -39,6 +39,8 @@ struct smh_ac_dev {
     uint64_t *d_queue;
     uint32_t *d_depth_first;
     smh_ac_cold_ctx *d_cold; /* what the kernels' rare paths read (ac_lane.h), pointers into this set and the hv handle's */
+    uint32_t *d_dense_pair;   /* dense plan (smh_internal.h): 64 KiB pair bit set, and the plain 4^m-bit set */
+    uint32_t *d_dense_filter;
     int32_t *d_transition;
     uint32_t *d_supply;
     uint32_t *d_final;
@@ -325,6 +327,8 @@ static void ac_dev_free_one(smh_ac_dev *dev)
     (void)hipFree(dev->d_queue);
     (void)hipFree(dev->d_depth_first);
     (void)hipFree(dev->d_cold);
+    (void)hipFree(dev->d_dense_pair);
+    (void)hipFree(dev->d_dense_filter);
     (void)hipFree(dev->d_transition);
     (void)hipFree(dev->d_supply);
     (void)hipFree(dev->d_final);
@@ -353,6 +357,11 @@ static int ac_ensure_device(struct smh_ac *ac, smh_ac_dev **out)
             d->d_trunc1 = d->d_scan;
         } else if ((rc = upload(&d->d_trunc1, ac->trunc1_table, (size_t)ac->trunc1_bytes, 256 * 4)) != SMH_OK) {
             return rc;
+        }
+        if (ac->scan_dense) {
+            const size_t fbytes = ((size_t)1 << (2 * ac->m)) / 8;
+            if ((rc = upload((void **)&d->d_dense_pair, ac->dense_pair, 65536, 0)) != SMH_OK) return rc;
+            if ((rc = upload((void **)&d->d_dense_filter, ac->dense_filter, fbytes < 4 ? 4 : fbytes, 0)) != SMH_OK) return rc;
         }
         if (!ac->scan_exact) {
             const size_t qbytes = (size_t)smh_ac_max_blocks(n_cus) * (SMH_BLOCK_THREADS / 64) * SMH_AC_QCAP * 8;
@@ -486,6 +495,13 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         L.d_transition = dv->d_transition; L.d_supply = dv->d_supply; L.d_final = dv->d_final;
         L.d_count = d_count; L.n_cus = n_cus;
         HIP_TRY(smh_launch_ac_table(L, (hipStream_t)stream));
+    } else if (variant == SMH_VARIANT_TUNED && ac->scan_dense) {
+        /* the dense plan: the rolling code of the last m symbols IS the state; two END columns per lookup of the accepting-
+         * set bits (the lane code of wm_pair_kernel: smh_wm_pair_thread in wm_lane.h, here fed with the automaton's bits) */
+        smh_wm_launch W = {};
+        W.d_text = d_text; W.n = n; W.m = ac->m; W.bits = 2; W.block_symbols = ac->m; W.filter_log2 = 2 * ac->m; W.filter_exact = 1;
+        W.d_filter = dv->d_dense_filter; W.d_pair = dv->d_dense_pair; W.d_count = d_count; W.n_cus = n_cus;
+        HIP_TRY(smh_launch_wm_block(W, (hipStream_t)stream));
     } else if (variant == SMH_VARIANT_TUNED) {
         smh_ac_launch L = {};
         L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
@@ -527,6 +543,14 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    if (ac->scan_dense && ((uintptr_t)d_text & 15u) == 0) {
+        smh_wm_launch W = {};
+        W.d_text = d_text; W.n = n; W.m = ac->m; W.bits = 2; W.block_symbols = ac->m; W.filter_log2 = 2 * ac->m; W.filter_exact = 1;
+        W.d_filter = dv->d_dense_filter; W.d_pair = dv->d_dense_pair; W.d_count = NULL; W.n_cus = n_cus;
+        W.po.out = d_positions; W.po.capacity = capacity; W.po.cursor = d_cursor;
+        HIP_TRY(smh_launch_wm_block_positions(W, (hipStream_t)stream));
+        return SMH_OK;
+    }
     smh_ac_verify_ctx V = {};
     V.text = d_text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;
     if ((rc = ac_fill_cold(ac, dv, V)) != SMH_OK) return rc;

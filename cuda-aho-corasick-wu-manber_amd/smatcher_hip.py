@@ -40,7 +40,7 @@ class AcInfo(C.Structure):
                 ("finals", C.c_uint32), ("rows", C.c_uint32), ("entry_bytes", C.c_uint32),
                 ("lds_rows", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_bytes", C.c_uint64),
                 ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
-                ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("reserved", C.c_uint32)]
+                ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32)]
 
 
 class WmInfo(C.Structure):

@@ -112,7 +112,9 @@ typedef struct smh_ac_info {
                               * smh_ac_scan / smh_ac_positions run the suffix-filter kernels on the same patterns
                               * -- same count, several times faster.  smh_ac_set_scan_plan with a forced stride or
                               * depth switches back to the automaton kernels; (0, 0) restores the choice. */
-    uint32_t reserved;
+    uint32_t scan_dense;     /* 1: the dense plan scans (alphabet 4, m <= 8): the automaton completed to all 4^m strings, its
+                              * state the rolling code of the last m symbols, acceptance one bit per string in LDS
+                              * (two END columns per lookup); scan_stride / scan_depth describe the ordinary plan kept beside it */
 } smh_ac_info;
 
 /* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
@@ -121,8 +123,8 @@ smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *s
 /* from patterns: builds the reference tables internally, then compiles them */
 smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
 int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out);
-/* tuning / test knob: rebuild the LDS scan automaton with a forced stride (1 or 2, 3 = hybrid stride 2;
- * 0 = choose) and a forced depth K (1..min(m,65); 0 = the deepest that fits; for the hybrid image
+/* tuning / test knob: rebuild the LDS scan automaton with a forced stride (1 or 2, 3 = hybrid stride 2,
+ * 4 = the dense plan of smh_ac_info.scan_dense; 0 = choose) and a forced depth K (1..min(m,65); 0 = the deepest that fits; for the hybrid image
  * bits 8..15 may force the depth D of its full rows).  SMH_EUNSUP when it does not fit LDS. */
 int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth);
 /* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).

@@ -187,6 +187,10 @@ extern "C" uint64_t emu_ac_scan(const smh_ac *ac, const uint8_t *text_in, uint64
             for (uint64_t t = 0; t < nthreads; ++t)
                 total += smh_ac_table_thread(t, nthreads, text, n, ac->m, ac->g_transition, ac->g_supply,
                                              ac->g_final, ac->alphabet);
+        } else if (ac->scan_dense) { /* the dense plan: as smh_ac_scan, the pair lane code over the automaton's accepting bits */
+            const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
+            for (uint64_t t = 0; t < nthreads; ++t)
+                total += smh_wm_pair_thread<SMH_PREFETCH != 0>(t, smh_sched_static(t >> 6, nthreads >> 6), text, n, ac->m, ac->dense_pair, ac->dense_filter);
         } else {
             smh_ac_verify_ctx V = {};
             V.text = text; V.n = n; V.m = ac->m; V.K = ac->scan_depth; V.sigma = ac->alphabet;

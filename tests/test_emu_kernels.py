@@ -151,3 +151,33 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
     total, pos = E.wm_positions(wm, text, want + 8, 2)
     assert total == want and len(set(pos.tolist())) == want
 
+
+
+@pytest.mark.parametrize("m,p", [(8, 8000), (8, 20000), (6, 3000), (3, 40), (5, 900), (8, 3)])
+def test_dense_plan(m, p):
+    """The dense plan of the automaton engine (alphabet 4, m <= 8: state = the last m symbols, acceptance one bit per
+    string, ac_host.c dense_build): chosen by itself where the stride-2 image does not fit, forced (stride code 4) on the
+    others; the accepting bits come from walking the compiled DFA, so duplicates and dense sets are the interesting cases."""
+    sigma, n = 4, 70_001
+    rng = np.random.RandomState(m * 1000 + p)
+    pat = rng.randint(0, sigma, size=m * p).astype(np.uint8)
+    pat[:m] = pat[m:2 * m] if p > 1 else pat[:m]  # a duplicate
+    text = rng.randint(0, sigma, size=n).astype(np.uint8)
+    text[:m] = pat[:m]
+    text[n - m:] = pat[-m:]
+    want = O.count_bruteforce(pat, m, p, text)
+    assert want >= 2
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    chosen = ac.info().scan_dense
+    assert chosen == (1 if (m, p) in ((8, 8000), (8, 20000)) else chosen)  # the big 8-mer sets take it by themselves
+    assert E.ac_scan(ac, text, 0, 2) == want
+    ac.set_scan_plan(4, 0)
+    assert ac.info().scan_dense == 1 and ac.info().scan_engine == S.ALGO_AC
+    for blocks in (1, 3):
+        assert E.ac_scan(ac, text, 0, blocks) == want
+    ac.set_scan_plan(1, 0)
+    assert ac.info().scan_dense == 0 and E.ac_scan(ac, text, 0, 1) == want
+    ac.set_scan_plan(0, 0)
+    assert ac.info().scan_dense == chosen
+    with pytest.raises(S.SmhError):
+        S.AcAutomaton.from_patterns(rng.randint(0, sigma, size=9 * 10).astype(np.uint8), 9, 10, sigma).set_scan_plan(4, 0)

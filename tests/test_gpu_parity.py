@@ -265,6 +265,37 @@ def test_hybrid_kernel_instantiations_agree(tune, monkeypatch):
         assert ran >= 2
 
 
+@pytest.mark.parametrize("m,p", [(8, 8000), (8, 300), (5, 700), (3, 50)])
+def test_dense_plan_on_the_gpu(m, p):
+    """The dense plan of the automaton engine (smh_ac_info.scan_dense): counts and positions against the oracle, chosen
+    (8000 8-mers) and forced; the ordinary plans of the same handle must agree."""
+    import torch
+    sigma, n = 4, (6 << 20) + 4321
+    text = O.gen_text(n, 91, sigma)
+    pat = O.gen_patterns_mixed(m, p, 400 + m, sigma, 91, n, 2)
+    want, _ = O.oracle_ac(pat, m, p, sigma, text)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    if (m, p) == (8, 8000):
+        assert ac.info().scan_dense == 1 and ac.info().scan_engine == S.ALGO_AC
+    assert ac.count_host(text, S.VARIANT_TUNED)[0] == want
+    ac.set_scan_plan(4, 0)
+    assert ac.info().scan_dense == 1
+    assert ac.count_host(text, S.VARIANT_TUNED)[0] == want
+    dev = torch.device("cuda", 0)
+    dtext = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    dtext[:n] = torch.from_numpy(text).to(dev)
+    cap = want + 16
+    out = torch.zeros(cap, dtype=torch.int64, device=dev)
+    cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    ac.positions_device(dtext.data_ptr(), n, out.data_ptr(), cap, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cur.item()) == want
+    ref = O.positions_bruteforce(pat, m, p, text)  # END columns
+    assert len(ref) == want and np.array_equal(np.sort(out[:want].cpu().numpy()), np.sort(ref))
+    ac.set_scan_plan(1, 0)
+    assert ac.info().scan_dense == 0 and ac.count_host(text, S.VARIANT_TUNED)[0] == want
+
+
 def test_baseline_size_properties():
     """BASELINE configs[1]/[2] size: 1 GiB DNA text in HBM.  The oracle cannot scan that in seconds,
     so: (a) oracle on a 32 MiB slice, (b) AC == WM on the full text, (c) sum over the 8 byte-range
