@@ -466,13 +466,12 @@ def main():
         if args.share_device:
             out["rehearsal"] = "--share-device: every rank on device 0, process group over gloo; rates are not N-GPU rates"
 
-    # ---- what a pure streaming read of the same 1 GiB reaches on this device, same run: the best of the
-    #      grid-stride probe and four scan-shaped ones (wave-chunks from the LDS counter, 16 / 32 waves per CU, plain /
-    #      non-temporal loads)
+    # ---- what a pure streaming read of the same 1 GiB reaches on this device, same run: the best of five
+    #      read-only kernels (tools/readsweep.hip picked their shapes: about 32 KiB in flight per CU streams best)
     if rank == 0:
         probe = torch.zeros(1, dtype=torch.int64, device=dev)
-        names = ["grid-stride, 16-byte loads", "4 KiB wave-chunks, 16 waves/CU", "4 KiB wave-chunks, 32 waves/CU",
-                 "4 KiB wave-chunks, 16 waves/CU, non-temporal loads", "4 KiB wave-chunks, 32 waves/CU, non-temporal loads"]
+        names = ["grid-stride, 16-byte loads, 32 waves/CU", "4 KiB wave-chunks, 8 waves/CU", "grid-stride, 8 waves/CU",
+                 "4 KiB wave-chunks, two in flight, 4 waves/CU", "4 KiB wave-chunks from the LDS counter, 16 waves/CU (the scan kernels' shape)"]
         variants = {}
         for v, nm in enumerate(names):
             def launch(v=v):

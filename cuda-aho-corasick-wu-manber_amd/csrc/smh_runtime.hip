@@ -245,15 +245,50 @@ extern "C" int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t
     return SMH_OK;
 }
 
-/* The same measurement with the scan kernels' access shape: contiguous 4 KiB wave-chunks taken from the workgroup's
- * LDS counter (lane_common.h smh_chunk_sched), a lane's 64-byte segment as four 16-byte loads, 16 or 32 waves per
- * CU (dynamic LDS sized so that one or two workgroups fit), plain or non-temporal loads.  The grid-stride probe
- * above was beaten by a real scan kernel (5.8 against 6.3 TB/s): a probe that is to serve as "what streaming
- * reaches here" must at least stream the way the fastest scan does.  smh_stream_read_probe_variant(v):
- *   0 grid-stride (above)   1 chunks, 16 waves/CU   2 chunks, 32 waves/CU   3 = 1 non-temporal   4 = 2 non-temporal */
-template <bool NT>
-__global__ __launch_bounds__(1024) void smh_stream_chunk_kernel(const uint8_t *__restrict__ text, uint64_t n_chunks,
-                                                                unsigned long long *out)
+/* More shapes of the same measurement.  The grid-stride probe above was beaten by real scan kernels (5.8 against 6.3
+ * TB/s in round 2): "what a streaming read reaches here" depends on how much is in flight per CU.  tools/readsweep.hip
+ * swept waves per CU x loads in flight x access shape on this device (gpurun_out/r03_b/readsweep.log): the best pure
+ * reads keep about 32 KiB in flight per CU -- 8 waves x 4 KiB -- and reach 6.4-6.5 TB/s; 16 and 32 waves per CU lose
+ * 5-15 %, non-temporal loads 40 %.  smh_stream_read_probe_variant(v):
+ *   0  grid-stride, 16-byte loads, 4 in flight, 32 waves/CU (the round-2 probe)
+ *   1  4 KiB wave-chunks (a lane's 64-byte segment as four 16-byte loads: the scan kernels' shape), dealt round-robin
+ *      to 8 waves/CU (256 threads x 2 workgroups)
+ *   2  grid-stride, 4 loads in flight, 8 waves/CU (512 threads x 1)
+ *   3  4 KiB wave-chunks, two chunks in flight per wave, 4 waves/CU
+ *   4  4 KiB wave-chunks taken from the workgroup's LDS counter at 16 waves/CU -- exactly how the scan kernels run
+ * bench.py reports the best of them. */
+typedef uint32_t smh_v4u __attribute__((ext_vector_type(4)));
+template <int C>
+__global__ __launch_bounds__(1024) void smh_stream_chunk_kernel(const uint8_t *__restrict__ text, uint64_t n_chunks, unsigned long long *out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t acc = 0;
+    uint64_t k = wave;
+    for (; k + (uint64_t)(C - 1) * nw < n_chunks; k += (uint64_t)C * nw) {
+        smh_v4u v[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[c][q] = *reinterpret_cast<const smh_v4u *>(text + (k + (uint64_t)c * nw) * 4096u + lane * 64u + 16u * q);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc ^= v[c][q].x ^ v[c][q].y ^ v[c][q].z ^ v[c][q].w;
+    }
+    for (; k < n_chunks; k += nw) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const smh_v4u t = *reinterpret_cast<const smh_v4u *>(text + k * 4096u + lane * 64u + 16u * q);
+            acc ^= t.x ^ t.y ^ t.z ^ t.w;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_down(acc, off, 64);
+    if (lane == 0 && acc) atomicXor(out, (unsigned long long)acc);
+}
+
+__global__ __launch_bounds__(1024) void smh_stream_sched_kernel(const uint8_t *__restrict__ text, uint64_t n_chunks, unsigned long long *out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char probe_lds[];
     const smh_chunk_sched S = smh_sched_init(probe_lds, 0);
@@ -261,11 +296,10 @@ __global__ __launch_bounds__(1024) void smh_stream_chunk_kernel(const uint8_t *_
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t acc = 0;
     for (uint64_t k = S.take(n_chunks); k < n_chunks; k = S.take(n_chunks)) {
-        typedef uint32_t smh_v4u __attribute__((ext_vector_type(4)));
         const smh_v4u *p = reinterpret_cast<const smh_v4u *>(text + k * 4096u + (uint64_t)lane * 64u);
         smh_v4u v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = NT ? __builtin_nontemporal_load(p + q) : p[q];
+        for (int q = 0; q < 4; ++q) v[q] = p[q];
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
     }
@@ -283,17 +317,22 @@ extern "C" int smh_stream_read_probe_variant(const void *d_buf, uint64_t bytes, 
     }
     int n_cus = 0, rc;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
-    const bool nt = variant >= 3;
-    const int per_cu = (variant == 1 || variant == 3) ? 1 : 2;
-    const uint32_t lds = per_cu == 1 ? 96u * 1024u : 48u * 1024u; /* what limits the scan kernels too: their table */
-    static smh_attr_cache cache_plain, cache_nt;
-    int q = 0;
-    if (nt) HIP_TRY(cache_nt.get(smh_stream_chunk_kernel<true>, lds, 1024, &q));
-    else HIP_TRY(cache_plain.get(smh_stream_chunk_kernel<false>, lds, 1024, &q));
-    if (q < per_cu) { smh_set_error("smh_stream_read_probe_variant: %d workgroup(s) per CU fit, %d wanted", q, per_cu); return SMH_EUNSUP; }
-    const dim3 grid((unsigned)(n_cus * per_cu));
-    if (nt) hipLaunchKernelGGL(smh_stream_chunk_kernel<true>, grid, dim3(1024), lds, (hipStream_t)stream, (const uint8_t *)d_buf, bytes / 4096u, (unsigned long long *)d_out);
-    else hipLaunchKernelGGL(smh_stream_chunk_kernel<false>, grid, dim3(1024), lds, (hipStream_t)stream, (const uint8_t *)d_buf, bytes / 4096u, (unsigned long long *)d_out);
+    const uint8_t *t = (const uint8_t *)d_buf;
+    unsigned long long *o = (unsigned long long *)d_out;
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 1) {
+        hipLaunchKernelGGL(smh_stream_chunk_kernel<1>, dim3((unsigned)n_cus * 2u), dim3(256), 0, st, t, bytes / 4096u, o);
+    } else if (variant == 2) {
+        hipLaunchKernelGGL(smh_stream_read_kernel, dim3((unsigned)n_cus), dim3(512), 0, st, (const uint4 *)d_buf, bytes / 16u, o);
+    } else if (variant == 3) {
+        hipLaunchKernelGGL(smh_stream_chunk_kernel<2>, dim3((unsigned)n_cus), dim3(256), 0, st, t, bytes / 4096u, o);
+    } else {
+        const uint32_t lds = 96u * 1024u; /* one workgroup per CU, as a scan kernel whose table fills LDS */
+        static smh_attr_cache cache;
+        int q = 0;
+        HIP_TRY(cache.get(smh_stream_sched_kernel, lds, 1024, &q));
+        hipLaunchKernelGGL(smh_stream_sched_kernel, dim3((unsigned)n_cus), dim3(1024), lds, st, t, bytes / 4096u, o);
+    }
     HIP_TRY(hipGetLastError());
     return SMH_OK;
 }

@@ -65,9 +65,10 @@ int smh_stream_synchronize(void *stream);
  * words into *d_out (device uint64) -- so that a bench can report what a read-only kernel reaches on
  * the same buffer in the same run.  d_buf must be 16-byte aligned. */
 int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t *d_out, void *stream);
-/* the same with the scan kernels' access shape (4 KiB wave-chunks from an LDS counter, four 16-byte loads per lane):
- * variant 0 = the grid-stride kernel above, 1 / 2 = chunks at 16 / 32 waves per CU, 3 / 4 = the same with
- * non-temporal loads.  A bench reports the best of them as "what a streaming read reaches on this device". */
+/* other shapes of the same read (csrc/smh_runtime.hip, tools/readsweep.hip): variant 0 = the kernel above, 1 = 4 KiB
+ * wave-chunks at 8 waves per CU, 2 = grid-stride at 8 waves per CU, 3 = two wave-chunks in flight at 4 waves per CU,
+ * 4 = wave-chunks from the LDS counter at 16 waves per CU (how the scan kernels run).  A bench reports the best of
+ * them as "what a streaming read reaches on this device". */
 int smh_stream_read_probe_variant(const void *d_buf, uint64_t bytes, uint64_t *d_out, void *stream, int variant);
 
 /* ---- synthetic corpus (clean-room stand-in for the reference's missing helper.c:

@@ -140,7 +140,7 @@ def test_stream_read_probe_variants_read_every_byte():
     """the five read-only probes (bench.py `stream_read`) XOR all dwords of the buffer: same value, the host's"""
     import torch
     dev = torch.device("cuda", 0)
-    n = 96 << 20  # a multiple of the 4 KiB wave-chunk
+    n = (96 << 20) + 4096 * 7  # a multiple of the 4 KiB wave-chunk, not of the two-chunk stride
     buf = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev)
     want = int(np.bitwise_xor.reduce(buf.cpu().numpy().view(np.uint32)))
     out = torch.zeros(1, dtype=torch.int64, device=dev)
