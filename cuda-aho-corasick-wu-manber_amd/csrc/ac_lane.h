@@ -153,9 +153,9 @@ struct smh_ac_queue {
 SMH_LANE void smh_ac_drain(smh_ac_queue &Q, const smh_ac_verify_ctx &V)
 {
     if (Q.count == 0) return;
-    /* the entries were written by this wave with write-through (sc1) stores; wait for them,
-     * then read them back past the L1.  (Kept inline: an out-of-line drain measured 17 % slower
-     * on the m = 32 set -- the call's register save/restore lands in the scan loop.) */
+    /* the entries were written by this wave with write-through (sc1) stores; wait for them, then read them back past the
+     * L1.  (Kept inline: an out-of-line drain measured 17 % slower on the m = 32 set in round 1 and twice as slow in
+     * round 3 -- a call anywhere in the kernel puts the text registers on the stack.) */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t lane = threadIdx.x & 63u;
     if (V.pos.cursor) {
@@ -202,6 +202,10 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
     }
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (cond) {
+        /* (Round 3 measured what this one store costs the scan: 5-7 % -- 0.200 ms/GiB with it, vector or atomic, 0.188
+         * with the very same code and the store left out; on gfx9 vector stores share the vmcnt counter with the loads.
+         * Scalar stores (s_store_dwordx2, tools/sstore_probe.hip) would avoid that but their write-back is not ordered by
+         * any counter the reader can wait on; not used.) */
         const uint64_t ent = pos | ((uint64_t)(row | (kind << 22)) << 40);
         __hip_atomic_store(Q.slots + Q.count + before, ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
