@@ -95,12 +95,14 @@ def measured_traffic(info):
     halo = info.scan_depth - 1
     hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
     entry = "unsigned short" if (info.scan_stride == 2 or info.lds_rows <= 32768) else "unsigned int"
-    stride = 3 if info.scan_full_rows else info.scan_stride  # template value of the hybrid image
-    prefix = "ac_dfa_kernel<%s, 4, %d, %d, %s," % (entry, stride, hc, "true" if info.scan_exact else "false")
-    for name, k in rec.get("kernels", {}).items():
-        if name.startswith(prefix) and not name.endswith("true>"):  # "..., true>" = the positions-mode instance
-            return k["hbm_bytes"], "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, build %s, %s)" % (
-                have, rec.get("profile", "?"))
+    # template value of the stride: the hybrid image runs as 4 (full-row lookup left out of range, device probed) or 3 (clamped)
+    strides = (4, 3) if info.scan_full_rows else (info.scan_stride,)
+    for stride in strides:
+        prefix = "ac_dfa_kernel<%s, 4, %d, %d, %s," % (entry, stride, hc, "true" if info.scan_exact else "false")
+        for name, k in rec.get("kernels", {}).items():
+            if name.startswith(prefix) and ", true, 1024>" not in name:  # "..., true, 1024>" = the positions-mode instance
+                return k["hbm_bytes"], "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, build %s, %s)" % (
+                    have, rec.get("profile", "?"))
     return None, "no counter pass for " + prefix
 
 
