@@ -248,8 +248,10 @@ extern "C" int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t
 /* More shapes of the same measurement.  The grid-stride probe above was beaten by real scan kernels (5.8 against 6.3
  * TB/s in round 2): "what a streaming read reaches here" depends on how much is in flight per CU.  tools/readsweep.hip
  * swept waves per CU x loads in flight x access shape on this device (gpurun_out/r03_b/readsweep.log): the best pure
- * reads keep about 32 KiB in flight per CU -- 8 waves x 4 KiB -- and reach 6.4-6.5 TB/s; 16 and 32 waves per CU lose
- * 5-15 %, non-temporal loads 40 %.  smh_stream_read_probe_variant(v):
+ * reads keep about 32 KiB in flight per CU -- 8 waves x 4 KiB -- and reach 6.4-6.5 TB/s; 32 waves per CU lose 5-10 %,
+ * non-temporal loads 40 %.  Every probe adds its result with ONE atomic per workgroup: the first 16-wave probes of round 3
+ * used one per wave and read "5.5 TB/s" -- 25 us of same-address atomics at the end; with the reduction they read 6.43.
+ * smh_stream_read_probe_variant(v):
  *   0  grid-stride, 16-byte loads, 4 in flight, 32 waves/CU (the round-2 probe)
  *   1  4 KiB wave-chunks (a lane's 64-byte segment as four 16-byte loads: the scan kernels' shape), dealt round-robin
  *      to 8 waves/CU (256 threads x 2 workgroups)
@@ -258,6 +260,20 @@ extern "C" int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t
  *   4  4 KiB wave-chunks taken from the workgroup's LDS counter at 16 waves/CU -- exactly how the scan kernels run
  * bench.py reports the best of them. */
 typedef uint32_t smh_v4u __attribute__((ext_vector_type(4)));
+/* XOR of a workgroup's values into *out with ONE atomic: one per wave is 4096 same-address atomics at ~12 ns each when the
+ * waves finish together -- a 25 us tail on a 170 us probe, which is what made the 16-wave probes of this file look slow */
+__device__ __forceinline__ void smh_probe_block_xor(uint32_t acc, unsigned long long *out, uint32_t *part /* 16 words of LDS */)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63u) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t v = 0;
+        for (unsigned w = 0; w < (blockDim.x >> 6); ++w) v ^= part[w];
+        if (v) atomicXor(out, (unsigned long long)v);
+    }
+}
 template <int C>
 __global__ __launch_bounds__(1024) void smh_stream_chunk_kernel(const uint8_t *__restrict__ text, uint64_t n_chunks, unsigned long long *out)
 {
@@ -283,9 +299,8 @@ __global__ __launch_bounds__(1024) void smh_stream_chunk_kernel(const uint8_t *_
             acc ^= t.x ^ t.y ^ t.z ^ t.w;
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_down(acc, off, 64);
-    if (lane == 0 && acc) atomicXor(out, (unsigned long long)acc);
+    __shared__ uint32_t probe_part[16];
+    smh_probe_block_xor(acc, out, probe_part);
 }
 
 __global__ __launch_bounds__(1024) void smh_stream_sched_kernel(const uint8_t *__restrict__ text, uint64_t n_chunks, unsigned long long *out)
@@ -303,9 +318,8 @@ __global__ __launch_bounds__(1024) void smh_stream_sched_kernel(const uint8_t *_
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc ^= __shfl_down(acc, off, 64);
-    if (lane == 0 && acc) atomicXor(out, (unsigned long long)acc);
+    __syncthreads(); /* every wave is done with the chunk counter */
+    smh_probe_block_xor(acc, out, reinterpret_cast<uint32_t *>(probe_lds + 64));
 }
 
 extern "C" int smh_stream_read_probe_variant(const void *d_buf, uint64_t bytes, uint64_t *d_out, void *stream, int variant)
