@@ -16,7 +16,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "smh_internal.h"
 #include "smh_launch.h"
@@ -113,6 +115,8 @@ static int ensure_device_set(D **head, void (*free_one)(D *), Build build, D **o
     d->device = dev;
     const int now = ++g_builds_now;
     for (int peak = g_builds_peak.load(); now > peak && !g_builds_peak.compare_exchange_weak(peak, now);) {}
+    if (const char *e = getenv("SMH_TEST_BUILD_DELAY_MS")) /* test hook: makes "two builds overlap" deterministic */
+        std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e)));
     const int rc = build(d);
     --g_builds_now;
     if (rc != SMH_OK) { free_one(d); return rc; }

@@ -97,12 +97,15 @@ def test_first_count_call_is_as_fast_as_the_tenth_after_prepare():
 
 
 @pytest.mark.gpu
-def test_table_sets_of_two_handles_are_built_side_by_side():
+def test_table_sets_of_two_handles_are_built_side_by_side(monkeypatch):
     """ensure_device_set builds outside the process-wide mutex: two host threads preparing two handles overlap
-    (smh_dev_build_peak counts the builds in flight together)."""
+    (smh_dev_build_peak counts the builds in flight together).  SMH_TEST_BUILD_DELAY_MS stretches every build by 150 ms
+    so that the overlap does not depend on scheduling luck: with the mutex held across the build the second thread
+    could not even start its own."""
     import threading
+    monkeypatch.setenv("SMH_TEST_BUILD_DELAY_MS", "150")
     n, sigma = 1 << 20, 256
-    handles = [S.WmTables.from_patterns(S.corpus_patterns(12, 60000, 11 + i, sigma, 42, n, 2), 12, 60000, sigma) for i in range(2)]
+    handles = [S.WmTables.from_patterns(S.corpus_patterns(12, 20000, 11 + i, sigma, 42, n, 2), 12, 20000, sigma) for i in range(2)]
     S.lib.smh_dev_build_peak(1)
     S.lib.smh_wm_prepare_device.argtypes = [S.C.c_void_p]
     gate = threading.Barrier(2)
@@ -111,12 +114,8 @@ def test_table_sets_of_two_handles_are_built_side_by_side():
     def work(i):
         gate.wait()
         rcs[i] = S.lib.smh_wm_prepare_device(handles[i].h)
-    for _ in range(3):  # a scheduling hiccup can serialise one attempt; the handles of a failed attempt are rebuilt
-        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        assert rcs == [0, 0]
-        if S.lib.smh_dev_build_peak(0) >= 2:
-            break
-        handles = [S.WmTables.from_patterns(S.corpus_patterns(12, 60000, 21 + i, sigma, 42, n, 2), 12, 60000, sigma) for i in range(2)]
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert rcs == [0, 0]
     assert S.lib.smh_dev_build_peak(0) >= 2
