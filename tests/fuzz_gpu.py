@@ -18,7 +18,7 @@ import smatcher_hip as S  # noqa: E402
 
 def make_case(rng):
     sigma = int(rng.choice([2, 4, 4, 4, 8, 20, 128, 256]))
-    m = int(rng.randint(3, 41))
+    m = int(rng.randint(3, 41)) if rng.rand() < 0.75 else int(rng.randint(3, 9))
     p = int(rng.choice([1, 2, 7, 50, 300, 1000, 3000] if not os.environ.get("FUZZ_BIG") else [3000, 8000, 20000]))
     n = int(rng.randint(m, 1_500_000))
     text = rng.randint(0, sigma, size=n).astype(np.uint8)
@@ -74,6 +74,8 @@ def run(cases, seed, verbose=True):
         if sigma == 4:
             plans += [(2, min(m, 33)), (2, max(1, m // 2)), (3, min(m, 33) | (1 << 8)), (3, min(m, 33) | (3 << 8)),
                       (3, max(4, m // 2) | (2 << 8)), (3, min(m, 20))]
+        if sigma == 4 and 3 <= m <= 8:
+            plans.append((4, 0))  # the dense plan: the automaton completed to all 4^m strings (smh_ac_info.scan_dense)
         for stride, depth in plans:
             try:
                 ac.set_scan_plan(stride, depth)
