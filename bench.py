@@ -577,6 +577,19 @@ def main():
                 objs["m%d" % m] = obj
             if rank == 0:
                 out[label] = dict(workload=workload, text_bytes_total=n_tot, sharding="byte-range x%d, m-1 halo, counts all-reduced" % world, **objs)
+                if algo == "ac" and "stream_read" in out and not reuse:
+                    # the streaming-read ceiling for a shard of THIS size (a 4 GiB launch amortises its start and end better
+                    # than a 1 GiB one: the probes read 1-2 % faster on it, and so do the scan kernels)
+                    probe = torch.zeros(1, dtype=torch.int64, device=dev)
+                    best = None
+                    for v in range(5):
+                        def launch(v=v):
+                            rc = S.lib.smh_stream_read_probe_variant(C.c_void_p(t.data_ptr()), shard, C.c_void_p(probe.data_ptr()), C.c_void_p(stream), v)
+                            if rc != 0:
+                                raise SystemExit("stream probe %d: %s" % (v, S.lib.smh_last_error().decode()))
+                        pms = sorted(timed(launch, 4, probe))[1]
+                        best = pms if best is None or pms < best else best
+                    out["stream_read"]["shard"] = dict(bytes=shard, ms=round(best, 4), **{k: v for k, v in rate(shard, best).items() if k != "Gbit_s"})
 
         # BASELINE configs[3]: AC, 8000 patterns; 32 GB over 8 GPUs = a 4 GiB byte range per GPU
         shard_config("ac_8000_patterns", "ac", SIGMA, AC_LENGTHS, C4_PATTERNS, PAT_SEED + 3,
