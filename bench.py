@@ -58,6 +58,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd")
 sys.path.insert(0, PKG)
 
+CONDITION_MS = 25.0  # device time under load before anything is timed (bench.py `conditioned`)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 TEXT_SEED, PAT_SEED, SIGMA = 42, 7, 4
 AC_LENGTHS = (8, 16, 32)
@@ -80,11 +81,26 @@ def kernel_build_id():
     return h.hexdigest()[:12]
 
 
-def measured_traffic(info):
-    """-> (HBM bytes per launch or None, source string) for the AC kernel instance `info` (smh_ac_info) selects.
-    bench.py cannot read PMC counters itself; profiles/hbm_traffic.json is produced from this same command under
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/collect_counters.sh; FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md) and carries the build id it was taken on."""
+def ac_kernel_name(info):
+    """Prefix of the kernel instance (as rocprofv3 prints it) that serves the Aho-Corasick entry point for the handle `info`
+    (smh_ac_info) describes."""
+    if info.scan_dense:  # the dense plan: the pair lookup kernel with the automaton's accepting-bit set
+        return "wm_pair_kernel<false, 1024>"
+    if info.scan_engine == 1:  # SMH_ALGO_WM: the pair-gram filter scans (ac_host.c, end of the compile); STG = halo staged / 16
+        return "wm_gram_kernel<1, false, %d, false>" % ((1 if info.m <= 17 else 2) + (4 if info.verify_in_registers else 0))
+    halo = info.scan_depth - 1
+    hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
+    entry = "unsigned short" if (info.scan_stride == 2 or info.lds_rows <= 32768) else "unsigned int"
+    # template value of the stride: the hybrid image runs as 4 (full-row lookup left out of range, device probed) or 3 (clamped)
+    stride = 4 if info.scan_full_rows else info.scan_stride
+    return "ac_dfa_kernel<%s, 4, %d, %d, %s," % (entry, stride, hc, "true" if info.scan_exact else "false")
+
+
+def measured_traffic(info, nbytes):
+    """-> (HBM bytes per launch or None, source string) for the kernel instance that scans the set `info` (smh_ac_info)
+    describes over `nbytes` of text.  bench.py cannot read PMC counters itself; profiles/hbm_traffic.json is produced from
+    this same command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (tools/collect_counters.sh; FETCH_SIZE doubled per
+    the gfx950 correction of MI355X_MICROARCH.md) and carries the build id it was taken on."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if not os.path.exists(path):
         return None, "no committed counter pass"
@@ -92,16 +108,17 @@ def measured_traffic(info):
     have, want = rec.get("build_id"), kernel_build_id()
     if have != want:
         return None, "profiles/hbm_traffic.json was taken on build %s, this is build %s: not quoted" % (have, want)
-    halo = info.scan_depth - 1
-    hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
-    entry = "unsigned short" if (info.scan_stride == 2 or info.lds_rows <= 32768) else "unsigned int"
-    # template value of the stride: the hybrid image runs as 4 (full-row lookup left out of range, device probed) or 3 (clamped)
-    strides = (4, 3) if info.scan_full_rows else (info.scan_stride,)
-    for stride in strides:
-        prefix = "ac_dfa_kernel<%s, 4, %d, %d, %s," % (entry, stride, hc, "true" if info.scan_exact else "false")
+    prefix = ac_kernel_name(info)
+    prefixes = (prefix, prefix.replace(", 4, 4,", ", 4, 3,")) if info.scan_full_rows else (prefix,)
+    for pre in prefixes:
         for name, k in rec.get("kernels", {}).items():
-            if name.startswith(prefix) and ", true, 1024>" not in name:  # "..., true, 1024>" = the positions-mode instance
-                return k["hbm_bytes"], "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, build %s, %s)" % (
+            if name.startswith(pre) and ", true, 1024>" not in name:  # "..., true, 1024>" = the positions-mode instance
+                # an instance that also served the 4 GiB shards: the group of dispatches whose volume is this text's
+                groups = [g["hbm_read_bytes"] + k.get("hbm_write_bytes", 0) for g in k.get("by_text_size", [])] or [k["hbm_bytes"]]
+                best = min(groups, key=lambda v: abs(v - nbytes))
+                if not 0.9 * nbytes < best < 2.0 * nbytes:
+                    continue
+                return best, "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, build %s, %s)" % (
                     have, rec.get("profile", "?"))
     return None, "no counter pass for " + prefix
 
@@ -347,10 +364,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def conditioned(launch, est_ms, ms=CONDITION_MS):
+        """Launches `launch` back to back for about `ms` of device time, no synchronisation behind it.  After an idle gap
+        (a torch.cuda.synchronize(), the CPU legs) the device runs ~13 launches at its steady rate, then 3-9 ms into the
+        load every kernel takes 15-20 % longer for a few milliseconds, then settles again (profiles/r03_s/exp_sustain.log:
+        per-launch times of 60-300 back-to-back scans): a transient of the power management, not of the kernels.  The
+        driver's --warmup 5 covers the first 2.6 ms of it and put the hump inside the timed steps.  Every measurement of this
+        file therefore starts on a device that has been under the same load for CONDITION_MS."""
+        for _ in range(max(2, int(ms / max(est_ms, 1e-3)) + 1)):
+            launch()
+
     def timed(launch, reps, counter):
         """`reps` launches bracketed by events on the launch stream -> list of ms"""
+        a0, b0 = ev(), ev()
+        a0.record()
         launch()
+        b0.record()
         torch.cuda.synchronize()
+        conditioned(launch, a0.elapsed_time(b0))
         evs = [(ev(), ev()) for _ in range(reps)]
         for a, b in evs:
             counter.zero_()
@@ -388,6 +419,14 @@ def main():
                 events[i + 1].record()
         return sharded.reduce_count_async(c)
 
+    # steady state first (see `conditioned`): the step's scans without the reduce, into the scratch row, for CONDITION_MS
+    def scans_only():
+        for i, m in enumerate(AC_LENGTHS):
+            acs[m].scan_device(text.data_ptr(), shard_len[m], step_counts[-1].data_ptr() + 8 * i, S.VARIANT_TUNED, stream)
+    scans_only()
+    torch.cuda.synchronize()
+    barrier()
+    conditioned(scans_only, 0.6)
     sharded.finish([step(k) for k in range(args.warmup)])
     evs = [[ev() for _ in range(len(AC_LENGTHS) + 1)] for _ in range(args.steps)]
     barrier()
@@ -440,22 +479,27 @@ def main():
                                         per_gpu_ms=[round(r[m], 4) for r in all_kern_ms],
                                         dfa_rows=info.rows, lds_rows=info.lds_rows, lds_bytes=info.lds_bytes,
                                         scan_stride=info.scan_stride, scan_depth=info.scan_depth,
-                                        scan_exact=info.scan_exact, scan_full_rows=info.scan_full_rows,
+                                        scan_exact=info.scan_exact, scan_full_rows=info.scan_full_rows, scan_dense=info.scan_dense,
+                                        kernel_instance=ac_kernel_name(info),
                                         scan_engine="suffix-filter kernels" if info.scan_engine == S.ALGO_WM else "automaton kernels",
                                         matches=total_counts[i])
         dom = max(AC_LENGTHS, key=lambda m: mean(kern_ms[m]))
         dom_ms = mean(kern_ms[dom])
         achieved = shard_len[dom] / (dom_ms * 1e-3) / 1e9
-        traffic, traffic_source = measured_traffic(acs[dom].info())
+        traffic, traffic_source = measured_traffic(acs[dom].info(), shard_len[dom])
         roofline = dict(bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=traffic_source,
-                        kernel="ac_dfa_kernel (m=%d set)" % dom, launch_ms=round(dom_ms, 4),
+                        kernel="%s (m=%d set)" % (ac_kernel_name(acs[dom].info()).split("<")[0], dom),
+                        kernel_instance=ac_kernel_name(acs[dom].info()), launch_ms=round(dom_ms, 4),
                         algorithmic_bytes_per_launch=shard_len[dom])
         out = {
             "metric": "Gbit/s text scanned (AC and WM) at 1/2/4/8 MI355X; % HBM roofline",
             "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "conditioning": "the step's scans run back to back for %.0f ms of device time before the %d warm-up steps (and every "
+                            "side measurement's launch likewise before its timed repetitions): steady-state clocks -- 3-9 ms after an "
+                            "idle gap every kernel runs 15-20 %% slower for a few ms (profiles/r03_s/exp_sustain.log)" % (CONDITION_MS, args.warmup),
             "config": {"workload": "AC on MI355X: %d MiB synthetic DNA text per GPU resident in HBM, %d patterns per set, "
                                    "pattern lengths 8-32 as fixed-length sets m=8/16/32 (BASELINE configs[1]); "
                                    "step = 3 scans + count all-reduce" % (args.mib_per_gpu, AC_PATTERNS),
@@ -501,8 +545,10 @@ def main():
                                 equals_count=int(pcur.item()) == local_counts[AC_LENGTHS.index(m_pos)])
 
     # ---- one pattern set over every rank's shard of a sharded text: per-rank kernel time (events), counts all-reduced
-    def sharded_set(name, algo, pat, m, p, sigma, dtext, n_m, reps):
+    def sharded_set(name, algo, pat, m, p, sigma, dtext, n_m, reps, engine=None):
         handle = (S.AcAutomaton if algo == "ac" else S.WmTables).from_patterns(pat, m, p, sigma)
+        if engine is not None:
+            handle.set_scan_engine(engine)
         cnt = torch.zeros(1, dtype=torch.int64, device=dev)
         handle.scan_device(dtext.data_ptr(), n_m, cnt.data_ptr(), S.VARIANT_TUNED, stream)  # tables up, code loaded
         barrier()  # the ranks' launches run side by side, as in the job
@@ -537,6 +583,22 @@ def main():
         if rank == 0:
             out["wm_long"] = dict(workload="WM: same text, the headline's %d-pattern sets of length %s through the Wu-Manber entry "
                                            "point (q-gram shift-or filter in LDS + staged verify)" % (AC_PATTERNS, "/".join(str(m) for m in AC_LENGTHS[1:])), **wl)
+
+        # the headline sets whose depth-cut automaton plan handed the scan to the pair-gram filter (ac_host.c, end of the
+        # compile; `ac.mNN.scan_engine`), through the AUTOMATON kernels all the same: what the choice is worth, and parity
+        # of the engine that is not the default
+        aa = {}
+        for m in AC_LENGTHS:
+            if acs[m].info().scan_engine == S.ALGO_WM:
+                obj, h = sharded_set("ac_automaton.m%d" % m, "ac", pats[m], m, AC_PATTERNS, SIGMA, text, shard_len[m], args.steps,
+                                     engine=S.ALGO_AC)
+                hi = h.info()
+                aa["m%d" % m] = dict(**obj, scan_stride=hi.scan_stride, scan_depth=hi.scan_depth, scan_exact=hi.scan_exact,
+                                     scan_full_rows=hi.scan_full_rows, lds_bytes=hi.lds_bytes, kernel_instance=ac_kernel_name(hi))
+        if rank == 0 and aa:
+            out["ac_automaton"] = dict(workload="AC: the headline sets whose entry point chose the pair-gram filter, forced onto the "
+                                                "automaton kernels (smh_ac_set_scan_engine(SMH_ALGO_AC)): hybrid stride-2 image, depth-cut, "
+                                                "three chains per lane", **aa)
 
     # ---- BASELINE configs[1] read literally: ONE set of 1000 patterns whose lengths run from 8 to 32 (40 per length),
     #      through the pattern-set entry points (smh_pset_*: the reference API carries one length per run); N = 1

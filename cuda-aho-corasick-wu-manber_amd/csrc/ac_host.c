@@ -177,10 +177,20 @@ void smh_ac_host_free(struct smh_ac *ac)
     free(ac->g_final);
     free(ac->dense_pair);
     free(ac->dense_filter);
+    if (ac->hv_wm != ac->alt_wm) smh_wm_free(ac->hv_wm); /* one handle may serve both roles */
     smh_wm_free(ac->alt_wm);
-    smh_wm_free(ac->hv_wm);
     ac->magic = 0;
     free(ac);
+}
+
+/* the chosen automaton plan in ms per GiB on MI355X: the plan model's cost is in units of the exact stride-1 scan
+ * (0.289 ms/GiB) and ranks the automaton plans among themselves; the hybrid image's kernels measure 0.183 (exact, two
+ * chains + prefetch) and 0.205 (depth-cut, three chains) where the model says 0.15 / 0.17 (profiles/r03_q) */
+static double ac_plan_ms(const struct smh_ac *ac)
+{
+    double ms = ac->scan_cost * 0.289;
+    if (ac->scan_full_rows) ms += ac->scan_exact ? 0.03 : 0.035;
+    return ms;
 }
 
 /* the patterns of a fixed-length goto trie, depth-first: `count` strings of m symbols (NULL on a
@@ -449,8 +459,16 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
         if (pats) {
             struct smh_wm *w = smh_wm_compile(pats, m, (int)ac->finals, alphabet); /* NULL: stay with the automaton / the walk */
             free(pats);
-            if (w && ac->scan_cost > SMH_AC_ALT_ENGINE_COST) ac->alt_wm = w;
-            else ac->hv_wm = w;
+            /* Round 3: a depth-cut plan is a prefix filter with a verify stage behind it, and so is the pair-gram
+             * shift-or filter -- but that one covers the WHOLE pattern with its planes (next to nothing survives) and
+             * its lookups do not depend on each other, where the automaton's form one chain per lane: measured on the
+             * headline sets (1000 patterns of 16 / 32 symbols) 0.174 against 0.205 ms/GiB.  The faster estimate scans;
+             * the handle keeps serving the automaton kernels' verify stage when a plan is forced. */
+            const int verify_bound = ac->scan_cost > SMH_AC_ALT_ENGINE_COST;
+            const int filter_faster = w && !ac->scan_exact && w->gram_kind != SMH_GRAM_NONE && !w->alt_ac &&
+                                      w->scan_ms_est + SMH_AC_ALT_ENGINE_MARGIN_MS < ac_plan_ms(ac);
+            if (w && (verify_bound || filter_faster)) ac->alt_wm = w;
+            if (w && !verify_bound) ac->hv_wm = w;
         }
         --smh_alt_engine_depth;
     }
@@ -688,7 +706,10 @@ static double deep_rate(const struct smh_ac *ac, int D)
 }
 
 /* dense plan tables: walk the full DFA over every m-symbol string (4^m <= 65536 of them) and note the accepting ones */
-#define SMH_AC_DENSE_COST 0.70 /* 0.20 ms/GiB measured for the pair lookup, against 0.289 for the exact stride-1 scan */
+/* 0.164-0.166 ms/GiB measured for the pair lookup at one workgroup per CU (profiles/r03_q: configs[2] and the 8000 x 8 set)
+ * against 0.289 for the exact stride-1 scan -- and 0.178-0.187 for the exact stride-2 image (cost 0.62), which it therefore
+ * replaces as well: every 4-letter set of 3..8 symbols scans by the dense plan (until the occupancy fix it ran 0.20: 0.70) */
+#define SMH_AC_DENSE_COST 0.57
 static int dense_build(struct smh_ac *ac)
 {
     const int m = ac->m;
@@ -938,6 +959,10 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_full_rows = ac->scan_full_rows;
     out->scan_engine = ac->alt_wm && !ac->alt_off ? SMH_ALGO_WM : SMH_ALGO_AC;
     out->scan_dense = (uint32_t)ac->scan_dense;
+    if (out->scan_engine == SMH_ALGO_WM) {
+        smh_wm_info wi;
+        if (smh_wm_get_info(ac->alt_wm, &wi) == SMH_OK) out->verify_in_registers = wi.verify_in_registers;
+    }
     return SMH_OK;
 }
 
@@ -956,6 +981,20 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
     if (ac->dev) smh_ac_dev_free(ac->dev); /* device copies are rebuilt on the next scan */
     ac->dev = NULL;
     ac->alt_off = stride != 0 || depth != 0; /* a forced plan means "run the automaton kernels" */
+    return SMH_OK;
+}
+
+int smh_ac_set_scan_engine(smh_ac *ac, int engine)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC)) {
+        smh_set_error("smh_ac_set_scan_engine: bad arguments");
+        return SMH_EINVAL;
+    }
+    if (engine == SMH_ALGO_WM && !ac->alt_wm) {
+        smh_set_error("smh_ac_set_scan_engine: this set has no suffix-filter engine (its automaton plan is exact or estimated faster)");
+        return SMH_EUNSUP;
+    }
+    ac->alt_off = engine == SMH_ALGO_AC;
     return SMH_OK;
 }
 

@@ -39,6 +39,9 @@
 #ifndef SMH_PREFETCH
 #define SMH_PREFETCH 0
 #endif
+#ifndef SMH_REGV_MAX_PER_CHUNK
+#define SMH_REGV_MAX_PER_CHUNK 8.0 /* == smh_internal.h: surviving columns per 4 KiB wave-chunk up to which the pair-gram kernels verify in registers */
+#endif
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 #define SMH_LANE __device__ __forceinline__

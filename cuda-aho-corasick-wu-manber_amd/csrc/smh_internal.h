@@ -128,6 +128,10 @@ extern _Thread_local int smh_alt_engine_depth;
 #define SMH_HYB_COMPACT0 0x8000u /* hybrid stride-2 image: id of the first item slot of the compact part (== lane_common.h) */
 #endif
 #define SMH_AC_ALT_ENGINE_COST 2.5 /* above this plan cost (< ~1.4 TB/s) the suffix-filter engine scans the set */
+#ifndef SMH_REGV_MAX_PER_CHUNK
+#define SMH_REGV_MAX_PER_CHUNK 8.0 /* == lane_common.h; surviving columns per 4 KiB wave-chunk up to which the pair-gram kernels verify in registers (wm_lane.h smh_wm_regv_columns) */
+#endif
+#define SMH_AC_ALT_ENGINE_MARGIN_MS 0.01 /* a depth-cut plan hands the scan to the gram filter when that is estimated this much faster (ms/GiB) */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
 int smh_ac_prepare_device(struct smh_ac *ac); /* smh_runtime.hip: table set of the current device, no launch */

@@ -136,14 +136,24 @@ SMH_LANE uint32_t smh_wm_verify(const uint8_t *text, uint64_t e, const smh_wm_pa
  * MAXD + 1 aligned dwords a window of up to 4 * MAXD bytes can touch are requested up front (independent LDS reads,
  * one round trip instead of one per dword; the buffer is padded for the ones past the window) and mixed in as far
  * as the window reaches. */
+template <int MAXD>
+SMH_LANE uint32_t smh_wm_tag_dwords(const uint32_t (&d)[MAXD + 1], uint32_t sh, int m);
+
 template <int MAXD, typename RD>
 SMH_LANE uint32_t smh_wm_tag_staged(RD rd, uint32_t s0, int m)
 {
     const uint32_t a0 = s0 & ~3u, sh = (s0 & 3u) * 8u;
-    const int nd = (m + 3) >> 2;
     uint32_t d[MAXD + 1];
 #pragma unroll
     for (int j = 0; j <= MAXD; ++j) d[j] = rd(a0 + 4u * (uint32_t)j);
+    return smh_wm_tag_dwords<MAXD>(d, sh, m);
+}
+
+/* the hash of the m-byte window that starts `sh` bits into d[0] (d[j] = consecutive aligned dwords) */
+template <int MAXD>
+SMH_LANE uint32_t smh_wm_tag_dwords(const uint32_t (&d)[MAXD + 1], uint32_t sh, int m)
+{
+    const int nd = (m + 3) >> 2;
     uint32_t tag = 0x811C9DC5u;
 #pragma unroll
     for (int j = 0; j < MAXD; ++j) {
@@ -380,6 +390,16 @@ SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, 
     return smh_wm_probe2(text, e0, e1, tag0, tag1, P, r1);
 }
 
+/* The STG template value of the gram kernels says how a surviving column gets its window hash:
+ *   0      no staging: windows are re-read from HBM by the drain
+ *   1, 2   staged verify: the chunk is copied to LDS (16 / 32 bytes of halo), smh_wm_stage_*
+ *   5, 6   in-register verify (round 3, pair form): the lane selects the window's dwords out of its OWN text registers
+ *          and the previous lane's last 16 / 32 bytes (DPP) with a barrel of conditional moves -- no copy, no lock, no
+ *          queue, no LDS round trip; smh_wm_regv_columns */
+constexpr bool smh_stg_regv(int STG) { return STG >= 5; }
+constexpr bool smh_stg_staged(int STG) { return STG == 1 || STG == 2; }
+constexpr int smh_stg_hp(int STG) { return STG >= 5 ? STG - 4 : (STG > 0 ? STG : 1); } /* 16-byte pieces of text kept from in front of the chunk */
+
 #define SMH_WM_QCAP 128u /* END columns per wave, 1 KiB of LDS behind the filter */
 struct smh_wm_queue {
     uint64_t *slots; /* SMH_WM_QCAP entries, private to this wave (LDS on the GPU) */
@@ -396,6 +416,7 @@ struct smh_wm_queue {
     uint32_t pend_tag;
     uint64_t pend_e;
     smh_u32x4 pend_q;
+    uint32_t pend_mine;   /* in-register verify: per lane, this lane holds a pending column (there is no compaction) */
 };
 
 /* ---- staged verify: the window hash of a surviving column is computed from an ON-CHIP copy of the wave-chunk.
@@ -488,20 +509,34 @@ SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_
  * hold in w (and lane 0 the 16*STG bytes in front of it in `halo`) -- and remove them; at most 128 entries; all 64
  * lanes must call it */
 /* request the first bucket of the pending columns (call between chunks, before the next chunk's text is requested) */
+template <bool RV = false>
 SMH_LANE void smh_wm_pend_issue(smh_wm_queue &Q, const smh_wm_params &P)
 {
     if (Q.pend_n == 0 || Q.pend_loaded) return;
+    if constexpr (RV) { /* only the lanes that hold a column ask for a bucket */
+        if (Q.pend_mine) Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
+    } else {
     Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
+    }
     Q.pend_loaded = 1u;
 }
 /* decide the pending columns; all 64 lanes must call it */
+template <bool RV = false>
 SMH_LANE void smh_wm_pend_finish(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
 {
     if (Q.pend_n == 0) return;
+    if constexpr (RV) {
+        uint32_t r = 0;
+        if (Q.pend_mine) r = smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
+        Q.matches += r;
+        if (Q.po) smh_append_bits(r, Q.pend_e, *Q.po);
+        Q.pend_mine = 0u;
+    } else {
     const bool mine = (threadIdx.x & 63u) < Q.pend_n;
     const uint32_t r = smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
     Q.matches += mine ? r : 0u;
     if (Q.po) smh_append_bits(mine ? r : 0u, Q.pend_e, *Q.po);
+    }
     Q.pend_n = 0u;
     Q.pend_loaded = 0u;
 }
@@ -1077,6 +1112,113 @@ SMH_LANE uint32_t smh_wm_pair_thread(uint64_t gthread, const smh_chunk_sched &S,
     return cnt;
 }
 
+/* ---- in-register verify (STG 5 / 6; round 3).  The staged verify costs a wave ~3000 cycles per chunk that has a surviving
+ * column whatever their number -- try-lock, 4 KiB copy, queue and window reads are LDS round trips behind fifteen other
+ * waves' lookups, and prefetching the next chunk hides next to none of it (gpurun_out/r03_r/prefetch.log) -- which is
+ * what 8000 DNA patterns of 16 symbols pay at 4.4 survivors per chunk (0.26 against 0.174 ms/GiB for the bare scan).
+ * With FEW survivors the lane that found one can hash the window itself: the window lies in its own 16 text registers
+ * and the previous lane's last 4 * HP (one DPP move each), at a per-lane dword offset sd that registers cannot be
+ * indexed with -- so the MAXD + 1 dwords from sd on are brought into place by a barrel of conditional moves, one level
+ * per bit of sd (39 v_cndmask for HP = 1, 59 for HP = 2; all lanes execute them, each for its own column).  No LDS, no
+ * lock, no compaction; the bucket probe is software-pipelined as before, one pending column PER LANE.  A lane with a
+ * second survivor in the same chunk (rare by the launcher's choice of this form) decides its first one at once. */
+
+/* one level of the barrel: `mask` ? t : f per lane.  On the GPU an explicit v_cndmask_b32 on the ballot of the level's
+ * condition: written as a C++ conditional over local arrays, LLVM turns "c ? x[i + 8] : x[i]" into a LOAD from a selected
+ * address, i.e. puts the arrays into scratch memory (measured: the kernel 37 % slower even on sets without survivors) */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+typedef uint64_t smh_lanemask;
+SMH_LANE smh_lanemask smh_lane_mask(bool b) { return __ballot(b); }
+SMH_LANE uint32_t smh_sel(smh_lanemask mask, uint32_t t, uint32_t f)
+{
+    uint32_t d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(f), "v"(t), "s"(mask));
+    return d;
+}
+#else
+typedef bool smh_lanemask;
+SMH_LANE smh_lanemask smh_lane_mask(bool b) { return b; }
+SMH_LANE uint32_t smh_sel(smh_lanemask mask, uint32_t t, uint32_t f) { return mask ? t : f; }
+#endif
+
+/* hash of the m-byte window that ends at column c (0..63) of the lane's segment: w = the segment, prev = the 16 * HP
+ * bytes in front of it */
+template <int HP>
+SMH_LANE uint32_t smh_regv_tag(const uint32_t (&w)[16], const uint32_t (&prev)[4 * HP], uint32_t c, int m)
+{
+    constexpr int NP = 4 * HP, NA = NP + 16, MAXD = NP + 1; /* MAXD == SMH_STAGE_MAXD(HP) */
+    const uint32_t s0 = 16u * HP + c + 1u - (uint32_t)m; /* first byte of the window, counted from prev[0]; m - 1 <= 16 * HP */
+    const uint32_t sd = s0 >> 2, sh = (s0 & 3u) * 8u;    /* sd <= NP + 15 */
+    /* level 16: only the first NP entries can come from 16 further on (sd >= 16 leaves a shift of < NP behind it; what
+     * lies beyond the segment's last dword is outside every window and never reaches the hash) */
+    uint32_t x4[MAXD + 16];
+    {
+        const smh_lanemask b = smh_lane_mask((sd & 16u) != 0);
+#pragma unroll
+        for (int i = 0; i < MAXD + 16; ++i) {
+            const uint32_t lo = i < NP ? prev[i < NP ? i : 0] : (i < NA ? w[i < NA && i >= NP ? i - NP : 0] : 0u);
+            x4[i] = i < NP ? smh_sel(b, w[i < NP ? i + 16 - NP : 0], lo) : lo;
+        }
+    }
+    uint32_t x3[MAXD + 8];
+    {
+        const smh_lanemask b = smh_lane_mask((sd & 8u) != 0);
+#pragma unroll
+        for (int i = 0; i < MAXD + 8; ++i) x3[i] = smh_sel(b, x4[i + 8], x4[i]);
+    }
+    uint32_t x2[MAXD + 4];
+    {
+        const smh_lanemask b = smh_lane_mask((sd & 4u) != 0);
+#pragma unroll
+        for (int i = 0; i < MAXD + 4; ++i) x2[i] = smh_sel(b, x3[i + 4], x3[i]);
+    }
+    uint32_t x1[MAXD + 2];
+    {
+        const smh_lanemask b = smh_lane_mask((sd & 2u) != 0);
+#pragma unroll
+        for (int i = 0; i < MAXD + 2; ++i) x1[i] = smh_sel(b, x2[i + 2], x2[i]);
+    }
+    uint32_t d[MAXD + 1];
+    {
+        const smh_lanemask b = smh_lane_mask((sd & 1u) != 0);
+#pragma unroll
+        for (int i = 0; i <= MAXD; ++i) d[i] = smh_sel(b, x1[i + 1], x1[i]);
+    }
+    return smh_wm_tag_dwords<MAXD>(d, sh, m);
+}
+
+/* the surviving columns `msk` (bit b = column a + b) of the lane's segment; all 64 lanes must call it */
+template <int HP>
+SMH_LANE void smh_wm_regv_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t a, uint64_t msk, const uint32_t (&w)[16],
+                                  const uint32_t (&halo)[4 * HP], const smh_wm_params &P)
+{
+    if (!SMH_WAVE_ANY(msk != 0)) return;
+    uint32_t prev[4 * HP]; /* lane 0: the bytes in front of the wave-chunk */
+#pragma unroll
+    for (int q = 0; q < 4 * HP; ++q) prev[q] = smh_prev_lane_word(w[16 - 4 * HP + q], halo[q], text, a - 16u * HP + 4u * (uint32_t)q);
+    do {
+        const bool have = msk != 0;
+        const uint32_t c = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
+        const uint32_t tag = smh_regv_tag<HP>(w, prev, c, P.m);
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        /* the column this lane (or another) still holds from an earlier chunk -- its bucket arrived while this chunk was
+         * scanned -- or from the round before (a second survivor in one lane: decided without the pipelining) */
+        smh_wm_pend_finish<true>(Q, text, P);
+        Q.pend_n = 64u;
+        Q.pend_mine = have ? 1u : 0u;
+        Q.pend_e = a + c;
+        Q.pend_tag = tag;
+#else
+        if (have) {
+            const uint32_t hit = smh_wm_probe(text, a + c, tag, P);
+            Q.matches += hit;
+            if (hit && Q.po) smh_append_bits(1u, a + c, *Q.po);
+        }
+#endif
+        msk &= msk - 1u;
+    } while (SMH_WAVE_ANY(msk != 0));
+}
+
 /* ------------------------------------------------------------------ gram filter (q-gram shift-or)
  * smh_internal.h "gram filter" describes the tables.  A lane owns the 64 END columns of its segment, keeps the
  * shift-or state S in one register (bit b CLEAR = "the last b+1 grams are in planes b .. 0 in order"; a column is a
@@ -1249,11 +1391,11 @@ SMH_LANE uint32_t smh_wm_gram2_lane_slow(const uint8_t *text, uint64_t n, uint64
 /* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
  * `edge` = the 8 bytes in front of the wave-chunk (wave-uniform).  Returns nothing: candidates go to the queue. */
 template <int KIND, bool POS, int STG = 0, bool QD = true>
-SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&halo)[STG > 0 ? 4 * STG : 4],
+SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&halo)[4 * smh_stg_hp(STG)],
                                     const void *tab, const smh_wm_params &P, smh_wm_queue &Q)
 {
-    /* halo = the 16 * max(STG, 1) bytes in front of the wave-chunk (wave-uniform); its last two dwords prime lane 0 */
-    constexpr int HD = STG > 0 ? 4 * STG : 4;
+    /* halo = the 16 * HP bytes in front of the wave-chunk (wave-uniform); its last two dwords prime lane 0 */
+    constexpr int HP = smh_stg_hp(STG), HD = 4 * HP;
     /* pair form: J planes (2..15), the low J-1 bits assumed alive */
     [[maybe_unused]] const uint32_t jw = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u, jmask = (1u << jw) - 1u;
     [[maybe_unused]] uint32_t fl16[4] = {0, 0, 0, 0};
@@ -1366,7 +1508,7 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
              * computed from the halo -- the last NP pairs of columns in front of the chunk decide its low J-1 bits; same
              * values in every lane, the lookups are broadcasts -- and lane 0 is corrected like the others. */
             if (P.gram_jb >= 0 /* the launcher's choice: wm_kernels.inc launch_gram_stg */ && __builtin_amdgcn_readfirstlane((int)(fl16[0] & jmask)) != 0) {
-                constexpr int NP = STG == 1 ? 5 : 7, ND = (2 * NP + 6) / 4; /* pairs of columns (>= J-1 columns), dwords of halo */
+                constexpr int NP = HP == 1 ? 5 : 7, ND = (2 * NP + 6) / 4; /* pairs of columns (>= J-1 columns), dwords of halo */
                 uint32_t c2 = 0, Th = 0;
 #pragma unroll
                 for (int d = 0; d < ND; ++d) {
@@ -1395,7 +1537,10 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
             msk |= (uint64_t)((flb[0] & (fixb | ~wmask)) | (flb[1] << 24)) | ((uint64_t)(flb[1] >> 8) << 32) | ((uint64_t)flb[2] << 48);
         }
     }
-    if constexpr (STG > 0) {
+    if constexpr (smh_stg_regv(STG)) {
+        /* in-register verify: few surviving columns, each hashed by its own lane out of the text registers */
+        smh_wm_regv_columns<HP>(Q, text, a, msk, w, halo, P);
+    } else if constexpr (STG > 0) {
         /* staged verify: chunks with many surviving columns hash their windows from an LDS copy of the chunk */
         smh_wm_stage_columns<STG, QD, true>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
     } else {
@@ -1466,7 +1611,8 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
     Q.matches = 0;
     Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
-    constexpr int HP = STG > 0 ? STG : 1, HD = 4 * HP; /* 16-byte pieces / dwords of text kept from in front of the chunk */
+    constexpr int HP = smh_stg_hp(STG), HD = 4 * HP; /* 16-byte pieces / dwords of text kept from in front of the chunk */
+    [[maybe_unused]] constexpr bool RV = smh_stg_regv(STG);
     uint32_t cur[16], nxt[16], cur_halo[HD], nxt_halo[HD];
     uint64_t k = S.take(n_chunks);
     /* the fast path needs eight bytes in front of the chunk and, for the columns to have full windows, m - 1 of
@@ -1505,7 +1651,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         /* staged verify, pipelined: the buckets of the columns hashed at the end of the last chunk are requested now
          * and looked at after this chunk's scan (by the next flush, or below) */
-        if (STG > 0) smh_wm_pend_issue(Q, P);
+        if (STG > 0) smh_wm_pend_issue<RV>(Q, P);
 #endif
         if (SMH_PREFETCH && nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
@@ -1529,7 +1675,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
             cnt += smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P);
         }
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish(Q, text, P); /* a chunk without a flush of its own */
+        if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish<RV>(Q, text, P); /* a chunk without a flush of its own */
 #endif
         if (nxt_fast) {
             if (SMH_PREFETCH) {
@@ -1545,7 +1691,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         k = kn;
     }
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-    if (STG > 0) smh_wm_pend_finish(Q, text, P);
+    if (STG > 0) smh_wm_pend_finish<RV>(Q, text, P);
 #endif
     if (QD) smh_wm_drain(Q, text, P);
     return cnt + Q.matches;

@@ -40,7 +40,8 @@ class AcInfo(C.Structure):
                 ("finals", C.c_uint32), ("rows", C.c_uint32), ("entry_bytes", C.c_uint32),
                 ("lds_rows", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_bytes", C.c_uint64),
                 ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
-                ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32)]
+                ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32),
+                ("verify_in_registers", C.c_uint32)]
 
 
 class WmInfo(C.Structure):
@@ -49,7 +50,7 @@ class WmInfo(C.Structure):
                 ("block_symbols", C.c_uint32), ("filter_log2", C.c_uint32),
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
-                ("gram_planes", C.c_uint32)]
+                ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32)]
 
 
 class PsetInfo(C.Structure):
@@ -92,7 +93,7 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_stream_read_probe_variant",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
-               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
+               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_set_scan_engine", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
                "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info", "smh_wm_set_scan_engine",
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free", "smh_pset_compile", "smh_pset_get_info",
                "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
@@ -138,6 +139,7 @@ def _load():
     lib.smh_ac_compile_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
     lib.smh_ac_get_info.argtypes = [C.c_void_p, C.POINTER(AcInfo)]
     lib.smh_ac_set_scan_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.smh_ac_set_scan_engine.argtypes = [C.c_void_p, C.c_int]
     lib.smh_ac_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
     lib.smh_ac_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.smh_wm_positions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -329,6 +331,9 @@ class AcAutomaton:
 
     def set_scan_plan(self, stride=0, depth=0):
         _check(lib.smh_ac_set_scan_plan(self.h, stride, depth), "smh_ac_set_scan_plan")
+
+    def set_scan_engine(self, engine):
+        _check(lib.smh_ac_set_scan_engine(self.h, engine), "smh_ac_set_scan_engine")
 
     def scan_device(self, d_text_ptr, n, d_count_ptr, variant=VARIANT_TUNED, stream=None):
         _check(lib.smh_ac_scan(self.h, C.c_void_p(d_text_ptr), n, C.c_void_p(d_count_ptr), variant,

@@ -111,11 +111,15 @@ typedef struct smh_ac_info {
     uint32_t scan_engine;    /* SMH_ALGO_AC: the automaton kernels scan; SMH_ALGO_WM: even the best LDS automaton
                               * would be verify-bound (alphabet-256 sets, thousands of long DNA patterns), so
                               * smh_ac_scan / smh_ac_positions run the suffix-filter kernels on the same patterns
-                              * -- same count, several times faster.  smh_ac_set_scan_plan with a forced stride or
-                              * depth switches back to the automaton kernels; (0, 0) restores the choice. */
+                              * -- same count, several times faster; round 3: also a depth-cut plan (K < m) whose
+                              * estimate the pair-gram filter beats (the headline's 1000 patterns of 16 / 32 symbols:
+                              * 0.174 against 0.205 ms/GiB).  smh_ac_set_scan_plan with a forced stride or depth, or
+                              * smh_ac_set_scan_engine(SMH_ALGO_AC), switches back to the automaton kernels; (0, 0) /
+                              * -1 restores the choice. */
     uint32_t scan_dense;     /* 1: the dense plan scans (alphabet 4, m <= 8): the automaton completed to all 4^m strings, its
                               * state the rolling code of the last m symbols, acceptance one bit per string in LDS
                               * (two END columns per lookup); scan_stride / scan_depth describe the ordinary plan kept beside it */
+    uint32_t verify_in_registers; /* scan_engine == SMH_ALGO_WM: smh_wm_info.verify_in_registers of that engine */
 } smh_ac_info;
 
 /* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
@@ -128,6 +132,9 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out);
  * 4 = the dense plan of smh_ac_info.scan_dense; 0 = choose) and a forced depth K (1..min(m,65); 0 = the deepest that fits; for the hybrid image
  * bits 8..15 may force the depth D of its full rows).  SMH_EUNSUP when it does not fit LDS. */
 int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth);
+/* test / tuning knob, the mirror of smh_wm_set_scan_engine: SMH_ALGO_AC runs the automaton kernels on the plan the handle
+ * holds, SMH_ALGO_WM the suffix-filter engine (SMH_EUNSUP when the compile kept none), -1 restores the compile's choice */
+int smh_ac_set_scan_engine(smh_ac *ac, int engine);
 /* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).
  * d_text must be 16-byte aligned; n may exceed 2^32.  A handle owns one candidate-queue workspace
  * per device: scans of the SAME handle must not overlap in time (use one stream per handle, or
@@ -167,6 +174,9 @@ typedef struct smh_wm_info {
                                * than a non-exact direct filter; same count) -- see smh_wm_set_scan_engine */
     uint32_t gram_planes;     /* > 0: the scan runs the q-gram shift-or filter with this many positional planes
                                * (one lookup per column, or per two columns on the 4-letter alphabet) */
+    uint32_t verify_in_registers; /* 1: pair form (4-letter alphabet) with few surviving columns per 4 KiB of text and
+                               * m <= 33: a survivor's window is hashed by its own lane out of the text registers
+                               * (kernel instance wm_gram_kernel<1, ., 5 | 6, false>), not from a staged LDS copy */
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */

@@ -261,14 +261,21 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     /* staged verify as launch_gram (wm_kernels.inc) picks it */
-    const int stg = wm->m - 1 <= 16 ? 1 : wm->m - 1 <= 32 ? 2 : 0;
+    int stg = wm->m - 1 <= 16 ? 1 : wm->m - 1 <= 32 ? 2 : 0;
+    /* pair form with few survivors per chunk: in-register verify (STG 5 / 6), as launch_gram */
+    bool regv = wm->gram_kind == SMH_GRAM_PAIR && stg > 0 && wm->gram_density * 4096.0 <= 8.0;
+    if (const char *tn = getenv("SMH_WM_TUNE")) {
+        if (strstr(tn, "regv=0")) regv = false;
+        if (strstr(tn, "regv=1")) regv = wm->gram_kind == SMH_GRAM_PAIR && stg > 0;
+    }
+    if (regv) stg += 4;
     for (uint64_t t = 0; t < nthreads; ++t) {
         const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
 #define GRAM_CALL(KIND, STG) (po ? smh_wm_gram_thread<KIND, true, STG>(t, S, text, n, wm->gram_table, P, nullptr, po) \
                                  : smh_wm_gram_thread<KIND, false, STG>(t, S, text, n, wm->gram_table, P, nullptr, po))
 #define GRAM_STG(KIND) (stg == 1 ? GRAM_CALL(KIND, 1) : stg == 2 ? GRAM_CALL(KIND, 2) : GRAM_CALL(KIND, 0))
         if (wm->gram_kind == SMH_GRAM_PAIR)
-            total += GRAM_STG(1);
+            total += stg == 5 ? GRAM_CALL(1, 5) : stg == 6 ? GRAM_CALL(1, 6) : GRAM_STG(1);
         else if (wm->gram_kind == SMH_GRAM_OCT)
             total += GRAM_STG(3);
         else

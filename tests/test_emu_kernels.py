@@ -153,6 +153,38 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
 
 
 
+@pytest.mark.parametrize("m", [11, 12, 13, 14, 16, 17, 18, 21, 24, 29, 32, 33])
+def test_in_register_verify_every_column_and_length(m, monkeypatch):
+    """Round 3: the pair form's in-register verify (wm_lane.h smh_regv_tag: the window's dwords selected out of the lane's
+    text registers and the previous lane's tail by a barrel of conditional moves).  One occurrence ending at EVERY column
+    residue 0..63 of a segment -- in lane 0 of a wave-chunk (window out of the halo), in lanes 1 and 63, across a chunk
+    boundary -- for every window length class (whole dwords, +1, +2, +3 bytes; 16 and 32 bytes of halo); forced on, forced off
+    (staged verify), both equal to the definition."""
+    sigma, p = 4, 64 * 4
+    rng = np.random.RandomState(500 + m)
+    n = 4 * 4096 + 100
+    text = rng.randint(0, sigma, size=n).astype(np.uint8)
+    ends = []
+    for r in range(64):
+        ends += [4096 + r,                     # lane 0 of chunk 1: the window reaches into the bytes in front of the chunk
+                 4096 + 64 * (1 + r % 3) + r,  # lanes 1..3
+                 2 * 4096 + 64 * 63 + r,       # lane 63
+                 3 * 4096 + 64 * (r % 64) + r] # every lane once
+    pat = np.stack([text[e - m + 1:e + 1] for e in ends]).astype(np.uint8)
+    want = O.count_bruteforce(pat.reshape(-1), m, p, text)
+    assert want >= len(set(ends))
+    for tune in ("gram=1,regv=1", "gram=1,regv=0"):
+        monkeypatch.setenv("SMH_WM_TUNE", tune)
+        wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
+        if wm.info().scan_engine != S.ALGO_WM:
+            wm.set_scan_engine(S.ALGO_WM)
+        assert wm.info().gram_planes == min(15, m - 6)
+        for blocks in (1, 2):
+            assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want, tune
+        total, pos = E.wm_positions(wm, text, want + 8, 2)
+        assert total == want and set(ends) <= set(int(x) for x in pos), tune
+
+
 @pytest.mark.parametrize("m,p", [(8, 8000), (8, 20000), (6, 3000), (3, 40), (5, 900), (8, 3)])
 def test_dense_plan(m, p):
     """The dense plan of the automaton engine (alphabet 4, m <= 8: state = the last m symbols, acceptance one bit per

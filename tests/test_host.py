@@ -193,8 +193,19 @@ def test_scan_engine_choice_is_made_on_the_host():
                                      v["sigma"], v["m"]).info().scan_engine == S.ALGO_WM
     dna = S.corpus_patterns(16, 8000, 7, 4, 42, 1 << 24, 2)
     assert S.AcAutomaton.from_patterns(dna, 16, 8000, 4).info().scan_engine == S.ALGO_WM
-    small = S.corpus_patterns(16, 1000, 7, 4, 42, 1 << 24, 2)
-    assert S.AcAutomaton.from_patterns(small, 16, 1000, 4).info().scan_engine == S.ALGO_AC
+    # round 3: a depth-cut plan (K < m: a prefix filter + verify) hands over when the pair-gram filter is estimated faster ...
+    cut = S.AcAutomaton.from_patterns(S.corpus_patterns(16, 1000, 7, 4, 42, 1 << 24, 2), 16, 1000, 4)
+    assert cut.info().scan_exact == 0 and cut.info().scan_engine == S.ALGO_WM
+    cut.set_scan_engine(S.ALGO_AC)                                        # ... the knob keeps the plan and runs the automaton kernels
+    assert cut.info().scan_engine == S.ALGO_AC and cut.info().scan_full_rows > 0
+    cut.set_scan_engine(-1)
+    assert cut.info().scan_engine == S.ALGO_WM
+    # ... an exact plan (K == m) never does: the automaton alone counts
+    for m, p in ((8, 1000), (12, 1000), (16, 100)):
+        i = S.AcAutomaton.from_patterns(S.corpus_patterns(m, p, 7, 4, 42, 1 << 24, 2), m, p, 4).info()
+        assert i.scan_exact == 1 and i.scan_engine == S.ALGO_AC
+    with pytest.raises(S.SmhError):
+        S.AcAutomaton.from_patterns(S.corpus_patterns(8, 1000, 7, 4, 42, 1 << 24, 2), 8, 1000, 4).set_scan_engine(S.ALGO_WM)
 
 
 def test_wm_scan_engine_choice_and_knob():

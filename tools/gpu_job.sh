@@ -11,6 +11,7 @@
 #   trace            rocprofv3 --kernel-trace --stats over bench-fast only
 #   env:K=V          export K=V for the following steps (SMH_AC_TUNE=..., SMH_WM_TUNE=...)
 #   py:FILE[:ARGS]   python FILE ARGS (comma-separated) with output to gpurun_out/TAG/<file>.log
+#   sh:FILE          bash FILE TAG (an experiment script that may rebuild the library: put it last)
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -33,6 +34,7 @@ PY
                 ;;
     env:*)      export "${step#env:}";;
     py:*)       IFS=: read -r _ file pargs <<< "$step"; timeout -k 10 900 python $file ${pargs//,/ } > $O/$(basename $file .py).log 2>&1; rc=$?; tail -40 $O/$(basename $file .py).log; [ $rc -eq 0 ] || fail "$file rc $rc";;
+    sh:*)       timeout -k 10 1000 bash "${step#sh:}" $TAG; rc=$?; [ $rc -eq 0 ] || fail "${step#sh:} rc $rc";;
     *)          fail "unknown step $step";;
   esac
   if grep -qs "Memory access fault" $O/*.log $O/*.err; then fail "GPU memory access fault"; fi
