@@ -70,6 +70,12 @@ def run(cases, seed, verbose=True):
         assert ac.count_host(text)[0] == want, (tag, "ac auto", ac.info().scan_engine)
         assert ac.count_host(text, S.VARIANT_TABLE)[0] == want, (tag, "ac table")
         positions(ac)
+        if ac.info().scan_engine == S.ALGO_WM:  # the entry point chose the filter engine: the automaton kernels on the same plan
+            ac.set_scan_engine(S.ALGO_AC)
+            assert ac.count_host(text)[0] == want, (tag, "ac own kernels", ac.info().scan_stride, ac.info().scan_depth)
+            positions(ac)
+            ac.set_scan_engine(-1)
+            checks += 2
         plans = [(1, min(m, 33)), (1, max(1, m // 2)), (1, 2)]
         if sigma == 4:
             plans += [(2, min(m, 33)), (2, max(1, m // 2)), (3, min(m, 33) | (1 << 8)), (3, min(m, 33) | (3 << 8)),

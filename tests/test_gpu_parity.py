@@ -425,15 +425,16 @@ def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, monkeypatch):
     assert sorted(out[:want].tolist()) == O.positions_bruteforce(pat.reshape(-1), m, p, text).tolist()
 
 
-@pytest.mark.parametrize("stage", ["", ",stage=0"], ids=["staged", "hbm_windows"])
+@pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1"], ids=["default", "hbm_windows", "staged", "in_registers"])
 @pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 17, 6000), (1, 4, 33, 50), (1, 4, 40, 50),
                                             (3, 4, 11, 200), (3, 4, 16, 20000), (3, 4, 32, 500), (2, 256, 5, 3000),
                                             (2, 256, 12, 30000), (2, 256, 17, 100000), (2, 256, 18, 1000), (2, 256, 33, 2000),
                                             (2, 256, 34, 2000), (2, 128, 7, 100)])
 def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, monkeypatch):
     """Each q-gram shift-or form forced (development knob), with the staged verify (window hashes from the LDS copy
-    of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them) and with windows
-    re-read from HBM; texts with planted occurrences at chunk / segment boundaries and a stretch where EVERY column
+    of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them), with the pair form's
+    in-register verify forced on and off (round 3; the stretch where every column survives gives a lane 64 rounds of it)
+    and with windows re-read from HBM; texts with planted occurrences at chunk / segment boundaries and a stretch where EVERY column
     survives the filter (a pattern repeated back to back), so lists overflow and are flushed mid-chunk."""
     monkeypatch.setenv("SMH_WM_TUNE", "gram=%d%s" % (kind, stage))
     rng = np.random.RandomState(1000 * kind + m)
