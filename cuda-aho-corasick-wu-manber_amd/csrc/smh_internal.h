@@ -131,6 +131,9 @@ extern _Thread_local int smh_alt_engine_depth;
 #ifndef SMH_REGV_MAX_PER_CHUNK
 #define SMH_REGV_MAX_PER_CHUNK 8.0 /* == lane_common.h; surviving columns per 4 KiB wave-chunk up to which the pair-gram kernels verify in registers (wm_lane.h smh_wm_regv_columns) */
 #endif
+#ifndef SMH_REGV_WANTED
+#define SMH_REGV_WANTED(per_chunk) ((per_chunk) < 0.5 || ((per_chunk) > 3.0 && (per_chunk) <= SMH_REGV_MAX_PER_CHUNK)) /* == lane_common.h */
+#endif
 #define SMH_AC_ALT_ENGINE_MARGIN_MS 0.01 /* a depth-cut plan hands the scan to the gram filter when that is estimated this much faster (ms/GiB) */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */

@@ -263,7 +263,7 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     /* staged verify as launch_gram (wm_kernels.inc) picks it */
     int stg = wm->m - 1 <= 16 ? 1 : wm->m - 1 <= 32 ? 2 : 0;
     /* pair form with few survivors per chunk: in-register verify (STG 5 / 6), as launch_gram */
-    bool regv = wm->gram_kind == SMH_GRAM_PAIR && stg > 0 && wm->gram_density * 4096.0 <= 8.0;
+    bool regv = wm->gram_kind == SMH_GRAM_PAIR && stg > 0 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
     if (const char *tn = getenv("SMH_WM_TUNE")) {
         if (strstr(tn, "regv=0")) regv = false;
         if (strstr(tn, "regv=1")) regv = wm->gram_kind == SMH_GRAM_PAIR && stg > 0;
