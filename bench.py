@@ -407,7 +407,7 @@ def main():
 
     # every step has its own count buffer: its all-reduce is started behind its three scans and runs on RCCL's stream
     # while the next step's scans run on ours; all of them are waited for inside the timed region
-    step_counts = torch.zeros((args.warmup + args.steps + 1, len(AC_LENGTHS)), dtype=torch.int64, device=dev)
+    step_counts = torch.zeros((2 * (args.warmup + args.steps) + 1, len(AC_LENGTHS)), dtype=torch.int64, device=dev)
 
     def step(k, events=None):
         c = step_counts[k]  # zero since its allocation: every step accumulates into a row of its own
@@ -436,6 +436,16 @@ def main():
     elapsed = time.perf_counter() - t0
     counts = step_counts[args.warmup + args.steps - 1] if args.steps else step_counts[0]
     elapsed = max(sharded.gather_objects(elapsed))  # the job's time is the slowest rank's
+    # for the record: the same W + K steps started on an IDLE device, i.e. what this file measured before it conditioned
+    # the device (the transient of `conditioned` falls into the timed steps)
+    time.sleep(0.3)
+    base = args.warmup + args.steps
+    sharded.finish([step(base + k) for k in range(args.warmup)])
+    barrier()
+    t0 = time.perf_counter()
+    sharded.finish([step(base + args.warmup + k) for k in range(args.steps)])
+    barrier()
+    idle_elapsed = max(sharded.gather_objects(time.perf_counter() - t0))
     total_counts = [int(x) for x in counts.tolist()]
     # per-GPU counts for the report: one untimed pass without the reduce, then one small all-gather
     counts = step_counts[-1]
@@ -506,6 +516,10 @@ def main():
                        "text_bytes_per_gpu": per_gpu, "alphabet": SIGMA, "patterns": AC_PATTERNS,
                        "pattern_lengths": list(AC_LENGTHS), "text_seed": TEXT_SEED, "pattern_seed": PAT_SEED,
                        "sharding": "byte-range x%d, m-1 halo, RCCL sum of counts" % world},
+            "after_idle": {"what": "the same %d warm-up + %d timed steps started on an idle device, without the conditioning: the "
+                                   "power-management transient falls into the timed steps" % (args.warmup, args.steps),
+                           "ms_per_step": round(idle_elapsed / max(args.steps, 1) * 1e3, 4),
+                           "value": round(bits_per_step * args.steps / idle_elapsed / 1e9, 2) if args.steps else None},
             "roofline": roofline, "ac": ac_detail, "device": S.device_name(), "kernel_build_id": kernel_build_id(),
             "per_gpu_matches": {"m%d" % m: [int(r[i]) for r in per_gpu_counts] for i, m in enumerate(AC_LENGTHS)},
         }

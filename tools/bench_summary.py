@@ -9,6 +9,7 @@ if not lines:
 d = json.loads(lines[-1])
 print("value", d["value"], d["unit"], "n_gpus", d["n_gpus"], "ms_per_step", d["ms_per_step"], "build", d.get("kernel_build_id"))
 print("roofline", d["roofline"])
+print("after_idle", d.get("after_idle"))
 for k in ("ac", "ac_automaton", "wm", "wm_long", "mixed_8_32", "ac_8000_patterns", "wm_ascii", "table_kernels", "smh_multi"):
     v = d.get(k)
     if not isinstance(v, dict):
