@@ -1,0 +1,45 @@
+"""bench.py's bookkeeping that needs no GPU: which kernel instance serves a handle at the Aho-Corasick entry point, and the
+lookup of its measured HBM traffic in profiles/hbm_traffic.json (quoted only for the same build, per text size)."""
+import json
+import os
+import sys
+import types
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _info(**kw):
+    d = dict(m=16, scan_dense=0, scan_engine=0, verify_in_registers=0, scan_depth=12, scan_stride=2, lds_rows=7816,
+             scan_full_rows=4817, scan_exact=0)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def test_kernel_instance_names():
+    assert bench.ac_kernel_name(_info(m=8, scan_dense=1)) == "wm_pair_kernel<false, 1024>"
+    assert bench.ac_kernel_name(_info(scan_engine=1, verify_in_registers=1)) == "wm_gram_kernel<1, false, 5, false>"
+    assert bench.ac_kernel_name(_info(m=32, scan_engine=1, verify_in_registers=1)) == "wm_gram_kernel<1, false, 6, false>"
+    assert bench.ac_kernel_name(_info(m=32, scan_engine=1)) == "wm_gram_kernel<1, false, 2, false>"
+    assert bench.ac_kernel_name(_info()) == "ac_dfa_kernel<unsigned short, 4, 4, 1, false,"          # hybrid, depth-cut
+    assert bench.ac_kernel_name(_info(scan_full_rows=0, scan_exact=1, scan_depth=8)) == "ac_dfa_kernel<unsigned short, 4, 2, 1, true,"
+
+
+def test_traffic_is_quoted_per_text_size_and_only_for_the_same_build(monkeypatch):
+    rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    monkeypatch.setattr(bench, "kernel_build_id", lambda: rec["build_id"])
+    gib = 1 << 30
+    for info in (_info(m=8, scan_dense=1), _info(scan_engine=1, verify_in_registers=1), _info(m=32, scan_engine=1, verify_in_registers=1)):
+        name = bench.ac_kernel_name(info)
+        if not any(k.startswith(name) for k in rec["kernels"]):
+            pytest.skip("profiles/hbm_traffic.json predates kernel instance " + name)
+        got, src = bench.measured_traffic(info, gib)
+        assert got is not None and 1.0 * gib <= got < 1.1 * gib, (name, got, src)   # the 1 GiB launches, not the 4 GiB shards'
+        got4, _ = bench.measured_traffic(info, 4 * gib)
+        assert got4 is not None and 4.0 * gib <= got4 < 4.4 * gib, (name, got4)
+    monkeypatch.setattr(bench, "kernel_build_id", lambda: "another build")
+    got, src = bench.measured_traffic(_info(m=8, scan_dense=1), gib)
+    assert got is None and "not quoted" in src
