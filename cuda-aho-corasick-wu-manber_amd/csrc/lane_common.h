@@ -42,11 +42,11 @@
 #ifndef SMH_REGV_MAX_PER_CHUNK
 #define SMH_REGV_MAX_PER_CHUNK 8.0 /* == smh_internal.h: surviving columns per 4 KiB wave-chunk up to which the pair-gram kernels verify in registers */
 #endif
-/* ... except between 0.5 and 3 per chunk, where the staged kernel that also drains sparse chunks from HBM (QD) measures 1.5 %
- * faster (profiles/r03_experiments/regv_ab_threshold.log: 2000 x 13 and 4000 x 14; 8000 x 16 at 4.4 per chunk: in
- * registers 10 % faster; 0.2 per chunk and below: 0-2.5 % faster) */
+/* (8000 x 16 at 4.4 per chunk: in registers 10 % faster than staged; 0.2 per chunk and below: 0-2.5 % faster; between 0.5
+ * and 3 per chunk against the staged kernel that also drains sparse chunks from HBM: -3 % .. +2 %, within the noise of the
+ * interleaved A/Bs -- profiles/r03_experiments/regv_ab_threshold.log, gram_forms_ab.log; 20 per chunk: 12 % slower) */
 #ifndef SMH_REGV_WANTED
-#define SMH_REGV_WANTED(per_chunk) ((per_chunk) < 0.5 || ((per_chunk) > 3.0 && (per_chunk) <= SMH_REGV_MAX_PER_CHUNK))
+#define SMH_REGV_WANTED(per_chunk) ((per_chunk) <= SMH_REGV_MAX_PER_CHUNK)
 #endif
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)

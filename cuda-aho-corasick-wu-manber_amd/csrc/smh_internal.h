@@ -132,7 +132,7 @@ extern _Thread_local int smh_alt_engine_depth;
 #define SMH_REGV_MAX_PER_CHUNK 8.0 /* == lane_common.h; surviving columns per 4 KiB wave-chunk up to which the pair-gram kernels verify in registers (wm_lane.h smh_wm_regv_columns) */
 #endif
 #ifndef SMH_REGV_WANTED
-#define SMH_REGV_WANTED(per_chunk) ((per_chunk) < 0.5 || ((per_chunk) > 3.0 && (per_chunk) <= SMH_REGV_MAX_PER_CHUNK)) /* == lane_common.h */
+#define SMH_REGV_WANTED(per_chunk) ((per_chunk) <= SMH_REGV_MAX_PER_CHUNK) /* == lane_common.h */
 #endif
 #define SMH_AC_ALT_ENGINE_MARGIN_MS 0.01 /* a depth-cut plan hands the scan to the gram filter when that is estimated this much faster (ms/GiB) */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
@@ -303,7 +303,16 @@ struct smh_wm {
      *                  overlapping grams pass together: 0.4 % of the columns survive eight planes; the 8-symbol
      *                  planes are 12 % full and 1e-7 survive)
      *   SMH_GRAM_BYTE  8-bit symbols: 3-byte grams, index = top 17 bits of (gram as a little-endian 24-bit
-     *                  number) * SMH_GRAM_MUL mod 2^32, 8-bit entries */
+     *                  number) * SMH_GRAM_MUL mod 2^32, 8-bit entries
+     *   SMH_GRAM_OCT2  alphabet 4, round 3: 8-symbol grams with ONE lookup per TWO columns.  The lookup of a pair of
+     *                  columns is indexed by the eight symbols that end at the pair's second column and yields a 16-bit
+     *                  value with J <= 16 planes at ALL offsets: bit J-1-j CLEAR = "this 8-gram ends j symbols before the
+     *                  end of some pattern".  S = (S << 2) | E chains every SECOND offset: after a lookup, bit J-1 clear =
+     *                  the grams at offsets 0, 2, 4, ... are in place = candidate END at the pair's second column; bit J-2
+     *                  clear = offsets 1, 3, 5, ... = candidate END at the NEXT column.  Half the tests per END column, but
+     *                  of grams four times as selective and less correlated than the pair form's overlapping 7-symbol
+     *                  grams (8000 patterns of 16 symbols: 1.4 instead of 4.4 surviving columns per 4 KiB; 16 000 of 20:
+     *                  0.7, at half the lookups of SMH_GRAM_OCT) */
     int gram_kind;
     int gram_planes;
     int gram_jb;         /* SMH_GRAM_PAIR2: planes of the short-pattern group (0 = no such group) */
@@ -360,6 +369,7 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
  * against every length class.  Behind the 128 KiB image: 32 KiB of per-gram values G_A | G_B << 8 for the
  * bounds-checked path. */
 #define SMH_GRAM_PAIR2 4
+#define SMH_GRAM_OCT2 5
 #define SMH_PSET_GROUPED_DENSITY 0.0005 /* candidates per column above which the grouped form is not used */
 #define SMH_GRAM_PAIR2_SPLIT 14 /* patterns at least this long have all eight planes */
 #define SMH_GRAM_BYTES (128u * 1024u)

@@ -161,6 +161,15 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
     uint64_t seed = 0x5EEDull, hits = 0;
     uint32_t S = ~0u, code = 0, k0 = 0, k1 = 0;
     const int cand_bit = kind == SMH_GRAM_PAIR ? planes - 1 : 7; /* the pair form holds J-bit values, candidate = bit J-1 */
+    if (kind == SMH_GRAM_OCT2) { /* a lookup every second column, two END columns decided per lookup */
+        for (int x = 0; x < COLS; ++x) {
+            code = ((code << 2) | (uint32_t)(gram_rng(&seed) & 3u)) & 0xFFFFu;
+            if (!(x & 1)) continue;
+            S = (S << 2) | ((const uint16_t *)tab)[code];
+            if (x >= 64) hits += (((S >> (planes - 1)) & 1u) ^ 1u) + (((S >> (planes - 2)) & 1u) ^ 1u);
+        }
+        return (double)hits / (double)(COLS - 64);
+    }
     for (int x = 0; x < COLS; ++x) {
         const uint32_t c = (uint32_t)(gram_rng(&seed) % (uint64_t)alphabet);
         uint32_t G;
@@ -188,6 +197,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
  * grams 0.26 and byte grams 0.238 (one LDS lookup per column). */
 #define SMH_GRAM_PAIR_MS 0.173
 #define SMH_GRAM_OCT_MS 0.26
+#define SMH_GRAM_OCT2_MS 0.178 /* the pair form's lookups + lane 0's inherited state from the halo in every chunk */
 #define SMH_GRAM_BYTE_MS 0.238
 /* verify stage, ms per GiB for a fraction `dens` of surviving columns.  Staged (m <= 33: window hashes from the LDS
  * copy of the chunk, probe pipelined): the cost is mostly per wave-chunk that has any survivor -- lock, copy, hash
@@ -277,6 +287,30 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_OCT; best_planes = J; best_bytes = 65536; best_ms = ms; best_dens = dens;
+        } else {
+            free(tab);
+        }
+    }
+    if (wm->alphabet == 4 && m >= 10 && m <= 33 && GRAM_WANTED(SMH_GRAM_OCT2)) {
+        /* 8-symbol grams, a lookup per two columns (smh_internal.h SMH_GRAM_OCT2); m <= 33: lane 0 of a wave-chunk needs the
+         * state it inherits in EVERY chunk (its first column's candidate bit comes from the lookup in front of the chunk),
+         * which the kernels work out from the 16 or 32 bytes of halo they keep */
+        int J = m - 7;
+        if (J > 16) J = 16;
+        uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES);
+        if (!tab) { free(best); return -1; }
+        for (uint32_t c = 0; c < 65536; ++c) tab[c] = (uint16_t)((1u << J) - 1u); /* bit J-1-j SET = the gram is NOT in plane j */
+        for (int p = 0; p < d; ++p)
+            for (int j = 0; j < J; ++j) {
+                const unsigned char *g = pats + (size_t)p * m + (m - 8 - j);
+                uint32_t code = 0;
+                for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
+                tab[code] &= (uint16_t)~(1u << (J - 1 - j));
+            }
+        const double dens = gram_survivors(SMH_GRAM_OCT2, tab, 4, J), ms = SMH_GRAM_OCT2_MS + gram_verify_ms(m, dens);
+        if (ms < best_ms) {
+            free(best);
+            best = tab; best_kind = SMH_GRAM_OCT2; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
         } else {
             free(tab);
         }
@@ -722,7 +756,7 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->lds_bytes = (uint32_t)(((size_t)1 << wm->filter_log2) / 8);
     out->scan_engine = wm->alt_ac && !wm->alt_off ? SMH_ALGO_AC : SMH_ALGO_WM;
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
-    out->verify_in_registers = wm->gram_kind == SMH_GRAM_PAIR && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
+    out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
     if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : SMH_GRAM_BYTES;
     return SMH_OK;
 }

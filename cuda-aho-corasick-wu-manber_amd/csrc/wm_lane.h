@@ -1271,6 +1271,12 @@ SMH_LANE uint32_t smh_gram_flags16(uint32_t S, int J)
     return (smh_bitrev32(~s) >> 9) & 0xFFFFu;
 }
 
+/* SMH_GRAM_OCT2 (J planes): after the eighth lookup of a group of 16 columns the candidate bits of its lookups t = 0..7
+ * stand at bits J-2+2(7-t) (END = the column after lookup t's pair) and J-1+2(7-t) (END = the pair's second column):
+ * bit o SET of the result = the column at offset o from the group's SECOND column (its first one's flag came with the
+ * lookup in front of the group) is a candidate */
+SMH_LANE uint32_t smh_gram_flags16_oct2(uint32_t S, int J) { return (smh_bitrev32(~(S >> (J - 2))) >> 16) & 0xFFFFu; }
+
 /* byte-gram key of column i of the segment: the three bytes that end there, as the low 24 bits of a dword.
  * `pre` holds the four bytes in front of the segment. */
 template <int I>
@@ -1339,6 +1345,22 @@ SMH_LANE uint32_t smh_gram1_state_before(const uint8_t *text, uint64_t a, const 
     return S & ((1u << (J - 1)) - 1u);
 }
 
+/* SMH_GRAM_OCT2 (KIND 5): the low J-1 state bits a lane inherits, true value (0 = alive): the lookups at the odd columns in
+ * front of a (a is a multiple of 64), oldest first */
+SMH_LANE uint32_t smh_gram5_state_before(const uint8_t *text, uint64_t a, const void *tab, int J)
+{
+    const int NL = J / 2 + 1; /* lookups that reach the low J-1 bits */
+    if (a < (uint64_t)(2 * NL + 6)) return 0u; /* lookups without eight symbols in front of them: keep the assumption (superset) */
+    uint32_t S = 0u;
+    for (int t = NL - 1; t >= 0; --t) {
+        const uint64_t c = a - 1u - 2u * (uint64_t)t;
+        uint32_t code = 0;
+        for (int i = 7; i >= 0; --i) code = (code << 2) | (text[c - (uint64_t)i] & 3u);
+        S = smh_gram_step2(S, smh_lds_u16(tab, 2u * code));
+    }
+    return S & ((1u << (J - 1)) - 1u);
+}
+
 /* ---- grouped pairs (KIND 4, mixed-length sets; smh_internal.h SMH_GRAM_PAIR2): two shift-or states per lane.
  * State A as in the pair form (candidate = bit 7 clear); state B has jb planes, candidate = bit jb-1 clear. */
 SMH_LANE void smh_gram2_state_before(const uint8_t *text, uint64_t a, const uint8_t *gx, uint32_t &SA, uint32_t &SB)
@@ -1397,9 +1419,11 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     /* halo = the 16 * HP bytes in front of the wave-chunk (wave-uniform); its last two dwords prime lane 0 */
     constexpr int HP = smh_stg_hp(STG), HD = 4 * HP;
     /* pair form: J planes (2..15), the low J-1 bits assumed alive */
-    [[maybe_unused]] const uint32_t jw = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u, jmask = (1u << jw) - 1u;
+    [[maybe_unused]] const uint32_t jw = KIND == 1 || KIND == 5 ? (uint32_t)P.gram_planes - 1u : 7u, jmask = (1u << jw) - 1u;
     [[maybe_unused]] uint32_t fl16[4] = {0, 0, 0, 0};
-    uint32_t T = KIND == 1 ? ~jmask : SMH_GRAM_S0, fl[3] = {0, 0, 0};
+    /* OCT2: the low J-2 bits assumed alive; bits J-2 and J-1 of the inherited state are candidate bits of columns that
+     * are decided elsewhere (the first column's: below, from the inherited state itself) */
+    uint32_t T = KIND == 1 ? ~jmask : KIND == 5 ? ~(jmask >> 1) : SMH_GRAM_S0, fl[3] = {0, 0, 0};
     /* grouped pairs: the short group's state (jb planes: the low jb-1 bits assumed alive), its flags, and the shift
      * that brings its candidate bit (jb-1) to bit 7 */
     [[maybe_unused]] const uint32_t bup = KIND == 4 && P.gram_jb ? 8u - (uint32_t)P.gram_jb : 0u;
@@ -1427,6 +1451,27 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
                 T = smh_gram_step2(T, smh_lds_u16(tab, code2)); /* columns a + 4q + 2k and + 1 */
             }
             if ((q & 3) == 3) fl16[q >> 2] = smh_gram_flags16(T, P.gram_planes); /* J planes: flags every 16 columns */
+        }
+    } else if constexpr (KIND == 5) {
+        /* 8-symbol grams, a lookup per two columns: the pair form's rolling code and step; the entry carries the planes
+         * of ALL offsets and the state chains every second one (smh_internal.h SMH_GRAM_OCT2) */
+        uint32_t code2 = 0;
+        {
+            const uint32_t x0 = (pre0 << 10) | pre0, x1 = (pre1 << 10) | pre1;
+            code2 = (code2 << 4) | smh_bfe(x0, 7, 5);
+            code2 = (code2 << 4) | smh_bfe(x0, 23, 5);
+            code2 = (code2 << 4) | smh_bfe(x1, 7, 5);
+            code2 = (code2 << 4) | smh_bfe(x1, 23, 5);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t x = (w[q] << 10) | w[q];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                code2 = ((code2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
+                T = smh_gram_step2(T, smh_lds_u16(tab, code2)); /* decides END columns a + 4q + 2k + 1 and + 2 */
+            }
+            if ((q & 3) == 3) fl16[q >> 2] = smh_gram_flags16_oct2(T, P.gram_planes);
         }
     } else if constexpr (KIND == 4) {
         /* grouped pairs: the pair form's lookup, two states (A above B in the entry) */
@@ -1491,10 +1536,39 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
 #else
     if constexpr (KIND == 4) smh_gram2_state_before(text, a, P.gram_g7, prevT, prevB);
     else if constexpr (KIND == 1) prevT = smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes);
+    else if constexpr (KIND == 5) prevT = smh_gram5_state_before(text, a, tab, P.gram_planes);
     else prevT = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7);
 #endif
     uint64_t msk;
-    if constexpr (KIND == 1) {
+    if constexpr (KIND == 5) {
+        /* Column q <= J-2 of the segment is a candidate only if bit J-2-q of the inherited state is alive too (the chain of
+         * every second offset reaches back into the previous lane's lookups); column 0 has nothing but that bit.  Lane 0 of
+         * a wave has no neighbour: the state the chunk inherits is worked out from the halo -- the last NP lookups in front
+         * of the chunk, the same in every lane, so the reads are broadcasts -- in EVERY chunk (with the assumption alone
+         * column 0 of every chunk would reach the verify stage). */
+        uint32_t pv = prevT;
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        {
+            constexpr int NP = HP == 1 ? 5 : 8, ND = (2 * NP + 6 + 3) / 4; /* lookups (>= J / 2), dwords of halo that hold their symbols */
+            static_assert(ND <= HD, "the halo kept in registers covers the lookups that reach the inherited state");
+            uint32_t c2 = 0, Th = 0;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const uint32_t hw = halo[HD - ND + d], x = (hw << 10) | hw;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    c2 = ((c2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
+                    if (2 * d + k >= 3) Th = smh_gram_step2(Th, smh_lds_u16(tab, c2));
+                }
+            }
+            if ((threadIdx.x & 63u) == 0) pv = Th;
+        }
+#endif
+        const uint32_t fixj = smh_bitrev32(~pv & jmask) >> (32u - jw); /* bit q SET = bit J-2-q of the inherited state alive; J >= 3 */
+        /* fl16[k] bit o = column 16 k + 1 + o; the flag of column 64 belongs to the next lane */
+        const uint64_t later = (uint64_t)(fl16[0] | (fl16[1] << 16)) | ((uint64_t)(fl16[2] | (fl16[3] << 16)) << 32);
+        msk = ((later << 1) | 1u) & ((uint64_t)(fixj | ~jmask) | 0xFFFFFFFF00000000ull);
+    } else if constexpr (KIND == 1) {
         /* bit t (t < J-1) SET = bit J-2-t of the inherited state alive; lane 0's default (all of SMH_GRAM_S0's low
          * seven bits clear) is the assumption for J <= 8 and merely a subset of it above: its bits 7.. read as dead,
          * which would lose candidates, so lane 0 is given the assumption explicitly */
@@ -1564,6 +1638,27 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     if (a >= n) return 0;
     uint64_t end = a + SMH_SEG;
     if (end > n) end = n;
+    if constexpr (KIND == 5) {
+        /* from the definition: END column e is a candidate when the 8-gram that ends at every ODD column c in (e - J, e]
+         * is in plane e - c (a lookup without eight symbols in front of it cannot rule anything out) */
+        const int J = P.gram_planes;
+        uint32_t cnt5 = 0;
+        for (uint64_t e = a; e < end; ++e) {
+            if (e + 1 < (uint64_t)P.m) continue;
+            bool cand = true;
+            for (int64_t c = (int64_t)(e | 1u) - ((e & 1u) ? 0 : 2); cand && c >= 7 && (int64_t)e - c < (int64_t)J; c -= 2) {
+                uint32_t code = 0;
+                for (int i = 7; i >= 0; --i) code = (code << 2) | (text[(uint64_t)c - (uint64_t)i] & 3u);
+                if ((smh_lds_u16(tab, 2u * code) >> (J - 1 - (int)((int64_t)e - c))) & 1u) cand = false;
+            }
+            if (cand) {
+                const uint32_t hit = smh_wm_verify(text, e, P);
+                cnt5 += hit;
+                if (match_mask && hit) *match_mask |= 1ull << (e - a);
+            }
+        }
+        return cnt5;
+    }
     const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
     const uint32_t cand_bit = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u;
     uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes) : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7), cnt = 0;

@@ -263,10 +263,11 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     /* staged verify as launch_gram (wm_kernels.inc) picks it */
     int stg = wm->m - 1 <= 16 ? 1 : wm->m - 1 <= 32 ? 2 : 0;
     /* pair form with few survivors per chunk: in-register verify (STG 5 / 6), as launch_gram */
-    bool regv = wm->gram_kind == SMH_GRAM_PAIR && stg > 0 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
+    const bool pairlike = wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2;
+    bool regv = pairlike && stg > 0 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
     if (const char *tn = getenv("SMH_WM_TUNE")) {
         if (strstr(tn, "regv=0")) regv = false;
-        if (strstr(tn, "regv=1")) regv = wm->gram_kind == SMH_GRAM_PAIR && stg > 0;
+        if (strstr(tn, "regv=1")) regv = pairlike && stg > 0;
     }
     if (regv) stg += 4;
     for (uint64_t t = 0; t < nthreads; ++t) {
@@ -276,6 +277,8 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
 #define GRAM_STG(KIND) (stg == 1 ? GRAM_CALL(KIND, 1) : stg == 2 ? GRAM_CALL(KIND, 2) : GRAM_CALL(KIND, 0))
         if (wm->gram_kind == SMH_GRAM_PAIR)
             total += stg == 5 ? GRAM_CALL(1, 5) : stg == 6 ? GRAM_CALL(1, 6) : GRAM_STG(1);
+        else if (wm->gram_kind == SMH_GRAM_OCT2)
+            total += stg == 5 ? GRAM_CALL(5, 5) : stg == 6 ? GRAM_CALL(5, 6) : GRAM_STG(5);
         else if (wm->gram_kind == SMH_GRAM_OCT)
             total += GRAM_STG(3);
         else

@@ -124,6 +124,7 @@ def test_grid_size_does_not_change_the_count():
 
 
 @pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 14, 4000), (1, 4, 21, 9000), (1, 4, 33, 50), (3, 4, 11, 200), (3, 4, 16, 2000),
+                                            (5, 4, 11, 30), (5, 4, 12, 200), (5, 4, 16, 8000), (5, 4, 17, 500), (5, 4, 18, 3000), (5, 4, 23, 20000), (5, 4, 24, 100), (5, 4, 33, 50),
                                             (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
                                             (2, 128, 7, 100)])
 def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
@@ -141,7 +142,7 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
     pat[p // 2] = pat[0]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
     info = wm.info()
-    assert info.gram_planes == min(15 if kind == 1 else 8, m - {1: 6, 3: 7, 2: 2}[kind])
+    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7}[kind])
     if info.scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
@@ -153,8 +154,9 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
 
 
 
+@pytest.mark.parametrize("kind", [1, 5])
 @pytest.mark.parametrize("m", [11, 12, 13, 14, 16, 17, 18, 21, 24, 29, 32, 33])
-def test_in_register_verify_every_column_and_length(m, monkeypatch):
+def test_in_register_verify_every_column_and_length(m, kind, monkeypatch):
     """Round 3: the pair form's in-register verify (wm_lane.h smh_regv_tag: the window's dwords selected out of the lane's
     text registers and the previous lane's tail by a barrel of conditional moves).  One occurrence ending at EVERY column
     residue 0..63 of a segment -- in lane 0 of a wave-chunk (window out of the halo), in lanes 1 and 63, across a chunk
@@ -173,12 +175,12 @@ def test_in_register_verify_every_column_and_length(m, monkeypatch):
     pat = np.stack([text[e - m + 1:e + 1] for e in ends]).astype(np.uint8)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
     assert want >= len(set(ends))
-    for tune in ("gram=1,regv=1", "gram=1,regv=0"):
+    for tune in ("gram=%d,regv=1" % kind, "gram=%d,regv=0" % kind):
         monkeypatch.setenv("SMH_WM_TUNE", tune)
         wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
         if wm.info().scan_engine != S.ALGO_WM:
             wm.set_scan_engine(S.ALGO_WM)
-        assert wm.info().gram_planes == min(15, m - 6)
+        assert wm.info().gram_planes == (min(15, m - 6) if kind == 1 else min(16, m - 7))
         for blocks in (1, 2):
             assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want, tune
         total, pos = E.wm_positions(wm, text, want + 8, 2)
