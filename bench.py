@@ -87,7 +87,7 @@ def ac_kernel_name(info):
     if info.scan_dense:  # the dense plan: the pair lookup kernel with the automaton's accepting-bit set
         return "wm_pair_kernel<false, 1024>"
     if info.scan_engine == 1:  # SMH_ALGO_WM: the pair-gram filter scans (ac_host.c, end of the compile); STG = halo staged / 16
-        return "wm_gram_kernel<1, false, %d, false>" % ((1 if info.m <= 17 else 2) + (4 if info.verify_in_registers else 0))
+        return "wm_gram_kernel<%d, false, %d, false>" % (info.gram_kind, (1 if info.m <= 17 else 2) + (4 if info.verify_in_registers else 0))
     halo = info.scan_depth - 1
     hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
     entry = "unsigned short" if (info.scan_stride == 2 or info.lds_rows <= 32768) else "unsigned int"
@@ -648,7 +648,8 @@ def main():
                 obj, h = sharded_set("%s.m%d" % (label, m), algo, pat, m, p, sigma, t, lens[m], 5)
                 if algo == "ac":
                     i4 = h.info()
-                    obj.update(scan_engine="suffix-filter kernels" if i4.scan_engine == S.ALGO_WM else "automaton kernels",
+                    obj.update(kernel_instance=ac_kernel_name(i4),
+                               scan_engine="suffix-filter kernels" if i4.scan_engine == S.ALGO_WM else "automaton kernels",
                                scan_stride=i4.scan_stride, scan_depth=i4.scan_depth)
                 objs["m%d" % m] = obj
             if rank == 0:

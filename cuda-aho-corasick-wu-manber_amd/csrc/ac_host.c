@@ -961,7 +961,10 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_dense = (uint32_t)ac->scan_dense;
     if (out->scan_engine == SMH_ALGO_WM) {
         smh_wm_info wi;
-        if (smh_wm_get_info(ac->alt_wm, &wi) == SMH_OK) out->verify_in_registers = wi.verify_in_registers;
+        if (smh_wm_get_info(ac->alt_wm, &wi) == SMH_OK) {
+            out->verify_in_registers = wi.verify_in_registers;
+            out->gram_kind = wi.gram_kind;
+        }
     }
     return SMH_OK;
 }

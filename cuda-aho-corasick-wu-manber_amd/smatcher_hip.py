@@ -41,7 +41,7 @@ class AcInfo(C.Structure):
                 ("lds_rows", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_bytes", C.c_uint64),
                 ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
                 ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32),
-                ("verify_in_registers", C.c_uint32)]
+                ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32)]
 
 
 class WmInfo(C.Structure):
@@ -50,7 +50,7 @@ class WmInfo(C.Structure):
                 ("block_symbols", C.c_uint32), ("filter_log2", C.c_uint32),
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
-                ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32)]
+                ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32)]
 
 
 class PsetInfo(C.Structure):

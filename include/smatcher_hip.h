@@ -120,6 +120,7 @@ typedef struct smh_ac_info {
                               * state the rolling code of the last m symbols, acceptance one bit per string in LDS
                               * (two END columns per lookup); scan_stride / scan_depth describe the ordinary plan kept beside it */
     uint32_t verify_in_registers; /* scan_engine == SMH_ALGO_WM: smh_wm_info.verify_in_registers of that engine */
+    uint32_t gram_kind;      /* scan_engine == SMH_ALGO_WM: smh_wm_info.gram_kind of that engine */
 } smh_ac_info;
 
 /* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
@@ -176,7 +177,10 @@ typedef struct smh_wm_info {
                                * (one lookup per column, or per two columns on the 4-letter alphabet) */
     uint32_t verify_in_registers; /* 1: pair form (4-letter alphabet) with few surviving columns per 4 KiB of text and
                                * m <= 33: a survivor's window is hashed by its own lane out of the text registers
-                               * (kernel instance wm_gram_kernel<1, ., 5 | 6, false>), not from a staged LDS copy */
+                               * (kernel instance wm_gram_kernel<1 | 5, ., 5 | 6, false>), not from a staged LDS copy */
+    uint32_t gram_kind;       /* form of the q-gram filter (== the kernels' KIND template value): 0 none, 1 symbol pairs (7-symbol
+                               * grams, two columns per lookup), 2 hashed byte grams, 3 8-symbol grams, 5 8-symbol grams at two
+                               * columns per lookup */
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */

@@ -13,7 +13,7 @@ import bench  # noqa: E402
 
 
 def _info(**kw):
-    d = dict(m=16, scan_dense=0, scan_engine=0, verify_in_registers=0, scan_depth=12, scan_stride=2, lds_rows=7816,
+    d = dict(m=16, scan_dense=0, scan_engine=0, verify_in_registers=0, gram_kind=1, scan_depth=12, scan_stride=2, lds_rows=7816,
              scan_full_rows=4817, scan_exact=0)
     d.update(kw)
     return types.SimpleNamespace(**d)
@@ -24,6 +24,7 @@ def test_kernel_instance_names():
     assert bench.ac_kernel_name(_info(scan_engine=1, verify_in_registers=1)) == "wm_gram_kernel<1, false, 5, false>"
     assert bench.ac_kernel_name(_info(m=32, scan_engine=1, verify_in_registers=1)) == "wm_gram_kernel<1, false, 6, false>"
     assert bench.ac_kernel_name(_info(m=32, scan_engine=1)) == "wm_gram_kernel<1, false, 2, false>"
+    assert bench.ac_kernel_name(_info(scan_engine=1, verify_in_registers=1, gram_kind=5)) == "wm_gram_kernel<5, false, 5, false>"
     assert bench.ac_kernel_name(_info()) == "ac_dfa_kernel<unsigned short, 4, 4, 1, false,"          # hybrid, depth-cut
     assert bench.ac_kernel_name(_info(scan_full_rows=0, scan_exact=1, scan_depth=8)) == "ac_dfa_kernel<unsigned short, 4, 2, 1, true,"
 
