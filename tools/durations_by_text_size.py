@@ -33,31 +33,37 @@ def main():
 
 
 def timed_steps(path, steps=10):
-    """bench.py's step = its three headline scans back to back; the first long run of launches in the trace is conditioning +
-    warm-up + timed steps.  -> mean duration per kernel instance over the LAST `steps` steps of that run (the timed ones)."""
+    """bench.py's step = its three headline scans back to back.  The first run of launches in the trace is conditioning +
+    warm-up + timed steps; after an idle gap the same warm-up + timed steps follow once more (`after_idle`).  -> mean duration
+    per kernel instance over the LAST `steps` steps of each of the two runs."""
     rows = []
     for f in glob.glob(path + "/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
             if any(k in name for k in KEEP):
-                rows.append((int(r["Start_Timestamp"]), name, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
     rows.sort()
-    # the run: from the first launch, as long as the kernel names repeat with period 3
-    run = []
-    for i, (_, name, us) in enumerate(rows):
-        if i >= 3 and name != rows[i - 3][1]:
+    # the launches whose kernel names repeat with period 3, split where the device sat idle for more than 50 ms
+    runs, cur = [], []
+    for i, (t0, t1, name) in enumerate(rows):
+        if i >= 3 and name != rows[i - 3][2]:
             break
-        run.append((name, us))
-    if len(run) < 3 * steps:
-        return
-    last = run[len(run) - len(run) % 3 - 3 * steps: len(run) - len(run) % 3]
-    print("\nthe step's launches: first run of %d launches (conditioning + warm-up + timed steps); its last %d steps:" % (len(run), steps))
-    per = collections.OrderedDict()
-    for name, us in last:
-        per.setdefault(name, []).append(us)
-    for name, v in per.items():
-        print("%-62s n=%d avg %.1f us min %.1f max %.1f" % (name[:62], len(v), sum(v) / len(v), min(v), max(v)))
-    print("whole run, per kernel: " + "  ".join("%s avg %.1f" % (n.split("<")[0] + "<" + n.split("<")[1][:14], sum(u for m, u in run if m == n) / sum(1 for m, u in run if m == n)) for n in per))
+        if cur and t0 - rows[i - 1][1] > 50_000_000:
+            runs.append(cur)
+            cur = []
+        cur.append((name, (t1 - t0) / 1e3))
+    runs.append(cur)
+    labels = ["conditioning + warm-up + timed steps (the line's `value`)", "after an idle gap: warm-up + timed steps (`after_idle`)"]
+    for run, label in zip(runs[:2], labels):
+        if len(run) < 3 * steps:
+            continue
+        last = run[len(run) - len(run) % 3 - 3 * steps: len(run) - len(run) % 3]
+        print("\n%s: %d launches; its last %d steps:" % (label, len(run), steps))
+        per = collections.OrderedDict()
+        for name, us in last:
+            per.setdefault(name, []).append(us)
+        for name, v in per.items():
+            print("%-62s n=%d avg %.1f us min %.1f max %.1f" % (name[:62], len(v), sum(v) / len(v), min(v), max(v)))
 
 
 if __name__ == "__main__":
