@@ -370,10 +370,23 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
  * bounds-checked path. */
 #define SMH_GRAM_PAIR2 4
 #define SMH_GRAM_OCT2 5
+/* 8-bit symbols, round 3: ONE set for the 3-byte grams of all offsets -- a Bloom bit array of 2^20 bits with one hash
+ * function (bit = the top 20 bits of gram * SMH_GRAM_MUL mod 2^32, stored INVERTED) -- instead of one plane per offset; the
+ * shift-or state then simply asks "were the last J grams all in the set".  J planes of 100 000 keys in 2^17 slots each are
+ * 53 % full whatever J is; the flat set holds J x 100 000 keys in 2^20 slots: 25 / 32 / 39 / 45 % full for m = 5 / 6 / 7 / 8
+ * (J = m - 2 grams), so 1.6 / 1.0 / 0.9 / 0.8 % of random columns pass instead of 15 / 8 / 4 / 2.2 % -- short byte patterns
+ * get a gram filter at all (m = 5..7 had the 12-VALU blocked-Bloom test), m = 8 a better one; from ten grams on the set is
+ * fuller than the planes and SMH_GRAM_BYTE wins.  Costs two VALU more per column than SMH_GRAM_BYTE (bit index, bit). */
+#define SMH_GRAM_FLAT 6
 #define SMH_PSET_GROUPED_DENSITY 0.0005 /* candidates per column above which the grouped form is not used */
 #define SMH_GRAM_PAIR2_SPLIT 14 /* patterns at least this long have all eight planes */
 #define SMH_GRAM_BYTES (128u * 1024u)
-#define SMH_GRAM_MUL 0x9E3779u /* 24-bit multiplier of the byte-gram index (v_mul_u32_u24) */
+/* 24-bit multiplier of the byte-gram index (v_mul_u32_u24).  Round 3: 0xD6E8FF instead of the golden-ratio constant
+ * 0x9E3779, whose products' MIDDLE bits are badly spread -- over all 2^24 grams, bits 12..31 of gram * 0x9E3779 reach 40 %
+ * of their 2^20 values (a random gram then falls on a set bit 2.9 times as often as the set's load says), and bits 15..31
+ * load the 2^17 table entries with 67..155 grams each instead of 126..130: 100 000 patterns of 12 bytes let 0.85 % of random
+ * columns through the eight planes, with this constant 0.66 % (the ideal for the load: 0.62 %) */
+#define SMH_GRAM_MUL 0xD6E8FFu
 
 #ifdef __cplusplus
 }

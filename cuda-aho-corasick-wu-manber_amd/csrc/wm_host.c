@@ -179,6 +179,12 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
         } else if (kind == SMH_GRAM_OCT) {
             code = ((code << 2) | c) & 0xFFFFu;
             G = ((const uint8_t *)tab)[code];
+        } else if (kind == SMH_GRAM_FLAT) {
+            const uint32_t key = k0 | (k1 << 8) | (c << 16);
+            k0 = k1;
+            k1 = c;
+            const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
+            G = ((((const uint8_t *)tab)[prod >> 15] >> ((prod >> 12) & 7u)) & 1u) ? (0xFFu & ~((1u << (8 - planes)) - 1u)) : 0u;
         } else {
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
             k0 = k1;
@@ -199,6 +205,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
 #define SMH_GRAM_OCT_MS 0.26
 #define SMH_GRAM_OCT2_MS 0.178 /* the pair form's lookups + lane 0's inherited state from the halo in every chunk */
 #define SMH_GRAM_BYTE_MS 0.238
+#define SMH_GRAM_FLAT_MS 0.27 /* SMH_GRAM_BYTE's lookup per column + two VALU (bit index, bit) */
 /* verify stage, ms per GiB for a fraction `dens` of surviving columns.  Staged (m <= 33: window hashes from the LDS
  * copy of the chunk, probe pipelined): the cost is mostly per wave-chunk that has any survivor -- lock, copy, hash
  * round trips -- and grows slowly with their number (pair form, 16 symbols, survivors per 4 KiB chunk -> ms/GiB over the
@@ -332,6 +339,33 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_BYTE; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
+        } else {
+            free(tab);
+        }
+    }
+    if (wm->bits_per_symbol >= 7 && m >= 5 && GRAM_WANTED(SMH_GRAM_FLAT)) {
+        /* one Bloom set for the grams of all offsets (smh_internal.h SMH_GRAM_FLAT); bit = 1: NOT in the set */
+        int J = m - 2;
+        if (J > 8) J = 8;
+        uint8_t *tab = (uint8_t *)malloc(SMH_GRAM_BYTES);
+        if (!tab) { free(best); return -1; }
+        memset(tab, 0xFF, SMH_GRAM_BYTES);
+        for (int p = 0; p < d; ++p)
+            for (int j = 0; j < J; ++j) {
+                const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
+                const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
+                const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
+                tab[prod >> 15] &= (uint8_t)~(1u << ((prod >> 12) & 7u));
+            }
+        if (getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "debug")) {
+            uint64_t zeros = 0;
+            for (uint32_t i = 0; i < SMH_GRAM_BYTES; ++i) zeros += 8u - (uint32_t)__builtin_popcount(tab[i]);
+            fprintf(stderr, "flat byte grams: %d patterns x %d grams, %.1f %% of the 2^20 bits in the set\n", d, J, 100.0 * (double)zeros / 1048576.0);
+        }
+        const double dens = gram_survivors(SMH_GRAM_FLAT, tab, wm->alphabet, J), ms = SMH_GRAM_FLAT_MS + gram_verify_ms(m, dens);
+        if (ms < best_ms) {
+            free(best);
+            best = tab; best_kind = SMH_GRAM_FLAT; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
         } else {
             free(tab);
         }

@@ -26,7 +26,7 @@
 #include "lane_common.h"
 
 #define SMH_WM_HASH_MUL 0x9E3779B1u /* == SMH_HASH_MUL in smh_internal.h */
-#define SMH_GRAM_MUL_DEV 0x9E3779u  /* == SMH_GRAM_MUL in smh_internal.h */
+#define SMH_GRAM_MUL_DEV 0xD6E8FFu  /* == SMH_GRAM_MUL in smh_internal.h */
 #include <utility>
 
 struct smh_wm_params {
@@ -1292,12 +1292,34 @@ SMH_LANE uint32_t smh_gram_key(const uint32_t (&w)[16], uint32_t pre)
     }
 }
 
-template <int... Is>
-SMH_LANE void smh_gram_byte_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &T, uint32_t (&fl)[3],
+/* G of a byte-gram column from its key (the three bytes that end there, in the low 24 bits).
+ *   KIND 2  one plane per offset: the table byte at the top 17 bits of key * SMH_GRAM_MUL
+ *   KIND 6  (round 3, SMH_GRAM_FLAT) ONE set for the grams of all offsets, a 2^20-bit array: byte address = the same 17
+ *           bits, bit = the three below them; the array holds the set INVERTED, so a sign-extending 1-bit field extract
+ *           yields 0 (in the set) or all ones (not), masked to the J plane bits `gmask` -- every plane tests the same set */
+template <int KIND>
+SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask)
+{
+    const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
+    const uint32_t b = smh_lds_u8(tab, prod >> 15);
+    if constexpr (KIND == 6) {
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        return (uint32_t)__builtin_amdgcn_sbfe((int)b, smh_bfe(prod, 12, 3), 1u) & gmask;
+#else
+        return ((b >> ((prod >> 12) & 7u)) & 1u) ? gmask : 0u;
+#endif
+    } else {
+        (void)gmask;
+        return b;
+    }
+}
+
+template <int KIND, int... Is>
+SMH_LANE void smh_gram_byte_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t gmask, uint32_t &T, uint32_t (&fl)[3],
                                     std::integer_sequence<int, Is...>)
 {
     /* columns in order; flags are collected after columns 23, 47 and 63 */
-    ((T = smh_gram_step(T, smh_lds_u8(tab, smh_mul24(smh_gram_key<Is>(w, pre), SMH_GRAM_MUL_DEV) >> 15)),
+    ((T = smh_gram_step(T, smh_gram_byte_G<KIND>(smh_gram_key<Is>(w, pre), tab, gmask)),
       (Is == 23 ? (void)(fl[0] = smh_gram_flags(T, 24)) : Is == 47 ? (void)(fl[1] = smh_gram_flags(T, 24))
                                                         : Is == 63 ? (void)(fl[2] = smh_gram_flags(T, 16)) : (void)0)),
      ...);
@@ -1307,7 +1329,7 @@ SMH_LANE void smh_gram_byte_columns(const uint32_t (&w)[16], uint32_t pre, const
  * value: the CPU emulation and the bounds-checked path compute it by running the recurrence over those columns.
  * `tab` = the LDS image; `g7` = the pair form's per-gram bytes in HBM (smh_wm_params::gram_g7). */
 template <int KIND>
-SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const void *tab, const uint8_t *g7)
+SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const void *tab, const uint8_t *g7, uint32_t gmask = 0xFFu)
 {
     uint32_t S = 0u;
     if (KIND == 3) {
@@ -1324,7 +1346,7 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
         if (a < 10) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
             const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
-            S = smh_gram_step(S, smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15));
+            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, gmask));
         }
     }
     return S & 0x7Fu;
@@ -1525,7 +1547,7 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
         }
     } else {
         (void)pre0;
-        smh_gram_byte_columns(w, pre1, tab, T, fl, std::make_integer_sequence<int, 64>{});
+        smh_gram_byte_columns<KIND>(w, pre1, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), T, fl, std::make_integer_sequence<int, 64>{});
     }
     /* correct the first seven columns with the state the previous lane ended in */
     uint32_t prevT;
@@ -1537,7 +1559,7 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     if constexpr (KIND == 4) smh_gram2_state_before(text, a, P.gram_g7, prevT, prevB);
     else if constexpr (KIND == 1) prevT = smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes);
     else if constexpr (KIND == 5) prevT = smh_gram5_state_before(text, a, tab, P.gram_planes);
-    else prevT = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7);
+    else prevT = smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u));
 #endif
     uint64_t msk;
     if constexpr (KIND == 5) {
@@ -1661,7 +1683,8 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     }
     const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
     const uint32_t cand_bit = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u;
-    uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes) : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7), cnt = 0;
+    uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes)
+                           : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u)), cnt = 0;
     for (uint64_t e = a; e < end; ++e) {
         uint32_t G = 0u; /* a column without a whole gram in front of it cannot be ruled out */
         if (e + 1 >= q) {
@@ -1677,7 +1700,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
                 G = g;
             } else {
                 const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
-                G = smh_lds_u8(tab, smh_mul24(key, SMH_GRAM_MUL_DEV) >> 15);
+                G = smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u));
             }
         }
         T = smh_gram_step(T, G);

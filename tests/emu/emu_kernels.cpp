@@ -281,6 +281,8 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
             total += stg == 5 ? GRAM_CALL(5, 5) : stg == 6 ? GRAM_CALL(5, 6) : GRAM_STG(5);
         else if (wm->gram_kind == SMH_GRAM_OCT)
             total += GRAM_STG(3);
+        else if (wm->gram_kind == SMH_GRAM_FLAT)
+            total += GRAM_STG(6);
         else
             total += GRAM_STG(2);
 #undef GRAM_STG

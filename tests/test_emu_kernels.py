@@ -124,6 +124,7 @@ def test_grid_size_does_not_change_the_count():
 
 
 @pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 14, 4000), (1, 4, 21, 9000), (1, 4, 33, 50), (3, 4, 11, 200), (3, 4, 16, 2000),
+                                            (6, 256, 5, 300), (6, 256, 6, 3000), (6, 256, 7, 100), (6, 256, 8, 5000), (6, 128, 7, 100), (6, 256, 12, 3000), (6, 256, 20, 500),
                                             (5, 4, 11, 30), (5, 4, 12, 200), (5, 4, 16, 8000), (5, 4, 17, 500), (5, 4, 18, 3000), (5, 4, 23, 20000), (5, 4, 24, 100), (5, 4, 33, 50),
                                             (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
                                             (2, 128, 7, 100)])
@@ -142,7 +143,7 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
     pat[p // 2] = pat[0]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
     info = wm.info()
-    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7}[kind])
+    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2}[kind]) and info.gram_kind == kind
     if info.scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)

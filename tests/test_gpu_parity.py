@@ -428,6 +428,7 @@ def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, monkeypatch):
 @pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1"], ids=["default", "hbm_windows", "staged", "in_registers"])
 @pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 17, 6000), (1, 4, 33, 50), (1, 4, 40, 50),
                                             (3, 4, 11, 200), (3, 4, 16, 20000), (3, 4, 32, 500), (2, 256, 5, 3000),
+                                            (6, 256, 5, 3000), (6, 256, 6, 100000), (6, 256, 7, 100), (6, 256, 8, 30000), (6, 256, 17, 1000), (6, 256, 33, 2000),
                                             (5, 4, 11, 30), (5, 4, 16, 8000), (5, 4, 17, 6000), (5, 4, 18, 300), (5, 4, 23, 20000), (5, 4, 33, 50),
                                             (2, 256, 12, 30000), (2, 256, 17, 100000), (2, 256, 18, 1000), (2, 256, 33, 2000),
                                             (2, 256, 34, 2000), (2, 128, 7, 100)])
@@ -450,7 +451,7 @@ def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, monkeypatch):
         text[off:off + m] = pat[(7 * i + 3) % p]
     pat[p // 2] = pat[3]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
-    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7}[kind])
+    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2}[kind]) and wm.info().gram_kind == kind
     if wm.info().scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
