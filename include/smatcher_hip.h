@@ -179,8 +179,8 @@ typedef struct smh_wm_info {
                                * m <= 33: a survivor's window is hashed by its own lane out of the text registers
                                * (kernel instance wm_gram_kernel<1 | 5, ., 5 | 6, false>), not from a staged LDS copy */
     uint32_t gram_kind;       /* form of the q-gram filter (== the kernels' KIND template value): 0 none, 1 symbol pairs (7-symbol
-                               * grams, two columns per lookup), 2 hashed byte grams, 3 8-symbol grams, 5 8-symbol grams at two
-                               * columns per lookup */
+                               * grams, two columns per lookup), 2 hashed byte grams (one plane per offset), 3 8-symbol grams, 5 8-symbol
+                               * grams at two columns per lookup, 6 flat byte grams (one Bloom set for all offsets) */
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */
