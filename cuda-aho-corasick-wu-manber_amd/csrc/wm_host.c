@@ -202,7 +202,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
  * Shift-or steps (one v_lshl_or per column, per two columns in the pair form): pairs 0.178 (HBM-bound), 8-symbol
  * grams 0.26 and byte grams 0.238 (one LDS lookup per column). */
 #define SMH_GRAM_PAIR_MS 0.173
-#define SMH_GRAM_OCT_MS 0.26
+#define SMH_GRAM_OCT_MS 0.24 /* 0.218 at 2000 patterns .. 0.243 at 12 000 with next to no survivors (lane 0 of a wave-chunk keeps the assumption) */
 #define SMH_GRAM_OCT2_MS 0.178 /* the pair form's lookups + lane 0's inherited state from the halo in every chunk */
 #define SMH_GRAM_BYTE_MS 0.238
 #define SMH_GRAM_FLAT_MS 0.27 /* SMH_GRAM_BYTE's lookup per column + two VALU (bit index, bit) */
@@ -218,6 +218,17 @@ static double gram_verify_ms(int m, double dens)
     if (m > 33) return (12.0 + 3.0 * m) * dens;
     const double pc = dens * 4096.0; /* survivors per wave-chunk; beyond a queue's worth several flushes per chunk */
     return 0.04 * log(1.0 + 1.5 * pc) + (pc > 30.0 ? 0.0015 * (pc - 30.0) : 0.0);
+}
+/* the same for the pair-like forms (two columns per lookup), refit at steady state on 35 DNA sets x 3 forms (2000..40 000
+ * patterns of 12..28 symbols, profiles/r03_experiments/gram_forms_sweep.log): up to SMH_REGV_MAX_PER_CHUNK survivors per chunk
+ * they verify in registers, 0.02 / 0.045 / 0.07 ms/GiB at 1.5 / 4.4 / 8 per chunk -- 0.7 of the staged model -- and between
+ * 8 and 40 per chunk the staged verify measures 1.2 of it (0.137 at 8.8, m = 12).  With these and SMH_GRAM_OCT_MS the form
+ * the compile keeps is the fastest of the three, or within 1.5 % of it, on 33 of the 35 sets (the other two: 4.5 %) */
+static double gram_verify_ms_pairlike(int m, double dens)
+{
+    const double pc = dens * 4096.0;
+    const double f = m > 33 ? 1.0 : pc <= SMH_REGV_MAX_PER_CHUNK ? 0.7 : pc <= 40.0 ? 1.2 : 1.0;
+    return f * gram_verify_ms(m, dens);
 }
 #define SMH_HASHED_VERIFY_MS(m) (6.0 + 1.05 * (m))
 #define SMH_DIRECT_VERIFY_MS(m) ((m) > 4 ? 1.9 * (m) - 3.0 : 4.6)
@@ -260,7 +271,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
             }
         /* entry of eight symbols = (G of the older seven << 1) | G of the newer seven: one v_lshl_or does both columns */
         for (uint32_t x = 0; x < 65536; ++x) tab[x] = (uint16_t)(((uint32_t)g7[x >> 2] << 1) | g7[x & 0x3FFFu]);
-        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4, J), ms = SMH_GRAM_PAIR_MS + gram_verify_ms(m, dens);
+        const double dens = gram_survivors(SMH_GRAM_PAIR, tab, 4, J), ms = SMH_GRAM_PAIR_MS + gram_verify_ms_pairlike(m, dens);
         /* lane 0 of a wave-chunk starts from "every plane still alive": its column c passes on planes 0..c alone */
         double lane0 = 0.0, run = 1.0;
         for (int j = 0; j < J - 1; ++j) {
@@ -314,7 +325,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
                 tab[code] &= (uint16_t)~(1u << (J - 1 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_OCT2, tab, 4, J), ms = SMH_GRAM_OCT2_MS + gram_verify_ms(m, dens);
+        const double dens = gram_survivors(SMH_GRAM_OCT2, tab, 4, J), ms = SMH_GRAM_OCT2_MS + gram_verify_ms_pairlike(m, dens);
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_OCT2; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
