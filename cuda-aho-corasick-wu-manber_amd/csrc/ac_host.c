@@ -789,7 +789,10 @@ static int plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, i
                 /* round 2 refit (leaner step, dynamic chunk scheduling): K12D9 cut 0.205 ms/GiB with three chains per
                  * lane (halo <= 16 bytes; 0.220 with two), 0.255 with one, against 0.289 for the exact stride-1 scan */
                 const double base = K - 1 <= 16 ? 0.51 : 0.67;
-                const double cost = base + 2.0 * (1.0 - pow(1.0 - q, 64.0)) + (K < ac->m ? 0.07 + 300.0 * r : 0.0);
+                /* round 3: + 7 q -- the resolution loop runs as long as ANY lane walks items, and with most lanes deep
+                 * (3000 patterns of 16 symbols, K = 15 with rows to depth 5 only: q = 0.73) the image measured 2.18 ms/GiB
+                 * = 7.5 units where "any lane deep" alone said 2.5; the stride-1 K = 11 plan of the same set: 0.62 */
+                const double cost = base + 2.0 * (1.0 - pow(1.0 - q, 64.0)) + 7.0 * q + (K < ac->m ? 0.07 + 300.0 * r : 0.0);
                 if (cost < best_cost) { best_cost = cost; best_s = 3; best_k[3] = K; best_d = D; }
                 break;
             }
