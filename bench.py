@@ -313,6 +313,8 @@ def main():
                     help="rehearsal of the N > 1 control flow on ONE card: every rank uses device 0, process group over gloo")
     args = ap.parse_args()
 
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("bench.py: --steps must be >= 1 and --warmup >= 0")
     if args.multi_leg:
         return multi_leg(args)
     world_env = os.environ.get("WORLD_SIZE")
@@ -460,7 +462,7 @@ def main():
     kern_ms = {m: [evs[k][i].elapsed_time(evs[k][i + 1]) for k in range(args.steps)] for i, m in enumerate(AC_LENGTHS)}
     bits_per_step = 8.0 * sum(sum(sl.values()) for sl in sharded.gather_objects(shard_len))
     value = bits_per_step * args.steps / elapsed / 1e9
-    mean = lambda xs: sum(xs) / len(xs)
+    mean = lambda xs: sum(xs) / len(xs) if xs else 0.0
     all_kern_ms = sharded.gather_objects({m: mean(kern_ms[m]) for m in AC_LENGTHS})  # [rank][m]
 
     out = None
