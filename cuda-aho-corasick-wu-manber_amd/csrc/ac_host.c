@@ -35,7 +35,13 @@ void smh_set_error(const char *fmt, ...)
 
 const char *smh_last_error(void) { return g_err; }
 _Thread_local int smh_alt_engine_depth = 0;
-const char *smh_version(void) { return "mi355x-smatcher 0.1 (gfx950)"; }
+const char *smh_version(void) { return "mi355x-smatcher 0.2 (gfx950)"; }
+
+uint64_t smh_handle_serial(void)
+{
+    static uint64_t next = 0;
+    return __atomic_add_fetch(&next, 1, __ATOMIC_RELAXED);
+}
 
 /* reference: fail() from the absent ../helper2.h -- message, then exit */
 void fail(const char *msg)
@@ -179,6 +185,7 @@ void smh_ac_host_free(struct smh_ac *ac)
     free(ac->dense_filter);
     if (ac->hv_wm != ac->alt_wm) smh_wm_free(ac->hv_wm); /* one handle may serve both roles */
     smh_wm_free(ac->alt_wm);
+    smh_ac_free(ac->flat_ac);
     ac->magic = 0;
     free(ac);
 }
@@ -186,7 +193,7 @@ void smh_ac_host_free(struct smh_ac *ac)
 /* the chosen automaton plan in ms per GiB on MI355X: the plan model's cost is in units of the exact stride-1 scan
  * (0.289 ms/GiB) and ranks the automaton plans among themselves; the hybrid image's kernels measure 0.183 (exact, two
  * chains + prefetch) and 0.205 (depth-cut, three chains) where the model says 0.15 / 0.17 (profiles/r03_q) */
-static double ac_plan_ms(const struct smh_ac *ac)
+double smh_ac_plan_ms(const struct smh_ac *ac)
 {
     double ms = ac->scan_cost * 0.289;
     if (ac->scan_full_rows) ms += ac->scan_exact ? 0.03 : 0.035;
@@ -263,6 +270,7 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
     uint32_t *canon = (uint32_t *)malloc((size_t)R * sizeof(uint32_t));
     uint32_t *newid = (uint32_t *)malloc((size_t)R * sizeof(uint32_t));
     struct smh_ac *ac = (struct smh_ac *)calloc(1, sizeof *ac);
+    if (ac) ac->engine_forced = -1, ac->serial = smh_handle_serial();
     uint32_t *full = NULL;
     if (!order || !depth || !seen || !leaf || !canon || !newid || !ac) goto oom;
 
@@ -466,9 +474,11 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
              * the handle keeps serving the automaton kernels' verify stage when a plan is forced. */
             const int verify_bound = ac->scan_cost > SMH_AC_ALT_ENGINE_COST;
             const int filter_faster = w && !ac->scan_exact && w->gram_kind != SMH_GRAM_NONE && !w->alt_ac &&
-                                      w->scan_ms_est + SMH_AC_ALT_ENGINE_MARGIN_MS < ac_plan_ms(ac);
+                                      w->scan_ms_est + SMH_AC_ALT_ENGINE_MARGIN_MS < smh_ac_plan_ms(ac);
             if (w && (verify_bound || filter_faster)) ac->alt_wm = w;
             if (w && !verify_bound) ac->hv_wm = w;
+            /* both engines stay at hand when both could serve (round 4): which one runs is then decided per text */
+            if (w && !verify_bound && !ac->scan_exact && w->gram_kind != SMH_GRAM_NONE && !w->alt_ac) ac->flex_wm = w;
         }
         --smh_alt_engine_depth;
     }
@@ -476,6 +486,25 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
         /* nothing can fail any more: ownership has passed, shrink the adopted block (a failed shrink leaves it valid) */
         void *t = realloc(ac->g_transition, (size_t)ac->states * (size_t)alphabet * sizeof(int32_t));
         if (t) ac->g_transition = (int32_t *)t;
+    }
+    /* Round 4: the hybrid image is fast while the lanes stay in its full rows -- on random text nearly always.  On text
+     * that keeps matching long pattern prefixes (repeats, low-complexity runs, the patterns themselves recurring: the
+     * reference's genomes and proteins, main.c:39-109) most lanes sit in compact rows and every step takes the resolution
+     * path: measured 2-4.5 ms/GiB where the plan says 0.2.  A PLAIN stride-1 image has no such path: one lookup per symbol
+     * whatever the text, 0.29 ms/GiB.  When the whole automaton fits LDS in that form (K = m: exact, no verify stage) it is
+     * kept beside the preferred plan as the engine with a guarantee, and the runtime switches to it when the launches
+     * report that the text is of that kind (smh_runtime.hip "adaptive engine"). */
+    if (ac->fixed_length_ok && ac->scan_full_rows && !ac->scan_dense && ac->g_transition && smh_alt_engine_depth == 0) {
+        ++smh_alt_engine_depth;
+        struct smh_ac *flat = smh_ac_compile_tables_impl(ac->g_transition, ac->g_supply, ac->g_final, (uint64_t)ac->states,
+                                                         alphabet, m, SMH_AC_REF_NONE);
+        if (flat && (!flat->fixed_length_ok || smh_ac_plan_scan(flat, SMH_AC_LDS_BUDGET, 1, 0) != SMH_OK || !flat->scan_exact ||
+                     flat->scan_full_rows || flat->scan_stride != 1)) {
+            smh_ac_free(flat);
+            flat = NULL;
+        }
+        ac->flat_ac = flat;
+        --smh_alt_engine_depth;
     }
     return ac;
 
@@ -960,11 +989,12 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_stride = (uint32_t)ac->scan_stride;
     out->scan_exact = (uint32_t)ac->scan_exact;
     out->scan_full_rows = ac->scan_full_rows;
-    out->scan_engine = ac->alt_wm && !ac->alt_off ? SMH_ALGO_WM : SMH_ALGO_AC;
+    out->scan_engine = ac->engine_forced >= 0 ? (uint32_t)ac->engine_forced : (ac->alt_wm ? SMH_ALGO_WM : SMH_ALGO_AC);
     out->scan_dense = (uint32_t)ac->scan_dense;
+    out->adaptive = (ac->flex_wm || ac->flat_ac) && ac->engine_forced < 0 ? 1u : 0u;
     if (out->scan_engine == SMH_ALGO_WM) {
         smh_wm_info wi;
-        if (smh_wm_get_info(ac->alt_wm, &wi) == SMH_OK) {
+        if (smh_wm_get_info(ac->alt_wm ? ac->alt_wm : ac->flex_wm, &wi) == SMH_OK) {
             out->verify_in_registers = wi.verify_in_registers;
             out->gram_kind = wi.gram_kind;
         }
@@ -986,21 +1016,33 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
     if (rc != SMH_OK) return rc; /* the handle keeps its current plan and device tables */
     if (ac->dev) smh_ac_dev_free(ac->dev); /* device copies are rebuilt on the next scan */
     ac->dev = NULL;
+    smh_adapt_dev_free(ac->adapt); /* what was measured belongs to the old plan */
+    ac->adapt = NULL;
     ac->alt_off = stride != 0 || depth != 0; /* a forced plan means "run the automaton kernels" */
+    ac->engine_forced = ac->alt_off ? SMH_ALGO_AC : -1;
+    if (ac->scan_exact || ac->scan_dense) ac->flex_wm = NULL; /* an exact plan never hands over */
+    else if (ac->hv_wm && ac->hv_wm->gram_kind != SMH_GRAM_NONE && !ac->hv_wm->alt_ac) ac->flex_wm = ac->hv_wm;
+    ++ac->generation;
     return SMH_OK;
 }
 
 int smh_ac_set_scan_engine(smh_ac *ac, int engine)
 {
-    if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC)) {
+    if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT)) {
         smh_set_error("smh_ac_set_scan_engine: bad arguments");
         return SMH_EINVAL;
     }
-    if (engine == SMH_ALGO_WM && !ac->alt_wm) {
-        smh_set_error("smh_ac_set_scan_engine: this set has no suffix-filter engine (its automaton plan is exact or estimated faster)");
+    if (engine == SMH_ENGINE_AC_FLAT && !ac->flat_ac) {
+        smh_set_error("smh_ac_set_scan_engine: this set keeps no plain stride-1 automaton (its plan is not a hybrid image, or the whole automaton does not fit LDS)");
+        return SMH_EUNSUP;
+    }
+    if (engine == SMH_ALGO_WM && !ac->alt_wm && !ac->flex_wm) {
+        smh_set_error("smh_ac_set_scan_engine: this set has no suffix-filter engine (its automaton plan is exact)");
         return SMH_EUNSUP;
     }
     ac->alt_off = engine == SMH_ALGO_AC;
+    ac->engine_forced = engine;
+    ++ac->generation;
     return SMH_OK;
 }
 
@@ -1009,5 +1051,7 @@ void smh_ac_free(smh_ac *ac)
     if (!ac) return;
     if (ac->dev) smh_ac_dev_free(ac->dev);
     ac->dev = NULL;
+    smh_adapt_dev_free(ac->adapt);
+    ac->adapt = NULL;
     smh_ac_host_free(ac);
 }

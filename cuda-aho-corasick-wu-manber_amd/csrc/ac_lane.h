@@ -147,6 +147,7 @@ struct smh_ac_queue {
     uint64_t *slots; /* SMH_AC_QCAP entries in HBM, private to this wave */
     uint32_t count;  /* wave-uniform */
     uint32_t matches;
+    uint32_t events; /* wave-uniform: candidates this wave queued (smh_stats.h) */
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -210,6 +211,7 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
         __hip_atomic_store(Q.slots + Q.count + before, ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     Q.count += np;
+    Q.events += np;
 }
 #else
 SMH_LANE void smh_ac_drain(smh_ac_queue &, const smh_ac_verify_ctx &) {}
@@ -805,7 +807,7 @@ SMH_LANE uint32_t smh_ac_piece(const FMT &fmt, const smh_ac_verify_ctx &V, uint6
  * value is then the number of matches this lane appended; the kernels ignore it). */
 template <typename FMT, int HC, int NCH, bool EXACT, int PREFETCH = SMH_PREFETCH, int SW = 16, bool POS = false>
 SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chunk_sched &S, const void *tab,
-                                const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base)
+                                const smh_ac_verify_ctx &V, const smh_ac_df &df, uint64_t *queue_base, uint32_t *events_out = nullptr)
 {
     if (V.n < (uint64_t)V.m) return 0;
     const uint64_t n_starts = V.n - (uint64_t)V.m + 1;
@@ -818,6 +820,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chun
     Q.slots = queue_base ? queue_base + smh_uniform64(wave) * SMH_AC_QCAP : nullptr;
     Q.count = 0;
     Q.matches = 0;
+    Q.events = 0;
     uint32_t cnt = 0;
     /* software pipeline: the segments of the wave's NEXT chunk are requested before the current
      * chunk is scanned, so the HBM latency of a chunk hides behind a whole chunk of lookups */
@@ -886,6 +889,7 @@ SMH_LANE uint32_t smh_ac_thread(const FMT &fmt, uint64_t gthread, const smh_chun
         k = kn;
     }
     if (!EXACT) smh_ac_drain(Q, V);
+    if (events_out) *events_out = Q.events;
     return cnt + Q.matches;
 }
 

@@ -20,6 +20,7 @@ extern "C" {
 #define SMH_MAGIC_SBOM 0x53424f4du /* "SBOM" */
 
 void smh_set_error(const char *fmt, ...);
+uint64_t smh_handle_serial(void); /* ac_host.c: 1, 2, 3, ... */
 
 /* ------------------------------------------------------------------ AC
  * Device automaton (DESIGN.md "AC layout").
@@ -83,8 +84,18 @@ struct smh_ac {
     int scan_dense;
     uint32_t *dense_pair;   /* 16384 dwords = 64 KiB */
     uint32_t *dense_filter; /* max(1, 4^m / 32) dwords */
-    struct smh_wm *alt_wm; /* suffix-filter engine for sets whose best automaton plan is verify-bound, else NULL */
-    int alt_off;          /* a scan plan was forced: scans use the automaton kernels regardless */
+    struct smh_wm *alt_wm; /* suffix-filter engine for sets whose best automaton plan is verify-bound or estimated slower, else NULL */
+    int alt_off;          /* a scan plan was forced: scans use the automaton kernels regardless (== engine_forced == SMH_ALGO_AC) */
+    /* round 4: the engine is a property of the handle AND the text.  flex_wm = the suffix-filter engine of a depth-cut plan
+     * whichever engine the compile preferred (the same handle as hv_wm): with both engines at hand the runtime follows what
+     * the launches report about the text (smh_runtime.hip "adaptive engine").  engine_forced: -1 = let it, else the engine
+     * smh_ac_set_scan_engine / a forced plan named */
+    struct smh_wm *flex_wm;
+    struct smh_ac *flat_ac; /* a hybrid plan's plain stride-1 twin with K = m when the whole automaton fits LDS that way (ac_host.c, end of the compile): the engine whose speed does not depend on the text */
+    int engine_forced;
+    uint32_t generation;  /* bumped by every re-plan / forced engine: what was prepared or warmed for the handle before is stale */
+    uint64_t serial;      /* unique per compiled handle (smh_handle_serial): an address can be reused after a free, a serial cannot */
+    struct smh_adapt_dev *adapt; /* per device: stats block, measurements, current engine (smh_runtime.hip) */
     struct smh_wm *hv_wm; /* verify table + patterns for the automaton kernels' verify stage (hash the window, probe), else NULL */
     /* stride-1 depth-K table in HBM: the slow path and the resolution of stride-2 "first symbol"
      * candidates read it; identical to scan_table when scan_stride == 1 */
@@ -123,6 +134,7 @@ extern thread_local int smh_alt_engine_depth;
 #else
 extern _Thread_local int smh_alt_engine_depth;
 #endif
+#define SMH_WM_FLEX_ENGINE_COST 1.5 /* automaton plan cost up to which a Wu-Manber handle keeps the automaton as its second engine */
 #define SMH_WM_ALT_ENGINE_COST 1.15 /* automaton plan cost (1.0 = 3.5 TB/s) below which it beats the non-exact direct filter */
 #ifndef SMH_HYB_COMPACT0
 #define SMH_HYB_COMPACT0 0x8000u /* hybrid stride-2 image: id of the first item slot of the compact part (== lane_common.h) */
@@ -137,6 +149,9 @@ extern _Thread_local int smh_alt_engine_depth;
 #define SMH_AC_ALT_ENGINE_MARGIN_MS 0.01 /* a depth-cut plan hands the scan to the gram filter when that is estimated this much faster (ms/GiB) */
 #define SMH_AC_MAX_SCAN_DEPTH 65 /* fast paths cover a halo of K - 1 <= 64 bytes */
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
+struct smh_adapt_dev;
+void smh_adapt_dev_free(struct smh_adapt_dev *list); /* smh_runtime.hip */
+double smh_ac_plan_ms(const struct smh_ac *ac); /* ac_host.c: the plan model's estimate for the automaton kernels, ms per GiB */
 int smh_ac_prepare_device(struct smh_ac *ac); /* smh_runtime.hip: table set of the current device, no launch */
 
 /* ------------------------------------------------------------------ mixed-length automaton (acm_host.c)
@@ -331,6 +346,11 @@ struct smh_wm {
     struct smh_wm_dev *dev;
     struct smh_ac *alt_ac; /* automaton engine for small-alphabet sets of long patterns when it is the faster one, else NULL */
     int alt_off;           /* smh_wm_set_scan_engine(SMH_ALGO_WM): scans use this path's own kernels regardless */
+    struct smh_ac *flex_ac; /* round 4: the automaton engine kept at hand even when it is the slower one on random text (== alt_ac when that is set) */
+    int engine_forced;     /* -1 = the runtime follows the launches' reports (round 4), else the engine smh_wm_set_scan_engine named */
+    uint32_t generation;   /* bumped by smh_wm_set_scan_engine */
+    uint64_t serial;       /* unique per compiled handle */
+    struct smh_adapt_dev *adapt; /* per device: stats block, measurements, current engine / verify mode (smh_runtime.hip) */
 };
 
 struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int p_size, int alphabet,

@@ -11,9 +11,12 @@
 #include "ac_lane.h"
 #include "wm_lane.h"
 #include "acm_lane.h"
+#include "corpus_gen.h"
+#include "smh_stats.h"
 
 #define SMH_BLOCK_THREADS 1024
 #define SMH_LDS_BUDGET (156u * 1024u) /* of the 160 KiB per CU; the rest is left to the runtime */
+#define SMH_LDS_MIN 256u               /* smallest dynamic LDS a scan kernel is launched with: its final reduction uses the first 128 bytes */
 #define SMH_MAX_HALO_CHUNKS 4          /* fast paths cover m - 1 <= 64 */
 #define SMH_DEPTH_FIRST_MIN 72         /* depth_first[] is padded to max(this, m + 2): indexed with h + 1 <= 65 and t + 1 <= m */
 
@@ -77,12 +80,14 @@ struct smh_ac_launch {
     uint64_t *d_count;
     int n_cus;
     uint64_t *d_wave_times;     /* development aid: 3 ticks per wave (ac_kernels.inc), else NULL */
+    smh_stats_arg stats;        /* st != NULL: the launch reports its candidates and its duration (smh_stats.h) */
 };
 uint32_t smh_ac_max_blocks(int n_cus);
 hipError_t smh_launch_ac_dfa(const smh_ac_launch &L, hipStream_t stream);
 hipError_t smh_launch_ac_dfa_positions(const smh_ac_launch &L, hipStream_t stream);
 hipError_t smh_launch_ac_dfa_wide(const smh_ac_launch &L, hipStream_t stream);
-bool smh_lds_oob_reads_zero(hipStream_t stream); /* ac_kernels.inc: per-device probe behind the unclamped hybrid kernels */ /* 32-bit entries; called by smh_launch_ac_dfa */
+bool smh_lds_oob_probe(int n_cus);   /* ac_kernels.inc: the per-device probe behind the unclamped hybrid kernels; blocking, run where a table set is built */
+bool smh_lds_oob_reads_zero(void);   /* the cached answer (false while the device has not been probed) */
 
 struct smh_ac_table_launch {
     const uint8_t *d_text;
@@ -180,6 +185,9 @@ struct smh_wm_launch {
     smh_pos_out po;       /* positions mode only */
     int n_classes;        /* > 0: mixed-length set in one pass, d_classes[n_classes] on the device */
     const smh_wm_class *d_classes;
+    smh_stats_arg stats;  /* st != NULL: the launch reports its surviving columns and its duration (smh_stats.h) */
+    int verify_mode;      /* gram kernels: 0 = choose from gram_density, 1 = staged verify, 2 = in-register verify (the runtime's
+                           * choice from the survivors it has measured on this text) */
 };
 uint32_t smh_wm_max_blocks(int n_cus);
 hipError_t smh_launch_wm_block(const smh_wm_launch &L, hipStream_t stream);
@@ -203,5 +211,7 @@ hipError_t smh_launch_wm_positions(const smh_wm_table_launch &L, uint64_t *d_pos
 
 hipError_t smh_launch_corpus_text(uint8_t *d_out, uint64_t n, uint64_t offset, uint64_t seed,
                                   int alphabet, hipStream_t stream);
+hipError_t smh_launch_corpus_text_kind(uint8_t *d_out, uint64_t n, uint64_t offset, uint64_t seed, int alphabet, int kind,
+                                       const smh_corpus_tabs &T, hipStream_t stream);
 
 #endif

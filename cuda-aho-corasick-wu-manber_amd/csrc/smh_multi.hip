@@ -97,6 +97,15 @@ struct smh_multi_dev {
     ncclComm_t comm;
 };
 
+/* a handle as it was when it was warmed up: its address can be reused after a free and its plan or engine can be changed
+ * (smh_ac_set_scan_plan, smh_*_set_scan_engine), its serial cannot and every such change bumps the generation */
+struct smh_warm_key {
+    uint64_t serial;
+    uint32_t generation;
+    bool operator==(const smh_warm_key &o) const { return serial == o.serial && generation == o.generation; }
+};
+extern "C" void smh_dev_set_slot(int slot); /* smh_runtime.hip */
+
 struct smh_multi {
     uint32_t magic;
     int n;
@@ -105,7 +114,8 @@ struct smh_multi {
     uint64_t per;     /* ceil(n_total / n): main.c:375-378 */
     int halo;         /* bytes kept beyond every range: scans with m - 1 <= halo are possible */
     std::vector<smh_multi_dev> dev;
-    std::vector<const void *> warmed; /* handles whose kernels have run once on every device (prepare_all) */
+    int share;        /* SMH_MULTI_SHARE_DEVICE: logical shards may sit on one card (per-shard table sets by slot: smh_dev_set_slot) */
+    std::vector<smh_warm_key> warmed; /* handles (serial, plan generation) whose kernels have run once on every device (prepare_all) */
 };
 #define SMH_MAGIC_MULTI 0x4d554c54u /* "MULT" */
 
@@ -141,29 +151,40 @@ extern "C" int smh_multi_create(smh_multi **out, const int *devices, int n_devic
     *out = NULL;
     int visible = 0;
     if (hipGetDeviceCount(&visible) != hipSuccess) visible = 0;
+    /* the one-card rehearsal of the N-device flow: logical shard i on device i mod (visible devices), every shard with a
+     * stream, a text range, a counter and -- through the runtime's slot keys -- table sets of its own; counts are added on
+     * the host (a communicator takes a device once).  The flag, or SMH_MULTI_SHARE_DEVICE=1 in the environment. */
+    if (const char *e = getenv("SMH_MULTI_SHARE_DEVICE"); e && atoi(e) != 0) flags |= SMH_MULTI_SHARE_DEVICE;
+    const int share = (flags & SMH_MULTI_SHARE_DEVICE) != 0;
     std::vector<int> ids(n_devices);
+    bool twice = false;
     for (int i = 0; i < n_devices; ++i) {
-        ids[i] = devices ? devices[i] : i;
+        ids[i] = devices ? devices[i] : (share && visible > 0 ? i % visible : i);
         if (ids[i] < 0 || ids[i] >= visible) {
             smh_set_error("smh_multi_create: device %d of %d asked for, %d visible", ids[i], n_devices, visible);
             return SMH_ENODEV;
         }
         for (int j = 0; j < i; ++j)
             if (ids[j] == ids[i]) {
-                smh_set_error("smh_multi_create: device %d listed twice (an RCCL communicator takes a device once)", ids[i]);
-                return SMH_EINVAL;
+                if (!share) {
+                    smh_set_error("smh_multi_create: device %d listed twice (an RCCL communicator takes a device once; "
+                                  "SMH_MULTI_SHARE_DEVICE rehearses several shards on one card)", ids[i]);
+                    return SMH_EINVAL;
+                }
+                twice = true;
             }
     }
     int rccl = 1;
-    if (rccl_load() != SMH_OK) {
+    if (twice || (flags & SMH_MULTI_NO_RCCL)) rccl = 0;
+    if (rccl && rccl_load() != SMH_OK) {
         if (!(flags & SMH_MULTI_HOST_SUM)) return SMH_ENODEV;
         rccl = 0;
     }
-    if (flags & SMH_MULTI_NO_RCCL) rccl = 0;
     smh_multi *mg = new smh_multi();
     mg->magic = SMH_MAGIC_MULTI;
     mg->n = n_devices;
     mg->rccl = rccl;
+    mg->share = share;
     mg->n_total = 0;
     mg->per = 0;
     mg->halo = 0;
@@ -276,7 +297,7 @@ extern "C" int smh_multi_generate_text(smh_multi *mg, uint64_t n_total, uint64_t
  * cuda/cuda_wm.cu:271-283).  The count calls run it themselves before their clock starts; calling it ahead of time
  * makes the first count call as fast as the tenth. */
 template <typename Prep, typename Scan>
-static int prepare_all(smh_multi *mg, const void *key, int m, Prep prep, Scan scan)
+static int prepare_all(smh_multi *mg, const smh_warm_key &key, int m, Prep prep, Scan scan)
 {
     if (m - 1 > mg->halo && mg->n_total) {
         smh_set_error("smh_multi: pattern length %d needs a halo of %d bytes, the text was placed with %d", m, m - 1, mg->halo);
@@ -285,7 +306,7 @@ static int prepare_all(smh_multi *mg, const void *key, int m, Prep prep, Scan sc
     int prev = 0;
     (void)hipGetDevice(&prev);
     bool warm = false; /* the table sets are looked up every time (a list walk); the warm-up scan runs once per handle */
-    for (const void *k : mg->warmed) warm = warm || k == key;
+    for (const smh_warm_key &k : mg->warmed) warm = warm || k == key;
     std::vector<int> rcs((size_t)mg->n, SMH_OK);
     std::vector<std::string> errs((size_t)mg->n);
     auto work = [&](int i) {
@@ -295,6 +316,7 @@ static int prepare_all(smh_multi *mg, const void *key, int m, Prep prep, Scan sc
             smh_set_error("smh_multi: hipSetDevice(%d) failed", d.device);
             rc = SMH_ENODEV;
         }
+        smh_dev_set_slot(mg->share ? i + 1 : 0);
         if (rc == SMH_OK) rc = prep();
         if (rc == SMH_OK && !warm && d.d_text && d.bytes >= (uint64_t)m) {
             const uint64_t len = d.bytes < 16384u ? d.bytes : 16384u;
@@ -304,11 +326,12 @@ static int prepare_all(smh_multi *mg, const void *key, int m, Prep prep, Scan sc
                 rc = SMH_ENODEV;
             }
         }
+        smh_dev_set_slot(0);
         rcs[(size_t)i] = rc;
         if (rc != SMH_OK) errs[(size_t)i] = smh_last_error(); /* the message is thread-local: carry it over */
     };
-    if (mg->n == 1) {
-        work(0);
+    if (mg->n == 1 || warm) { /* every device has its table set: a list walk each, not worth a thread */
+        for (int i = 0; i < mg->n; ++i) work(i);
     } else {
         std::vector<std::thread> th;
         for (int i = 0; i < mg->n; ++i) th.emplace_back(work, i);
@@ -326,7 +349,7 @@ static int prepare_all(smh_multi *mg, const void *key, int m, Prep prep, Scan sc
 
 /* launch `scan(device text, shard length, device counter, stream)` on every device, reduce, read back */
 template <typename Prep, typename Scan>
-static int count_all(smh_multi *mg, const void *key, int m, uint64_t *total, uint64_t *per_device, double *seconds, Prep prep, Scan scan)
+static int count_all(smh_multi *mg, const smh_warm_key &key, int m, uint64_t *total, uint64_t *per_device, double *seconds, Prep prep, Scan scan)
 {
     if (!total) { smh_set_error("smh_multi: NULL result"); return SMH_EINVAL; }
     if (m - 1 > mg->halo) {
@@ -353,7 +376,9 @@ static int count_all(smh_multi *mg, const void *key, int m, uint64_t *total, uin
             rc = SMH_ENODEV;
             break;
         }
+        smh_dev_set_slot(mg->share ? i + 1 : 0);
         rc = scan(d.d_text, len, d.d_count, (void *)d.stream); /* asynchronous: the devices scan side by side */
+        smh_dev_set_slot(0);
     }
     if (rc == SMH_OK && mg->rccl) {
         /* the MPI_Reduce of main.c:656 as one RCCL all-reduce of a 64-bit count per device */
@@ -405,7 +430,7 @@ extern "C" int smh_multi_ac_count(smh_multi *mg, smh_ac *ac, uint64_t *total, ui
     if (rc != SMH_OK) return rc;
     smh_ac_info info;
     if ((rc = smh_ac_get_info(ac, &info)) != SMH_OK) return rc;
-    return count_all(mg, ac, (int)info.m, total, per_device, seconds, [&]() { return smh_ac_prepare_device(ac); },
+    return count_all(mg, smh_warm_key{ac->serial, ac->generation}, (int)info.m, total, per_device, seconds, [&]() { return smh_ac_prepare_device(ac); },
                      [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
                          return smh_ac_scan(ac, t, len, c, SMH_VARIANT_TUNED, s);
                      });
@@ -417,7 +442,7 @@ extern "C" int smh_multi_wm_count(smh_multi *mg, smh_wm *wm, uint64_t *total, ui
     if (rc != SMH_OK) return rc;
     smh_wm_info info;
     if ((rc = smh_wm_get_info(wm, &info)) != SMH_OK) return rc;
-    return count_all(mg, wm, (int)info.m, total, per_device, seconds, [&]() { return smh_wm_prepare_device(wm); },
+    return count_all(mg, smh_warm_key{wm->serial, wm->generation}, (int)info.m, total, per_device, seconds, [&]() { return smh_wm_prepare_device(wm); },
                      [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
                          return smh_wm_scan(wm, t, len, c, SMH_VARIANT_TUNED, s);
                      });
@@ -429,7 +454,7 @@ extern "C" int smh_multi_ac_prepare(smh_multi *mg, smh_ac *ac)
     if (rc != SMH_OK) return rc;
     smh_ac_info info;
     if ((rc = smh_ac_get_info(ac, &info)) != SMH_OK) return rc;
-    return prepare_all(mg, ac, (int)info.m, [&]() { return smh_ac_prepare_device(ac); },
+    return prepare_all(mg, smh_warm_key{ac->serial, ac->generation}, (int)info.m, [&]() { return smh_ac_prepare_device(ac); },
                        [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
                            return smh_ac_scan(ac, t, len, c, SMH_VARIANT_TUNED, s);
                        });
@@ -441,7 +466,7 @@ extern "C" int smh_multi_wm_prepare(smh_multi *mg, smh_wm *wm)
     if (rc != SMH_OK) return rc;
     smh_wm_info info;
     if ((rc = smh_wm_get_info(wm, &info)) != SMH_OK) return rc;
-    return prepare_all(mg, wm, (int)info.m, [&]() { return smh_wm_prepare_device(wm); },
+    return prepare_all(mg, smh_warm_key{wm->serial, wm->generation}, (int)info.m, [&]() { return smh_wm_prepare_device(wm); },
                        [&](unsigned char *t, uint64_t len, uint64_t *c, void *s) {
                            return smh_wm_scan(wm, t, len, c, SMH_VARIANT_TUNED, s);
                        });

@@ -17,11 +17,14 @@
 #include <string.h>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <math.h>
 #include <mutex>
 #include <thread>
 #include <vector>
 #include "smh_internal.h"
 #include "smh_launch.h"
+#include "smh_stats.h"
 
 #define HIP_TRY(expr)                                                                     \
     do {                                                                                  \
@@ -87,12 +90,28 @@ static int current_cus(int *n_cus)
     return SMH_OK;
 }
 
+/* One process may drive several LOGICAL devices that share a card (smh_multi.hip with SMH_MULTI_SHARE_DEVICE: the
+ * one-card rehearsal of the N-device flow): the calling thread names its logical slot and every per-device list of
+ * this file is keyed by (device, slot), so each logical shard has a table set, a candidate-queue workspace and an
+ * adaptive state of its own, exactly as on N cards.  Slot 0 = the plain case. */
+static thread_local int g_dev_slot = 0;
+extern "C" void smh_dev_set_slot(int slot) { g_dev_slot = slot < 0 ? 0 : slot; }
+static int current_dev_key(int *key)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    *key = dev | (g_dev_slot << 8);
+    return SMH_OK;
+}
+
 /* find the table set of the current device in a handle's list, or build one with `build` and publish it
  * only when every upload succeeded (a half-built set is freed, so the next call retries cleanly).  The build
  * -- synchronous hipMalloc + hipMemcpy of the tables -- runs OUTSIDE the mutex: a process that drives every
  * GPU of a node prepares its devices from one thread each (smh_multi_*_prepare) and those uploads must run
- * side by side; the list is only searched and extended under the lock.  Two threads that build a set for the
- * same handle on the same device at once both succeed, and the loser's set is freed. */
+ * side by side; the list is only searched and extended under the lock.  A second thread that wants the set of the
+ * SAME list and device while it is being built waits for it (round 4: it used to build a second copy and free the
+ * loser's -- transiently twice the device memory of a multi-GB table set). */
+#ifdef SMH_TESTING
 static std::atomic<int> g_builds_now{0}, g_builds_peak{0};
 extern "C" int smh_dev_build_peak(int reset) /* test hook: most table-set builds ever in flight together */
 {
@@ -100,37 +119,52 @@ extern "C" int smh_dev_build_peak(int reset) /* test hook: most table-set builds
     if (reset) g_builds_peak.store(0);
     return v;
 }
+#endif
+struct smh_building { const void *head; int key; };
+static std::vector<smh_building> g_building; /* guarded by g_dev_mu */
+static std::condition_variable g_building_cv;
 template <typename D, typename Build>
 static int ensure_device_set(D **head, void (*free_one)(D *), Build build, D **out)
 {
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
+    int rc0 = current_dev_key(&dev);
+    if (rc0 != SMH_OK) return rc0;
     {
-        std::lock_guard<std::mutex> lock(g_dev_mu);
-        for (D *d = *head; d; d = d->next)
-            if (d->device == dev) { *out = d; return SMH_OK; }
+        std::unique_lock<std::mutex> lock(g_dev_mu);
+        for (;;) {
+            for (D *d = *head; d; d = d->next)
+                if (d->device == dev) { *out = d; return SMH_OK; }
+            bool busy = false;
+            for (const smh_building &b : g_building) busy = busy || (b.head == (const void *)head && b.key == dev);
+            if (!busy) break;
+            g_building_cv.wait(lock); /* another thread is building exactly this set: take its result (or retry after its failure) */
+        }
+        g_building.push_back(smh_building{(const void *)head, dev});
     }
     D *d = new D();
     memset(d, 0, sizeof *d);
     d->device = dev;
+#ifdef SMH_TESTING
     const int now = ++g_builds_now;
     for (int peak = g_builds_peak.load(); now > peak && !g_builds_peak.compare_exchange_weak(peak, now);) {}
     if (const char *e = getenv("SMH_TEST_BUILD_DELAY_MS")) /* test hook: makes "two builds overlap" deterministic */
         std::this_thread::sleep_for(std::chrono::milliseconds(atoi(e)));
+#endif
     const int rc = build(d);
+#ifdef SMH_TESTING
     --g_builds_now;
-    if (rc != SMH_OK) { free_one(d); return rc; }
-    D *mine = d;
+#endif
     {
         std::lock_guard<std::mutex> lock(g_dev_mu);
-        for (D *o = *head; o; o = o->next)
-            if (o->device == dev) { d = o; break; }
-        if (d == mine) {
+        for (size_t i = 0; i < g_building.size(); ++i)
+            if (g_building[i].head == (const void *)head && g_building[i].key == dev) { g_building.erase(g_building.begin() + (long)i); break; }
+        if (rc == SMH_OK) {
             d->next = *head;
             *head = d;
         }
     }
-    if (d != mine) free_one(mine); /* another thread published a set for this device meanwhile */
+    g_building_cv.notify_all();
+    if (rc != SMH_OK) { free_one(d); return rc; }
     *out = d;
     return SMH_OK;
 }
@@ -364,6 +398,19 @@ extern "C" int smh_corpus_text_device(unsigned char *d_out, uint64_t n, uint64_t
     return SMH_OK;
 }
 
+extern "C" int smh_corpus_tabs_build(struct smh_corpus_tabs *T, uint64_t seed, int alphabet, int kind); /* corpus.c */
+extern "C" int smh_corpus_text_device_kind(unsigned char *d_out, uint64_t n, uint64_t offset, uint64_t seed, int alphabet,
+                                           int kind, void *stream)
+{
+    if (kind == SMH_CORPUS_UNIFORM) return smh_corpus_text_device(d_out, n, offset, seed, alphabet, stream);
+    if (!d_out || ((uintptr_t)d_out & 15u) != 0) { smh_set_error("smh_corpus_text_device_kind: buffer must be 16-byte aligned"); return SMH_EINVAL; }
+    smh_corpus_tabs T;
+    const int rc = smh_corpus_tabs_build(&T, seed, alphabet, kind);
+    if (rc != SMH_OK) return rc;
+    HIP_TRY(smh_launch_corpus_text_kind(d_out, n, offset, seed, alphabet, kind, T, (hipStream_t)stream));
+    return SMH_OK;
+}
+
 /* upload `bytes` of host data into a fresh device buffer padded to `pad_to` extra readable bytes */
 static int upload(void **d, const void *h, size_t bytes, size_t pad)
 {
@@ -373,6 +420,190 @@ static int upload(void **d, const void *h, size_t bytes, size_t pad)
     HIP_TRY(hipMemset(*d, 0, total));
     if (bytes) HIP_TRY(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
     return SMH_OK;
+}
+
+/* ------------------------------------------------------------------ adaptive engine (round 4; smh_stats.h)
+ * A handle that holds several engines -- an automaton with a depth-cut or hybrid plan, the suffix-filter kernels over
+ * the same patterns (smh_ac.flex_wm / smh_wm.flex_ac), the plain stride-1 automaton (smh_ac.flat_ac) -- starts with the
+ * one its compile estimated fastest on random text and then follows the launches' own reports: every count launch of
+ * 16 MiB or more publishes its duration (device clock, first workgroup's start to last workgroup's end) and the number of
+ * columns it had to verify.  Before the NEXT launch the host compares, per GiB, the running engine's measured time
+ * (the better of its last two reports: an engine's first launch on a device runs cold) with the best of the others
+ * (measured on this text, else the compile's estimate) and switches when that is clearly better -- after the first
+ * report when the running engine is three times slower than estimated, else after the second.  What was measured of an
+ * engine that is not running is forgotten, so that it is tried again, when the running engine's events per 4 KiB move by
+ * a factor of two (another kind of text) or, while it lies within 1.5 x of the running engine's, every 32 reports.  The
+ * filter kernels' verify mode (in registers / staged) follows the measured survivors per chunk the same way.  Nothing
+ * here synchronises: a launch that has not finished has simply not reported yet.  SMH_ADAPT=0 in the environment
+ * (read once) turns all of it off; a forced engine or plan is never overridden. */
+struct smh_adapt_dev {
+    int device;
+    smh_adapt_dev *next;
+    smh_scan_stats *d_stats;
+    unsigned long long *h_rec; /* pinned host record the last workgroup of a launch writes (SMH_STATS_HOST_WORDS) */
+    unsigned int seen;
+    int engine;            /* the kernels that run next; -1 before the first launch */
+    int fresh;             /* a report of the running engine arrived since the last decision */
+    double last[SMH_ENGINES][2]; /* per engine: ms per GiB of its last two reports, [0] the newer */
+    int n[SMH_ENGINES];    /* reports held (0..2); 0 = not measured on this text */
+    uint32_t age[SMH_ENGINES]; /* reports of other engines since */
+    double sig[SMH_ENGINES]; /* events per 4 KiB at the engine's last report */
+    double ref_sig;
+    int ref_valid;
+    uint32_t reports, flips;
+    double mode_density;   /* survivors per column handed to the gram launcher (< 0: the compile's estimate so far) */
+};
+
+static bool adapt_enabled()
+{
+    static const int on = [] { const char *e = getenv("SMH_ADAPT"); return e && atoi(e) == 0 ? 0 : 1; }();
+    return on != 0;
+}
+
+static void adapt_free_one(smh_adapt_dev *a)
+{
+    (void)hipFree(a->d_stats);
+    if (a->h_rec) (void)hipHostFree(a->h_rec);
+    delete a;
+}
+
+extern "C" void smh_adapt_dev_free(struct smh_adapt_dev *a)
+{
+    while (a) {
+        smh_adapt_dev *next = a->next;
+        adapt_free_one(a);
+        a = next;
+    }
+}
+
+static int adapt_get(smh_adapt_dev **head, smh_adapt_dev **out)
+{
+    return ensure_device_set<smh_adapt_dev>(head, adapt_free_one, [&](smh_adapt_dev *a) -> int {
+        a->engine = -1;
+        a->mode_density = -1.0;
+        HIP_TRY(hipHostMalloc((void **)&a->h_rec, SMH_STATS_HOST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+        memset(a->h_rec, 0, SMH_STATS_HOST_WORDS * sizeof(unsigned long long));
+        smh_scan_stats init = {};
+        init.t_min = ~0ull;
+        init.host = a->h_rec; /* pinned host memory has one address on both sides */
+        HIP_TRY(hipMalloc((void **)&a->d_stats, sizeof init));
+        HIP_TRY(hipMemcpy(a->d_stats, &init, sizeof init, hipMemcpyHostToDevice));
+        return SMH_OK;
+    }, out);
+}
+
+/* the adaptive state of the current device if one exists (never creates) */
+static smh_adapt_dev *adapt_find(smh_adapt_dev *const *head)
+{
+    int key = 0;
+    if (current_dev_key(&key) != SMH_OK) return NULL;
+    std::lock_guard<std::mutex> lock(g_dev_mu);
+    for (smh_adapt_dev *a = *head; a; a = a->next)
+        if (a->device == key) return a;
+    return NULL;
+}
+
+static double adapt_ms(const smh_adapt_dev *A, int e)
+{
+    if (A->n[e] == 0) return 0.0;
+    return A->n[e] == 1 || A->last[e][0] < A->last[e][1] ? A->last[e][0] : A->last[e][1];
+}
+
+#define SMH_ADAPT_MIN_BYTES (16ull << 20) /* smaller launches are mostly table staging and tail: not a rate */
+static void adapt_poll(smh_adapt_dev *A)
+{
+    volatile unsigned long long *h = A->h_rec;
+    const unsigned int seq = (unsigned int)h[0];
+    if (seq == A->seen) return;
+    const unsigned long long ev = h[1], ticks = h[2], bytes = h[3], tag = h[4];
+    if ((unsigned int)h[0] != seq) return; /* the next launch is publishing right now: next time */
+    A->seen = seq;
+    const int e = (int)(tag & 3u);
+    if (bytes < SMH_ADAPT_MIN_BYTES || ticks == 0 || e >= SMH_ENGINES) return;
+    A->last[e][1] = A->last[e][0];
+    A->last[e][0] = (double)ticks * 1e-5 * (double)(1ull << 30) / (double)bytes; /* 100 MHz ticks -> ms per GiB */
+    if (A->n[e] < 2) ++A->n[e];
+    A->sig[e] = (double)ev * 4096.0 / (double)bytes;
+    A->age[e] = 0;
+    for (int o = 0; o < SMH_ENGINES; ++o)
+        if (o != e) ++A->age[o];
+    ++A->reports;
+    if (e == A->engine) A->fresh = 1;
+}
+
+/* which engine runs the next launch; est[e] = the compile's estimate in ms per GiB, <= 0: the handle has no such engine */
+static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int initial)
+{
+    if (A->engine < 0) { A->engine = initial; return initial; }
+    if (!A->fresh) return A->engine;
+    A->fresh = 0;
+    const int cur = A->engine;
+    const double c_cur = adapt_ms(A, cur);
+    if (c_cur <= 0) return cur;
+    if (A->n[cur] < 2 && !(est[cur] > 0 && c_cur > 3.0 * est[cur])) return cur; /* a first report runs cold: wait for the second */
+    if (!A->ref_valid) {
+        A->ref_sig = A->sig[cur];
+        A->ref_valid = 1;
+    } else {
+        const double a = A->sig[cur], b = A->ref_sig;
+        if (fabs(a - b) > 0.05 && (a > 2.0 * b || b > 2.0 * a)) { /* another kind of text: what the others did on the old one says nothing */
+            for (int o = 0; o < SMH_ENGINES; ++o)
+                if (o != cur) A->n[o] = 0;
+            A->ref_sig = a;
+        }
+    }
+    int best = -1;
+    double c_best = 0, m_best = 1.0;
+    for (int o = 0; o < SMH_ENGINES; ++o) {
+        if (o == cur || est[o] <= 0) continue;
+        if (A->n[o] > 0 && adapt_ms(A, o) < 1.5 * c_cur && A->age[o] >= 32u) A->n[o] = 0; /* a close race is re-run now and then */
+        const double c = A->n[o] > 0 ? adapt_ms(A, o) : est[o], margin = A->n[o] > 0 ? 1.03 : 1.08;
+        if (best < 0 || c * margin < c_best * m_best) { best = o; c_best = c; m_best = margin; }
+    }
+    if (best >= 0 && c_best * m_best < c_cur) {
+        A->engine = best;
+        A->n[best] = 0; /* a fresh series for the engine that takes over */
+        A->ref_valid = 0;
+        ++A->flips;
+    }
+    return A->engine;
+}
+
+/* surviving columns per text column the gram launcher should plan its verify mode for: the compile's estimate until
+ * the filter kernels have reported from this text, then what they measured -- replaced only when it moves by more than a
+ * quarter, so that a rate near one of the launcher's thresholds does not flip the kernel instance from launch to launch */
+static float adapt_density(smh_adapt_dev *A, const struct smh_wm *wm)
+{
+    if (!A) return (float)wm->gram_density;
+    if (A->mode_density < 0) A->mode_density = wm->gram_density;
+    if (A->n[SMH_ALGO_WM] > 0) {
+        const double meas = A->sig[SMH_ALGO_WM] / 4096.0, old = A->mode_density;
+        if (fabs(meas - old) > 0.25 * (meas > old ? meas : old)) A->mode_density = meas;
+    }
+    return (float)A->mode_density;
+}
+
+static smh_stats_arg adapt_arg(smh_adapt_dev *A, uint64_t n, int engine)
+{
+    smh_stats_arg sa = {};
+    if (A) { sa.st = A->d_stats; sa.bytes = n; sa.tag = (unsigned int)engine; }
+    return sa;
+}
+
+static void adapt_report(const smh_adapt_dev *A, int adaptive, int engine_static, const double est[SMH_ENGINES], smh_adapt_info *out)
+{
+    const uint32_t size = out->struct_size;
+    memset(out, 0, sizeof *out);
+    out->struct_size = size;
+    out->adaptive = (uint32_t)adaptive;
+    out->engine = (uint32_t)(adaptive && A && A->engine >= 0 ? A->engine : engine_static);
+    for (int e = 0; e < SMH_ENGINES; ++e) out->est_ms_per_gib[e] = est[e];
+    out->verify_density = -1.0;
+    if (!A) return;
+    out->flips = A->flips;
+    out->reports = A->reports;
+    for (int e = 0; e < SMH_ENGINES; ++e) { out->ms_per_gib[e] = adapt_ms(A, e); out->events_per_4k[e] = A->sig[e]; }
+    out->verify_density = A->mode_density;
 }
 
 /* ------------------------------------------------------------------ AC */
@@ -407,6 +638,9 @@ static int ac_ensure_device(struct smh_ac *ac, smh_ac_dev **out)
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
     return ensure_device_set<smh_ac_dev>(&ac->dev, ac_dev_free_one, [&](smh_ac_dev *d) -> int {
         int rc;
+        /* a hybrid image may run with its full-row lookups left out of range: ask the device once, here, where blocking is
+         * expected -- never inside a scan call (ac_kernels.inc) */
+        if (ac->scan_full_rows) (void)smh_lds_oob_probe(n_cus);
         /* 256 entries of slack: a text byte >= alphabet may index just past the last row */
         if ((rc = upload(&d->d_table, ac->table, (size_t)ac->table_bytes, 256 * 4)) != SMH_OK) return rc;
         if ((rc = upload(&d->d_scan, ac->scan_table, (size_t)ac->scan_bytes, 0)) != SMH_OK) return rc;
@@ -494,15 +728,45 @@ static int ac_fill_cold(struct smh_ac *ac, smh_ac_dev *dv, smh_ac_verify_ctx &V)
     V.cold = dv->d_cold;
     return SMH_OK;
 }
+static int ac_engine_static(const struct smh_ac *ac)
+{
+    if (ac->engine_forced >= 0) return ac->engine_forced;
+    return ac->alt_wm ? SMH_ALGO_WM : SMH_ALGO_AC;
+}
+static struct smh_wm *ac_filter_engine(const struct smh_ac *ac) { return ac->alt_wm ? ac->alt_wm : ac->flex_wm; }
+/* the engine the next tuned scan on the current device runs (positions, info) */
+static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac) && adapt_enabled(); }
+static void ac_estimates(const struct smh_ac *ac, double est[SMH_ENGINES])
+{
+    est[SMH_ALGO_AC] = smh_ac_plan_ms(ac);
+    est[SMH_ALGO_WM] = ac->flex_wm ? ac->flex_wm->scan_ms_est : 0.0;
+    est[SMH_ENGINE_AC_FLAT] = ac->flat_ac ? smh_ac_plan_ms(ac->flat_ac) : 0.0;
+}
+static int ac_engine_now(struct smh_ac *ac)
+{
+    if (ac->engine_forced < 0 && ac_adaptive(ac))
+        if (smh_adapt_dev *A = adapt_find(&ac->adapt); A && A->engine >= 0) return A->engine;
+    return ac_engine_static(ac);
+}
+
 static int ac_prepare(struct smh_ac *ac, int variant)
 {
-    if (variant == SMH_VARIANT_TUNED && ac->alt_wm && !ac->alt_off) return wm_prepare(ac->alt_wm, variant);
+    const bool both = variant == SMH_VARIANT_TUNED && ac->engine_forced < 0 && ac_adaptive(ac);
+    if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ALGO_WM && !both) return wm_prepare(ac_filter_engine(ac), variant);
+    if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_AC_FLAT && !both) return ac_prepare(ac->flat_ac, variant);
     smh_ac_dev *d = NULL;
     int rc = ac_ensure_device(ac, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = ac_ensure_reference_tables(ac, d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TUNED) {
         smh_ac_verify_ctx V = {};
         rc = ac_fill_cold(ac, d, V); /* the hash-verify handle's tables and the kernels' cold context */
+    }
+    if (rc == SMH_OK && both) { /* any of the engines may serve the next launch */
+        smh_wm_dev *wd = NULL;
+        if (ac->flex_wm) rc = wm_ensure_device(ac->flex_wm, &wd);
+        if (rc == SMH_OK && ac->flat_ac) rc = ac_prepare(ac->flat_ac, variant);
+        smh_adapt_dev *A = NULL;
+        if (rc == SMH_OK) rc = adapt_get(&ac->adapt, &A);
     }
     return rc;
 }
@@ -518,6 +782,46 @@ extern "C" int smh_wm_prepare_device(struct smh_wm *wm)
 {
     if (!wm || wm->magic != SMH_MAGIC_WM) { smh_set_error("smh_wm_prepare_device: bad handle"); return SMH_EINVAL; }
     return wm_prepare(wm, SMH_VARIANT_TUNED);
+}
+
+static int wm_launch_own(struct smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream,
+                         const smh_stats_arg &SA, float density);
+
+/* the automaton kernels on the plan the handle holds (no engine routing) */
+static int ac_launch_own(struct smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream,
+                         const smh_stats_arg &SA)
+{
+    smh_ac_dev *dv = NULL;
+    int rc = ac_ensure_device(ac, &dv);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    if (ac->scan_dense) {
+        /* the dense plan: the rolling code of the last m symbols IS the state; two END columns per lookup of the accepting-
+         * set bits (the lane code of wm_pair_kernel: smh_wm_pair_thread in wm_lane.h, here fed with the automaton's bits) */
+        smh_wm_launch W = {};
+        W.d_text = d_text; W.n = n; W.m = ac->m; W.bits = 2; W.block_symbols = ac->m; W.filter_log2 = 2 * ac->m; W.filter_exact = 1;
+        W.d_filter = dv->d_dense_filter; W.d_pair = dv->d_dense_pair; W.d_count = d_count; W.n_cus = n_cus;
+        HIP_TRY(smh_launch_wm_block(W, (hipStream_t)stream));
+        return SMH_OK;
+    }
+    smh_ac_launch L = {};
+    L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
+    if ((rc = ac_fill_cold(ac, dv, L.V)) != SMH_OK) return rc;
+    L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
+    L.d_scan_table = dv->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = dv->d_queue;
+    for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
+    L.full_rows = ac->scan_full_rows;
+    if (L.full_rows) /* hybrid image: compact rows are not numbered by depth; the halo's "deep enough"
+                      * test treats every compact row as deep (conservative, see ac_lane.h) */
+        for (int i = 0; i < SMH_AC_DF_LEN; ++i)
+            if (L.df.v[i] > L.full_rows) L.df.v[i] = L.full_rows;
+    L.d_count = d_count; L.n_cus = n_cus;
+    L.V.pos.out = NULL; L.V.pos.capacity = 0; L.V.pos.cursor = NULL;
+    L.d_wave_times = g_wave_trace;
+    L.stats = SA;
+    HIP_TRY(smh_launch_ac_dfa(L, (hipStream_t)stream));
+    return SMH_OK;
 }
 
 extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
@@ -538,47 +842,58 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         return SMH_EUNSUP;
     }
     if (n < (uint64_t)ac->m) return SMH_OK;
-    if (variant == SMH_VARIANT_TUNED && ac->alt_wm && !ac->alt_off) /* engine choice: ac_host.c, end of the compile */
-        return smh_wm_scan(ac->alt_wm, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
+    if (variant == SMH_VARIANT_TUNED) {
+        /* engine choice: ac_host.c, end of the compile; with both engines at hand, what the launches report (above) */
+        int engine = ac_engine_static(ac), rc;
+        if (!ac_adaptive(ac)) {
+            if (engine == SMH_ALGO_WM) return smh_wm_scan(ac_filter_engine(ac), d_text, n, d_count, SMH_VARIANT_TUNED, stream);
+            if (engine == SMH_ENGINE_AC_FLAT && ac->flat_ac) return ac_launch_own(ac->flat_ac, d_text, n, d_count, stream, smh_stats_arg{});
+            return ac_launch_own(ac, d_text, n, d_count, stream, smh_stats_arg{});
+        }
+        smh_adapt_dev *A = NULL;
+        if ((rc = adapt_get(&ac->adapt, &A)) != SMH_OK) return rc;
+        adapt_poll(A);
+        if (ac->engine_forced < 0) {
+            double est[SMH_ENGINES];
+            ac_estimates(ac, est);
+            engine = adapt_choose(A, est, engine);
+        } else {
+            A->engine = engine;
+        }
+        const smh_stats_arg SA = adapt_arg(A, n, engine);
+        if (engine == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), d_text, n, d_count, stream, SA, adapt_density(A, ac_filter_engine(ac)));
+        if (engine == SMH_ENGINE_AC_FLAT) return ac_launch_own(ac->flat_ac, d_text, n, d_count, stream, SA);
+        return ac_launch_own(ac, d_text, n, d_count, stream, SA);
+    }
+    if (variant != SMH_VARIANT_TABLE) {
+        smh_set_error("smh_ac_scan: unknown variant %d", variant);
+        return SMH_EINVAL;
+    }
     smh_ac_dev *dv = NULL;
     int rc = ac_ensure_device(ac, &dv);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
-    if (variant == SMH_VARIANT_TABLE) {
-        if ((rc = ac_ensure_reference_tables(ac, dv)) != SMH_OK) return rc;
-        smh_ac_table_launch L;
-        L.d_text = d_text; L.n = n; L.m = ac->m; L.alphabet = ac->alphabet;
-        L.d_transition = dv->d_transition; L.d_supply = dv->d_supply; L.d_final = dv->d_final;
-        L.d_count = d_count; L.n_cus = n_cus;
-        HIP_TRY(smh_launch_ac_table(L, (hipStream_t)stream));
-    } else if (variant == SMH_VARIANT_TUNED && ac->scan_dense) {
-        /* the dense plan: the rolling code of the last m symbols IS the state; two END columns per lookup of the accepting-
-         * set bits (the lane code of wm_pair_kernel: smh_wm_pair_thread in wm_lane.h, here fed with the automaton's bits) */
-        smh_wm_launch W = {};
-        W.d_text = d_text; W.n = n; W.m = ac->m; W.bits = 2; W.block_symbols = ac->m; W.filter_log2 = 2 * ac->m; W.filter_exact = 1;
-        W.d_filter = dv->d_dense_filter; W.d_pair = dv->d_dense_pair; W.d_count = d_count; W.n_cus = n_cus;
-        HIP_TRY(smh_launch_wm_block(W, (hipStream_t)stream));
-    } else if (variant == SMH_VARIANT_TUNED) {
-        smh_ac_launch L = {};
-        L.V.text = d_text; L.V.n = n; L.V.m = ac->m; L.V.K = ac->scan_depth; L.V.sigma = ac->alphabet;
-        if ((rc = ac_fill_cold(ac, dv, L.V)) != SMH_OK) return rc;
-        L.stride = ac->scan_stride; L.exact = ac->scan_exact; L.scan_entry_bytes = ac->scan_entry_bytes;
-        L.d_scan_table = dv->d_scan; L.lds_bytes = ac->scan_bytes; L.d_queue = dv->d_queue;
-        for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = i <= ac->max_depth + 1 ? ac->depth_first[i] : ac->rows;
-        L.full_rows = ac->scan_full_rows;
-        if (L.full_rows) /* hybrid image: compact rows are not numbered by depth; the halo's "deep enough"
-                          * test treats every compact row as deep (conservative, see ac_lane.h) */
-            for (int i = 0; i < SMH_AC_DF_LEN; ++i)
-                if (L.df.v[i] > L.full_rows) L.df.v[i] = L.full_rows;
-        L.d_count = d_count; L.n_cus = n_cus;
-        L.V.pos.out = NULL; L.V.pos.capacity = 0; L.V.pos.cursor = NULL;
-        L.d_wave_times = g_wave_trace;
-        HIP_TRY(smh_launch_ac_dfa(L, (hipStream_t)stream));
-    } else {
-        smh_set_error("smh_ac_scan: unknown variant %d", variant);
+    if ((rc = ac_ensure_reference_tables(ac, dv)) != SMH_OK) return rc;
+    smh_ac_table_launch L;
+    L.d_text = d_text; L.n = n; L.m = ac->m; L.alphabet = ac->alphabet;
+    L.d_transition = dv->d_transition; L.d_supply = dv->d_supply; L.d_final = dv->d_final;
+    L.d_count = d_count; L.n_cus = n_cus;
+    HIP_TRY(smh_launch_ac_table(L, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_ac_get_adapt(smh_ac *ac, smh_adapt_info *out)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC || !out || out->struct_size != sizeof *out) {
+        smh_set_error("smh_ac_get_adapt: bad arguments (set struct_size = sizeof(smh_adapt_info))");
         return SMH_EINVAL;
     }
+    double est[SMH_ENGINES];
+    ac_estimates(ac, est);
+    if (!ac->flex_wm && ac->alt_wm) est[SMH_ALGO_WM] = ac->alt_wm->scan_ms_est;
+    const int adaptive = ac->engine_forced < 0 && ac_adaptive(ac);
+    adapt_report(ac_adaptive(ac) ? adapt_find(&ac->adapt) : NULL, adaptive, ac_engine_static(ac), est, out);
     return SMH_OK;
 }
 
@@ -594,7 +909,10 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
         return SMH_EUNSUP;
     }
     if (n < (uint64_t)ac->m) return SMH_OK;
-    if (ac->alt_wm && !ac->alt_off) return smh_wm_positions(ac->alt_wm, d_text, n, d_positions, capacity, d_cursor, stream);
+    if (const int engine = ac_engine_now(ac); engine == SMH_ALGO_WM)
+        return smh_wm_positions(ac_filter_engine(ac), d_text, n, d_positions, capacity, d_cursor, stream);
+    else if (engine == SMH_ENGINE_AC_FLAT)
+        return smh_ac_positions(ac->flat_ac, d_text, n, d_positions, capacity, d_cursor, stream);
     smh_ac_dev *dv = NULL;
     int rc = ac_ensure_device(ac, &dv);
     if (rc != SMH_OK) return rc;
@@ -633,19 +951,143 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
     return SMH_OK;
 }
 
-/* shared by the two *_count_host helpers: text up, zeroed counter, timed launch, count down */
+/* ---- the legacy host-pointer path: what search_ac / search_wu / cuda_* run (the text is a pageable host buffer, as
+ * main.c:582-648 hands it over).  Round 3 did hipMalloc(n) + one copy + kernel + hipFree per call: 36 GB/s.  Now the text
+ * crosses PCIe in pieces of SMH_HOST_PIECE bytes through TWO device buffers of a grow-only workspace: piece k+1 is
+ * copied (copy stream) while piece k is scanned (scan stream), so device memory is 2 x (piece + halo) whatever n is and
+ * nothing is allocated per call.  The piece math is the shard formula (main.c:467-477, smh_shard_range): piece k holds
+ * text[k P, min((k+1) P + m - 1, n)) and its scan counts the END columns that lie in it with a whole window -- every END
+ * column of [m-1, n) belongs to exactly one piece.  Workspaces are pooled per device and handed to one call at a time;
+ * nothing is cached by the caller's pointer (the caller may rewrite its buffer between calls).
+ * SMH_HOST_PIECE_KIB (environment) overrides the piece size: the tests run it at 4 KiB so that a small text has hundreds
+ * of piece boundaries. */
+#define SMH_HOST_PIECE (64ull << 20)
+struct smh_host_ws {
+    int device;
+    unsigned char *d_buf[2];
+    uint64_t cap; /* bytes of each buffer */
+    uint64_t *d_count;
+    hipStream_t copy_stream, scan_stream;
+    hipEvent_t copied[2], k0[2], k1[2];
+    smh_host_ws *next;
+};
+static std::mutex g_ws_mu;
+static smh_host_ws *g_ws_free = NULL;
+
+static void host_ws_destroy(smh_host_ws *w)
+{
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(w->d_buf[b]);
+        if (w->copied[b]) (void)hipEventDestroy(w->copied[b]);
+        if (w->k0[b]) (void)hipEventDestroy(w->k0[b]);
+        if (w->k1[b]) (void)hipEventDestroy(w->k1[b]);
+    }
+    (void)hipFree(w->d_count);
+    if (w->copy_stream) (void)hipStreamDestroy(w->copy_stream);
+    if (w->scan_stream) (void)hipStreamDestroy(w->scan_stream);
+    delete w;
+}
+
+/* frees the pooled workspaces of every device (they are kept between calls otherwise); for leak checks and tidy exits */
+extern "C" void smh_host_path_release(void)
+{
+    smh_host_ws *w;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        w = g_ws_free;
+        g_ws_free = NULL;
+    }
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    while (w) {
+        smh_host_ws *next = w->next;
+        if (hipSetDevice(w->device) == hipSuccess) host_ws_destroy(w);
+        w = next;
+    }
+    (void)hipSetDevice(prev);
+}
+
+static int host_ws_acquire(uint64_t need, smh_host_ws **out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    smh_host_ws *w = NULL;
+    {
+        std::lock_guard<std::mutex> lock(g_ws_mu);
+        for (smh_host_ws **pp = &g_ws_free; *pp; pp = &(*pp)->next)
+            if ((*pp)->device == dev) { w = *pp; *pp = w->next; break; }
+    }
+    if (!w) {
+        w = new smh_host_ws();
+        memset(w, 0, sizeof *w);
+        w->device = dev;
+        hipError_t e = hipStreamCreateWithFlags(&w->copy_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->scan_stream, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+            e = hipEventCreateWithFlags(&w->copied[b], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreate(&w->k0[b]);
+            if (e == hipSuccess) e = hipEventCreate(&w->k1[b]);
+        }
+        if (e == hipSuccess) e = hipMalloc((void **)&w->d_count, 16);
+        if (e != hipSuccess) {
+            smh_set_error("host-pointer path: workspace: %s", hipGetErrorString(e));
+            host_ws_destroy(w);
+            return SMH_ENODEV;
+        }
+    }
+    if (w->cap < need) { /* grow-only */
+        for (int b = 0; b < 2; ++b) { (void)hipFree(w->d_buf[b]); w->d_buf[b] = NULL; }
+        w->cap = 0;
+        for (int b = 0; b < 2; ++b) {
+            const hipError_t e = hipMalloc((void **)&w->d_buf[b], need);
+            if (e != hipSuccess) {
+                smh_set_error("host-pointer path: hipMalloc(%llu): %s", (unsigned long long)need, hipGetErrorString(e));
+                host_ws_destroy(w);
+                return e == hipErrorOutOfMemory ? SMH_ENOMEM : SMH_ENODEV;
+            }
+        }
+        w->cap = need;
+    }
+    *out = w;
+    return SMH_OK;
+}
+
+static void host_ws_release(smh_host_ws *w)
+{
+    std::lock_guard<std::mutex> lock(g_ws_mu);
+    w->next = g_ws_free;
+    g_ws_free = w;
+}
+
+static uint64_t host_piece_bytes(void)
+{
+    uint64_t p = SMH_HOST_PIECE;
+    if (const char *e = getenv("SMH_HOST_PIECE_KIB")) {
+        const long long v = atoll(e);
+        if (v >= 4) p = ((uint64_t)v << 10) & ~(uint64_t)4095;
+    }
+    return p;
+}
+
+/* shared by the *_count_host helpers.  m = the pattern length (pieces overlap by m - 1 bytes); prepare() = table uploads,
+ * outside every event: *kernel_seconds is the kernels' time alone, as the reference's cudaEvents bracket the launch only
+ * (cuda/cuda_wm.cu:271-283); launch(d_text, len, d_count, stream) = one asynchronous scan */
 template <typename Prepare, typename Launch>
-static int count_host(const unsigned char *text, uint64_t n, uint64_t *count, double *kernel_seconds, Prepare prepare,
+static int count_host(const unsigned char *text, uint64_t n, int m, uint64_t *count, double *kernel_seconds, Prepare prepare,
                       Launch launch)
 {
     if (!count || (n && !text)) { smh_set_error("count_host: bad arguments"); return SMH_EINVAL; }
     *count = 0;
     if (kernel_seconds) *kernel_seconds = 0.0;
-    unsigned char *d_text = NULL;
-    uint64_t *d_count = NULL;
-    hipEvent_t ev0 = NULL, ev1 = NULL;
-    int rc = SMH_OK;
-    float ms = 0.f;
+    if (m < 1) m = 1;
+    uint64_t P = host_piece_bytes();
+    const uint64_t halo = (uint64_t)(m - 1);
+    if (halo * 8u > P || n <= P + halo) P = n > 4096u ? (n + 4095u) & ~(uint64_t)4095 : 4096u; /* one piece */
+    smh_host_ws *w = NULL;
+    int rc = host_ws_acquire(P + ((halo + 15u) & ~(uint64_t)15) + 4096u, &w);
+    if (rc != SMH_OK) return rc;
+    double ksecs = 0.0;
+    uint64_t n_pieces = 0;
 #define CH_TRY(expr)                                                                       \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
@@ -655,29 +1097,43 @@ static int count_host(const unsigned char *text, uint64_t n, uint64_t *count, do
             goto done;                                                                     \
         }                                                                                  \
     } while (0)
-    CH_TRY(hipMalloc((void **)&d_text, ((n + 15) / 16) * 16 + 16));
-    CH_TRY(hipMalloc((void **)&d_count, 16));
-    CH_TRY(hipMemset(d_count, 0, 16));
-    if (n) CH_TRY(hipMemcpy(d_text, text, n, hipMemcpyHostToDevice));
-    CH_TRY(hipEventCreate(&ev0));
-    CH_TRY(hipEventCreate(&ev1));
-    /* table uploads happen here, outside the events: *kernel_seconds is the kernel's time, as the
-     * reference's cudaEvents bracket the launch only (cuda/cuda_wm.cu:271-283) */
+    CH_TRY(hipMemsetAsync(w->d_count, 0, 16, w->scan_stream));
     rc = prepare();
     if (rc != SMH_OK) goto done;
-    CH_TRY(hipEventRecord(ev0, 0));
-    rc = launch(d_text, d_count);
-    if (rc != SMH_OK) goto done;
-    CH_TRY(hipEventRecord(ev1, 0));
-    CH_TRY(hipEventSynchronize(ev1));
-    CH_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    CH_TRY(hipMemcpy(count, d_count, 8, hipMemcpyDeviceToHost));
-    if (kernel_seconds) *kernel_seconds = (double)ms / 1000.0;
+    for (uint64_t off = 0; off < n; off += P, ++n_pieces) {
+        const int b = (int)(n_pieces & 1u);
+        uint64_t len = n - off;
+        if (len > P + halo) len = P + halo;
+        if (len < (uint64_t)m && n_pieces) break; /* the tail inside the piece before's halo: no END column of its own */
+        if (n_pieces >= 2) { /* the buffer's last scan must be over before it is overwritten */
+            CH_TRY(hipEventSynchronize(w->k1[b]));
+            float ms = 0.f;
+            if (kernel_seconds) { CH_TRY(hipEventElapsedTime(&ms, w->k0[b], w->k1[b])); ksecs += (double)ms / 1000.0; }
+        }
+        CH_TRY(hipMemcpyAsync(w->d_buf[b], text + off, len, hipMemcpyHostToDevice, w->copy_stream));
+        CH_TRY(hipEventRecord(w->copied[b], w->copy_stream));
+        CH_TRY(hipStreamWaitEvent(w->scan_stream, w->copied[b], 0));
+        CH_TRY(hipEventRecord(w->k0[b], w->scan_stream));
+        rc = launch(w->d_buf[b], len, w->d_count, (void *)w->scan_stream);
+        if (rc != SMH_OK) goto done;
+        CH_TRY(hipEventRecord(w->k1[b], w->scan_stream));
+    }
+    CH_TRY(hipMemcpyAsync(count, w->d_count, 8, hipMemcpyDeviceToHost, w->scan_stream));
+    CH_TRY(hipStreamSynchronize(w->scan_stream));
+    if (kernel_seconds) {
+        for (uint64_t k = n_pieces >= 2 ? n_pieces - 2 : 0; k < n_pieces; ++k) {
+            float ms = 0.f;
+            CH_TRY(hipEventElapsedTime(&ms, w->k0[k & 1u], w->k1[k & 1u]));
+            ksecs += (double)ms / 1000.0;
+        }
+        *kernel_seconds = ksecs;
+    }
 done:
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    (void)hipFree(d_text);
-    (void)hipFree(d_count);
+    if (rc != SMH_OK) { /* leave nothing in flight on a workspace that goes back to the pool */
+        (void)hipStreamSynchronize(w->copy_stream);
+        (void)hipStreamSynchronize(w->scan_stream);
+    }
+    host_ws_release(w);
     return rc;
 #undef CH_TRY
 }
@@ -686,9 +1142,9 @@ extern "C" int smh_ac_count_host(smh_ac *ac, const unsigned char *text, uint64_t
                                  double *kernel_seconds)
 {
     if (!ac || ac->magic != SMH_MAGIC_AC) { smh_set_error("smh_ac_count_host: bad handle"); return SMH_EINVAL; }
-    return count_host(text, n, count, kernel_seconds,
+    return count_host(text, n, ac->m, count, kernel_seconds,
                       [&]() { return n < (uint64_t)ac->m || !ac->fixed_length_ok ? SMH_OK : ac_prepare(ac, variant); },
-                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_ac_scan(ac, d_text, n, d_count, variant, NULL); });
+                      [&](unsigned char *d_text, uint64_t len, uint64_t *d_count, void *st) { return smh_ac_scan(ac, d_text, len, d_count, variant, st); });
 }
 
 /* ------------------------------------------------------------------ WM */
@@ -766,13 +1222,55 @@ static int wm_ensure_reference_tables(struct smh_wm *wm, smh_wm_dev *d)
     return SMH_OK;
 }
 
+static int wm_engine_static(const struct smh_wm *wm)
+{
+    if (wm->engine_forced >= 0) return wm->engine_forced;
+    return wm->alt_ac ? SMH_ALGO_AC : SMH_ALGO_WM;
+}
+static struct smh_ac *wm_automaton_engine(const struct smh_wm *wm) { return wm->alt_ac ? wm->alt_ac : wm->flex_ac; }
+/* do this path's own kernels report (smh_stats.h)?  All but the pair lookup kernel (exact, m <= 8) */
+static bool wm_reports(const struct smh_wm *wm) { return wm->gram_table || !wm->pair_table; }
+static int wm_engine_now(struct smh_wm *wm)
+{
+    if (wm->engine_forced < 0 && wm->flex_ac && adapt_enabled())
+        if (smh_adapt_dev *A = adapt_find(&wm->adapt); A && A->engine >= 0) return A->engine;
+    return wm_engine_static(wm);
+}
+
 static int wm_prepare(struct smh_wm *wm, int variant)
 {
-    if (variant == SMH_VARIANT_TUNED && wm->alt_ac && !wm->alt_off) return ac_prepare(wm->alt_ac, variant);
+    const bool both = variant == SMH_VARIANT_TUNED && wm->flex_ac && wm->engine_forced < 0 && adapt_enabled();
+    if (variant == SMH_VARIANT_TUNED && wm_engine_static(wm) == SMH_ALGO_AC && !both) return ac_prepare(wm_automaton_engine(wm), variant);
     smh_wm_dev *d = NULL;
     int rc = wm_ensure_device(wm, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = wm_ensure_reference_tables(wm, d);
+    if (rc == SMH_OK && both) rc = ac_prepare(wm->flex_ac, variant);
+    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && adapt_enabled() && wm_reports(wm)) {
+        smh_adapt_dev *A = NULL;
+        rc = adapt_get(&wm->adapt, &A);
+    }
     return rc;
+}
+
+/* this path's own tuned kernels (no engine routing); density = surviving columns per column the gram launcher plans for */
+static int wm_launch_own(struct smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream,
+                         const smh_stats_arg &SA, float density)
+{
+    smh_wm_dev *dv = NULL;
+    int rc = wm_ensure_device(wm, &dv);
+    if (rc != SMH_OK) return rc;
+    int n_cus = 0;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_wm_launch L = {};
+    L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
+    L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
+    L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
+    L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind; L.gram_density = density < 0 ? (float)wm->gram_density : density; L.gram_lane0 = (float)wm->gram_lane0; L.gram_planes = wm->gram_planes;
+    L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
+    L.po.out = NULL; L.po.capacity = 0; L.po.cursor = NULL;
+    L.stats = SA;
+    HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
+    return SMH_OK;
 }
 
 extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
@@ -787,33 +1285,51 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         return SMH_EINVAL;
     }
     if (n < (uint64_t)wm->m) return SMH_OK;
-    if (variant == SMH_VARIANT_TUNED && wm->alt_ac && !wm->alt_off) /* engine choice: wm_host.c, end of the compile */
-        return smh_ac_scan(wm->alt_ac, d_text, n, d_count, SMH_VARIANT_TUNED, stream);
+    if (variant == SMH_VARIANT_TUNED) {
+        /* engine choice: wm_host.c, end of the compile; with both engines at hand, what the launches report ("adaptive
+         * engine" above).  A handle with one engine still learns its verify mode from its own reports. */
+        int engine = wm_engine_static(wm), rc;
+        smh_adapt_dev *A = NULL;
+        if (adapt_enabled() && (wm->flex_ac || wm_reports(wm))) {
+            if ((rc = adapt_get(&wm->adapt, &A)) != SMH_OK) return rc;
+            adapt_poll(A);
+            if (wm->flex_ac && wm->engine_forced < 0) {
+                const double est[SMH_ENGINES] = {smh_ac_plan_ms(wm->flex_ac), wm->scan_ms_est, 0.0};
+                engine = adapt_choose(A, est, engine);
+            } else {
+                A->engine = engine;
+            }
+        }
+        if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine));
+        return wm_launch_own(wm, d_text, n, d_count, stream, adapt_arg(wm_reports(wm) ? A : NULL, n, engine), adapt_density(A, wm));
+    }
+    if (variant != SMH_VARIANT_TABLE) {
+        smh_set_error("smh_wm_scan: unknown variant %d", variant);
+        return SMH_EINVAL;
+    }
     smh_wm_dev *dv = NULL;
     int rc = wm_ensure_device(wm, &dv);
     if (rc != SMH_OK) return rc;
     int n_cus = 0;
     if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
-    if (variant == SMH_VARIANT_TABLE) {
-        if ((rc = wm_ensure_reference_tables(wm, dv)) != SMH_OK) return rc;
-        smh_wm_table_launch L;
-        L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = dv->d_shift;
-        L.d_bucket_off = dv->d_bucket_off; L.d_bucket = dv->d_bucket; L.d_pat_orig = dv->d_pat_orig;
-        L.d_count = d_count; L.n_cus = n_cus;
-        HIP_TRY(smh_launch_wm_table(L, (hipStream_t)stream));
-    } else if (variant == SMH_VARIANT_TUNED) {
-        smh_wm_launch L = {};
-        L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
-        L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
-        L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
-        L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind; L.gram_density = (float)wm->gram_density; L.gram_lane0 = (float)wm->gram_lane0; L.gram_planes = wm->gram_planes;
-        L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
-        L.po.out = NULL; L.po.capacity = 0; L.po.cursor = NULL;
-        HIP_TRY(smh_launch_wm_block(L, (hipStream_t)stream));
-    } else {
-        smh_set_error("smh_wm_scan: unknown variant %d", variant);
+    if ((rc = wm_ensure_reference_tables(wm, dv)) != SMH_OK) return rc;
+    smh_wm_table_launch L;
+    L.d_text = d_text; L.n = n; L.m = wm->m; L.shiftsize = wm->shiftsize; L.d_shift = dv->d_shift;
+    L.d_bucket_off = dv->d_bucket_off; L.d_bucket = dv->d_bucket; L.d_pat_orig = dv->d_pat_orig;
+    L.d_count = d_count; L.n_cus = n_cus;
+    HIP_TRY(smh_launch_wm_table(L, (hipStream_t)stream));
+    return SMH_OK;
+}
+
+extern "C" int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out)
+{
+    if (!wm || wm->magic != SMH_MAGIC_WM || !out || out->struct_size != sizeof *out) {
+        smh_set_error("smh_wm_get_adapt: bad arguments (set struct_size = sizeof(smh_adapt_info))");
         return SMH_EINVAL;
     }
+    const double est[SMH_ENGINES] = {wm->flex_ac ? smh_ac_plan_ms(wm->flex_ac) : 0.0, wm->scan_ms_est, 0.0};
+    const int adaptive = wm->flex_ac && wm->engine_forced < 0 && adapt_enabled();
+    adapt_report(adapt_find(&wm->adapt), adaptive, wm_engine_static(wm), est, out);
     return SMH_OK;
 }
 
@@ -825,7 +1341,7 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         return SMH_EINVAL;
     }
     if (n < (uint64_t)wm->m) return SMH_OK;
-    if (wm->alt_ac && !wm->alt_off) return smh_ac_positions(wm->alt_ac, d_text, n, d_positions, capacity, d_cursor, stream);
+    if (wm_engine_now(wm) == SMH_ALGO_AC) return smh_ac_positions(wm_automaton_engine(wm), d_text, n, d_positions, capacity, d_cursor, stream);
     smh_wm_dev *dv = NULL;
     int rc = wm_ensure_device(wm, &dv);
     if (rc != SMH_OK) return rc;
@@ -940,9 +1456,9 @@ extern "C" int smh_wm_count_host(smh_wm *wm, const unsigned char *text, uint64_t
                                  double *kernel_seconds)
 {
     if (!wm || wm->magic != SMH_MAGIC_WM) { smh_set_error("smh_wm_count_host: bad handle"); return SMH_EINVAL; }
-    return count_host(text, n, count, kernel_seconds,
+    return count_host(text, n, wm->m, count, kernel_seconds,
                       [&]() { return n < (uint64_t)wm->m ? SMH_OK : wm_prepare(wm, variant); },
-                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_wm_scan(wm, d_text, n, d_count, variant, NULL); });
+                      [&](unsigned char *d_text, uint64_t len, uint64_t *d_count, void *st) { return smh_wm_scan(wm, d_text, len, d_count, variant, st); });
 }
 
 /* ------------------------------------------------------------------ mixed-length automaton (acm_host.c) */
@@ -1085,9 +1601,9 @@ extern "C" int smh_sh_count_host(smh_sh *sh, const unsigned char *text, uint64_t
                                  uint64_t *count, double *kernel_seconds)
 {
     if (!sh || sh->magic != SMH_MAGIC_SH) { smh_set_error("smh_sh_count_host: bad handle"); return SMH_EINVAL; }
-    return count_host(text, n, count, kernel_seconds,
+    return count_host(text, n, sh->m, count, kernel_seconds,
                       [&]() { return n < (uint64_t)sh->m ? SMH_OK : sh_prepare(sh, variant); },
-                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_sh_scan(sh, d_text, n, bmBc, d_count, variant, NULL); });
+                      [&](unsigned char *d_text, uint64_t len, uint64_t *d_count, void *st) { return smh_sh_scan(sh, d_text, len, bmBc, d_count, variant, st); });
 }
 
 /* ------------------------------------------------------------------ SBOM */
@@ -1169,9 +1685,9 @@ extern "C" int smh_sbom_count_host(smh_sbom *sb, const unsigned char *text, uint
                                    double *kernel_seconds)
 {
     if (!sb || sb->magic != SMH_MAGIC_SBOM) { smh_set_error("smh_sbom_count_host: bad handle"); return SMH_EINVAL; }
-    return count_host(text, n, count, kernel_seconds,
+    return count_host(text, n, sb->m, count, kernel_seconds,
                       [&]() { return n < (uint64_t)sb->m ? SMH_OK : sbom_prepare(sb, variant); },
-                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_sbom_scan(sb, d_text, n, d_count, variant, NULL); });
+                      [&](unsigned char *d_text, uint64_t len, uint64_t *d_count, void *st) { return smh_sbom_scan(sb, d_text, len, d_count, variant, st); });
 }
 
 /* ------------------------------------------------------------------ SOG */
@@ -1251,9 +1767,9 @@ extern "C" int smh_sog_count_host(smh_sog *sg, const unsigned char *text, uint64
                                   double *kernel_seconds)
 {
     if (!sg || sg->magic != SMH_MAGIC_SOG) { smh_set_error("smh_sog_count_host: bad handle"); return SMH_EINVAL; }
-    return count_host(text, n, count, kernel_seconds,
+    return count_host(text, n, 8, count, kernel_seconds,
                       [&]() { return n < 8 ? SMH_OK : sog_prepare(sg, variant); },
-                      [&](unsigned char *d_text, uint64_t *d_count) { return smh_sog_scan(sg, d_text, n, d_count, variant, NULL); });
+                      [&](unsigned char *d_text, uint64_t len, uint64_t *d_count, void *st) { return smh_sog_scan(sg, d_text, len, d_count, variant, st); });
 }
 
 /* ------------------------------------------------------------------ legacy names (smatcher.h) */

@@ -95,7 +95,7 @@ void smh_wm_host_free(struct smh_wm *wm)
     free(wm->l_bucket_off);
     free(wm->l_bucket);
     free(wm->pat_orig);
-    smh_ac_free(wm->alt_ac);
+    smh_ac_free(wm->flex_ac ? wm->flex_ac : wm->alt_ac); /* alt_ac, when set, is the same handle */
     wm->magic = 0;
     free(wm);
 }
@@ -482,6 +482,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
             return NULL;
         }
     struct smh_wm *wm = (struct smh_wm *)calloc(1, sizeof *wm);
+    if (wm) wm->engine_forced = -1, wm->serial = smh_handle_serial();
     if (!wm) goto oom;
     wm->magic = SMH_MAGIC_WM;
     wm->alphabet = alphabet;
@@ -751,6 +752,11 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         /* the automaton plan's cost is in units of the exact stride-1 scan, 0.289 ms/GiB */
         if (ac && ac->scan_cost <= SMH_WM_ALT_ENGINE_COST && ac->scan_cost * 0.289 < wm->scan_ms_est)
             wm->alt_ac = ac;
+        /* round 4: an automaton that is merely SLOWER on random text stays at hand -- a filter's speed is a property of the
+         * text (survivors are verified one by one), the automaton's next to none, and the runtime follows what the launches
+         * report (smh_runtime.hip "adaptive engine") */
+        if (ac && (wm->alt_ac == ac || (ac->fixed_length_ok && ac->scan_cost <= SMH_WM_FLEX_ENGINE_COST)))
+            wm->flex_ac = ac;
         else
             smh_ac_free(ac);
     }
@@ -799,7 +805,8 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->filter_hashed = (uint32_t)wm->filter_hashed;
     out->verify_slots = wm->filter_exact ? 0u : (1u << wm->verify_log2);
     out->lds_bytes = (uint32_t)(((size_t)1 << wm->filter_log2) / 8);
-    out->scan_engine = wm->alt_ac && !wm->alt_off ? SMH_ALGO_AC : SMH_ALGO_WM;
+    out->scan_engine = wm->engine_forced >= 0 ? (uint32_t)wm->engine_forced : (wm->alt_ac ? SMH_ALGO_AC : SMH_ALGO_WM);
+    out->adaptive = wm->flex_ac && wm->engine_forced < 0 ? 1u : 0u;
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
     out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
@@ -813,11 +820,13 @@ int smh_wm_set_scan_engine(smh_wm *wm, int engine)
         smh_set_error("smh_wm_set_scan_engine: bad arguments");
         return SMH_EINVAL;
     }
-    if (engine == SMH_ALGO_AC && !wm->alt_ac) {
+    if (engine == SMH_ALGO_AC && !wm->alt_ac && !wm->flex_ac) {
         smh_set_error("smh_wm_set_scan_engine: this set has no automaton engine (its automaton would be slower)");
         return SMH_EUNSUP;
     }
     wm->alt_off = engine == SMH_ALGO_WM;
+    wm->engine_forced = engine;
+    ++wm->generation;
     return SMH_OK;
 }
 
@@ -826,5 +835,7 @@ void smh_wm_free(smh_wm *wm)
     if (!wm) return;
     if (wm->dev) smh_wm_dev_free(wm->dev);
     wm->dev = NULL;
+    smh_adapt_dev_free(wm->adapt);
+    wm->adapt = NULL;
     smh_wm_host_free(wm);
 }

@@ -417,6 +417,7 @@ struct smh_wm_queue {
     uint64_t pend_e;
     smh_u32x4 pend_q;
     uint32_t pend_mine;   /* in-register verify: per lane, this lane holds a pending column (there is no compaction) */
+    uint32_t events;      /* wave-uniform: surviving columns this wave sent to the verify stage (smh_stats.h) */
 };
 
 /* ---- staged verify: the window hash of a surviving column is computed from an ON-CHIP copy of the wave-chunk.
@@ -477,6 +478,7 @@ SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_par
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (cond) Q.slots[Q.count + before] = e; /* LDS, written and read by this wave only */
     Q.count += np;
+    Q.events += np;
 }
 #else
 SMH_LANE void smh_wm_drain(smh_wm_queue &, const uint8_t *, const smh_wm_params &) {}
@@ -647,6 +649,7 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
             const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             if (have) reinterpret_cast<uint32_t *>(Q.slots)[Q.count + before] = (uint32_t)(a - chunk_base) + b;
             Q.count += (uint32_t)__popcll(mask);
+            Q.events += (uint32_t)__popcll(mask);
         }
         msk &= msk - 1u;
     } while (SMH_WAVE_ANY(msk != 0));
@@ -853,7 +856,8 @@ SMH_LANE uint32_t smh_wm_lane_table(const uint8_t *text, uint64_t n, uint64_t a,
 template <bool HASHED, bool EXACT, int HC, int FK = 0, bool POS = false, bool STG = false>
 SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n,
                                 const uint32_t *filter, const smh_wm_params &P, int block_symbols,
-                                uint64_t *queue_base, const smh_pos_out *po = nullptr, const smh_wm_queue *stage = nullptr)
+                                uint64_t *queue_base, const smh_pos_out *po = nullptr, const smh_wm_queue *stage = nullptr,
+                                uint32_t *events_out = nullptr)
 {
     if (n < (uint64_t)P.m) return 0;
     constexpr int H = HC > 0 ? HC : 1;
@@ -865,6 +869,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
     Q.slots = queue_base; /* this wave's slice (the kernel passes LDS) */
     Q.count = 0;
     Q.matches = 0;
+    Q.events = 0;
     Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
     uint32_t cur[4 * H + 16], nxt[4 * H + 16];
@@ -921,6 +926,7 @@ SMH_LANE uint32_t smh_wm_thread(uint64_t gthread, const smh_chunk_sched &S, cons
         k = kn;
     }
     if (!EXACT) smh_wm_drain(Q, text, P);
+    if (events_out) *events_out = Q.events;
     return cnt + Q.matches;
 }
 
@@ -1204,6 +1210,7 @@ SMH_LANE void smh_wm_regv_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t
         /* the column this lane (or another) still holds from an earlier chunk -- its bucket arrived while this chunk was
          * scanned -- or from the round before (a second survivor in one lane: decided without the pipelining) */
         smh_wm_pend_finish<true>(Q, text, P);
+        Q.events += (uint32_t)__popcll(__ballot(have));
         Q.pend_n = 64u;
         Q.pend_mine = have ? 1u : 0u;
         Q.pend_e = a + c;
@@ -1716,7 +1723,8 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
 template <int KIND, bool POS = false, int STG = 0, bool QD = true>
 SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n,
                                      const void *tab, const smh_wm_params &P, uint64_t *queue_base, const smh_pos_out *po = nullptr,
-                                     uint32_t smh_gram_drain_at = 64u, const smh_wm_queue *stage = nullptr)
+                                     uint32_t smh_gram_drain_at = 64u, const smh_wm_queue *stage = nullptr,
+                                     uint32_t *events_out = nullptr)
 {
     if (n < (uint64_t)P.m) return 0;
     const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
@@ -1727,6 +1735,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
     Q.slots = queue_base;
     Q.count = 0;
     Q.matches = 0;
+    Q.events = 0;
     Q.po = POS ? po : nullptr;
     uint32_t cnt = 0;
     constexpr int HP = smh_stg_hp(STG), HD = 4 * HP; /* 16-byte pieces / dwords of text kept from in front of the chunk */
@@ -1812,6 +1821,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
     if (STG > 0) smh_wm_pend_finish<RV>(Q, text, P);
 #endif
     if (QD) smh_wm_drain(Q, text, P);
+    if (events_out) *events_out = Q.events;
     return cnt + Q.matches;
 }
 

@@ -23,6 +23,8 @@ VARIANT_TUNED = 0
 VARIANT_TABLE = 1
 ALGO_AC = 0
 ALGO_WM = 1
+ENGINE_AC_FLAT = 2
+ENGINE_NAMES = {0: "automaton kernels", 1: "suffix-filter kernels", 2: "plain stride-1 automaton"}
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int)
@@ -41,7 +43,8 @@ class AcInfo(C.Structure):
                 ("lds_rows", C.c_uint32), ("lds_bytes", C.c_uint32), ("table_bytes", C.c_uint64),
                 ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
                 ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32),
-                ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32)]
+                ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32), ("adaptive", C.c_uint32),
+                ("reserved", C.c_uint32 * 7)]
 
 
 class WmInfo(C.Structure):
@@ -50,7 +53,15 @@ class WmInfo(C.Structure):
                 ("block_symbols", C.c_uint32), ("filter_log2", C.c_uint32),
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
-                ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32)]
+                ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32),
+                ("adaptive", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+
+
+class AdaptInfo(C.Structure):
+    """smh_adapt_info: what the adaptive engine knows about the text on the current device"""
+    _fields_ = [("struct_size", C.c_uint32), ("adaptive", C.c_uint32), ("engine", C.c_uint32), ("flips", C.c_uint32),
+                ("reports", C.c_uint32), ("reserved", C.c_uint32), ("ms_per_gib", C.c_double * 3),
+                ("events_per_4k", C.c_double * 3), ("est_ms_per_gib", C.c_double * 3), ("verify_density", C.c_double)]
 
 
 class PsetInfo(C.Structure):
@@ -90,10 +101,11 @@ LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_s
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
                "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
-               "smh_stream_read_probe_variant",
+               "smh_stream_read_probe_variant", "smh_host_path_release",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
-               "smh_corpus_patterns", "smh_shard_range", "smh_ac_compile_tables",
-               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_set_scan_plan", "smh_ac_set_scan_engine", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
+               "smh_corpus_patterns", "smh_corpus_text_host_kind", "smh_corpus_text_device_kind", "smh_corpus_patterns_kind",
+               "smh_shard_range", "smh_ac_compile_tables",
+               "smh_ac_compile_patterns", "smh_ac_get_info", "smh_ac_get_adapt", "smh_wm_get_adapt", "smh_ac_set_scan_plan", "smh_ac_set_scan_engine", "smh_ac_positions", "smh_wm_positions", "smh_ac_scan", "smh_ac_count_host",
                "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info", "smh_wm_set_scan_engine",
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free", "smh_pset_compile", "smh_pset_get_info",
                "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
@@ -124,6 +136,8 @@ def _load():
     lib.smh_stream_synchronize.argtypes = [C.c_void_p]
     lib.smh_stream_read_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     lib.smh_stream_read_probe_variant.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+    lib.smh_host_path_release.restype = None
+    lib.smh_host_path_release.argtypes = []
     lib.smh_splitmix64_at.restype = C.c_uint64
     lib.smh_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
     lib.smh_corpus_text_host.restype = None
@@ -131,6 +145,9 @@ def _load():
     lib.smh_corpus_text_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
     lib.smh_corpus_patterns.restype = None
     lib.smh_corpus_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int]
+    lib.smh_corpus_text_host_kind.argtypes = [u8p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
+    lib.smh_corpus_text_device_kind.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+    lib.smh_corpus_patterns_kind.argtypes = [u8p, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     lib.smh_shard_range.restype = None
     lib.smh_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int, u64p, u64p]
     lib.smh_ac_compile_tables.restype = C.c_void_p
@@ -138,6 +155,8 @@ def _load():
     lib.smh_ac_compile_patterns.restype = C.c_void_p
     lib.smh_ac_compile_patterns.argtypes = [u8p, C.c_int, C.c_int, C.c_int]
     lib.smh_ac_get_info.argtypes = [C.c_void_p, C.POINTER(AcInfo)]
+    lib.smh_ac_get_adapt.argtypes = [C.c_void_p, C.POINTER(AdaptInfo)]
+    lib.smh_wm_get_adapt.argtypes = [C.c_void_p, C.POINTER(AdaptInfo)]
     lib.smh_ac_set_scan_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.smh_ac_set_scan_engine.argtypes = [C.c_void_p, C.c_int]
     lib.smh_ac_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]
@@ -254,7 +273,6 @@ def _load():
     lib.smh_multi_wm_count.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), dblp]
     lib.smh_multi_ac_prepare.argtypes = [C.c_void_p, C.c_void_p]
     lib.smh_multi_wm_prepare.argtypes = [C.c_void_p, C.c_void_p]
-    lib.smh_dev_build_peak.argtypes = [C.c_int]
     lib.smh_multi_free.restype = None
     lib.smh_multi_free.argtypes = [C.c_void_p]
     return lib
@@ -287,15 +305,25 @@ def device_name():
     return buf.value.decode()
 
 
-def corpus_text(n, seed=42, alphabet=4, offset=0):
+CORPUS_UNIFORM, CORPUS_DNA_REPEATS, CORPUS_SKEWED, CORPUS_PLANTED = 0, 1, 2, 3
+CORPUS_NAMES = {CORPUS_UNIFORM: "uniform", CORPUS_DNA_REPEATS: "dna_repeats", CORPUS_SKEWED: "skewed", CORPUS_PLANTED: "planted"}
+
+
+def corpus_text(n, seed=42, alphabet=4, offset=0, kind=CORPUS_UNIFORM):
     out = np.empty(n, dtype=np.uint8)
-    lib.smh_corpus_text_host(out.ctypes.data_as(u8p), n, offset, seed, alphabet)
+    _check(lib.smh_corpus_text_host_kind(out.ctypes.data_as(u8p), n, offset, seed, alphabet, kind), "smh_corpus_text_host_kind")
     return out
 
 
-def corpus_patterns(m, p, seed=7, alphabet=4, text_seed=42, n_text=0, every=2):
+def corpus_text_device(d_ptr, n, seed=42, alphabet=4, offset=0, kind=CORPUS_UNIFORM, stream=None):
+    _check(lib.smh_corpus_text_device_kind(C.c_void_p(d_ptr), n, offset, seed, alphabet, kind, C.c_void_p(stream or 0)),
+           "smh_corpus_text_device_kind")
+
+
+def corpus_patterns(m, p, seed=7, alphabet=4, text_seed=42, n_text=0, every=2, kind=CORPUS_UNIFORM):
     out = np.empty(m * p, dtype=np.uint8)
-    lib.smh_corpus_patterns(out.ctypes.data_as(u8p), m, p, seed, alphabet, text_seed, n_text, every)
+    _check(lib.smh_corpus_patterns_kind(out.ctypes.data_as(u8p), m, p, seed, alphabet, text_seed, n_text, every, kind),
+           "smh_corpus_patterns_kind")
     return out
 
 
@@ -327,6 +355,11 @@ class AcAutomaton:
     def info(self):
         out = AcInfo()
         _check(lib.smh_ac_get_info(self.h, C.byref(out)), "smh_ac_get_info")
+        return out
+
+    def adapt(self):
+        out = AdaptInfo(struct_size=C.sizeof(AdaptInfo))
+        _check(lib.smh_ac_get_adapt(self.h, C.byref(out)), "smh_ac_get_adapt")
         return out
 
     def set_scan_plan(self, stride=0, depth=0):
@@ -386,6 +419,11 @@ class WmTables:
     def info(self):
         out = WmInfo()
         _check(lib.smh_wm_get_info(self.h, C.byref(out)), "smh_wm_get_info")
+        return out
+
+    def adapt(self):
+        out = AdaptInfo(struct_size=C.sizeof(AdaptInfo))
+        _check(lib.smh_wm_get_adapt(self.h, C.byref(out)), "smh_wm_get_adapt")
         return out
 
     def set_scan_engine(self, engine):
@@ -514,7 +552,7 @@ class SogTables:
             pass
 
 
-MULTI_HOST_SUM, MULTI_NO_RCCL = 1, 2
+MULTI_HOST_SUM, MULTI_NO_RCCL, MULTI_SHARE_DEVICE = 1, 2, 4
 
 
 class MultiGpu:

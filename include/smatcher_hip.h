@@ -71,6 +71,13 @@ int smh_stream_read_probe(const void *d_buf, uint64_t bytes, uint64_t *d_out, vo
  * them as "what a streaming read reaches on this device". */
 int smh_stream_read_probe_variant(const void *d_buf, uint64_t bytes, uint64_t *d_out, void *stream, int variant);
 
+/* The blocking *_count_host helpers and the legacy names of smatcher.h (search_ac, search_wu, cuda_* ...) take the text
+ * as a pageable host buffer.  It crosses PCIe in 64 MiB pieces through two device buffers of a pooled, grow-only workspace
+ * (piece k+1 copies while piece k is scanned; pieces overlap by m - 1 bytes: main.c:467-477), so such a call allocates
+ * nothing and needs 2 x (64 MiB + m) of device memory whatever the text's length.  The workspaces stay allocated
+ * between calls; this frees them (call it with no *_count_host / legacy call in flight). */
+void smh_host_path_release(void);
+
 /* ---- synthetic corpus (clean-room stand-in for the reference's missing helper.c:
  *      load_files / create_multiple_pattern_with_hits, main.c:49,453) ----
  * Counter-based splitmix64: symbol i = mix(seed + (i+1)*0x9E3779B97F4A7C15) % alphabet,
@@ -84,11 +91,39 @@ int smh_corpus_text_device(unsigned char *d_out, uint64_t n, uint64_t offset, ui
 void smh_corpus_patterns(unsigned char *out, int m, int p_size, uint64_t seed, int alphabet,
                          uint64_t text_seed, uint64_t n_text, int from_text_every);
 
+/* Non-uniform corpora (round 4; csrc/corpus_gen.h).  The reference's own data sets are E.coli, A.thaliana, swiss-prot
+ * and world192 (main.c:39-109; not in the upstream repository): repeats, low-complexity runs, skewed symbol
+ * frequencies -- i.i.d. uniform text is every filter engine's best case.  `kind`:
+ *   SMH_CORPUS_UNIFORM      the text of smh_corpus_text_host / _device
+ *   SMH_CORPUS_DNA_REPEATS  alphabet 4: order-3 Markov text with 15 % copies of 64 library blocks, 5 % tandem repeats,
+ *                           10 % low-complexity (poly-A) runs, in 1 KiB blocks
+ *   SMH_CORPUS_SKEWED       any alphabet: Zipf-like symbol frequencies (20 symbols: a protein's spread; 256: natural-
+ *                           language-like, 4.3 bits per symbol), 15 % library blocks, 5 % low-complexity runs
+ *   SMH_CORPUS_PLANTED      any alphabet: uniform text in which one 32-symbol word recurs in every 64-byte cell;
+ *                           smh_corpus_patterns_kind puts the word's first m symbols into the set as pattern 0
+ * Every slice [offset, offset + n) can be produced independently on host or device (same bytes).  Patterns that are
+ * not substrings of the text are slices of an unrelated text of the same kind.  SMH_EINVAL for a kind / alphabet
+ * that does not exist. */
+#define SMH_CORPUS_UNIFORM 0
+#define SMH_CORPUS_DNA_REPEATS 1
+#define SMH_CORPUS_SKEWED 2
+#define SMH_CORPUS_PLANTED 3
+int smh_corpus_text_host_kind(unsigned char *out, uint64_t n, uint64_t offset, uint64_t seed, int alphabet, int kind);
+int smh_corpus_text_device_kind(unsigned char *d_out, uint64_t n, uint64_t offset, uint64_t seed, int alphabet, int kind,
+                                void *stream);
+int smh_corpus_patterns_kind(unsigned char *out, int m, int p_size, uint64_t seed, int alphabet, uint64_t text_seed,
+                             uint64_t n_text, int from_text_every, int kind);
+
 /* ---- byte-range shards: main.c:375-378,464-477 with the true length of the last shard ---- */
 void smh_shard_range(uint64_t n, int n_shards, int shard, int m, uint64_t *begin, uint64_t *end);
 
 #define SMH_ALGO_AC 0
 #define SMH_ALGO_WM 1
+/* a third engine some Aho-Corasick handles keep (round 4): the automaton as a PLAIN stride-1 image with K = m in LDS -- one
+ * lookup per symbol whatever the text -- beside a preferred hybrid stride-2 image, whose speed depends on how deep the text
+ * keeps its lanes in the trie.  Only smh_ac_set_scan_engine and smh_adapt_info name it. */
+#define SMH_ENGINE_AC_FLAT 2
+#define SMH_ENGINES 3
 
 /* ---- Aho-Corasick ---- */
 typedef struct smh_ac smh_ac;
@@ -121,7 +156,32 @@ typedef struct smh_ac_info {
                               * (two END columns per lookup); scan_stride / scan_depth describe the ordinary plan kept beside it */
     uint32_t verify_in_registers; /* scan_engine == SMH_ALGO_WM: smh_wm_info.verify_in_registers of that engine */
     uint32_t gram_kind;      /* scan_engine == SMH_ALGO_WM: smh_wm_info.gram_kind of that engine */
+    uint32_t adaptive;       /* 1: the handle holds both engines and no engine or plan is forced: scan_engine is where every
+                              * device starts, and from then on the engine follows what the launches report about the text
+                              * (smh_ac_get_adapt) */
+    uint32_t reserved[7];    /* zero; library 0.2 grew this struct -- later fields will come out of here */
 } smh_ac_info;
+
+/* What the library has learned about the text it scans with a handle on the CURRENT device (round 4).  The engine that
+ * serves an entry point is chosen at compile time from rates measured on pseudo-random text; a filter engine's speed,
+ * though, depends on the text (every surviving column is verified one by one) -- the reference's own corpora are
+ * genomes, proteins and English (main.c:39-109).  The filter kernels and the depth-cut automaton kernels therefore
+ * report, per launch of 16 MiB or more, their duration on the device and the number of columns they had to verify,
+ * and a handle that holds both engines switches to the other one for the NEXT launch when that is measured (or, untried
+ * on this text, estimated) clearly faster; the filter kernels' verify mode follows the measured survivor rate the same
+ * way.  No synchronisation: a launch that has not finished has not reported.  SMH_ADAPT=0 in the environment disables it. */
+typedef struct smh_adapt_info {
+    uint32_t struct_size;      /* in: sizeof(smh_adapt_info) */
+    uint32_t adaptive;         /* 1: both engines at hand, none forced */
+    uint32_t engine;           /* SMH_ALGO_AC / SMH_ALGO_WM / SMH_ENGINE_AC_FLAT: the kernels the next tuned scan on this device runs */
+    uint32_t flips;            /* engine changes so far on this device */
+    uint32_t reports;          /* launches that have reported */
+    uint32_t reserved;
+    double ms_per_gib[SMH_ENGINES];     /* [SMH_ALGO_AC | SMH_ALGO_WM | SMH_ENGINE_AC_FLAT]: the better of the engine's last two measured launches, 0 = not measured on this text */
+    double events_per_4k[SMH_ENGINES];  /* [SMH_ALGO_AC]: candidates queued, [SMH_ALGO_WM]: surviving columns, per 4 KiB of text */
+    double est_ms_per_gib[SMH_ENGINES]; /* the compile's estimates on random text; 0 = the handle has no such engine */
+    double verify_density;     /* surviving columns per column the filter launcher currently plans its verify mode for (< 0: the compile's) */
+} smh_adapt_info;
 
 /* from the reference-layout tables preproc_ac filled (rows = m*p_size+1 as main.c:410-420 sizes them) */
 smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *state_supply,
@@ -129,12 +189,14 @@ smh_ac *smh_ac_compile_tables(const int *state_transition, const unsigned int *s
 /* from patterns: builds the reference tables internally, then compiles them */
 smh_ac *smh_ac_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
 int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out);
+int smh_ac_get_adapt(smh_ac *ac, smh_adapt_info *out);
 /* tuning / test knob: rebuild the LDS scan automaton with a forced stride (1 or 2, 3 = hybrid stride 2,
  * 4 = the dense plan of smh_ac_info.scan_dense; 0 = choose) and a forced depth K (1..min(m,65); 0 = the deepest that fits; for the hybrid image
  * bits 8..15 may force the depth D of its full rows).  SMH_EUNSUP when it does not fit LDS. */
 int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth);
 /* test / tuning knob, the mirror of smh_wm_set_scan_engine: SMH_ALGO_AC runs the automaton kernels on the plan the handle
- * holds, SMH_ALGO_WM the suffix-filter engine (SMH_EUNSUP when the compile kept none), -1 restores the compile's choice */
+ * holds, SMH_ALGO_WM the suffix-filter engine (SMH_EUNSUP when the compile kept none) -- either way the adaptive choice
+ * is off; -1 restores the compile's choice and the adaptive engine */
 int smh_ac_set_scan_engine(smh_ac *ac, int engine);
 /* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).
  * d_text must be 16-byte aligned; n may exceed 2^32.  A handle owns one candidate-queue workspace
@@ -181,6 +243,8 @@ typedef struct smh_wm_info {
     uint32_t gram_kind;       /* form of the q-gram filter (== the kernels' KIND template value): 0 none, 1 symbol pairs (7-symbol
                                * grams, two columns per lookup), 2 hashed byte grams (one plane per offset), 3 8-symbol grams, 5 8-symbol
                                * grams at two columns per lookup, 6 flat byte grams (one Bloom set for all offsets) */
+    uint32_t adaptive;        /* as smh_ac_info.adaptive: this handle also holds an automaton engine and follows the launches' reports */
+    uint32_t reserved[7];
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */
@@ -190,6 +254,7 @@ smh_wm *smh_wm_compile_tables(const unsigned char *pattern_flat, int m, int p_si
                               const int *SHIFT, const int *PREFIX_value, const int *PREFIX_index,
                               const int *PREFIX_size);
 int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out);
+int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out);
 /* test / tuning knob: SMH_ALGO_WM forces this path's own kernels, SMH_ALGO_AC the automaton engine
  * (SMH_EUNSUP when the set has none), -1 restores the choice made at compile time */
 int smh_wm_set_scan_engine(smh_wm *wm, int engine);
@@ -230,6 +295,11 @@ typedef struct smh_multi smh_multi;
 #define SMH_MULTI_MAX_DEVICES 16
 #define SMH_MULTI_HOST_SUM 1 /* smh_multi_create: when RCCL cannot be loaded, add the counts on the host instead of failing */
 #define SMH_MULTI_NO_RCCL 2  /* never create a communicator (host sum); for comparison runs */
+#define SMH_MULTI_SHARE_DEVICE 4 /* one-card rehearsal of the N-device flow: `devices` may name a device more than once (NULL:
+                                  * logical shard i sits on device i mod the visible ones); every logical shard keeps a stream,
+                                  * a text range, a counter and table sets of its own, the counts are added on the host (an RCCL
+                                  * communicator takes a device once).  Also switched on by SMH_MULTI_SHARE_DEVICE=1 in the
+                                  * environment, so that `smatcher -ranks 4` and bench.py's native leg can be rehearsed as they are */
 /* devices == NULL: devices 0 .. n_devices-1 */
 int smh_multi_create(smh_multi **out, const int *devices, int n_devices, int flags);
 int smh_multi_device_count(const smh_multi *mg);
