@@ -494,7 +494,9 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
      * whatever the text, 0.29 ms/GiB.  When the whole automaton fits LDS in that form (K = m: exact, no verify stage) it is
      * kept beside the preferred plan as the engine with a guarantee, and the runtime switches to it when the launches
      * report that the text is of that kind (smh_runtime.hip "adaptive engine"). */
-    if (ac->fixed_length_ok && ac->scan_full_rows && !ac->scan_dense && ac->g_transition && smh_alt_engine_depth == 0) {
+    static _Thread_local int flat_building = 0; /* the twin is compiled by this very function */
+    if (ac->fixed_length_ok && ac->scan_full_rows && !ac->scan_dense && ac->g_transition && !flat_building && smh_alt_engine_depth <= 1) {
+        ++flat_building;
         ++smh_alt_engine_depth;
         struct smh_ac *flat = smh_ac_compile_tables_impl(ac->g_transition, ac->g_supply, ac->g_final, (uint64_t)ac->states,
                                                          alphabet, m, SMH_AC_REF_NONE);
@@ -505,6 +507,7 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
         }
         ac->flat_ac = flat;
         --smh_alt_engine_depth;
+        --flat_building;
     }
     return ac;
 

@@ -426,13 +426,13 @@ static int upload(void **d, const void *h, size_t bytes, size_t pad)
  * A handle that holds several engines -- an automaton with a depth-cut or hybrid plan, the suffix-filter kernels over
  * the same patterns (smh_ac.flex_wm / smh_wm.flex_ac), the plain stride-1 automaton (smh_ac.flat_ac) -- starts with the
  * one its compile estimated fastest on random text and then follows the launches' own reports: every count launch of
- * 16 MiB or more publishes its duration (device clock, first workgroup's start to last workgroup's end) and the number of
+ * 32 MiB or more publishes its duration (device clock, first workgroup's start to last workgroup's end) and the number of
  * columns it had to verify.  Before the NEXT launch the host compares, per GiB, the running engine's measured time
  * (the better of its last two reports: an engine's first launch on a device runs cold) with the best of the others
  * (measured on this text, else the compile's estimate) and switches when that is clearly better -- after the first
- * report when the running engine is three times slower than estimated, else after the second.  What was measured of an
+ * report when a launch of 256 MiB or more ran four times slower than estimated, else after the second.  What was measured of an
  * engine that is not running is forgotten, so that it is tried again, when the running engine's events per 4 KiB move by
- * a factor of two (another kind of text) or, while it lies within 1.5 x of the running engine's, every 32 reports.  The
+ * a factor of two (another kind of text) and after 32 reports of the others -- 64, 128, ... 4096 when it keeps losing.  The
  * filter kernels' verify mode (in registers / staged) follows the measured survivors per chunk the same way.  Nothing
  * here synchronises: a launch that has not finished has simply not reported yet.  SMH_ADAPT=0 in the environment
  * (read once) turns all of it off; a forced engine or plan is never overridden. */
@@ -447,7 +447,10 @@ struct smh_adapt_dev {
     double last[SMH_ENGINES][2]; /* per engine: ms per GiB of its last two reports, [0] the newer */
     int n[SMH_ENGINES];    /* reports held (0..2); 0 = not measured on this text */
     uint32_t age[SMH_ENGINES]; /* reports of other engines since */
+    uint32_t keep[SMH_ENGINES]; /* reports of other engines after which the engine's measurement is forgotten: 32, doubling
+                                 * every time it is (an engine that keeps losing is tried ever more rarely), back to 32 when it wins */
     double sig[SMH_ENGINES]; /* events per 4 KiB at the engine's last report */
+    unsigned long long last_bytes; /* text length of the newest report */
     double ref_sig;
     int ref_valid;
     uint32_t reports, flips;
@@ -509,7 +512,8 @@ static double adapt_ms(const smh_adapt_dev *A, int e)
     return A->n[e] == 1 || A->last[e][0] < A->last[e][1] ? A->last[e][0] : A->last[e][1];
 }
 
-#define SMH_ADAPT_MIN_BYTES (16ull << 20) /* smaller launches are mostly table staging and tail: not a rate */
+#define SMH_ADAPT_MIN_BYTES (32ull << 20) /* smaller launches are mostly table staging and tail: not a rate */
+#define SMH_ADAPT_FIXED_TICKS 400.0        /* 4 us of every launch are table staging and the last wave's tail whatever the text's length: taken off before a duration becomes a rate */
 static void adapt_poll(smh_adapt_dev *A)
 {
     volatile unsigned long long *h = A->h_rec;
@@ -521,7 +525,10 @@ static void adapt_poll(smh_adapt_dev *A)
     const int e = (int)(tag & 3u);
     if (bytes < SMH_ADAPT_MIN_BYTES || ticks == 0 || e >= SMH_ENGINES) return;
     A->last[e][1] = A->last[e][0];
-    A->last[e][0] = (double)ticks * 1e-5 * (double)(1ull << 30) / (double)bytes; /* 100 MHz ticks -> ms per GiB */
+    double t = (double)ticks - SMH_ADAPT_FIXED_TICKS;
+    if (t < 0.25 * (double)ticks) t = 0.25 * (double)ticks;
+    A->last[e][0] = t * 1e-5 * (double)(1ull << 30) / (double)bytes; /* 100 MHz ticks -> ms per GiB */
+    A->last_bytes = bytes;
     if (A->n[e] < 2) ++A->n[e];
     A->sig[e] = (double)ev * 4096.0 / (double)bytes;
     A->age[e] = 0;
@@ -540,7 +547,8 @@ static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int ini
     const int cur = A->engine;
     const double c_cur = adapt_ms(A, cur);
     if (c_cur <= 0) return cur;
-    if (A->n[cur] < 2 && !(est[cur] > 0 && c_cur > 3.0 * est[cur])) return cur; /* a first report runs cold: wait for the second */
+    /* a first report runs cold: wait for the second -- unless a launch of 256 MiB or more took four times what was estimated */
+    if (A->n[cur] < 2 && !(est[cur] > 0 && c_cur > 4.0 * est[cur] && A->last_bytes >= (256ull << 20))) return cur;
     if (!A->ref_valid) {
         A->ref_sig = A->sig[cur];
         A->ref_valid = 1;
@@ -556,13 +564,18 @@ static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int ini
     double c_best = 0, m_best = 1.0;
     for (int o = 0; o < SMH_ENGINES; ++o) {
         if (o == cur || est[o] <= 0) continue;
-        if (A->n[o] > 0 && adapt_ms(A, o) < 1.5 * c_cur && A->age[o] >= 32u) A->n[o] = 0; /* a close race is re-run now and then */
+        if (A->keep[o] == 0) A->keep[o] = 32u;
+        if (A->n[o] > 0 && A->age[o] >= A->keep[o]) { /* the race is re-run now and then: the text may have changed in a way the running engine's events do not show */
+            A->n[o] = 0;
+            if (A->keep[o] < 4096u) A->keep[o] *= 2u;
+        }
         const double c = A->n[o] > 0 ? adapt_ms(A, o) : est[o], margin = A->n[o] > 0 ? 1.03 : 1.08;
         if (best < 0 || c * margin < c_best * m_best) { best = o; c_best = c; m_best = margin; }
     }
     if (best >= 0 && c_best * m_best < c_cur) {
         A->engine = best;
         A->n[best] = 0; /* a fresh series for the engine that takes over */
+        if (c_best * 1.5 < c_cur) A->keep[best] = 32u;
         A->ref_valid = 0;
         ++A->flips;
     }
@@ -1294,13 +1307,15 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
             if ((rc = adapt_get(&wm->adapt, &A)) != SMH_OK) return rc;
             adapt_poll(A);
             if (wm->flex_ac && wm->engine_forced < 0) {
-                const double est[SMH_ENGINES] = {smh_ac_plan_ms(wm->flex_ac), wm->scan_ms_est, 0.0};
+                const double est[SMH_ENGINES] = {smh_ac_plan_ms(wm->flex_ac), wm->scan_ms_est,
+                                                 wm->flex_ac->flat_ac ? smh_ac_plan_ms(wm->flex_ac->flat_ac) : 0.0};
                 engine = adapt_choose(A, est, engine);
             } else {
                 A->engine = engine;
             }
         }
         if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine));
+        if (engine == SMH_ENGINE_AC_FLAT) return ac_launch_own(wm->flex_ac->flat_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine));
         return wm_launch_own(wm, d_text, n, d_count, stream, adapt_arg(wm_reports(wm) ? A : NULL, n, engine), adapt_density(A, wm));
     }
     if (variant != SMH_VARIANT_TABLE) {
@@ -1327,7 +1342,8 @@ extern "C" int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out)
         smh_set_error("smh_wm_get_adapt: bad arguments (set struct_size = sizeof(smh_adapt_info))");
         return SMH_EINVAL;
     }
-    const double est[SMH_ENGINES] = {wm->flex_ac ? smh_ac_plan_ms(wm->flex_ac) : 0.0, wm->scan_ms_est, 0.0};
+    const double est[SMH_ENGINES] = {wm->flex_ac ? smh_ac_plan_ms(wm->flex_ac) : 0.0, wm->scan_ms_est,
+                                     wm->flex_ac && wm->flex_ac->flat_ac ? smh_ac_plan_ms(wm->flex_ac->flat_ac) : 0.0};
     const int adaptive = wm->flex_ac && wm->engine_forced < 0 && adapt_enabled();
     adapt_report(adapt_find(&wm->adapt), adaptive, wm_engine_static(wm), est, out);
     return SMH_OK;
@@ -1341,7 +1357,10 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         return SMH_EINVAL;
     }
     if (n < (uint64_t)wm->m) return SMH_OK;
-    if (wm_engine_now(wm) == SMH_ALGO_AC) return smh_ac_positions(wm_automaton_engine(wm), d_text, n, d_positions, capacity, d_cursor, stream);
+    if (const int engine = wm_engine_now(wm); engine == SMH_ALGO_AC)
+        return smh_ac_positions(wm_automaton_engine(wm), d_text, n, d_positions, capacity, d_cursor, stream);
+    else if (engine == SMH_ENGINE_AC_FLAT && wm->flex_ac && wm->flex_ac->flat_ac)
+        return smh_ac_positions(wm->flex_ac->flat_ac, d_text, n, d_positions, capacity, d_cursor, stream);
     smh_wm_dev *dv = NULL;
     int rc = wm_ensure_device(wm, &dv);
     if (rc != SMH_OK) return rc;

@@ -816,7 +816,11 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
 
 int smh_wm_set_scan_engine(smh_wm *wm, int engine)
 {
-    if (!wm || wm->magic != SMH_MAGIC_WM || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC)) {
+    if (engine == SMH_ENGINE_AC_FLAT && wm && wm->magic == SMH_MAGIC_WM && !(wm->flex_ac && wm->flex_ac->flat_ac)) {
+        smh_set_error("smh_wm_set_scan_engine: this set keeps no plain stride-1 automaton");
+        return SMH_EUNSUP;
+    }
+    if (!wm || wm->magic != SMH_MAGIC_WM || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT)) {
         smh_set_error("smh_wm_set_scan_engine: bad arguments");
         return SMH_EINVAL;
     }

@@ -166,7 +166,7 @@ typedef struct smh_ac_info {
  * serves an entry point is chosen at compile time from rates measured on pseudo-random text; a filter engine's speed,
  * though, depends on the text (every surviving column is verified one by one) -- the reference's own corpora are
  * genomes, proteins and English (main.c:39-109).  The filter kernels and the depth-cut automaton kernels therefore
- * report, per launch of 16 MiB or more, their duration on the device and the number of columns they had to verify,
+ * report, per launch of 32 MiB or more, their duration on the device and the number of columns they had to verify,
  * and a handle that holds both engines switches to the other one for the NEXT launch when that is measured (or, untried
  * on this text, estimated) clearly faster; the filter kernels' verify mode follows the measured survivor rate the same
  * way.  No synchronisation: a launch that has not finished has not reported.  SMH_ADAPT=0 in the environment disables it. */

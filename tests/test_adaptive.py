@@ -1,0 +1,152 @@
+"""The adaptive engine (csrc/smh_runtime.hip, csrc/smh_stats.h; round 4): a handle that holds several engines follows what
+its launches report about the TEXT.  The compile chooses from rates measured on pseudo-random text; the reference's own
+corpora (main.c:39-109) are genomes, proteins and English.  Counts never depend on the engine."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd"))
+import smatcher_hip as S  # noqa: E402
+
+
+def test_adapt_entry_points_exist_and_report_without_a_device():
+    pat = S.corpus_patterns(16, 300, 7, 4, 42, 1 << 20, 2)
+    ac = S.AcAutomaton.from_patterns(pat, 16, 300, 4)
+    info, ad = ac.info(), ac.adapt()
+    assert info.adaptive == ad.adaptive
+    assert ad.reports == 0 and ad.flips == 0 and ad.engine == info.scan_engine
+    assert ad.est_ms_per_gib[S.ALGO_AC] > 0
+    if info.adaptive:  # a depth-cut or hybrid plan keeps a second engine
+        assert ad.est_ms_per_gib[S.ALGO_WM] > 0 or ad.est_ms_per_gib[S.ENGINE_AC_FLAT] > 0
+    ac.set_scan_engine(S.ALGO_AC)  # a forced engine is never overridden
+    assert ac.adapt().adaptive == 0 and ac.info().scan_engine == S.ALGO_AC
+    ac.set_scan_engine(-1)
+    assert ac.adapt().adaptive == info.adaptive
+    bad = S.AdaptInfo(struct_size=8)
+    assert S.lib.smh_ac_get_adapt(ac.h, S.C.byref(bad)) != 0
+    wm = S.WmTables.from_patterns(pat, 16, 300, 4)
+    assert wm.adapt().adaptive == wm.info().adaptive
+    wm.close()
+    ac.close()
+    # the exact plans keep no second engine: their rate does not depend on the text
+    pat8 = S.corpus_patterns(8, 300, 7, 4, 42, 1 << 20, 2)
+    ac8 = S.AcAutomaton.from_patterns(pat8, 8, 300, 4)
+    assert ac8.info().adaptive == 0
+    with pytest.raises(S.SmhError):
+        ac8.set_scan_engine(S.ENGINE_AC_FLAT)
+    ac8.close()
+
+
+def _dev_text(n, sigma, kind, seed=42):
+    import torch
+    t = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    S.corpus_text_device(t.data_ptr(), n, seed, sigma, 0, kind)
+    torch.cuda.synchronize()
+    return t
+
+
+def _scan(h, t, n):
+    import torch
+    c = torch.zeros(1, dtype=torch.int64, device="cuda")
+    h.scan_device(t.data_ptr(), n, c.data_ptr())
+    torch.cuda.synchronize()
+    return int(c.item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["ac", "wm"])
+def test_engine_follows_the_text_and_counts_do_not_change(entry):
+    """1000 patterns of 16 symbols sampled from a repeat-rich genome-like text.  On uniform text the compile's choice (the
+    pair-gram filter or the hybrid automaton) stands; on the repeat-rich text, where most lanes of the hybrid image sit in
+    compact rows and every filter survivor is a real match, the handle moves to the plain stride-1 automaton within a few
+    launches and runs several times faster than either forced engine; back on uniform text it returns."""
+    n, m, p, sigma = 256 << 20, 16, 1000, 4
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, S.CORPUS_DNA_REPEATS)
+    h = (S.AcAutomaton if entry == "ac" else S.WmTables).from_patterns(pat, m, p, sigma)
+    assert h.info().adaptive == 1
+    uni, rep = _dev_text(n, sigma, S.CORPUS_UNIFORM), _dev_text(n, sigma, S.CORPUS_DNA_REPEATS)
+    host = {"uni": uni[:n].cpu().numpy(), "rep": rep[:n].cpu().numpy()}
+    want = {k: O.oracle_ac(pat, m, p, sigma, v[:8 << 20])[0] for k, v in host.items()}
+    assert _scan(h, uni, 8 << 20) == want["uni"] and _scan(h, rep, 8 << 20) == want["rep"]  # small launches do not report
+    assert h.adapt().reports == 0
+    first = h.info().scan_engine
+    counts = {k: None for k in host}
+
+    def run(text, key, launches):
+        engines = []
+        for _ in range(launches):
+            c = _scan(h, text, n)
+            counts[key] = c if counts[key] is None else counts[key]
+            assert c == counts[key]  # whichever engine ran
+            engines.append(int(h.adapt().engine))
+        return engines
+
+    e_uni = run(uni, "uni", 6)
+    assert e_uni[0] == first and h.adapt().reports >= 5
+    calm = h.adapt()
+    assert calm.flips == 0 and calm.engine == first and calm.ms_per_gib[calm.engine] > 0, e_uni
+    e_rep = run(rep, "rep", 8)
+    assert e_rep[0] == e_uni[-1]
+    hot = h.adapt()
+    assert hot.flips > calm.flips, (e_uni, e_rep)
+    assert e_rep[-1] == S.ENGINE_AC_FLAT, e_rep  # the engine whose speed does not depend on the text
+    assert e_rep.index(S.ENGINE_AC_FLAT) <= 4, e_rep  # ... reached within a few launches
+    assert hot.ms_per_gib[S.ENGINE_AC_FLAT] * 2.0 < max(hot.ms_per_gib[S.ALGO_AC], hot.ms_per_gib[S.ALGO_WM])
+    # forced engines agree on the counts (and are not overridden)
+    forced = 0
+    for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT):
+        try:
+            h.set_scan_engine(eng)
+        except S.SmhError:  # an exact hybrid plan keeps no filter engine
+            assert eng == S.ALGO_WM and entry == "ac"
+            continue
+        forced += 1
+        assert _scan(h, rep, n) == counts["rep"] and _scan(h, uni, n) == counts["uni"]
+        assert h.adapt().adaptive == 0
+    assert forced >= 2
+    h.set_scan_engine(-1)
+    # full-text counts against the oracle, once
+    assert counts["uni"] == O.oracle_ac(pat, m, p, sigma, host["uni"])[0]
+    assert counts["rep"] == O.oracle_ac(pat, m, p, sigma, host["rep"])[0]
+    h.close()
+
+
+@pytest.mark.gpu
+def test_verify_mode_follows_measured_survivors():
+    """8000 patterns of 16 symbols: on uniform text ~1.4 survivors per 4 KiB (verified in registers); on the planted text
+    -- one of the patterns recurs in every 64-byte cell -- over 60: the launcher is handed the measured rate and takes the
+    staged verify.  Same counts either way, and SMH_WM_TUNE can still force each mode."""
+    n, m, p, sigma = 64 << 20, 16, 8000, 4
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, S.CORPUS_PLANTED)
+    wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    uni, pla = _dev_text(n, sigma, S.CORPUS_UNIFORM), _dev_text(n, sigma, S.CORPUS_PLANTED)
+    want_uni = O.oracle_ac(pat, m, p, sigma, uni[:n].cpu().numpy())[0]
+    want_pla = O.oracle_ac(pat, m, p, sigma, pla[:n].cpu().numpy())[0]
+    assert want_pla > n // 64
+    for _ in range(3):
+        assert _scan(wm, uni, n) == want_uni
+    low = wm.adapt()
+    assert low.reports >= 2 and low.events_per_4k[S.ALGO_WM] < 8.0
+    for _ in range(4):
+        assert _scan(wm, pla, n) == want_pla
+    high = wm.adapt()
+    assert high.events_per_4k[S.ALGO_WM] > 60.0 and high.verify_density * 4096 > 8.0  # the launcher now plans for the staged verify
+    wm.close()
+
+
+@pytest.mark.gpu
+def test_small_launches_and_disabled_adaptation(monkeypatch):
+    n, m, p, sigma = 4 << 20, 16, 500, 4
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
+    t = _dev_text(n, sigma, S.CORPUS_UNIFORM)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    want = O.oracle_ac(pat, m, p, sigma, t[:n].cpu().numpy())[0]
+    for _ in range(4):
+        assert _scan(ac, t, n) == want
+    assert ac.adapt().reports == 0  # below 32 MiB a launch is mostly staging and tail: it reports nothing
+    ac.close()

@@ -26,7 +26,7 @@ def test_multi_entry_points_exist_and_fail_cleanly_without_devices():
     with pytest.raises(S.SmhError):
         S.MultiGpu(0)
     with pytest.raises(S.SmhError):
-        S.MultiGpu(2, devices=[0, 0])  # a device twice / not visible: refused either way
+        S.MultiGpu(2, devices=[0, 0])  # a device twice / not visible: refused either way (SMH_MULTI_SHARE_DEVICE rehearses it)
 
 
 def _case(n, m, p, sigma):
@@ -39,12 +39,15 @@ def _case(n, m, p, sigma):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_devices", [1, 2, 4, 8])
 def test_multi_device_counts_match_the_oracle(n_devices):
-    if S.device_count() < n_devices:
-        pytest.skip("%d device(s) visible" % S.device_count())
+    """With fewer cards than shards the N-device flow is REHEARSED on what is there (SMH_MULTI_SHARE_DEVICE: logical shard i
+    on device i mod the visible ones; per-shard streams, text ranges, counters and -- by the runtime's slot keys -- table
+    sets; host-side sum, since an RCCL communicator takes a device once): shard placement with the last shard's true
+    length, per-shard counts == the oracle's count of the main.c:467-477 range, the halo refusal."""
+    share = S.device_count() < n_devices
     n, m, p, sigma = 6_000_007, 16, 500, 4
     text, pat, want = _case(n, m, p, sigma)
-    mg = S.MultiGpu(n_devices)
-    assert mg.devices == n_devices and mg.uses_rccl
+    mg = S.MultiGpu(n_devices, flags=S.MULTI_SHARE_DEVICE if share else 0)
+    assert mg.devices == n_devices and mg.uses_rccl == (not share)
     mg.load_text(text, 63)
     ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
     wm = S.WmTables.from_patterns(pat, m, p, sigma)
@@ -66,7 +69,7 @@ def test_multi_device_counts_match_the_oracle(n_devices):
     mg.generate_text(n, 42, sigma, 31)
     assert mg.ac_count(ac)[0] == want
     # host-side sum instead of the communicator: same numbers
-    mg2 = S.MultiGpu(n_devices, flags=S.MULTI_NO_RCCL)
+    mg2 = S.MultiGpu(n_devices, flags=S.MULTI_NO_RCCL | (S.MULTI_SHARE_DEVICE if share else 0))
     assert not mg2.uses_rccl
     mg2.load_text(text, 15)
     assert mg2.ac_count(ac)[0] == want
@@ -96,26 +99,60 @@ def test_first_count_call_is_as_fast_as_the_tenth_after_prepare():
     mg.close()
 
 
+def _testing_lib():
+    """the product library with the runtime's test hooks compiled in (make emu: -DSMH_TESTING) -- libsmatcher_hip.so carries none"""
+    path = os.path.join(ROOT, "tests", "emu", "libsmatcher_hip_testing.so")
+    T = S.C.CDLL(path)
+    T.smh_wm_compile.restype = S.C.c_void_p
+    T.smh_wm_compile.argtypes = [S.u8p, S.C.c_int, S.C.c_int, S.C.c_int]
+    T.smh_wm_prepare_device.argtypes = [S.C.c_void_p]
+    T.smh_wm_free.argtypes = [S.C.c_void_p]
+    T.smh_wm_free.restype = None
+    T.smh_dev_build_peak.argtypes = [S.C.c_int]
+    return T
+
+
+def test_product_library_has_no_test_hooks():
+    with pytest.raises(AttributeError):
+        S.lib.smh_dev_build_peak
+    assert _testing_lib().smh_dev_build_peak(0) == 0
+
+
 @pytest.mark.gpu
 def test_table_sets_of_two_handles_are_built_side_by_side(monkeypatch):
     """ensure_device_set builds outside the process-wide mutex: two host threads preparing two handles overlap
     (smh_dev_build_peak counts the builds in flight together).  SMH_TEST_BUILD_DELAY_MS stretches every build by 150 ms
     so that the overlap does not depend on scheduling luck: with the mutex held across the build the second thread
-    could not even start its own."""
+    could not even start its own.  Two threads that prepare the SAME handle on the same device build ONE set: the second
+    waits for the first (round 4; it used to build a second copy and free the loser's)."""
     import threading
+    T = _testing_lib()
     monkeypatch.setenv("SMH_TEST_BUILD_DELAY_MS", "150")
     n, sigma = 1 << 20, 256
-    handles = [S.WmTables.from_patterns(S.corpus_patterns(12, 20000, 11 + i, sigma, 42, n, 2), 12, 20000, sigma) for i in range(2)]
-    S.lib.smh_dev_build_peak(1)
-    S.lib.smh_wm_prepare_device.argtypes = [S.C.c_void_p]
-    gate = threading.Barrier(2)
-    rcs = [None, None]
 
-    def work(i):
-        gate.wait()
-        rcs[i] = S.lib.smh_wm_prepare_device(handles[i].h)
-    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    [t.start() for t in th]
-    [t.join() for t in th]
-    assert rcs == [0, 0]
-    assert S.lib.smh_dev_build_peak(0) >= 2
+    def compile_one(seed):
+        pat = np.ascontiguousarray(S.corpus_patterns(12, 20000, seed, sigma, 42, n, 2))
+        h = T.smh_wm_compile(pat.ctypes.data_as(S.u8p), 12, 20000, sigma)
+        assert h
+        return S.C.c_void_p(h)
+
+    def race(handles):
+        T.smh_dev_build_peak(1)
+        gate = threading.Barrier(2)
+        rcs = [None, None]
+
+        def work(i):
+            gate.wait()
+            rcs[i] = T.smh_wm_prepare_device(handles[i])
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert rcs == [0, 0]
+        return T.smh_dev_build_peak(0)
+
+    a, b = compile_one(11), compile_one(12)
+    assert race([a, b]) >= 2
+    c = compile_one(13)
+    assert race([c, c]) == 1
+    for h in (a, b, c):
+        T.smh_wm_free(h)
