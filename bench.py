@@ -40,6 +40,12 @@ Extra objects on the JSON line (every one of them at every N unless it says othe
   cpu_baseline*          N = 1 only (rank 0): the reference's own compiled search_ac / search_wu2 (oracle/_ref;
                          the oracle port when absent), one thread and all cores, on bounded prefixes
   stream_read            what a pure streaming read of the same 1 GiB reaches in this run (best of five variants)
+  skewed                 N = 1 only (round 4): the BASELINE pattern shapes on text that is NOT i.i.d. uniform -- a genome-like
+                         DNA text with repeats / tandem repeats / poly-A runs, a protein-like 20-symbol text, a natural-language-
+                         like 256-symbol text, and a text in which one planted pattern recurs every 64 columns (csrc/corpus_gen.h;
+                         the reference's own data: main.c:39-109), patterns sampled from those texts.  Per set: the entry point as
+                         compiled (the adaptive engine, csrc/smh_runtime.hip, after a few launches), every engine forced,
+                         chosen_vs_best_forced, all counts verified against the restated search_ac over the full text
   table_kernels          N = 1 only: the table-walking kernels behind cuda_ac1/2, cuda_wm1/2, cuda_sh1/2,
                          cuda_sbom1/2, cuda_sog1/2 on a 64 MiB prefix (latency-bound by design: the reference's
                          tables walked as given)
@@ -66,6 +72,7 @@ AC_PATTERNS = 1000
 WM_PATTERNS, WM_LENGTH = 10000, 8
 C4_PATTERNS = 8000
 C5_PATTERNS, C5_LENGTHS, C5_SIGMA = 100000, (5, 8, 12, 20), 256
+C5_MORE_LENGTHS = (6, 7, 9, 10, 16)  # the form boundaries of the byte-gram filters (flat <= 9 / hashed above): kernel time + slice verification
 
 
 def kernel_build_id():
@@ -258,7 +265,8 @@ def multi_leg(args):
     per_gpu, shard = args.mib_per_gpu << 20, args.shard_mib << 20
     out = {"devices": n_dev, "reduce": "ncclAllReduce(uint64, sum) over ncclCommInitAll" if mg.uses_rccl else "host sum",
            "what": "ONE process drives all devices through smh_multi_* (csrc/smh_multi.hip); seconds = launches on every "
-                   "device + the count all-reduce + read-back, table sets prepared before the clock"}
+                   "device + the count all-reduce + read-back, table sets prepared before the clock; timed after %.0f ms of "
+                   "back-to-back count calls (the per-rank path's conditioning)" % CONDITION_MS}
 
     def run(name, algo, sigma, lengths, p, seed, n_each, workload):
         n_total = n_each * n_dev
@@ -271,13 +279,20 @@ def multi_leg(args):
             t0 = time.perf_counter()
             mg.prepare(h)
             prep = time.perf_counter() - t0
-            runs = [count(h) for _ in range(args.steps)]
+            # the same steady state the per-rank path measures at (`conditioned` in main): count calls back to back for
+            # CONDITION_MS before the timed ones -- the first milliseconds after an idle gap run 15-20 % slower
+            first = count(h)
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < CONDITION_MS * 1e-3:
+                count(h)
+            runs = [first] + [count(h) for _ in range(args.steps)]
+            first_call = runs.pop(0)[2]
             secs = sorted(r[2] for r in runs)
             total, per = runs[-1][0], runs[-1][1]
             assert all(r[0] == total for r in runs)
             med = secs[len(secs) // 2]
             gbs = n_total / med / 1e9
-            obj["m%d" % m] = dict(seconds=round(med, 6), first_call_seconds=round(runs[0][2], 6), min_seconds=round(secs[0], 6),
+            obj["m%d" % m] = dict(seconds=round(med, 6), first_call_seconds=round(first_call, 6), min_seconds=round(secs[0], 6),
                                   prepare_seconds=round(prep, 4), GBps=round(gbs, 1), Gbit_s=round(8 * gbs, 1),
                                   hbm_frac_per_gpu=round(gbs / n_dev / HBM_PEAK_GBS, 4), matches=total, per_gpu_matches=per)
             h.close()
@@ -308,6 +323,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines and the verification")
     ap.add_argument("--no-wm", action="store_true", help="skip the side configurations (WM, configs[3], configs[4])")
     ap.add_argument("--no-multi", action="store_true", help="skip the one-process smh_multi leg")
+    ap.add_argument("--no-skewed", action="store_true", help="skip the non-uniform corpora (the `skewed` object)")
     ap.add_argument("--multi-leg", type=int, default=0, help=argparse.SUPPRESS)  # internal: the child of the smh_multi leg
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal of the N > 1 control flow on ONE card: every rank uses device 0, process group over gloo")
@@ -611,6 +627,19 @@ def main():
                 hi = h.info()
                 aa["m%d" % m] = dict(**obj, scan_stride=hi.scan_stride, scan_depth=hi.scan_depth, scan_exact=hi.scan_exact,
                                      scan_full_rows=hi.scan_full_rows, lds_bytes=hi.lds_bytes, kernel_instance=ac_kernel_name(hi))
+        if rank == 0:
+            # the line's roofline names the kernel the entry point chose for the slowest headline set; beside it, the automaton
+            # kernels (ac_dfa_kernel) on the same set: the engine north_star describes, whichever one the entry point runs
+            dkey = "m%d" % dom
+            if dkey in aa:
+                out["roofline"]["automaton"] = dict(kernel_instance=aa[dkey]["kernel_instance"], launch_ms=aa[dkey]["kernel_ms"],
+                                                    achieved=aa[dkey]["GBps"], frac=aa[dkey]["hbm_frac"],
+                                                    what="the same set with smh_ac_set_scan_engine(SMH_ALGO_AC): the automaton kernels")
+            else:
+                out["roofline"]["automaton"] = dict(kernel_instance=out["roofline"]["kernel_instance"], launch_ms=out["roofline"]["launch_ms"],
+                                                    achieved=out["roofline"]["achieved"], frac=out["roofline"]["frac"],
+                                                    what="the entry point runs the automaton kernels for this set")
+            out["roofline"]["chosen_engine"] = out["ac"][dkey]["scan_engine"]
         if rank == 0 and aa:
             out["ac_automaton"] = dict(workload="AC: the headline sets whose entry point chose the pair-gram filter, forced onto the "
                                                 "automaton kernels (smh_ac_set_scan_engine(SMH_ALGO_AC)): hybrid stride-2 image, depth-cut, "
@@ -679,6 +708,78 @@ def main():
                      "WM: %d MiB of 256-symbol text per GPU (BASELINE configs[4]), 100000 patterns per set, m=%s"
                      % (args.shard_mib, "/".join(str(m) for m in C5_LENGTHS)))
 
+        # the lengths at the byte-gram forms' boundaries (flat <= 9 / hashed above), same shard: kernel time + slice verification
+        shard_config("wm_ascii_more", "wm", C5_SIGMA, C5_MORE_LENGTHS, C5_PATTERNS, PAT_SEED + 2,
+                     "WM: the remaining lengths of BASELINE configs[4]'s 5-20 sweep that sit at filter-form boundaries, m=%s; verified on "
+                     "the first 512 MiB + the last 64 MiB of the shard" % "/".join(str(m) for m in C5_MORE_LENGTHS))
+
+    # ---- text that is NOT i.i.d. uniform (round 4): the BASELINE pattern shapes on genome-like / protein-like / natural-language-like
+    #      text and on a text in which one pattern recurs every 64 columns, patterns sampled from those texts; N = 1
+    if not args.no_wm and not args.no_skewed and rank == 0 and world == 1:
+        sk = {}
+        corpora = [("dna_repeats", S.CORPUS_DNA_REPEATS, 4), ("dna_planted", S.CORPUS_PLANTED, 4),
+                   ("protein_skewed", S.CORPUS_SKEWED, 20), ("ascii_skewed", S.CORPUS_SKEWED, 256)]
+        shapes = {4: [("ac", AC_PATTERNS, 8), ("ac", AC_PATTERNS, 16), ("ac", AC_PATTERNS, 32), ("wm", WM_PATTERNS, WM_LENGTH),
+                      ("ac", C4_PATTERNS, 16), ("ac", C4_PATTERNS, 32)],
+                  20: [("ac", AC_PATTERNS, 8), ("ac", AC_PATTERNS, 16), ("wm", WM_PATTERNS, WM_LENGTH)],
+                  256: [("wm", C5_PATTERNS, 8), ("wm", C5_PATTERNS, 12), ("wm", C5_PATTERNS, 20)]}
+        scnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        worst_ratio = 0.0
+        for cname, kind, sigma in corpora:
+            ktext = torch.empty(per_gpu + 64, dtype=torch.uint8, device=dev)
+            S.corpus_text_device(ktext.data_ptr(), per_gpu, TEXT_SEED, sigma, 0, kind, stream)
+            torch.cuda.synchronize()
+            cobj = {}
+            for algo, p, m in shapes[sigma]:
+                pat = S.corpus_patterns(m, p, PAT_SEED + 5, sigma, TEXT_SEED, per_gpu, 2, kind)
+                h = (S.AcAutomaton if algo == "ac" else S.WmTables).from_patterns(pat, m, p, sigma)
+                launch = lambda: h.scan_device(ktext.data_ptr(), per_gpu, scnt.data_ptr(), S.VARIANT_TUNED, stream)
+                # adaptation: launches with a synchronisation behind each, so that each one's report is read before the next
+                seq = []
+                for _ in range(6):
+                    scnt.zero_()
+                    launch()
+                    torch.cuda.synchronize()
+                    seq.append(int(h.adapt().engine))
+                settled = next((i for i in range(len(seq)) if all(e == seq[-1] for e in seq[i:])), len(seq))
+                ms = sorted(timed(launch, 5, scnt))[2]
+                matches = int(scnt.item())
+                ad = h.adapt()
+                rec = dict(patterns=p, m=m, entry=algo, adaptive=int(h.info().adaptive), compiled_engine=S.ENGINE_NAMES[int(h.info().scan_engine)],
+                           chosen=dict(engine=S.ENGINE_NAMES[int(ad.engine)], kernel_ms=round(ms, 4), **rate(per_gpu, ms), flips=int(ad.flips),
+                                       engines_per_launch=seq, launches_before_settled=settled,
+                                       events_per_4k=round(ad.events_per_4k[int(ad.engine)], 3)),
+                           matches=matches)
+                forced, equal = {}, True
+                for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT):
+                    try:
+                        h.set_scan_engine(eng)
+                    except S.SmhError:
+                        continue
+                    fms = sorted(timed(launch, 3, scnt))[1]
+                    forced[S.ENGINE_NAMES[eng]] = dict(kernel_ms=round(fms, 4), hbm_frac=rate(per_gpu, fms)["hbm_frac"], matches=int(scnt.item()))
+                    equal = equal and int(scnt.item()) == matches
+                h.set_scan_engine(-1)
+                rec["forced"] = forced
+                rec["engines_agree"] = equal
+                two = [v["kernel_ms"] for k, v in forced.items() if k != S.ENGINE_NAMES[S.ENGINE_AC_FLAT]]  # the two the compile weighs
+                if two:
+                    rec["chosen_vs_best_forced"] = round(ms / min(two), 3)
+                    worst_ratio = max(worst_ratio, ms / min(two))
+                parity_forced = equal
+                if not parity_forced:
+                    print(json.dumps({"skewed": {cname: rec}}))
+                    raise SystemExit("PARITY FAILURE: engines disagree on %s %s p=%d m=%d" % (cname, algo, p, m))
+                verify.append(("skewed.%s.%s_%d_m%d" % (cname, algo, p, m), "ac" if sigma == 4 else "wm", pat, m, p, sigma, ktext, per_gpu, matches, None))
+                cobj["%s_%d_m%d" % (algo, p, m)] = rec
+                h.close()
+            sk[cname] = cobj
+        out["skewed"] = dict(workload="the BASELINE pattern shapes on %d MiB of non-uniform text per corpus (csrc/corpus_gen.h), patterns sampled from "
+                                      "the text; chosen = the entry point as compiled after 6 launches (the adaptive engine follows the launches' "
+                                      "reports), forced = smh_*_set_scan_engine; chosen_vs_best_forced weighs the automaton and the filter kernels, "
+                                      "the plain stride-1 automaton is the adaptive engine's third choice" % args.mib_per_gpu,
+                             worst_chosen_vs_best_forced=round(worst_ratio, 3), **sk)
+
     # ---- the table-walking kernels (cuda_*1/2: the reference's tables walked as given) on a 64 MiB prefix, N = 1
     if not args.no_wm and rank == 0 and world == 1:
         tn = min(64 << 20, per_gpu)
@@ -730,6 +831,9 @@ def main():
             if agree and not all(agree.values()):
                 print(json.dumps(out))
                 raise SystemExit("PARITY FAILURE: smh_multi totals differ from the per-rank totals: %r" % agree)
+            if "error" in leg or not agree:  # a leg that did not run is not a leg that agreed (--no-multi skips it on purpose)
+                print(json.dumps(out))
+                raise SystemExit("smh_multi leg failed: %s" % leg.get("error", "no totals to compare"))
         sharded.host_barrier("smh_multi_after")
 
     # ---- bit-exact verification of every count above, every rank its own shards; CPU baselines at N = 1
@@ -748,16 +852,18 @@ def main():
                 host_cache[key] = dtext[off:off + max(ln, longest.get(key, 0))].cpu().numpy()
             return host_cache[key][:ln]
 
-        def slices_of(n, m):
+        def slices_of(n, m, name=""):
             # the headline's 1 GiB shards are recounted whole at every N; the 4 GiB shards within the budget
+            if name.startswith("wm_ascii_more"):
+                return sharded.verify_slices(n, m, 576 << 20)
             return sharded.verify_slices(n, m, 0 if n <= per_gpu + 64 else verify_budget)
 
         for v in verify:
-            for off, ln in slices_of(v[7], v[3]):
+            for off, ln in slices_of(v[7], v[3], v[0]):
                 longest[(id(v[6]), off)] = max(longest.get((id(v[6]), off), 0), ln)
         verify.sort(key=lambda v: id(v[6]))  # shards of the same text together: fewer device-to-host copies
         for name, algo, pat, m, p, sigma, dtext, n, got, scan in verify:
-            slices = slices_of(n, m)
+            slices = slices_of(n, m, name)
             count = cpu.counter(algo, pat, m, p, sigma)
             g, c = [], []
             for off, ln in slices:
@@ -810,14 +916,20 @@ def main():
                                           sample="search_wu2 (wu/wu.c:151-209) over the first %d MiB of the same text, %d patterns of "
                                                  "length %d, 1 thread, %.1f s" % (wsample >> 20, WM_PATTERNS, WM_LENGTH, wsecs))
             parity_ok = parity_ok and out["cpu_baseline_wm"]["counts_match"]
-        # the legacy host-pointer path (search_ac): device allocation + H2D copy + kernel, PCIe-bound; never `value`
-        t0 = time.perf_counter()
-        legacy_cnt, _ = acs[AC_LENGTHS[0]].count_host(prefix, S.VARIANT_TUNED)
-        secs = time.perf_counter() - t0
-        out["host_pointer_path"] = dict(what="smh_ac_count_host (what search_ac runs) on the same %d MiB sample: hipMalloc + "
-                                             "pageable H2D copy + kernel + D2H of the count" % (sample >> 20),
-                                        GBps=round(sample / secs / 1e9, 2), seconds=round(secs, 4),
-                                        count_matches=legacy_cnt == cpu_counts[AC_LENGTHS[0]])
+        # the legacy host-pointer path (search_ac as main.c calls it): the text is a pageable host buffer; PCIe-bound; never `value`
+        hp = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            legacy_cnt, ksecs = acs[AC_LENGTHS[0]].count_host(host_text, S.VARIANT_TUNED)
+            hp.append(time.perf_counter() - t0)
+        out["host_pointer_path"] = dict(what="smh_ac_count_host (what search_ac runs) on the whole %d MiB text in pageable host memory: 64 MiB "
+                                             "pieces through two device buffers of a pooled workspace, copy of piece k+1 beside the scan of "
+                                             "piece k, count read back (round 3: hipMalloc + one copy + kernel + hipFree, 36.6 GB/s)" % (per_gpu >> 20),
+                                        GBps=round(per_gpu / min(hp[1:]) / 1e9, 2), seconds=round(min(hp[1:]), 4),
+                                        first_call_GBps=round(per_gpu / hp[0] / 1e9, 2), kernel_seconds=round(ksecs, 5),
+                                        count_matches=legacy_cnt == local_counts[0])
+        parity_ok = parity_ok and out["host_pointer_path"]["count_matches"]
+        S.lib.smh_host_path_release()
         if cpu.kind == "reference":
             secs, ok, wall = cpu.ac_all_cores_reference(pats, AC_PATTERNS, SIGMA, prefix, cpu_counts)
             allc = dict(value=round(8.0 * sample * len(pats) / secs / 1e9, 3), unit="Gbit/s", cores=cpu.cores, kind="reference",

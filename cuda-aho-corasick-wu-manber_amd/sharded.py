@@ -136,13 +136,19 @@ def merge_verified(per_rank):
     return out, all(v["equal"] for v in out.values())
 
 
+_barrier_calls = {}
+
+
 def host_barrier(tag, timeout_s=1800.0):
     """A barrier that keeps the GPUs idle: ranks meet in the c10d store (TCP), not in a collective kernel -- an
     RCCL barrier spins on every device, which would sit on the CUs rank 0 is about to measure from one process
-    (bench.py's smh_multi leg).  Falls back to dist.barrier() when the store is not reachable."""
+    (bench.py's smh_multi leg).  Falls back to dist.barrier() when the store is not reachable.  A tag may be used
+    any number of times: every call of every rank appends its own call count, so the k-th call meets the k-th."""
     import time
     if world_size() == 1:
         return
+    _barrier_calls[tag] = _barrier_calls.get(tag, 0) + 1
+    tag = "%s#%d" % (tag, _barrier_calls[tag])
     try:
         store = dist.distributed_c10d._get_default_store()
         store.add(tag, 1)

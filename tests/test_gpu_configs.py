@@ -119,7 +119,7 @@ def test_c4_ac_8000_patterns(dna, m):
     assert dna.shards(forced, 3, m) == whole
 
 
-@pytest.mark.parametrize("m", [5, 12, 20])
+@pytest.mark.parametrize("m", [5, 8, 9, 10, 12, 20])  # 8 / 9: the flat byte-gram form's upper end, 10: the hashed form's first length
 def test_c5_wm_100k_patterns_alphabet_256(ascii_text, m):
     p, sigma = 100000, 256
     pat = S.corpus_patterns(m, p, 9, sigma, 42, SHARD, 2)
