@@ -147,7 +147,7 @@ struct smh_ac_queue {
     uint64_t *slots; /* SMH_AC_QCAP entries in HBM, private to this wave */
     uint32_t count;  /* wave-uniform */
     uint32_t matches;
-    uint32_t events; /* wave-uniform: candidates this wave queued (smh_stats.h) */
+    uint32_t events; /* per lane: candidates this lane queued (smh_stats.h) */
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -211,7 +211,7 @@ SMH_LANE void smh_ac_emit(smh_ac_queue &Q, const smh_ac_verify_ctx &V, bool cond
         __hip_atomic_store(Q.slots + Q.count + before, ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     Q.count += np;
-    Q.events += np;
+    Q.events += cond ? 1u : 0u;
 }
 #else
 SMH_LANE void smh_ac_drain(smh_ac_queue &, const smh_ac_verify_ctx &) {}

@@ -141,7 +141,7 @@ struct smh_chunk_sched {
 };
 /* place the counter behind `lds_used` bytes of dynamic LDS (the caller allocates SMH_SCHED_LDS more) and
  * zero it; the caller's next __syncthreads() publishes it */
-#define SMH_SCHED_LDS 16u
+#define SMH_SCHED_LDS 32u /* the counter (4 bytes); behind it, at +8 / +16 / +24: the launch's start time, stats block and tag (smh_stats.h) */
 SMH_LANE smh_chunk_sched smh_sched_init(unsigned char *lds, uint32_t lds_used)
 {
     const uint32_t off = (lds_used + 15u) & ~15u;

@@ -426,15 +426,15 @@ static int upload(void **d, const void *h, size_t bytes, size_t pad)
  * A handle that holds several engines -- an automaton with a depth-cut or hybrid plan, the suffix-filter kernels over
  * the same patterns (smh_ac.flex_wm / smh_wm.flex_ac), the plain stride-1 automaton (smh_ac.flat_ac) -- starts with the
  * one its compile estimated fastest on random text and then follows the launches' own reports: every count launch of
- * 32 MiB or more publishes its duration (device clock, first workgroup's start to last workgroup's end) and the number of
- * columns it had to verify.  Before the NEXT launch the host compares, per GiB, the running engine's measured time
+ * 32 MiB or more publishes its duration (device clock, one workgroup's prologue to its last chunk) and the number of
+ * columns it had to verify (a sample of eight workgroups, scaled: smh_stats.h).  Before the NEXT launch the host compares, per GiB, the running engine's measured time
  * (the better of its last two reports: an engine's first launch on a device runs cold) with the best of the others
  * (measured on this text, else the compile's estimate) and switches when that is clearly better -- after the first
  * report when a launch of 256 MiB or more ran four times slower than estimated, else after the second.  What was measured of an
  * engine that is not running is forgotten, so that it is tried again, when the running engine's events per 4 KiB move by
  * a factor of two (another kind of text) and after 32 reports of the others -- 64, 128, ... 4096 when it keeps losing.  The
- * filter kernels' verify mode (in registers / staged) follows the measured survivors per chunk the same way.  Nothing
- * here synchronises: a launch that has not finished has simply not reported yet.  SMH_ADAPT=0 in the environment
+ * filter kernels' verify mode (in registers / staged) follows the measured survivors per chunk the same way.  Not every
+ * launch reports (adapt_arg: a report costs its launch 2-4 us).  Nothing here synchronises: a launch that has not finished has simply not reported yet.  SMH_ADAPT=0 in the environment
  * (read once) turns all of it off; a forced engine or plan is never overridden. */
 struct smh_adapt_dev {
     int device;
@@ -454,6 +454,7 @@ struct smh_adapt_dev {
     double ref_sig;
     int ref_valid;
     uint32_t reports, flips;
+    uint32_t launches;     /* tuned count launches of the handle on this device */
     double mode_density;   /* survivors per column handed to the gram launcher (< 0: the compile's estimate so far) */
 };
 
@@ -487,7 +488,6 @@ static int adapt_get(smh_adapt_dev **head, smh_adapt_dev **out)
         HIP_TRY(hipHostMalloc((void **)&a->h_rec, SMH_STATS_HOST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
         memset(a->h_rec, 0, SMH_STATS_HOST_WORDS * sizeof(unsigned long long));
         smh_scan_stats init = {};
-        init.t_min = ~0ull;
         init.host = a->h_rec; /* pinned host memory has one address on both sides */
         HIP_TRY(hipMalloc((void **)&a->d_stats, sizeof init));
         HIP_TRY(hipMemcpy(a->d_stats, &init, sizeof init, hipMemcpyHostToDevice));
@@ -519,8 +519,9 @@ static void adapt_poll(smh_adapt_dev *A)
     volatile unsigned long long *h = A->h_rec;
     const unsigned int seq = (unsigned int)h[0];
     if (seq == A->seen) return;
-    const unsigned long long ev = h[1], ticks = h[2], bytes = h[3], tag = h[4];
-    if ((unsigned int)h[0] != seq) return; /* the next launch is publishing right now: next time */
+    const unsigned long long ev = h[1], ticks = h[2], bytes = h[3], tag = h[4], seq2 = h[5], sum = h[6];
+    /* the record is written without a fence between data and flag: it validates itself */
+    if ((unsigned int)seq2 != seq || (unsigned int)h[0] != seq || sum != (ev ^ ticks ^ bytes ^ tag ^ (unsigned long long)seq)) return;
     A->seen = seq;
     const int e = (int)(tag & 3u);
     if (bytes < SMH_ADAPT_MIN_BYTES || ticks == 0 || e >= SMH_ENGINES) return;
@@ -596,10 +597,19 @@ static float adapt_density(smh_adapt_dev *A, const struct smh_wm *wm)
     return (float)A->mode_density;
 }
 
+/* A report costs its launch 2-4 us (the reporting workgroups' atomics, the record's trip to host memory before the kernel
+ * may end: measured 1-3 % on the 175 us headline scans), so not every launch reports: the first four of a handle on a
+ * device, every launch while the running engine's series is incomplete (a decision is pending), then every eighth. */
 static smh_stats_arg adapt_arg(smh_adapt_dev *A, uint64_t n, int engine)
 {
     smh_stats_arg sa = {};
-    if (A) { sa.st = A->d_stats; sa.bytes = n; sa.tag = (unsigned int)engine; }
+    if (!A) return sa;
+    const uint32_t k = A->launches++;
+    if (k < 4u || (engine >= 0 && engine < SMH_ENGINES && A->n[engine] < 2) || (k & 7u) == 0u) {
+        sa.st = A->d_stats;
+        sa.bytes = n;
+        sa.tag = (unsigned int)engine;
+    }
     return sa;
 }
 

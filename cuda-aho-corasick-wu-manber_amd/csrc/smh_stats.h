@@ -5,10 +5,10 @@
  * (ac_host.c, wm_host.c).  A filter engine's speed, though, is a property of the TEXT: a column that survives the
  * filter costs a window hash and a table probe, and on repeat-rich text (the reference's E.coli / swiss-prot,
  * main.c:39-109) survivors are not rare.  So the filter kernels and the depth-cut automaton kernels count their
- * surviving columns / candidates (wave-uniform scalar adds beside the compaction they do anyway), every workgroup
- * adds its sum and its start / end time (the 100 MHz s_memrealtime counter) to a block in device memory, and the
- * LAST workgroup of the launch publishes {events, ticks from the first start to the last end, bytes, tag} to a
- * record in pinned host memory and clears the block.  The host reads the record before its NEXT launch of the handle
+ * surviving columns / candidates (one add per lane and event beside the compaction they do anyway), a sample of the
+ * launch's workgroups adds its sum to a block in device memory, and the LAST of them publishes {events scaled to the
+ * grid, its own duration on the 100 MHz s_memrealtime counter, bytes, tag} to a record in pinned host memory and clears
+ * the block.  The host reads the record before its NEXT launch of the handle
  * -- no synchronisation, a launch that has not finished simply has not reported yet -- and may then run the other
  * engine or another verify mode (smh_runtime.hip "adaptive engine").
  */
@@ -17,13 +17,14 @@
 
 #include <stdint.h>
 
-struct smh_scan_stats { /* device memory, one per (handle, device); zero except t_min = ~0 */
-    unsigned long long t_min, t_max, events;
-    unsigned int done, seq;
-    unsigned long long *host; /* SMH_STATS_HOST_WORDS words of pinned host memory: seq, events, ticks, bytes, tag */
-    unsigned long long pad[3];
+struct smh_scan_stats { /* device memory, one per (handle, device); zero */
+    unsigned long long ticket; /* low 16 bits: reporting workgroups done; above: their events */
+    unsigned int seq, pad0;
+    unsigned long long *host; /* SMH_STATS_HOST_WORDS words of pinned host memory: seq, events, ticks, bytes, tag, seq, checksum */
+    unsigned long long pad[5];
 };
 #define SMH_STATS_HOST_WORDS 8
+#define SMH_STATS_SAMPLE 8u /* workgroups of a launch that report (blockIdx.x below this) */
 
 struct smh_stats_arg { /* kernel argument; st == NULL: the launch reports nothing */
     smh_scan_stats *st;
@@ -33,42 +34,69 @@ struct smh_stats_arg { /* kernel argument; st == NULL: the launch reports nothin
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-__device__ __forceinline__ uint64_t smh_stats_now(const smh_stats_arg &A) { return A.st ? __builtin_amdgcn_s_memrealtime() : 0ull; }
-
-/* one thread per workgroup, after the workgroup's last text access */
-__device__ __forceinline__ void smh_stats_commit(const smh_stats_arg &A, uint64_t t_start, uint64_t events)
+/* The scan kernels run at the edge of their scalar register budget (the pair-gram kernel: 106 SGPRs, no spill): a
+ * start time, a pointer and a tag kept alive across the chunk loop for the epilogue's sake cost it nine spilled SGPRs.
+ * So thread 0 parks them in the 24 spare bytes behind the workgroup's chunk counter in LDS (lane_common.h
+ * SMH_SCHED_LDS) in the prologue and takes them back in the epilogue. */
+__device__ __forceinline__ void smh_stats_stash(uint32_t ctr_off, const smh_stats_arg &A)
 {
-    smh_scan_stats *st = A.st;
+    if (threadIdx.x == 0) {
+        const bool on = A.st && blockIdx.x < SMH_STATS_SAMPLE;
+        const unsigned long long t = on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 8u) = t;
+        *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 16u) = on ? (unsigned long long)(uintptr_t)A.st : 0ull;
+        *reinterpret_cast<__attribute__((address_space(3))) unsigned int *>(ctr_off + 24u) = A.tag;
+    }
+}
+
+/* One thread of each REPORTING workgroup, after the workgroup's last text access.  Same-address atomics of workgroups that
+ * finish together queue up behind each other at ~12 ns apiece (the reason the match count takes one per workgroup, not one
+ * per wave): a first version with four atomics in each of the 256 workgroups put 10 us on the end of a 175 us launch.
+ * So only the first SMH_STATS_SAMPLE workgroups report -- the chunks are dealt round-robin, every workgroup sees an even
+ * sample of the text and they all run until the chunks are gone -- with ONE atomic each: events and a ticket in one
+ * 64-bit add.  The last of them publishes the sample's events scaled to the grid and ITS OWN duration (start of its
+ * prologue to here) to the host record.  The record carries its sequence number twice and a checksum instead of a
+ * system-scope fence between data and flag (a PCIe round trip at the end of the kernel). */
+__device__ __forceinline__ void smh_stats_commit(smh_scan_stats *st, unsigned int tag, unsigned long long bytes, uint64_t t_start, uint64_t events)
+{
     const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-    if (events) atomicAdd(&st->events, (unsigned long long)events);
-    atomicMin(&st->t_min, (unsigned long long)t_start);
-    atomicMax(&st->t_max, t_end);
-    __threadfence();
-    const unsigned int ticket = atomicAdd(&st->done, 1u);
-    if (ticket + 1u == gridDim.x) {
-        __threadfence();
-        const unsigned long long e = atomicExch(&st->events, 0ull), t0 = atomicExch(&st->t_min, ~0ull),
-                                 t1 = atomicExch(&st->t_max, 0ull);
-        atomicExch(&st->done, 0u);
-        const unsigned int seq = atomicAdd(&st->seq, 1u) + 1u;
+    const unsigned int reporting = gridDim.x < SMH_STATS_SAMPLE ? gridDim.x : SMH_STATS_SAMPLE;
+    const unsigned long long old = atomicAdd(&st->ticket, ((unsigned long long)events << 16) | 1ull);
+    if ((unsigned int)(old & 0xFFFFu) + 1u == reporting) {
+        atomicExch(&st->ticket, 0ull);
+        const unsigned long long e = ((old >> 16) + events) * gridDim.x / reporting;
+        const unsigned int seq = ++st->seq; /* this thread alone, launches of a handle do not overlap */
+        const unsigned long long ticks = t_end - t_start;
         volatile unsigned long long *h = st->host;
         h[1] = e;
-        h[2] = t1 - t0;
-        h[3] = A.bytes;
-        h[4] = A.tag;
-        __threadfence_system();
+        h[2] = ticks;
+        h[3] = bytes;
+        h[4] = tag;
+        h[6] = e ^ ticks ^ bytes ^ (unsigned long long)tag ^ (unsigned long long)seq;
+        h[5] = seq;
         h[0] = seq;
     }
 }
 
-/* the workgroup's match count into *count with ONE atomic (as smh_block_add) and, when the launch reports, its events and
- * times into the stats block.  `wave_events` is wave-uniform.  `lds` may be the table region: the first barrier makes sure
- * every wave is done reading it. */
-__device__ __forceinline__ void smh_block_finish(uint32_t cnt, uint64_t *count, unsigned char *lds, const smh_stats_arg &A,
-                                                 uint64_t t_start, uint32_t wave_events)
+/* the workgroup's match count into *count with ONE atomic (as smh_block_add) and, when the workgroup reports, its events
+ * and duration into the stats block.  `wave_events` is the lane's own event count; ctr_off = the chunk counter's LDS offset
+ * (where the prologue parked the launch's stats pointer); bytes = the text length.  `lds` may be the table region: the first
+ * barrier makes sure every wave is done reading it. */
+__device__ __forceinline__ void smh_block_finish(uint32_t cnt, uint64_t *count, unsigned char *lds, uint32_t ctr_off,
+                                                 unsigned long long bytes, uint32_t wave_events)
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off, 64);
+        wave_events += __shfl_down(wave_events, off, 64);
+    }
+    unsigned long long t_start = 0, st_bits = 0;
+    unsigned int tag = 0;
+    if (threadIdx.x == 0) { /* before the reduction below reuses the front of LDS (a tiny table's counter sits there) */
+        t_start = *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 8u);
+        st_bits = *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 16u);
+        tag = *reinterpret_cast<__attribute__((address_space(3))) unsigned int *>(ctr_off + 24u);
+    }
     __syncthreads();
     uint32_t *part = reinterpret_cast<uint32_t *>(lds);
     if ((threadIdx.x & 63u) == 0) {
@@ -87,7 +115,7 @@ __device__ __forceinline__ void smh_block_finish(uint32_t cnt, uint64_t *count, 
         }
         if (threadIdx.x == 0) {
             if (v && count) atomicAdd((unsigned long long *)count, (unsigned long long)v);
-            if (A.st) smh_stats_commit(A, t_start, ev);
+            if (st_bits) smh_stats_commit(reinterpret_cast<smh_scan_stats *>((uintptr_t)st_bits), tag, bytes, t_start, ev);
         }
     }
 }

@@ -417,7 +417,7 @@ struct smh_wm_queue {
     uint64_t pend_e;
     smh_u32x4 pend_q;
     uint32_t pend_mine;   /* in-register verify: per lane, this lane holds a pending column (there is no compaction) */
-    uint32_t events;      /* wave-uniform: surviving columns this wave sent to the verify stage (smh_stats.h) */
+    uint32_t events;      /* per lane: surviving columns this lane sent to the verify stage (smh_stats.h) */
 };
 
 /* ---- staged verify: the window hash of a surviving column is computed from an ON-CHIP copy of the wave-chunk.
@@ -478,7 +478,7 @@ SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_par
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     if (cond) Q.slots[Q.count + before] = e; /* LDS, written and read by this wave only */
     Q.count += np;
-    Q.events += np;
+    Q.events += cond ? 1u : 0u;
 }
 #else
 SMH_LANE void smh_wm_drain(smh_wm_queue &, const uint8_t *, const smh_wm_params &) {}
@@ -649,7 +649,7 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
             const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
             if (have) reinterpret_cast<uint32_t *>(Q.slots)[Q.count + before] = (uint32_t)(a - chunk_base) + b;
             Q.count += (uint32_t)__popcll(mask);
-            Q.events += (uint32_t)__popcll(mask);
+            Q.events += have ? 1u : 0u;
         }
         msk &= msk - 1u;
     } while (SMH_WAVE_ANY(msk != 0));
@@ -1210,7 +1210,7 @@ SMH_LANE void smh_wm_regv_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t
         /* the column this lane (or another) still holds from an earlier chunk -- its bucket arrived while this chunk was
          * scanned -- or from the round before (a second survivor in one lane: decided without the pipelining) */
         smh_wm_pend_finish<true>(Q, text, P);
-        Q.events += (uint32_t)__popcll(__ballot(have));
+        Q.events += have ? 1u : 0u;
         Q.pend_n = 64u;
         Q.pend_mine = have ? 1u : 0u;
         Q.pend_e = a + c;

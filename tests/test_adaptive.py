@@ -87,15 +87,15 @@ def test_engine_follows_the_text_and_counts_do_not_change(entry):
         return engines
 
     e_uni = run(uni, "uni", 6)
-    assert e_uni[0] == first and h.adapt().reports >= 5
+    assert e_uni[0] == first and h.adapt().reports >= 2  # launches report until the running engine has two on record, then every eighth
     calm = h.adapt()
     assert calm.flips == 0 and calm.engine == first and calm.ms_per_gib[calm.engine] > 0, e_uni
-    e_rep = run(rep, "rep", 8)
+    e_rep = run(rep, "rep", 24)
     assert e_rep[0] == e_uni[-1]
     hot = h.adapt()
     assert hot.flips > calm.flips, (e_uni, e_rep)
     assert e_rep[-1] == S.ENGINE_AC_FLAT, e_rep  # the engine whose speed does not depend on the text
-    assert e_rep.index(S.ENGINE_AC_FLAT) <= 4, e_rep  # ... reached within a few launches
+    assert e_rep.index(S.ENGINE_AC_FLAT) <= 12, e_rep  # ... reached within a few REPORTS (one launch in eight reports once an engine has settled)
     assert hot.ms_per_gib[S.ENGINE_AC_FLAT] * 2.0 < max(hot.ms_per_gib[S.ALGO_AC], hot.ms_per_gib[S.ALGO_WM])
     # forced engines agree on the counts (and are not overridden)
     forced = 0
@@ -132,7 +132,7 @@ def test_verify_mode_follows_measured_survivors():
         assert _scan(wm, uni, n) == want_uni
     low = wm.adapt()
     assert low.reports >= 2 and low.events_per_4k[S.ALGO_WM] < 8.0
-    for _ in range(4):
+    for _ in range(12):
         assert _scan(wm, pla, n) == want_pla
     high = wm.adapt()
     assert high.events_per_4k[S.ALGO_WM] > 60.0 and high.verify_density * 4096 > 8.0  # the launcher now plans for the staged verify
