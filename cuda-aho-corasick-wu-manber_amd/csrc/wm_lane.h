@@ -432,6 +432,9 @@ struct smh_wm_queue {
  * fills LDS, so the workgroup's 16 waves share a few buffers through try-locks (a buffer is held for two LDS round
  * trips; whoever holds one never waits for anything else). */
 #define SMH_STAGE_BUF(STG) (16u * (STG) + 4096u + 48u) /* halo, chunk, pad for the dwords read past the last window */
+/* (Round 4 tried the chunk TRANSPOSED in the buffer -- piece q of lane l at q * 1024 + l * 16, so that the copy's four
+ * ds_write_b128 spread over all banks instead of every other lane starting in the same one: the address arithmetic it costs
+ * the window reads outweighed it, 100 000 byte patterns 1-6 % slower, DNA sets unchanged: gpurun_out/r04_i/ab_stage.log.) */
 #define SMH_STAGE_MAXD(STG) ((STG) == 1 ? 5 : 9)         /* dwords of the longest window: m <= 17 / m <= 33 */
 #define SMH_STAGE_MIN_DEFAULT 8u /* gpurun_out/r02_u: 1..16 within 3 % on the dense sets, 16+ better on sparse ones, 32+ loses 10-30 % */
 
@@ -1332,6 +1335,105 @@ SMH_LANE void smh_gram_byte_columns(const uint32_t (&w)[16], uint32_t pre, const
      ...);
 }
 
+/* ---- flat byte grams (KIND 6), round 4: a column's lookup yields ONE bit -- "this 3-byte gram is in no pattern" -- and the
+ * filter asks whether the last J columns' bits are all clear.  The plane-masked shift-or state of the other forms cost this
+ * one 8.7 VALU and one quarter-rate multiply per column (the bit became a plane mask with v_bfe_i32 + v_and, and the compiler
+ * turned the chain of shift-ors into a tree with v_mul_lo_u32): 12.7 issue slots per column, 76 % of the kernel.  Now the
+ * bits are simply COLLECTED -- H = alignbit(byte >> index, H, 1): after 32 columns bit i is column i's -- which is
+ * alignbyte, mul24, shift (address), shift (index), shift (bit), alignbit = 5.75 VALU per column, and the "last J all
+ * clear" test runs once per segment on the 96 collected bits (the previous lane's last 32 in front) with three or four
+ * shifted ORs. */
+SMH_LANE uint32_t smh_flat_push(uint32_t H, uint32_t t)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    return __builtin_amdgcn_alignbit(t, H, 1u);
+#else
+    return (H >> 1) | ((t & 1u) << 31);
+#endif
+}
+/* one column in two halves, so that a group's lookups are in flight together: the byte address of the gram `key` (three
+ * bytes in the low 24 bits) and its bit index, then bit 0 of the result = 1 when the gram is NOT in the set.  The index comes
+ * out of an asm v_bfe_u32: written as C++ the compiler recomputes "bits 12..14 of a 24-bit product" as the top bits of a
+ * second, FULL 32-bit multiply (v_mul_lo_u32: quarter rate) per column. */
+SMH_LANE uint32_t smh_flat_addr(uint32_t key, uint32_t &idx)
+{
+    const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    asm("v_bfe_u32 %0, %1, 12, 3" : "=v"(idx) : "v"(prod));
+#else
+    idx = (prod >> 12) & 7u;
+#endif
+    return prod >> 15;
+}
+SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab)
+{
+    uint32_t idx;
+    const uint32_t addr = smh_flat_addr(key, idx);
+    return smh_lds_u8(tab, addr) >> idx;
+}
+/* eight columns: addresses, the eight lookups in flight together, then the bits */
+template <int G>
+SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H)
+{
+    uint32_t addr[8], idx[8], b[8];
+    addr[0] = smh_flat_addr(smh_gram_key<8 * G + 0>(w, pre), idx[0]);
+    addr[1] = smh_flat_addr(smh_gram_key<8 * G + 1>(w, pre), idx[1]);
+    addr[2] = smh_flat_addr(smh_gram_key<8 * G + 2>(w, pre), idx[2]);
+    addr[3] = smh_flat_addr(smh_gram_key<8 * G + 3>(w, pre), idx[3]);
+    addr[4] = smh_flat_addr(smh_gram_key<8 * G + 4>(w, pre), idx[4]);
+    addr[5] = smh_flat_addr(smh_gram_key<8 * G + 5>(w, pre), idx[5]);
+    addr[6] = smh_flat_addr(smh_gram_key<8 * G + 6>(w, pre), idx[6]);
+    addr[7] = smh_flat_addr(smh_gram_key<8 * G + 7>(w, pre), idx[7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = smh_lds_u8(tab, addr[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) H = smh_flat_push(H, b[j] >> idx[j]);
+}
+SMH_LANE void smh_flat_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H0, uint32_t &H1)
+{
+    smh_flat_group<0>(w, pre, tab, H0);
+    smh_flat_group<1>(w, pre, tab, H0);
+    smh_flat_group<2>(w, pre, tab, H0);
+    smh_flat_group<3>(w, pre, tab, H0);
+    smh_flat_group<4>(w, pre, tab, H1);
+    smh_flat_group<5>(w, pre, tab, H1);
+    smh_flat_group<6>(w, pre, tab, H1);
+    smh_flat_group<7>(w, pre, tab, H1);
+}
+/* (hi:lo) << k for 0 < k < 32: bit i of the result = bit i - k of the 64-bit sequence whose upper word is hi */
+SMH_LANE uint32_t smh_shl_across(uint32_t hi, uint32_t lo, uint32_t k) { return (hi << k) | (lo >> (32u - k)); }
+/* columns of the segment (bit c of the result) whose own bit and the J - 1 before it are all clear; Z0 = the 32 columns in
+ * front of the segment, Z1 / Z2 = its columns 0..31 / 32..63 (bit SET = not in the set); 1 <= J <= 32 */
+SMH_LANE uint64_t smh_flat_candidates(uint32_t Z0, uint32_t Z1, uint32_t Z2, uint32_t J)
+{
+    uint32_t width = 1;
+    while (2u * width <= J) { /* wave-uniform: J is a launch parameter */
+        const uint32_t n2 = Z2 | smh_shl_across(Z2, Z1, width), n1 = Z1 | smh_shl_across(Z1, Z0, width);
+        Z0 |= Z0 << width;
+        Z1 = n1;
+        Z2 = n2;
+        width *= 2u;
+    }
+    if (width < J) {
+        const uint32_t k = J - width;
+        const uint32_t n2 = Z2 | smh_shl_across(Z2, Z1, k), n1 = Z1 | smh_shl_across(Z1, Z0, k);
+        Z1 = n1;
+        Z2 = n2;
+    }
+    return ~(((uint64_t)Z2 << 32) | Z1);
+}
+/* the 32 bits in front of the segment at a, true values (the emulator; the GPU takes the previous lane's H1) */
+SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const void *tab)
+{
+    uint32_t H = 0;
+    for (uint64_t x = a >= 32 ? a - 32 : 0; x < a; ++x) {
+        uint32_t t = 0; /* a column without a whole gram in front of it cannot be ruled out */
+        if (x >= 2) t = smh_flat_bit((uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16), tab);
+        H = smh_flat_push(H, t);
+    }
+    return H; /* (a < 32 never reaches the fast path: chunk 0 is bounds-checked) */
+}
+
 /* state the lane would have inherited from the columns in front of its segment (low 7 bits, 0 = alive), true
  * value: the CPU emulation and the bounds-checked path compute it by running the recurrence over those columns.
  * `tab` = the LDS image; `g7` = the pair form's per-gram bytes in HBM (smh_wm_params::gram_g7). */
@@ -1552,6 +1654,34 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
             if (q == 11) fl[1] = smh_gram_flags(T, 24);
             if (q == 15) fl[2] = smh_gram_flags(T, 16);
         }
+    } else if constexpr (KIND == 6) {
+        /* flat byte grams: the columns' bits are collected, the J-in-a-row test runs once on all of them (above) */
+        (void)pre0;
+        uint32_t H0 = 0, H1 = 0, Hp;
+        smh_flat_columns(w, pre1, tab, H0, H1);
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        /* the 32 columns in front of the segment: the previous lane's second half; lane 0 of a wave has no neighbour and
+         * assumes "all in the set" (a few more columns reach the verify stage, which is exact) */
+        Hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+#else
+        Hp = smh_flat_history_before(text, a, tab);
+#endif
+        const uint64_t msk6 = smh_flat_candidates(Hp, H0, H1, (uint32_t)P.gram_planes);
+        if constexpr (smh_stg_regv(STG)) {
+            smh_wm_regv_columns<HP>(Q, text, a, msk6, w, halo, P);
+        } else if constexpr (STG > 0) {
+            smh_wm_stage_columns<STG, QD, true>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk6, w, halo, P);
+        } else {
+            uint64_t mq = msk6;
+            while (SMH_WAVE_ANY(mq != 0)) {
+                if (Q.count + 64u > SMH_WM_QCAP) smh_wm_drain(Q, text, P);
+                const bool have = mq != 0;
+                const uint32_t b = have ? (uint32_t)__builtin_ctzll(mq) : 0u;
+                smh_wm_emit(Q, text, P, have, a + b);
+                mq &= mq - 1u;
+            }
+        }
+        return;
     } else {
         (void)pre0;
         smh_gram_byte_columns<KIND>(w, pre1, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), T, fl, std::make_integer_sequence<int, 64>{});
