@@ -155,6 +155,7 @@ static uint64_t gram_rng(uint64_t *s)
     return z ^ (z >> 31);
 }
 
+#define SMH_GRAM_FLAT_K2 (-6) /* gram_survivors only: the flat form with two bits per gram */
 static double gram_survivors(int kind, const void *tab, int alphabet, int planes)
 {
     enum { COLS = 1 << 18 };
@@ -179,12 +180,14 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
         } else if (kind == SMH_GRAM_OCT) {
             code = ((code << 2) | c) & 0xFFFFu;
             G = ((const uint8_t *)tab)[code];
-        } else if (kind == SMH_GRAM_FLAT) {
+        } else if (kind == SMH_GRAM_FLAT || kind == SMH_GRAM_FLAT_K2) {
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
             k0 = k1;
             k1 = c;
             const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
-            G = ((((const uint8_t *)tab)[prod >> 15] >> ((prod >> 12) & 7u)) & 1u) ? (0xFFu & ~((1u << (8 - planes)) - 1u)) : 0u;
+            const uint32_t b = ((const uint8_t *)tab)[prod >> 15];
+            const uint32_t out = (b >> ((prod >> 12) & 7u)) | (kind == SMH_GRAM_FLAT_K2 ? b >> ((prod >> 9) & 7u) : 0u);
+            G = (out & 1u) ? (0xFFu & ~((1u << (8 - planes)) - 1u)) : 0u;
         } else {
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
             k0 = k1;
@@ -373,10 +376,36 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
             for (uint32_t i = 0; i < SMH_GRAM_BYTES; ++i) zeros += 8u - (uint32_t)__builtin_popcount(tab[i]);
             fprintf(stderr, "flat byte grams: %d patterns x %d grams, %.1f %% of the 2^20 bits in the set\n", d, J, 100.0 * (double)zeros / 1048576.0);
         }
-        const double dens = gram_survivors(SMH_GRAM_FLAT, tab, wm->alphabet, J), ms = SMH_GRAM_FLAT_MS + gram_verify_ms(m, dens);
+        double dens = gram_survivors(SMH_GRAM_FLAT, tab, wm->alphabet, J), ms = SMH_GRAM_FLAT_MS + gram_verify_ms(m, dens);
+        int k2 = 0;
+        if (J <= 5) {
+            /* round 4: two bits per gram in its byte (wm_lane.h smh_flat_addr<true>) while the grams are few enough for the fuller
+             * array to pay -- 100 000 patterns of 5 bytes: 1.6 % -> 0.7 % of random columns pass; kept when it measures better */
+            uint8_t *t2 = (uint8_t *)malloc(SMH_GRAM_BYTES);
+            if (t2) {
+                memset(t2, 0xFF, SMH_GRAM_BYTES);
+                for (int p = 0; p < d; ++p)
+                    for (int j = 0; j < J; ++j) {
+                        const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
+                        const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
+                        const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
+                        t2[prod >> 15] &= (uint8_t)~((1u << ((prod >> 12) & 7u)) | (1u << ((prod >> 9) & 7u)));
+                    }
+                const double d2 = gram_survivors(SMH_GRAM_FLAT_K2, t2, wm->alphabet, J), ms2 = SMH_GRAM_FLAT_MS + 0.01 + gram_verify_ms(m, d2);
+                const char *tune = getenv("SMH_WM_TUNE"); /* development knob "flatk=1|2": one / two bits per gram regardless */
+                const int fk = tune && strstr(tune, "flatk=") ? atoi(strstr(tune, "flatk=") + 6) : 0;
+                if (fk == 2 || (fk != 1 && ms2 < ms)) {
+                    free(tab);
+                    tab = t2; dens = d2; ms = ms2; k2 = 1;
+                } else {
+                    free(t2);
+                }
+            }
+        }
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_FLAT; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
+            wm->gram_jb = k2;
         } else {
             free(tab);
         }

@@ -1308,17 +1308,16 @@ SMH_LANE uint32_t smh_gram_key(const uint32_t (&w)[16], uint32_t pre)
  *           bits, bit = the three below them; the array holds the set INVERTED, so a sign-extending 1-bit field extract
  *           yields 0 (in the set) or all ones (not), masked to the J plane bits `gmask` -- every plane tests the same set */
 template <int KIND>
-SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask)
+SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask, bool k2 = false)
 {
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
     const uint32_t b = smh_lds_u8(tab, prod >> 15);
-    if constexpr (KIND == 6) {
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        return (uint32_t)__builtin_amdgcn_sbfe((int)b, smh_bfe(prod, 12, 3), 1u) & gmask;
-#else
-        return ((b >> ((prod >> 12) & 7u)) & 1u) ? gmask : 0u;
-#endif
+    if constexpr (KIND == 6) { /* the bounds-checked path (the fast path: smh_flat_columns); k2: a gram has TWO bits in its byte */
+        uint32_t out = b >> ((prod >> 12) & 7u);
+        if (k2) out |= b >> ((prod >> 9) & 7u);
+        return (out & 1u) ? gmask : 0u;
     } else {
+        (void)k2;
         (void)gmask;
         return b;
     }
@@ -1355,50 +1354,60 @@ SMH_LANE uint32_t smh_flat_push(uint32_t H, uint32_t t)
  * bytes in the low 24 bits) and its bit index, then bit 0 of the result = 1 when the gram is NOT in the set.  The index comes
  * out of an asm v_bfe_u32: written as C++ the compiler recomputes "bits 12..14 of a 24-bit product" as the top bits of a
  * second, FULL 32-bit multiply (v_mul_lo_u32: quarter rate) per column. */
-SMH_LANE uint32_t smh_flat_addr(uint32_t key, uint32_t &idx)
+/* K2 (round 4, patterns of 5..7 bytes): a gram has TWO bits in its byte (indices = product bits 12..14 and 9..11) and is in
+ * the set when both are clear in the inverted array -- a blocked Bloom filter with 8-bit blocks.  With J = 3 grams of 100 000
+ * patterns one bit per gram fills 25 % of the 2^20 bits and passes 0.25^3 = 1.6 % of random columns (66 per 4 KiB); two bits
+ * fill 44 % and pass (0.44^2)^3 = 0.7 %.  From six grams on the fuller array loses and the compile keeps one bit (wm_host.c). */
+template <bool K2>
+SMH_LANE uint32_t smh_flat_addr(uint32_t key, uint32_t &idx, uint32_t &idx2)
 {
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
     asm("v_bfe_u32 %0, %1, 12, 3" : "=v"(idx) : "v"(prod));
+    if constexpr (K2) asm("v_bfe_u32 %0, %1, 9, 3" : "=v"(idx2) : "v"(prod));
+    else idx2 = 0;
 #else
     idx = (prod >> 12) & 7u;
+    idx2 = K2 ? (prod >> 9) & 7u : 0u;
 #endif
     return prod >> 15;
 }
-SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab)
+SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2)
 {
-    uint32_t idx;
-    const uint32_t addr = smh_flat_addr(key, idx);
-    return smh_lds_u8(tab, addr) >> idx;
+    uint32_t idx, idx2;
+    const uint32_t addr = smh_flat_addr<true>(key, idx, idx2);
+    const uint32_t b = smh_lds_u8(tab, addr);
+    return k2 ? (b >> idx) | (b >> idx2) : b >> idx;
 }
 /* eight columns: addresses, the eight lookups in flight together, then the bits */
-template <int G>
+template <int G, bool K2>
 SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H)
 {
-    uint32_t addr[8], idx[8], b[8];
-    addr[0] = smh_flat_addr(smh_gram_key<8 * G + 0>(w, pre), idx[0]);
-    addr[1] = smh_flat_addr(smh_gram_key<8 * G + 1>(w, pre), idx[1]);
-    addr[2] = smh_flat_addr(smh_gram_key<8 * G + 2>(w, pre), idx[2]);
-    addr[3] = smh_flat_addr(smh_gram_key<8 * G + 3>(w, pre), idx[3]);
-    addr[4] = smh_flat_addr(smh_gram_key<8 * G + 4>(w, pre), idx[4]);
-    addr[5] = smh_flat_addr(smh_gram_key<8 * G + 5>(w, pre), idx[5]);
-    addr[6] = smh_flat_addr(smh_gram_key<8 * G + 6>(w, pre), idx[6]);
-    addr[7] = smh_flat_addr(smh_gram_key<8 * G + 7>(w, pre), idx[7]);
+    uint32_t addr[8], idx[8], idx2[8], b[8];
+    addr[0] = smh_flat_addr<K2>(smh_gram_key<8 * G + 0>(w, pre), idx[0], idx2[0]);
+    addr[1] = smh_flat_addr<K2>(smh_gram_key<8 * G + 1>(w, pre), idx[1], idx2[1]);
+    addr[2] = smh_flat_addr<K2>(smh_gram_key<8 * G + 2>(w, pre), idx[2], idx2[2]);
+    addr[3] = smh_flat_addr<K2>(smh_gram_key<8 * G + 3>(w, pre), idx[3], idx2[3]);
+    addr[4] = smh_flat_addr<K2>(smh_gram_key<8 * G + 4>(w, pre), idx[4], idx2[4]);
+    addr[5] = smh_flat_addr<K2>(smh_gram_key<8 * G + 5>(w, pre), idx[5], idx2[5]);
+    addr[6] = smh_flat_addr<K2>(smh_gram_key<8 * G + 6>(w, pre), idx[6], idx2[6]);
+    addr[7] = smh_flat_addr<K2>(smh_gram_key<8 * G + 7>(w, pre), idx[7], idx2[7]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = smh_lds_u8(tab, addr[j]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) H = smh_flat_push(H, b[j] >> idx[j]);
+    for (int j = 0; j < 8; ++j) H = smh_flat_push(H, K2 ? (b[j] >> idx[j]) | (b[j] >> idx2[j]) : b[j] >> idx[j]);
 }
+template <bool K2>
 SMH_LANE void smh_flat_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H0, uint32_t &H1)
 {
-    smh_flat_group<0>(w, pre, tab, H0);
-    smh_flat_group<1>(w, pre, tab, H0);
-    smh_flat_group<2>(w, pre, tab, H0);
-    smh_flat_group<3>(w, pre, tab, H0);
-    smh_flat_group<4>(w, pre, tab, H1);
-    smh_flat_group<5>(w, pre, tab, H1);
-    smh_flat_group<6>(w, pre, tab, H1);
-    smh_flat_group<7>(w, pre, tab, H1);
+    smh_flat_group<0, K2>(w, pre, tab, H0);
+    smh_flat_group<1, K2>(w, pre, tab, H0);
+    smh_flat_group<2, K2>(w, pre, tab, H0);
+    smh_flat_group<3, K2>(w, pre, tab, H0);
+    smh_flat_group<4, K2>(w, pre, tab, H1);
+    smh_flat_group<5, K2>(w, pre, tab, H1);
+    smh_flat_group<6, K2>(w, pre, tab, H1);
+    smh_flat_group<7, K2>(w, pre, tab, H1);
 }
 /* (hi:lo) << k for 0 < k < 32: bit i of the result = bit i - k of the 64-bit sequence whose upper word is hi */
 SMH_LANE uint32_t smh_shl_across(uint32_t hi, uint32_t lo, uint32_t k) { return (hi << k) | (lo >> (32u - k)); }
@@ -1423,12 +1432,12 @@ SMH_LANE uint64_t smh_flat_candidates(uint32_t Z0, uint32_t Z1, uint32_t Z2, uin
     return ~(((uint64_t)Z2 << 32) | Z1);
 }
 /* the 32 bits in front of the segment at a, true values (the emulator; the GPU takes the previous lane's H1) */
-SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const void *tab)
+SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const void *tab, bool k2)
 {
     uint32_t H = 0;
     for (uint64_t x = a >= 32 ? a - 32 : 0; x < a; ++x) {
         uint32_t t = 0; /* a column without a whole gram in front of it cannot be ruled out */
-        if (x >= 2) t = smh_flat_bit((uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16), tab);
+        if (x >= 2) t = smh_flat_bit((uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16), tab, k2);
         H = smh_flat_push(H, t);
     }
     return H; /* (a < 32 never reaches the fast path: chunk 0 is bounds-checked) */
@@ -1438,7 +1447,7 @@ SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const
  * value: the CPU emulation and the bounds-checked path compute it by running the recurrence over those columns.
  * `tab` = the LDS image; `g7` = the pair form's per-gram bytes in HBM (smh_wm_params::gram_g7). */
 template <int KIND>
-SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const void *tab, const uint8_t *g7, uint32_t gmask = 0xFFu)
+SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const void *tab, const uint8_t *g7, uint32_t gmask = 0xFFu, bool k2 = false)
 {
     uint32_t S = 0u;
     if (KIND == 3) {
@@ -1455,7 +1464,7 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
         if (a < 10) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
             const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
-            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, gmask));
+            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, gmask, k2));
         }
     }
     return S & 0x7Fu;
@@ -1658,13 +1667,14 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
         /* flat byte grams: the columns' bits are collected, the J-in-a-row test runs once on all of them (above) */
         (void)pre0;
         uint32_t H0 = 0, H1 = 0, Hp;
-        smh_flat_columns(w, pre1, tab, H0, H1);
+        if (P.gram_jb > 0) smh_flat_columns<true>(w, pre1, tab, H0, H1); /* wave-uniform: two bits per gram (short patterns) */
+        else smh_flat_columns<false>(w, pre1, tab, H0, H1);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         /* the 32 columns in front of the segment: the previous lane's second half; lane 0 of a wave has no neighbour and
          * assumes "all in the set" (a few more columns reach the verify stage, which is exact) */
         Hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #else
-        Hp = smh_flat_history_before(text, a, tab);
+        Hp = smh_flat_history_before(text, a, tab, P.gram_jb > 0);
 #endif
         const uint64_t msk6 = smh_flat_candidates(Hp, H0, H1, (uint32_t)P.gram_planes);
         if constexpr (smh_stg_regv(STG)) {
@@ -1821,7 +1831,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
     const uint32_t cand_bit = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u;
     uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes)
-                           : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u)), cnt = 0;
+                           : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u), KIND == 6 && P.gram_jb > 0), cnt = 0;
     for (uint64_t e = a; e < end; ++e) {
         uint32_t G = 0u; /* a column without a whole gram in front of it cannot be ruled out */
         if (e + 1 >= q) {
@@ -1837,7 +1847,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
                 G = g;
             } else {
                 const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
-                G = smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u));
+                G = smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), KIND == 6 && P.gram_jb > 0);
             }
         }
         T = smh_gram_step(T, G);

@@ -258,6 +258,7 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     P.pat_sorted = padded.data();
     P.gram_g7 = wm->gram_kind == SMH_GRAM_PAIR ? (const uint8_t *)wm->gram_table + SMH_GRAM_BYTES : nullptr;
     P.gram_planes = wm->gram_planes;
+    if (wm->gram_kind == SMH_GRAM_FLAT) P.gram_jb = wm->gram_jb; /* 1: two bits per gram */
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     /* staged verify as launch_gram (wm_kernels.inc) picks it */

@@ -155,6 +155,31 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
 
 
 
+@pytest.mark.parametrize("m,p", [(5, 300), (5, 20000), (6, 3000), (7, 100), (7, 9000)])
+def test_flat_byte_grams_with_two_bits_per_gram(m, p, monkeypatch):
+    """Round 4: patterns of 5..7 bytes may keep TWO bits per gram in the flat Bloom set (a blocked Bloom filter with 8-bit
+    blocks: wm_lane.h smh_flat_addr<true>); forced here with the development knob, against brute force, both block counts,
+    positions mode, and the bounds-checked first / last chunks."""
+    monkeypatch.setenv("SMH_WM_TUNE", "gram=6,flatk=2")
+    rng = np.random.RandomState(77 * m + p)
+    n = 3 * 4096 + 555
+    text = rng.randint(0, 256, size=n).astype(np.uint8)
+    pat = rng.randint(0, 256, size=(p, m)).astype(np.uint8)
+    for i, off in enumerate([0, 300, 640 - m // 2, 4096 - m // 2, 8191, 8192 + 2 * m + 64, n - m]):
+        text[off:off + m] = pat[(7 * i) % p]
+    wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, 256)
+    assert wm.info().gram_kind == 6
+    want = O.count_bruteforce(pat.reshape(-1), m, p, text)
+    assert want >= 7
+    for blocks in (1, 3):
+        assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want
+    total, pos = E.wm_positions(wm, text, want + 8, 2)
+    assert total == want and len(set(pos.tolist())) == want
+    monkeypatch.setenv("SMH_WM_TUNE", "gram=6,flatk=1")
+    one = S.WmTables.from_patterns(pat.reshape(-1), m, p, 256)
+    assert E.wm_scan(one, text, S.VARIANT_TUNED, 2) == want
+
+
 @pytest.mark.parametrize("kind", [1, 5])
 @pytest.mark.parametrize("m", [11, 12, 13, 14, 16, 17, 18, 21, 24, 29, 32, 33])
 def test_in_register_verify_every_column_and_length(m, kind, monkeypatch):
