@@ -502,6 +502,28 @@ SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_par
 }
 #endif
 
+/* ---- the software-pipelined probe of the IN-REGISTER verify (smh_wm_regv_columns): one pending column per lane, its first
+ * bucket requested between chunks and looked at after the next chunk's scan.  Compiled for the CPU emulation too (round 4):
+ * the emulator runs a lane at a time, so "the lanes that hold a column" is simply "this lane", and it walks the very same
+ * issue / finish / carry-over-to-the-next-chunk control flow as the GPU. */
+SMH_LANE void smh_wm_pend_issue_rv(smh_wm_queue &Q, const smh_wm_params &P)
+{
+    if (Q.pend_n == 0 || Q.pend_loaded) return;
+    if (Q.pend_mine) Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
+    Q.pend_loaded = 1u;
+}
+SMH_LANE void smh_wm_pend_finish_rv(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
+{
+    if (Q.pend_n == 0) return;
+    uint32_t r = 0;
+    if (Q.pend_mine) r = smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
+    Q.matches += r;
+    if (Q.po) smh_append_bits(r, Q.pend_e, *Q.po);
+    Q.pend_mine = 0u;
+    Q.pend_n = 0u;
+    Q.pend_loaded = 0u;
+}
+
 /* ---- staged verify, wave level (description above SMH_STAGE_BUF) ---- */
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
 typedef uint32_t smh_lds_v4 __attribute__((ext_vector_type(4)));
@@ -517,31 +539,27 @@ SMH_LANE void smh_lds_store16(uint32_t byte_off, uint32_t a, uint32_t b, uint32_
 template <bool RV = false>
 SMH_LANE void smh_wm_pend_issue(smh_wm_queue &Q, const smh_wm_params &P)
 {
-    if (Q.pend_n == 0 || Q.pend_loaded) return;
     if constexpr (RV) { /* only the lanes that hold a column ask for a bucket */
-        if (Q.pend_mine) Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
-    } else {
-    Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
+        smh_wm_pend_issue_rv(Q, P);
+        return;
     }
+    if (Q.pend_n == 0 || Q.pend_loaded) return;
+    Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
     Q.pend_loaded = 1u;
 }
 /* decide the pending columns; all 64 lanes must call it */
 template <bool RV = false>
 SMH_LANE void smh_wm_pend_finish(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P)
 {
-    if (Q.pend_n == 0) return;
     if constexpr (RV) {
-        uint32_t r = 0;
-        if (Q.pend_mine) r = smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
-        Q.matches += r;
-        if (Q.po) smh_append_bits(r, Q.pend_e, *Q.po);
-        Q.pend_mine = 0u;
-    } else {
+        smh_wm_pend_finish_rv(Q, text, P);
+        return;
+    }
+    if (Q.pend_n == 0) return;
     const bool mine = (threadIdx.x & 63u) < Q.pend_n;
     const uint32_t r = smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
     Q.matches += mine ? r : 0u;
     if (Q.po) smh_append_bits(mine ? r : 0u, Q.pend_e, *Q.po);
-    }
     Q.pend_n = 0u;
     Q.pend_loaded = 0u;
 }
@@ -1209,22 +1227,14 @@ SMH_LANE void smh_wm_regv_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t
         const bool have = msk != 0;
         const uint32_t c = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
         const uint32_t tag = smh_regv_tag<HP>(w, prev, c, P.m);
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         /* the column this lane (or another) still holds from an earlier chunk -- its bucket arrived while this chunk was
          * scanned -- or from the round before (a second survivor in one lane: decided without the pipelining) */
-        smh_wm_pend_finish<true>(Q, text, P);
+        smh_wm_pend_finish_rv(Q, text, P);
         Q.events += have ? 1u : 0u;
         Q.pend_n = 64u;
         Q.pend_mine = have ? 1u : 0u;
         Q.pend_e = a + c;
         Q.pend_tag = tag;
-#else
-        if (have) {
-            const uint32_t hit = smh_wm_probe(text, a + c, tag, P);
-            Q.matches += hit;
-            if (hit && Q.po) smh_append_bits(1u, a + c, *Q.po);
-        }
-#endif
         msk &= msk - 1u;
     } while (SMH_WAVE_ANY(msk != 0));
 }
@@ -1550,6 +1560,48 @@ SMH_LANE uint32_t smh_wm_gram2_lane_slow(const uint8_t *text, uint64_t n, uint64
     return cnt;
 }
 
+/* the shift-or state the wave-chunk inherits, worked out from the halo registers (the last ND dwords of the HD in front of
+ * the chunk: the same in every lane, so the lookups are broadcasts): the pair forms' rolling code over the halo's symbols,
+ * one smh_gram_step2 per lookup from the fourth pair on (the first three only fill the eight-symbol code) */
+template <int HD, int ND>
+SMH_LANE uint32_t smh_gram_halo_state(const uint32_t (&halo)[HD], const void *tab)
+{
+    static_assert(ND <= HD, "the halo kept in registers covers the lookups that reach the inherited state");
+    uint32_t c2 = 0, Th = 0;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        const uint32_t hw = halo[HD - ND + d], x = (hw << 10) | hw;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            c2 = ((c2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
+            if (2 * d + k >= 3) Th = smh_gram_step2(Th, smh_lds_u16(tab, c2));
+        }
+    }
+    return Th;
+}
+/* is this the lane that owns a wave-chunk's first segment?  The GPU knows its lane id; the emulator, a lane at a time, sees it
+ * in the segment's offset */
+SMH_LANE bool smh_is_lane0(uint64_t a)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    (void)a;
+    return (threadIdx.x & 63u) == 0;
+#else
+    return ((a >> 6) & 63u) == 0;
+#endif
+}
+/* "does lane 0 of the wave see `cond`?"  wave-uniform on the GPU; the emulator answers for the lane it is running (a lane
+ * other than lane 0 has no use for the answer: it keeps its own inherited state) */
+SMH_LANE bool smh_lane0_any(bool cond, uint64_t a)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    (void)a;
+    return __builtin_amdgcn_readfirstlane((int)cond) != 0;
+#else
+    return smh_is_lane0(a) && cond;
+#endif
+}
+
 /* fast path: the 64 END columns of the segment at a (a >= 4096: not the text's first chunk; a + 64 <= n).
  * `edge` = the 8 bytes in front of the wave-chunk (wave-uniform).  Returns nothing: candidates go to the queue. */
 template <int KIND, bool POS, int STG = 0, bool QD = true>
@@ -1716,23 +1768,11 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
          * of the chunk, the same in every lane, so the reads are broadcasts -- in EVERY chunk (with the assumption alone
          * column 0 of every chunk would reach the verify stage). */
         uint32_t pv = prevT;
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         {
             constexpr int NP = HP == 1 ? 5 : 8, ND = (2 * NP + 6 + 3) / 4; /* lookups (>= J / 2), dwords of halo that hold their symbols */
-            static_assert(ND <= HD, "the halo kept in registers covers the lookups that reach the inherited state");
-            uint32_t c2 = 0, Th = 0;
-#pragma unroll
-            for (int d = 0; d < ND; ++d) {
-                const uint32_t hw = halo[HD - ND + d], x = (hw << 10) | hw;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    c2 = ((c2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
-                    if (2 * d + k >= 3) Th = smh_gram_step2(Th, smh_lds_u16(tab, c2));
-                }
-            }
-            if ((threadIdx.x & 63u) == 0) pv = Th;
+            const uint32_t Th = smh_gram_halo_state<HD, ND>(halo, tab);
+            if (smh_is_lane0(a)) pv = Th;
         }
-#endif
         const uint32_t fixj = smh_bitrev32(~pv & jmask) >> (32u - jw); /* bit q SET = bit J-2-q of the inherited state alive; J >= 3 */
         /* fl16[k] bit o = column 16 k + 1 + o; the flag of column 64 belongs to the next lane */
         const uint64_t later = (uint64_t)(fl16[0] | (fl16[1] << 16)) | ((uint64_t)(fl16[2] | (fl16[3] << 16)) << 32);
@@ -1742,30 +1782,20 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
          * seven bits clear) is the assumption for J <= 8 and merely a subset of it above: its bits 7.. read as dead,
          * which would lose candidates, so lane 0 is given the assumption explicitly */
         uint32_t pv = prevT;
-#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        if ((threadIdx.x & 63u) == 0) pv = 0u;
+        if (smh_is_lane0(a)) pv = 0u;
         if constexpr (STG > 0) {
             /* ... which lets column c of lane 0 through on c + 1 planes only: 0.06 surviving columns per wave-chunk at 1000
              * patterns, 0.6 at 8000 (one chunk in two staged for nothing: 8000 patterns of 32 symbols scanned at 0.226
              * ms/GiB with 0.2 real survivors per chunk).  So when lane 0 has such a flag, the state the chunk inherits is
              * computed from the halo -- the last NP pairs of columns in front of the chunk decide its low J-1 bits; same
-             * values in every lane, the lookups are broadcasts -- and lane 0 is corrected like the others. */
-            if (P.gram_jb >= 0 /* the launcher's choice: wm_kernels.inc launch_gram_stg */ && __builtin_amdgcn_readfirstlane((int)(fl16[0] & jmask)) != 0) {
+             * values in every lane, the lookups are broadcasts -- and lane 0 is corrected like the others.  (The CPU
+             * emulation, a lane at a time, takes the same decision from lane 0's own flags and runs the same arithmetic.) */
+            if (P.gram_jb >= 0 /* the launcher's choice: wm_kernels.inc launch_gram_stg */ && smh_lane0_any((fl16[0] & jmask) != 0, a)) {
                 constexpr int NP = HP == 1 ? 5 : 7, ND = (2 * NP + 6) / 4; /* pairs of columns (>= J-1 columns), dwords of halo */
-                uint32_t c2 = 0, Th = 0;
-#pragma unroll
-                for (int d = 0; d < ND; ++d) {
-                    const uint32_t hw = halo[HD - ND + d], x = (hw << 10) | hw;
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        c2 = ((c2 << 4) & 0x1FFFEu) | smh_bfe(x, k == 0 ? 7 : 23, 5);
-                        if (2 * d + k >= 3) Th = smh_gram_step2(Th, smh_lds_u16(tab, c2));
-                    }
-                }
-                if ((threadIdx.x & 63u) == 0) pv = Th;
+                const uint32_t Th = smh_gram_halo_state<HD, ND>(halo, tab);
+                if (smh_is_lane0(a)) pv = Th;
             }
         }
-#endif
         const uint32_t fixj = jw ? smh_bitrev32(~pv & jmask) >> (32u - jw) : 0u;
         msk = (uint64_t)((fl16[0] & (fixj | ~jmask)) | (fl16[1] << 16)) | ((uint64_t)(fl16[2] | (fl16[3] << 16)) << 32);
     } else {
@@ -1915,10 +1945,11 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
          * return in order behind everything the wave has in flight, so a drain entered while a prefetch is
          * outstanding also waits for that prefetch (measured: 2-3 x the cost per surviving column) */
         if (QD && Q.count >= smh_gram_drain_at) smh_wm_drain(Q, text, P);
+        /* staged / in-register verify, pipelined: the buckets of the columns hashed at the end of the last chunk are requested
+         * now and looked at after this chunk's scan (by the next flush, or below) */
+        if constexpr (RV) smh_wm_pend_issue_rv(Q, P);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        /* staged verify, pipelined: the buckets of the columns hashed at the end of the last chunk are requested now
-         * and looked at after this chunk's scan (by the next flush, or below) */
-        if (STG > 0) smh_wm_pend_issue<RV>(Q, P);
+        else if (STG > 0) smh_wm_pend_issue<false>(Q, P);
 #endif
         if (SMH_PREFETCH && nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
@@ -1941,8 +1972,9 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         } else {
             cnt += smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P);
         }
+        if constexpr (RV) { if (Q.pend_loaded) smh_wm_pend_finish_rv(Q, text, P); } /* a chunk without a flush of its own */
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish<RV>(Q, text, P); /* a chunk without a flush of its own */
+        else if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish<false>(Q, text, P);
 #endif
         if (nxt_fast) {
             if (SMH_PREFETCH) {
@@ -1957,8 +1989,9 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         cur_fast = nxt_fast;
         k = kn;
     }
+    if constexpr (RV) smh_wm_pend_finish_rv(Q, text, P);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-    if (STG > 0) smh_wm_pend_finish<RV>(Q, text, P);
+    else if (STG > 0) smh_wm_pend_finish<false>(Q, text, P);
 #endif
     if (QD) smh_wm_drain(Q, text, P);
     if (events_out) *events_out = Q.events;
