@@ -425,7 +425,13 @@ def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, monkeypatch):
     assert sorted(out[:want].tolist()) == O.positions_bruteforce(pat.reshape(-1), m, p, text).tolist()
 
 
-@pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1", ",flatk=2"], ids=["default", "hbm_windows", "staged", "in_registers", "flat_two_bits"])
+@pytest.mark.parametrize("m,p", [(5, 3000), (6, 100000), (7, 100)])
+def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, monkeypatch):
+    """the flat form of 5..7-byte patterns with two bits per gram forced (round 4): same text, same checks as below"""
+    test_gram_filter_forms_on_the_gpu(6, 256, m, p, ",flatk=2", monkeypatch)
+
+
+@pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1"], ids=["default", "hbm_windows", "staged", "in_registers"])
 @pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 17, 6000), (1, 4, 33, 50), (1, 4, 40, 50),
                                             (3, 4, 11, 200), (3, 4, 16, 20000), (3, 4, 32, 500), (2, 256, 5, 3000),
                                             (6, 256, 5, 3000), (6, 256, 6, 100000), (6, 256, 7, 100), (6, 256, 8, 30000), (6, 256, 17, 1000), (6, 256, 33, 2000),
@@ -438,8 +444,6 @@ def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, monkeypatch):
     in-register verify forced on and off (round 3; the stretch where every column survives gives a lane 64 rounds of it)
     and with windows re-read from HBM; texts with planted occurrences at chunk / segment boundaries and a stretch where EVERY column
     survives the filter (a pattern repeated back to back), so lists overflow and are flushed mid-chunk."""
-    if stage == ",flatk=2" and not (kind == 6 and m <= 7):
-        pytest.skip("two bits per gram: the flat form of 5..7-byte patterns only")
     monkeypatch.setenv("SMH_WM_TUNE", "gram=%d%s" % (kind, stage))
     rng = np.random.RandomState(1000 * kind + m)
     n = 9 * 4096 + 777
