@@ -258,12 +258,14 @@ def spawn_ranks(n):
 def multi_leg(args):
     import smatcher_hip as S
     n_dev = args.multi_leg
-    if S.device_count() < n_dev:
+    share = os.environ.get("SMH_MULTI_SHARE_DEVICE", "0") not in ("", "0")  # one-card rehearsal of the N-device flow (csrc/smh_multi.hip)
+    if S.device_count() < n_dev and not share:
         print(json.dumps({"error": "%d device(s) visible to the one-process leg, %d wanted" % (S.device_count(), n_dev)}))
         return
     mg = S.MultiGpu(n_dev)
     per_gpu, shard = args.mib_per_gpu << 20, args.shard_mib << 20
     out = {"devices": n_dev, "reduce": "ncclAllReduce(uint64, sum) over ncclCommInitAll" if mg.uses_rccl else "host sum",
+           "rehearsal": "SMH_MULTI_SHARE_DEVICE: %d logical shards on %d card(s); rates are not N-GPU rates" % (n_dev, S.device_count()) if share else None,
            "what": "ONE process drives all devices through smh_multi_* (csrc/smh_multi.hip); seconds = launches on every "
                    "device + the count all-reduce + read-back, table sets prepared before the clock; timed after %.0f ms of "
                    "back-to-back count calls (the per-rank path's conditioning)" % CONDITION_MS}

@@ -478,7 +478,9 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
             if (w && (verify_bound || filter_faster)) ac->alt_wm = w;
             if (w && !verify_bound) ac->hv_wm = w;
             /* both engines stay at hand when both could serve (round 4): which one runs is then decided per text */
-            if (w && !verify_bound && !ac->scan_exact && w->gram_kind != SMH_GRAM_NONE && !w->alt_ac) ac->flex_wm = w;
+            if (w && !verify_bound && !ac->scan_exact && !w->alt_ac && !w->pair_table && (w->gram_kind != SMH_GRAM_NONE || !w->filter_exact) &&
+                w->scan_ms_est > 0)
+                ac->flex_wm = w;
         }
         --smh_alt_engine_depth;
     }
@@ -1024,7 +1026,9 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
     ac->alt_off = stride != 0 || depth != 0; /* a forced plan means "run the automaton kernels" */
     ac->engine_forced = ac->alt_off ? SMH_ALGO_AC : -1;
     if (ac->scan_exact || ac->scan_dense) ac->flex_wm = NULL; /* an exact plan never hands over */
-    else if (ac->hv_wm && ac->hv_wm->gram_kind != SMH_GRAM_NONE && !ac->hv_wm->alt_ac) ac->flex_wm = ac->hv_wm;
+    else if (ac->hv_wm && !ac->hv_wm->alt_ac && !ac->hv_wm->pair_table && (ac->hv_wm->gram_kind != SMH_GRAM_NONE || !ac->hv_wm->filter_exact) &&
+             ac->hv_wm->scan_ms_est > 0)
+        ac->flex_wm = ac->hv_wm;
     ++ac->generation;
     return SMH_OK;
 }
