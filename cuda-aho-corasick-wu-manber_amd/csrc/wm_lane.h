@@ -396,9 +396,16 @@ SMH_LANE uint32_t smh_wm_verify2(const uint8_t *text, uint64_t e0, uint64_t e1, 
  *   5, 6   in-register verify (round 3, pair form): the lane selects the window's dwords out of its OWN text registers
  *          and the previous lane's last 16 / 32 bytes (DPP) with a barrel of conditional moves -- no copy, no lock, no
  *          queue, no LDS round trip; smh_wm_regv_columns */
+/*   3, 4   windows from L2 (round 4, byte-gram forms; m - 1 <= 16 / 32): no copy of the chunk at all -- the surviving columns
+ *          are compacted into the wave's queue as before, every lane takes one and REQUESTS its window's aligned dwords from
+ *          global memory (the chunk was streamed a few microseconds ago: L2 / Infinity Cache), and the requests ride through
+ *          the next chunk's scan; then the hash, the bucket request, another chunk's scan, the decision -- a two-stage
+ *          software pipeline with no LDS round trip a wave has to wait for; smh_wm_l2_columns */
 constexpr bool smh_stg_regv(int STG) { return STG >= 5; }
 constexpr bool smh_stg_staged(int STG) { return STG == 1 || STG == 2; }
-constexpr int smh_stg_hp(int STG) { return STG >= 5 ? STG - 4 : (STG > 0 ? STG : 1); } /* 16-byte pieces of text kept from in front of the chunk */
+constexpr bool smh_stg_l2(int STG) { return STG == 3 || STG == 4; }
+constexpr int smh_stg_hp(int STG) { return STG >= 5 ? STG - 4 : (STG == 1 || STG == 2 ? STG : 1); } /* 16-byte pieces of text kept from in front of the chunk */
+constexpr int smh_stg_l2_maxd(int STG) { return STG == 3 ? 5 : 9; } /* == SMH_STAGE_MAXD: dwords of the longest window */
 
 #define SMH_WM_QCAP 128u /* END columns per wave, 1 KiB of LDS behind the filter */
 struct smh_wm_queue {
@@ -418,6 +425,12 @@ struct smh_wm_queue {
     smh_u32x4 pend_q;
     uint32_t pend_mine;   /* in-register verify: per lane, this lane holds a pending column (there is no compaction) */
     uint32_t events;      /* per lane: surviving columns this lane sent to the verify stage (smh_stats.h) */
+    /* windows from L2 (STG 3 / 4): the first pipeline stage -- up to 64 columns, one per lane, whose window dwords are in flight */
+    uint32_t pa_n;        /* wave-uniform: lanes below it hold a column */
+    uint32_t pa_sh;       /* bit offset of the window in pa_w[0] */
+    uint64_t pa_e;
+    uint64_t pa_limit;    /* wave-uniform: the text's length (window requests near its end take the narrow form) */
+    uint32_t pa_w[10];
 };
 
 /* ---- staged verify: the window hash of a surviving column is computed from an ON-CHIP copy of the wave-chunk.
@@ -650,6 +663,7 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
                                    const uint32_t (&w)[16], const uint32_t (&halo)[4 * STG], const smh_wm_params &P)
 {
     if (!SMH_WAVE_ANY(msk != 0)) return;
+    if (Q.st_min == 0xFFFFFFFFu) return; /* development knob SMH_WM_TUNE="stmin=-1": survivors are dropped (what the bare filter scan costs; counts are wrong) */
     uint32_t from = QD ? Q.count : 0u; /* entries of earlier chunks */
     do {
         if (Q.count + 64u > SMH_WM_QCAP) {
@@ -698,6 +712,117 @@ SMH_LANE void smh_wm_stage_columns(smh_wm_queue &Q, const uint8_t *text, uint64_
 {
     while (msk) {
         smh_wm_stage_verify_emu<STG>(Q, text, chunk_base, (uint32_t)(a - chunk_base) + (uint32_t)__builtin_ctzll(msk), P);
+        msk &= msk - 1u;
+    }
+}
+#endif
+
+/* ---- windows from L2 (STG 3 / 4; description at smh_stg_l2) ----
+ * the aligned dwords of the m-byte window that ends at column e, requested in one go; dwords the window does not reach
+ * are not touched (the text buffer ends with its last byte's dword) */
+template <int MAXD>
+SMH_LANE uint32_t smh_wm_l2_request(const uint8_t *text, uint64_t e, int m, uint32_t (&d)[MAXD + 1], bool wide)
+{
+    const uint64_t s0 = e + 1 - (uint64_t)m;
+    const uint32_t *aligned = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
+    const uint32_t sh = (uint32_t)(s0 & 3u) * 8u;
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    if (MAXD == 9 && wide) {
+        /* wave-uniform: 40 bytes from the window's first dword on lie inside the text.  The long window as two 16-byte
+         * requests and an 8-byte one (dword-aligned) instead of ten 4-byte ones: 100 000 patterns of 20 bytes 1.21 -> 1.16 ms
+         * per 4 GiB.  (The short window -- six 4-byte requests, most of them bent onto its last dword -- is faster as it is:
+         * one 16-byte + one 8-byte request measured 1.13 -> 1.20 ms at 12 bytes; gpurun_out/r04_p/ab_l2wide.log.) */
+        typedef uint32_t v4a __attribute__((ext_vector_type(4), aligned(4)));
+        typedef uint32_t v2a __attribute__((ext_vector_type(2), aligned(4)));
+        const v4a q0 = *reinterpret_cast<const v4a *>(aligned);
+        d[0] = q0.x; d[1] = q0.y; d[2] = q0.z; d[3] = q0.w;
+        const v4a q1 = *reinterpret_cast<const v4a *>(aligned + 4);
+        d[(MAXD + 1) / 2 - 1] = q1.x; d[(MAXD + 1) / 2] = q1.y; d[(MAXD + 1) / 2 + 1] = q1.z; d[(MAXD + 1) / 2 + 2] = q1.w;
+        const v2a q2 = *reinterpret_cast<const v2a *>(aligned + (MAXD - 1));
+        d[MAXD - 1] = q2.x; d[MAXD] = q2.y;
+        return sh;
+    }
+#else
+    (void)wide;
+#endif
+    const uint32_t last = (sh + 8u * (uint32_t)m - 1u) >> 5; /* index of the dword that holds the window's last byte */
+    /* a dword beyond it is never part of the hash (smh_wm_tag_dwords masks the last dword to the window): the request is
+     * bent back onto dword `last` instead of predicated away */
+#pragma unroll
+    for (int j = 0; j <= MAXD; ++j) d[j] = aligned[(uint32_t)j < last ? (uint32_t)j : last];
+    return sh;
+}
+
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+/* the pipeline's step at a chunk boundary: decide the columns whose bucket has arrived, hash the windows that have arrived
+ * and request their buckets, take up to 64 new columns from the queue and request their windows.  All 64 lanes call it. */
+template <int MAXD>
+SMH_LANE void smh_wm_l2_step(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, const smh_wm_params &P, bool take)
+{
+    Q.pend_mine = 1u; /* (a field of the in-register verify, free here: "the pipeline has moved in this iteration") */
+    smh_wm_pend_finish<false>(Q, text, P);
+    if (Q.pa_n) {
+        uint32_t d[MAXD + 1];
+#pragma unroll
+        for (int j = 0; j <= MAXD; ++j) d[j] = Q.pa_w[j];
+        Q.pend_tag = smh_wm_tag_dwords<MAXD>(d, Q.pa_sh, P.m);
+        Q.pend_e = Q.pa_e;
+        Q.pend_n = Q.pa_n;
+        Q.pend_loaded = 0u;
+        Q.pa_n = 0u;
+        smh_wm_pend_issue<false>(Q, P);
+    }
+    if (!take || Q.count == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, cnt = Q.count;
+    const uint32_t *offs = reinterpret_cast<const uint32_t *>(Q.slots);
+    /* a lane without an entry re-requests entry 0 (a valid address; its answer is dropped) */
+    Q.pa_e = chunk_base + offs[lane < cnt ? lane : 0u];
+    uint32_t d[MAXD + 1];
+    Q.pa_sh = smh_wm_l2_request<MAXD>(text, Q.pa_e, P.m, d, chunk_base + 4096u + 4u * (MAXD + 1) <= Q.pa_limit);
+#pragma unroll
+    for (int j = 0; j <= MAXD; ++j) Q.pa_w[j] = d[j];
+    Q.pa_n = cnt < 64u ? cnt : 64u;
+    if (cnt > 64u) { /* the overflow of a dense chunk is decided at once (three dependent round trips: rare by the filter's design) */
+        const bool h1 = lane + 64u < cnt;
+        const uint64_t e1 = chunk_base + offs[h1 ? lane + 64u : 0u];
+        const uint32_t r1 = smh_wm_verify(text, e1, P);
+        Q.matches += h1 ? r1 : 0u;
+        if (Q.po) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
+    }
+    Q.count = 0u;
+}
+
+/* the surviving columns `msk` (bit b = column a + b) of a lane's segment in the wave-chunk at chunk_base */
+template <int MAXD>
+SMH_LANE void smh_wm_l2_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t chunk_base, uint64_t a, uint64_t msk, const smh_wm_params &P)
+{
+    if (!SMH_WAVE_ANY(msk != 0)) return;
+    if (Q.st_min == 0xFFFFFFFFu) return; /* development knob: survivors dropped (smh_wm_stage_columns) */
+    do {
+        if (Q.count + 64u > SMH_WM_QCAP) smh_wm_l2_step<MAXD>(Q, text, chunk_base, P, true); /* 128 queued: take them now */
+        const bool have = msk != 0;
+        const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
+        const uint64_t mask = __ballot(have);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (have) reinterpret_cast<uint32_t *>(Q.slots)[Q.count + before] = (uint32_t)(a - chunk_base) + b;
+        Q.count += (uint32_t)__popcll(mask);
+        Q.events += have ? 1u : 0u;
+        msk &= msk - 1u;
+    } while (SMH_WAVE_ANY(msk != 0));
+    smh_wm_l2_step<MAXD>(Q, text, chunk_base, P, true);
+}
+#else
+/* CPU emulation (one lane at a time): the same window request and hash, decided at once */
+template <int MAXD>
+SMH_LANE void smh_wm_l2_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t, uint64_t a, uint64_t msk, const smh_wm_params &P)
+{
+    while (msk) {
+        const uint64_t e = a + (uint64_t)__builtin_ctzll(msk);
+        uint32_t d[MAXD + 1];
+        const uint32_t sh = smh_wm_l2_request<MAXD>(text, e, P.m, d, false);
+        const uint32_t hit = smh_wm_probe(text, e, smh_wm_tag_dwords<MAXD>(d, sh, P.m), P);
+        Q.matches += hit;
+        if (hit && Q.po) smh_append_bits(1u, e, *Q.po);
         msk &= msk - 1u;
     }
 }
@@ -1360,52 +1485,58 @@ SMH_LANE uint32_t smh_flat_push(uint32_t H, uint32_t t)
     return (H >> 1) | ((t & 1u) << 31);
 #endif
 }
-/* one column in two halves, so that a group's lookups are in flight together: the byte address of the gram `key` (three
- * bytes in the low 24 bits) and its bit index, then bit 0 of the result = 1 when the gram is NOT in the set.  The index comes
- * out of an asm v_bfe_u32: written as C++ the compiler recomputes "bits 12..14 of a 24-bit product" as the top bits of a
- * second, FULL 32-bit multiply (v_mul_lo_u32: quarter rate) per column. */
 /* K2 (round 4, patterns of 5..7 bytes): a gram has TWO bits in its byte (indices = product bits 12..14 and 9..11) and is in
  * the set when both are clear in the inverted array -- a blocked Bloom filter with 8-bit blocks.  With J = 3 grams of 100 000
  * patterns one bit per gram fills 25 % of the 2^20 bits and passes 0.25^3 = 1.6 % of random columns (66 per 4 KiB); two bits
  * fill 44 % and pass (0.44^2)^3 = 0.7 %.  From six grams on the fuller array loses and the compile keeps one bit (wm_host.c). */
-template <bool K2>
-SMH_LANE uint32_t smh_flat_addr(uint32_t key, uint32_t &idx, uint32_t &idx2)
+/* the bit index (product bits 12..14; K2's second one: bits 9..11) out of an asm v_bfe_u32: written as C++ the compiler
+ * recomputes "bits 12..14 of a 24-bit product" as the top bits of a second, FULL 32-bit multiply (v_mul_lo_u32: quarter
+ * rate) per column */
+template <int OFF>
+SMH_LANE uint32_t smh_flat_idx(uint32_t prod)
 {
-    const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-    asm("v_bfe_u32 %0, %1, 12, 3" : "=v"(idx) : "v"(prod));
-    if constexpr (K2) asm("v_bfe_u32 %0, %1, 9, 3" : "=v"(idx2) : "v"(prod));
-    else idx2 = 0;
+    uint32_t idx;
+    if constexpr (OFF == 12) asm("v_bfe_u32 %0, %1, 12, 3" : "=v"(idx) : "v"(prod));
+    else asm("v_bfe_u32 %0, %1, 9, 3" : "=v"(idx) : "v"(prod));
+    return idx;
 #else
-    idx = (prod >> 12) & 7u;
-    idx2 = K2 ? (prod >> 9) & 7u : 0u;
+    return (prod >> OFF) & 7u;
 #endif
-    return prod >> 15;
 }
 SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2)
 {
-    uint32_t idx, idx2;
-    const uint32_t addr = smh_flat_addr<true>(key, idx, idx2);
-    const uint32_t b = smh_lds_u8(tab, addr);
-    return k2 ? (b >> idx) | (b >> idx2) : b >> idx;
+    const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
+    const uint32_t b = smh_lds_u8(tab, prod >> 15);
+    return k2 ? (b >> smh_flat_idx<12>(prod)) | (b >> smh_flat_idx<9>(prod)) : b >> smh_flat_idx<12>(prod);
 }
-/* eight columns: addresses, the eight lookups in flight together, then the bits */
+/* eight columns: the products, the eight lookups in flight together, then the bits (only the products and the bytes live
+ * across the lookups: with the indices kept beside them the two-bit variant ran out of registers) */
 template <int G, bool K2>
 SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H)
 {
-    uint32_t addr[8], idx[8], idx2[8], b[8];
-    addr[0] = smh_flat_addr<K2>(smh_gram_key<8 * G + 0>(w, pre), idx[0], idx2[0]);
-    addr[1] = smh_flat_addr<K2>(smh_gram_key<8 * G + 1>(w, pre), idx[1], idx2[1]);
-    addr[2] = smh_flat_addr<K2>(smh_gram_key<8 * G + 2>(w, pre), idx[2], idx2[2]);
-    addr[3] = smh_flat_addr<K2>(smh_gram_key<8 * G + 3>(w, pre), idx[3], idx2[3]);
-    addr[4] = smh_flat_addr<K2>(smh_gram_key<8 * G + 4>(w, pre), idx[4], idx2[4]);
-    addr[5] = smh_flat_addr<K2>(smh_gram_key<8 * G + 5>(w, pre), idx[5], idx2[5]);
-    addr[6] = smh_flat_addr<K2>(smh_gram_key<8 * G + 6>(w, pre), idx[6], idx2[6]);
-    addr[7] = smh_flat_addr<K2>(smh_gram_key<8 * G + 7>(w, pre), idx[7], idx2[7]);
+    uint32_t prod[8], b[8];
+    prod[0] = smh_mul24(smh_gram_key<8 * G + 0>(w, pre), SMH_GRAM_MUL_DEV);
+    prod[1] = smh_mul24(smh_gram_key<8 * G + 1>(w, pre), SMH_GRAM_MUL_DEV);
+    prod[2] = smh_mul24(smh_gram_key<8 * G + 2>(w, pre), SMH_GRAM_MUL_DEV);
+    prod[3] = smh_mul24(smh_gram_key<8 * G + 3>(w, pre), SMH_GRAM_MUL_DEV);
+    prod[4] = smh_mul24(smh_gram_key<8 * G + 4>(w, pre), SMH_GRAM_MUL_DEV);
+    prod[5] = smh_mul24(smh_gram_key<8 * G + 5>(w, pre), SMH_GRAM_MUL_DEV);
+    prod[6] = smh_mul24(smh_gram_key<8 * G + 6>(w, pre), SMH_GRAM_MUL_DEV);
+    prod[7] = smh_mul24(smh_gram_key<8 * G + 7>(w, pre), SMH_GRAM_MUL_DEV);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = smh_lds_u8(tab, addr[j]);
+    for (int j = 0; j < 8; ++j) b[j] = smh_lds_u8(tab, prod[j] >> 15);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) H = smh_flat_push(H, K2 ? (b[j] >> idx[j]) | (b[j] >> idx2[j]) : b[j] >> idx[j]);
+    for (int j = 0; j < 8; ++j) {
+        uint32_t t = b[j] >> smh_flat_idx<12>(prod[j]);
+        if constexpr (K2) t |= b[j] >> smh_flat_idx<9>(prod[j]);
+        H = smh_flat_push(H, t);
+    }
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    /* the groups do not depend on each other except through H, and left to itself the scheduler starts all eight at once:
+     * 128 VGPRs and spills to scratch.  One group's lookups in flight are what the LDS needs. */
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 template <bool K2>
 SMH_LANE void smh_flat_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H0, uint32_t &H1)
@@ -1474,7 +1605,7 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
         if (a < 10) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
             const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
-            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, gmask, k2));
+            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : 2>(key, tab, gmask, k2));
         }
     }
     return S & 0x7Fu;
@@ -1715,22 +1846,25 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
             if (q == 11) fl[1] = smh_gram_flags(T, 24);
             if (q == 15) fl[2] = smh_gram_flags(T, 16);
         }
-    } else if constexpr (KIND == 6) {
-        /* flat byte grams: the columns' bits are collected, the J-in-a-row test runs once on all of them (above) */
+    } else if constexpr (KIND == 6 || KIND == 7) {
+        /* flat byte grams: the columns' bits are collected, the J-in-a-row test runs once on all of them (above).  KIND 7 = the
+         * same with two bits per gram -- a kernel instance of its own: as a wave-uniform branch around two copies of the loop
+         * the compiler hoisted all 64 columns' products in front of the branch (128 VGPRs and spills to scratch) */
         (void)pre0;
         uint32_t H0 = 0, H1 = 0, Hp;
-        if (P.gram_jb > 0) smh_flat_columns<true>(w, pre1, tab, H0, H1); /* wave-uniform: two bits per gram (short patterns) */
-        else smh_flat_columns<false>(w, pre1, tab, H0, H1);
+        smh_flat_columns<KIND == 7>(w, pre1, tab, H0, H1);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         /* the 32 columns in front of the segment: the previous lane's second half; lane 0 of a wave has no neighbour and
          * assumes "all in the set" (a few more columns reach the verify stage, which is exact) */
         Hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #else
-        Hp = smh_flat_history_before(text, a, tab, P.gram_jb > 0);
+        Hp = smh_flat_history_before(text, a, tab, KIND == 7);
 #endif
         const uint64_t msk6 = smh_flat_candidates(Hp, H0, H1, (uint32_t)P.gram_planes);
         if constexpr (smh_stg_regv(STG)) {
             smh_wm_regv_columns<HP>(Q, text, a, msk6, w, halo, P);
+        } else if constexpr (smh_stg_l2(STG)) {
+            smh_wm_l2_columns<smh_stg_l2_maxd(STG)>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk6, P);
         } else if constexpr (STG > 0) {
             smh_wm_stage_columns<STG, QD, true>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk6, w, halo, P);
         } else {
@@ -1813,6 +1947,9 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
     if constexpr (smh_stg_regv(STG)) {
         /* in-register verify: few surviving columns, each hashed by its own lane out of the text registers */
         smh_wm_regv_columns<HP>(Q, text, a, msk, w, halo, P);
+    } else if constexpr (smh_stg_l2(STG)) {
+        /* windows from L2: requested now, hashed after the next chunk's scan, decided after the one after that */
+        smh_wm_l2_columns<smh_stg_l2_maxd(STG)>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, P);
     } else if constexpr (STG > 0) {
         /* staged verify: chunks with many surviving columns hash their windows from an LDS copy of the chunk */
         smh_wm_stage_columns<STG, QD, true>(Q, text, smh_uniform64(a & ~(uint64_t)4095), a, msk, w, halo, P);
@@ -1861,7 +1998,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
     const uint32_t cand_bit = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u;
     uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes)
-                           : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u), KIND == 6 && P.gram_jb > 0), cnt = 0;
+                           : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u), KIND == 7), cnt = 0;
     for (uint64_t e = a; e < end; ++e) {
         uint32_t G = 0u; /* a column without a whole gram in front of it cannot be ruled out */
         if (e + 1 >= q) {
@@ -1877,7 +2014,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
                 G = g;
             } else {
                 const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
-                G = smh_gram_byte_G<KIND == 6 ? 6 : 2>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), KIND == 6 && P.gram_jb > 0);
+                G = smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : 2>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), KIND == 7);
             }
         }
         T = smh_gram_step(T, G);
@@ -1907,6 +2044,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
     Q.matches = 0;
     Q.events = 0;
     Q.po = POS ? po : nullptr;
+    Q.pa_limit = n;
     uint32_t cnt = 0;
     constexpr int HP = smh_stg_hp(STG), HD = 4 * HP; /* 16-byte pieces / dwords of text kept from in front of the chunk */
     [[maybe_unused]] constexpr bool RV = smh_stg_regv(STG);
@@ -1949,7 +2087,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
          * now and looked at after this chunk's scan (by the next flush, or below) */
         if constexpr (RV) smh_wm_pend_issue_rv(Q, P);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        else if (STG > 0) smh_wm_pend_issue<false>(Q, P);
+        else if (STG > 0 && !smh_stg_l2(STG)) smh_wm_pend_issue<false>(Q, P);
 #endif
         if (SMH_PREFETCH && nxt_fast) load(kn, nxt, nxt_halo);
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
@@ -1974,7 +2112,10 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         }
         if constexpr (RV) { if (Q.pend_loaded) smh_wm_pend_finish_rv(Q, text, P); } /* a chunk without a flush of its own */
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-        else if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish<false>(Q, text, P);
+        else if constexpr (smh_stg_l2(STG)) { /* a chunk without survivors of its own still moves the pipeline on */
+            if (!Q.pend_mine && (Q.pend_n || Q.pa_n)) smh_wm_l2_step<smh_stg_l2_maxd(STG)>(Q, text, 0, P, false);
+            Q.pend_mine = 0u;
+        } else if (STG > 0 && Q.pend_loaded) smh_wm_pend_finish<false>(Q, text, P);
 #endif
         if (nxt_fast) {
             if (SMH_PREFETCH) {
@@ -1991,7 +2132,10 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
     }
     if constexpr (RV) smh_wm_pend_finish_rv(Q, text, P);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-    else if (STG > 0) smh_wm_pend_finish<false>(Q, text, P);
+    else if constexpr (smh_stg_l2(STG)) { /* run the pipeline dry */
+        smh_wm_l2_step<smh_stg_l2_maxd(STG)>(Q, text, 0, P, false);
+        smh_wm_l2_step<smh_stg_l2_maxd(STG)>(Q, text, 0, P, false);
+    } else if (STG > 0) smh_wm_pend_finish<false>(Q, text, P);
 #endif
     if (QD) smh_wm_drain(Q, text, P);
     if (events_out) *events_out = Q.events;

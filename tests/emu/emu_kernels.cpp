@@ -282,10 +282,17 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
             total += stg == 5 ? GRAM_CALL(5, 5) : stg == 6 ? GRAM_CALL(5, 6) : GRAM_STG(5);
         else if (wm->gram_kind == SMH_GRAM_OCT)
             total += GRAM_STG(3);
-        else if (wm->gram_kind == SMH_GRAM_FLAT)
-            total += GRAM_STG(6);
-        else
-            total += GRAM_STG(2);
+        else if (wm->gram_kind == SMH_GRAM_FLAT || wm->gram_kind == SMH_GRAM_BYTE) {
+            /* the byte forms: windows from L2 (STG 3 / 4) unless SMH_WM_TUNE says "l2=0", as launch_gram */
+            const char *tn = getenv("SMH_WM_TUNE");
+            const bool l2 = stg > 0 && !(tn && strstr(tn, "l2=0"));
+            if (wm->gram_kind == SMH_GRAM_FLAT && wm->gram_jb > 0) /* two bits per gram: kernel KIND 7 */
+                total += l2 ? (stg == 1 ? GRAM_CALL(7, 3) : GRAM_CALL(7, 4)) : GRAM_STG(7);
+            else if (wm->gram_kind == SMH_GRAM_FLAT)
+                total += l2 ? (stg == 1 ? GRAM_CALL(6, 3) : GRAM_CALL(6, 4)) : GRAM_STG(6);
+            else
+                total += l2 ? (stg == 1 ? GRAM_CALL(2, 3) : GRAM_CALL(2, 4)) : GRAM_STG(2);
+        }
 #undef GRAM_STG
 #undef GRAM_CALL
     }

@@ -155,6 +155,27 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
 
 
 
+@pytest.mark.parametrize("kind,m,p", [(6, 5, 300), (6, 8, 5000), (6, 17, 400), (6, 20, 500), (2, 5, 300), (2, 12, 3000), (2, 17, 300), (2, 33, 200)])
+def test_byte_gram_forms_staged_and_from_l2(kind, m, p, monkeypatch):
+    """The byte forms' two verify modes (round 4: windows from L2, the default; SMH_WM_TUNE="l2=0": the chunk staged in LDS)
+    give the count of the definition; the window request bends dwords the window does not reach back onto its last one."""
+    rng = np.random.RandomState(31 * kind + m)
+    n = 3 * 4096 + 999
+    text = rng.randint(0, 256, size=n).astype(np.uint8)
+    pat = rng.randint(0, 256, size=(p, m)).astype(np.uint8)
+    for i, off in enumerate([0, 300, 640 - m // 2, 4096 - m // 2, 8191, 8192 + 2 * m + 64, 2 * 4096 - 1, 2 * 4096, 3 * 4096 - m, n - m]):
+        text[off:off + m] = pat[(7 * i) % p]
+    want = O.count_bruteforce(pat.reshape(-1), m, p, text)
+    for tune in ("gram=%d" % kind, "gram=%d,l2=0" % kind):
+        monkeypatch.setenv("SMH_WM_TUNE", tune)
+        wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, 256)
+        assert wm.info().gram_kind == kind
+        for blocks in (1, 3):
+            assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want, tune
+        total, pos = E.wm_positions(wm, text, want + 8, 2)
+        assert total == want and len(set(pos.tolist())) == want
+
+
 @pytest.mark.parametrize("m,p", [(5, 300), (5, 20000), (6, 3000), (7, 100), (7, 9000)])
 def test_flat_byte_grams_with_two_bits_per_gram(m, p, monkeypatch):
     """Round 4: patterns of 5..7 bytes may keep TWO bits per gram in the flat Bloom set (a blocked Bloom filter with 8-bit

@@ -425,6 +425,15 @@ def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, monkeypatch):
     assert sorted(out[:want].tolist()) == O.positions_bruteforce(pat.reshape(-1), m, p, text).tolist()
 
 
+@pytest.mark.parametrize("kind,m,p", [(6, 5, 3000), (6, 6, 100000), (6, 8, 30000), (6, 17, 1000), (6, 33, 2000), (2, 5, 3000), (2, 12, 30000),
+                                      (2, 17, 100000), (2, 18, 1000), (2, 33, 2000)])
+def test_byte_gram_forms_with_the_staged_verify_on_the_gpu(kind, m, p, monkeypatch):
+    """Round 4: the byte forms take their survivors' windows from L2 (a two-stage pipeline across chunks, wm_lane.h
+    smh_wm_l2_columns; what the default / hbm_windows / staged / in_registers ids below run for kinds 2 and 6); this is the
+    round-3 staged verify (the chunk copied to LDS) on the same texts."""
+    test_gram_filter_forms_on_the_gpu(kind, 256, m, p, ",l2=0", monkeypatch)
+
+
 @pytest.mark.parametrize("m,p", [(5, 3000), (6, 100000), (7, 100)])
 def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, monkeypatch):
     """the flat form of 5..7-byte patterns with two bits per gram forced (round 4): same text, same checks as below"""
