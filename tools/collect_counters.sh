@@ -16,6 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $BENCH > $OU
 python3 $R/tools/pmc_summary.py $OUT/pmc_sq1 $OUT/pmc_sq2 > $OUT/pmc_sq_summary.txt 2>&1
 python3 $R/tools/make_traffic_json.py $OUT/pmc_fetch $OUT/pmc_write profiles/$TAG > $OUT/hbm_traffic.json 2> $OUT/traffic.err
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
+python3 $R/tools/durations_by_text_size.py $OUT/trace > $OUT/kernel_durations_by_text_size.txt 2>&1
 # keep the merge-back small: the raw per-dispatch CSVs are not needed once summarised
 find $OUT -name "*counter_collection.csv" -size +8M -delete
 find $OUT -name "*kernel_trace.csv" -size +8M -delete
