@@ -186,6 +186,7 @@ void smh_ac_host_free(struct smh_ac *ac)
     if (ac->hv_wm != ac->alt_wm) smh_wm_free(ac->hv_wm); /* one handle may serve both roles */
     smh_wm_free(ac->alt_wm);
     smh_ac_free(ac->flat_ac);
+    smh_ac_free(ac->flat_next);
     ac->magic = 0;
     free(ac);
 }
@@ -496,18 +497,49 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
      * whatever the text, 0.29 ms/GiB.  When the whole automaton fits LDS in that form (K = m: exact, no verify stage) it is
      * kept beside the preferred plan as the engine with a guarantee, and the runtime switches to it when the launches
      * report that the text is of that kind (smh_runtime.hip "adaptive engine"). */
-    static _Thread_local int flat_building = 0; /* the twin is compiled by this very function */
-    if (ac->fixed_length_ok && ac->scan_full_rows && !ac->scan_dense && ac->g_transition && !flat_building && smh_alt_engine_depth <= 1) {
+    /* The same guarantee for a set whose automaton does NOT fit LDS whole: the patterns in trie order cut into the fewest
+     * runs whose own automata do (a run's rows = 1 + the symbols its patterns do not share with their predecessor), one
+     * exact stride-1 image per run, scanned one after the other over the same text -- P launches of 0.27-0.29 ms/GiB
+     * whatever the text, where 1000 patterns of 32 symbols on repeat-rich DNA measured 2.4 ms/GiB through the filter
+     * kernels and 6.0 through the hybrid image (profiles/r04_final/bench.json "skewed").  Up to SMH_FLAT_MAX_PARTS runs;
+     * built from the patterns read back from the goto trie, so that a handle from preproc_ac has it too. */
+    static _Thread_local int flat_building = 0; /* the parts are compiled by this very function */
+    const uint64_t flat_cap_rows = SMH_AC_LDS_BUDGET / ((uint64_t)alphabet * 2u) < 32768u ? SMH_AC_LDS_BUDGET / ((uint64_t)alphabet * 2u) : 32768u;
+    if (ac->fixed_length_ok && !ac->scan_dense && !(ac->scan_exact && !ac->scan_full_rows) && !flat_building && smh_alt_engine_depth <= 1 &&
+        flat_cap_rows > (uint64_t)m + 1 && (uint64_t)ac->rows <= flat_cap_rows * SMH_FLAT_MAX_PARTS) {
         ++flat_building;
         ++smh_alt_engine_depth;
-        struct smh_ac *flat = smh_ac_compile_tables_impl(ac->g_transition, ac->g_supply, ac->g_final, (uint64_t)ac->states,
-                                                         alphabet, m, SMH_AC_REF_NONE);
-        if (flat && (!flat->fixed_length_ok || smh_ac_plan_scan(flat, SMH_AC_LDS_BUDGET, 1, 0) != SMH_OK || !flat->scan_exact ||
-                     flat->scan_full_rows || flat->scan_stride != 1)) {
-            smh_ac_free(flat);
-            flat = NULL;
+        const int *tsrc = ac->g_transition ? ac->g_transition : trans;
+        const unsigned int *fsrc = ac->g_final ? ac->g_final : final;
+        unsigned char *pats = ac_extract_patterns(tsrc, fsrc, ac->g_transition ? ac->states : R, alphabet, m, ac->finals);
+        struct smh_ac *head = NULL, **link = &head;
+        int parts = 0, ok = pats != NULL;
+        for (uint32_t j0 = 0; ok && j0 < ac->finals;) {
+            /* the longest run from j0 whose trie has at most flat_cap_rows nodes */
+            uint64_t rows_run = 1u + (uint64_t)m;
+            uint32_t j1 = j0 + 1;
+            for (; j1 < ac->finals; ++j1) {
+                const unsigned char *a = pats + (size_t)(j1 - 1) * (size_t)m, *b = pats + (size_t)j1 * (size_t)m;
+                int lcp = 0;
+                while (lcp < m && a[lcp] == b[lcp]) ++lcp;
+                if (rows_run + (uint64_t)(m - lcp) > flat_cap_rows) break;
+                rows_run += (uint64_t)(m - lcp);
+            }
+            struct smh_ac *part = ++parts <= SMH_FLAT_MAX_PARTS ? smh_ac_compile_patterns(pats + (size_t)j0 * (size_t)m, m, (int)(j1 - j0), alphabet) : NULL;
+            if (part && (!part->fixed_length_ok || smh_ac_plan_scan(part, SMH_AC_LDS_BUDGET, 1, 0) != SMH_OK || !part->scan_exact ||
+                         part->scan_full_rows || part->scan_stride != 1 || part->scan_dense)) {
+                smh_ac_free(part);
+                part = NULL;
+            }
+            if (!part) { ok = 0; break; }
+            *link = part;
+            link = &part->flat_next;
+            j0 = j1;
         }
-        ac->flat_ac = flat;
+        free(pats);
+        if (!ok) { smh_ac_free(head); head = NULL; parts = 0; }
+        ac->flat_ac = head;
+        ac->flat_parts = head ? parts : 0;
         --smh_alt_engine_depth;
         --flat_building;
     }
@@ -997,6 +1029,7 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_engine = ac->engine_forced >= 0 ? (uint32_t)ac->engine_forced : (ac->alt_wm ? SMH_ALGO_WM : SMH_ALGO_AC);
     out->scan_dense = (uint32_t)ac->scan_dense;
     out->adaptive = (ac->flex_wm || ac->flat_ac) && ac->engine_forced < 0 ? 1u : 0u;
+    out->flat_parts = (uint32_t)ac->flat_parts;
     if (out->scan_engine == SMH_ALGO_WM) {
         smh_wm_info wi;
         if (smh_wm_get_info(ac->alt_wm ? ac->alt_wm : ac->flex_wm, &wi) == SMH_OK) {
@@ -1040,7 +1073,7 @@ int smh_ac_set_scan_engine(smh_ac *ac, int engine)
         return SMH_EINVAL;
     }
     if (engine == SMH_ENGINE_AC_FLAT && !ac->flat_ac) {
-        smh_set_error("smh_ac_set_scan_engine: this set keeps no plain stride-1 automaton (its plan is not a hybrid image, or the whole automaton does not fit LDS)");
+        smh_set_error("smh_ac_set_scan_engine: this set keeps no plain stride-1 automata (its plan is exact and plain already, or more than %d parts would be needed)", SMH_FLAT_MAX_PARTS);
         return SMH_EUNSUP;
     }
     if (engine == SMH_ALGO_WM && !ac->alt_wm && !ac->flex_wm) {

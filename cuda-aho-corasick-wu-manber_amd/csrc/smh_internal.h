@@ -91,7 +91,11 @@ struct smh_ac {
      * the launches report about the text (smh_runtime.hip "adaptive engine").  engine_forced: -1 = let it, else the engine
      * smh_ac_set_scan_engine / a forced plan named */
     struct smh_wm *flex_wm;
-    struct smh_ac *flat_ac; /* a hybrid plan's plain stride-1 twin with K = m when the whole automaton fits LDS that way (ac_host.c, end of the compile): the engine whose speed does not depend on the text */
+    struct smh_ac *flat_ac; /* the engine whose speed does not depend on the text: the set as flat_parts exact stride-1 automata that each fit
+                             * LDS whole (ac_host.c, end of the compile), the first of them; NULL when the plan itself is of that kind or
+                             * more than SMH_FLAT_MAX_PARTS would be needed */
+    struct smh_ac *flat_next; /* in a part: the next part */
+    int flat_parts;
     int engine_forced;
     uint32_t generation;  /* bumped by every re-plan / forced engine: what was prepared or warmed for the handle before is stale */
     uint64_t serial;      /* unique per compiled handle (smh_handle_serial): an address can be reused after a free, a serial cannot */
@@ -127,6 +131,7 @@ void smh_ac_host_free(struct smh_ac *ac);
 /* choose K / stride for an LDS budget and build scan_table (+ trunc1_table); force_stride 0 = auto */
 int smh_ac_plan_scan(struct smh_ac *ac, uint32_t lds_budget, int force_stride, int force_depth);
 #define SMH_AC_LDS_BUDGET (160u * 1024u - 512u)
+#define SMH_FLAT_MAX_PARTS 16 /* passes over the text the text-independent engine may take (0.27-0.29 ms/GiB each) */
 /* engine choices compile a handle of the OTHER kind; while one is being built no further one is (an
  * automaton handle built as a Wu-Manber handle's engine must not build a Wu-Manber engine of its own) */
 #ifdef __cplusplus

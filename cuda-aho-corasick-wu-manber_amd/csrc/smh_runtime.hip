@@ -456,6 +456,8 @@ struct smh_adapt_dev {
     uint32_t reports, flips;
     uint32_t launches;     /* tuned count launches of the handle on this device */
     double mode_density;   /* survivors per column handed to the gram launcher (< 0: the compile's estimate so far) */
+    double slow;           /* the most a text-dependent engine has run over its estimate on this kind of text (>= 1) */
+    int tried[SMH_ENGINES]; /* the engine has reported on this kind of text */
 };
 
 static bool adapt_enabled()
@@ -485,6 +487,7 @@ static int adapt_get(smh_adapt_dev **head, smh_adapt_dev **out)
     return ensure_device_set<smh_adapt_dev>(head, adapt_free_one, [&](smh_adapt_dev *a) -> int {
         a->engine = -1;
         a->mode_density = -1.0;
+        a->slow = 1.0;
         HIP_TRY(hipHostMalloc((void **)&a->h_rec, SMH_STATS_HOST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
         memset(a->h_rec, 0, SMH_STATS_HOST_WORDS * sizeof(unsigned long long));
         smh_scan_stats init = {};
@@ -528,9 +531,11 @@ static void adapt_poll(smh_adapt_dev *A)
     A->last[e][1] = A->last[e][0];
     double t = (double)ticks - SMH_ADAPT_FIXED_TICKS;
     if (t < 0.25 * (double)ticks) t = 0.25 * (double)ticks;
-    A->last[e][0] = t * 1e-5 * (double)(1ull << 30) / (double)bytes; /* 100 MHz ticks -> ms per GiB */
+    const double launches = (double)(((tag >> 8) & 0xFFu) ? ((tag >> 8) & 0xFFu) : 1u); /* the first of that many equal launches reported (ac_flat_launch) */
+    A->last[e][0] = launches * t * 1e-5 * (double)(1ull << 30) / (double)bytes; /* 100 MHz ticks -> ms per GiB */
     A->last_bytes = bytes;
     if (A->n[e] < 2) ++A->n[e];
+    A->tried[e] = 1;
     A->sig[e] = (double)ev * 4096.0 / (double)bytes;
     A->age[e] = 0;
     for (int o = 0; o < SMH_ENGINES; ++o)
@@ -557,10 +562,17 @@ static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int ini
         const double a = A->sig[cur], b = A->ref_sig;
         if (fabs(a - b) > 0.05 && (a > 2.0 * b || b > 2.0 * a)) { /* another kind of text: what the others did on the old one says nothing */
             for (int o = 0; o < SMH_ENGINES; ++o)
-                if (o != cur) A->n[o] = 0;
+                if (o != cur) A->n[o] = 0, A->tried[o] = 0;
             A->ref_sig = a;
+            A->slow = 1.0;
         }
     }
+    /* An estimate is a rate on random text.  Text that slows one text-dependent engine (survivors to verify, lanes deep in
+     * compact rows) slows the other for the same reason -- measured on the non-uniform corpora 5-30 x for the filter
+     * kernels where the hybrid image ran 7-75 x over -- so an engine of that kind that has NOT run on this text yet is
+     * expected to be off by the factor the running one is; the plain stride-1 parts are not (their estimate holds on any
+     * text).  An engine whose measurement was merely forgotten (below) is re-tried at its plain estimate. */
+    if (cur != SMH_ENGINE_AC_FLAT && est[cur] > 0 && c_cur / est[cur] > A->slow) A->slow = c_cur / est[cur];
     int best = -1;
     double c_best = 0, m_best = 1.0;
     for (int o = 0; o < SMH_ENGINES; ++o) {
@@ -570,7 +582,9 @@ static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int ini
             A->n[o] = 0;
             if (A->keep[o] < 4096u) A->keep[o] *= 2u;
         }
-        const double c = A->n[o] > 0 ? adapt_ms(A, o) : est[o], margin = A->n[o] > 0 ? 1.03 : 1.08;
+        double c = A->n[o] > 0 ? adapt_ms(A, o) : est[o];
+        if (A->n[o] == 0 && o != SMH_ENGINE_AC_FLAT && !A->tried[o] && A->slow > 2.0) c *= A->slow;
+        const double margin = A->n[o] > 0 ? 1.03 : 1.08;
         if (best < 0 || c * margin < c_best * m_best) { best = o; c_best = c; m_best = margin; }
     }
     if (best >= 0 && c_best * m_best < c_cur) {
@@ -759,11 +773,20 @@ static int ac_engine_static(const struct smh_ac *ac)
 static struct smh_wm *ac_filter_engine(const struct smh_ac *ac) { return ac->alt_wm ? ac->alt_wm : ac->flex_wm; }
 /* the engine the next tuned scan on the current device runs (positions, info) */
 static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac) && adapt_enabled(); }
+/* the text-independent engine: one exact stride-1 launch per part (ac_host.c, end of the compile) */
+static double ac_flat_ms(const struct smh_ac *ac)
+{
+    double ms = 0.0;
+    for (const struct smh_ac *p = ac->flat_ac; p; p = p->flat_next) ms += smh_ac_plan_ms(p);
+    return ms;
+}
 static void ac_estimates(const struct smh_ac *ac, double est[SMH_ENGINES])
 {
-    est[SMH_ALGO_AC] = smh_ac_plan_ms(ac);
-    est[SMH_ALGO_WM] = ac->flex_wm ? ac->flex_wm->scan_ms_est : 0.0;
-    est[SMH_ENGINE_AC_FLAT] = ac->flat_ac ? smh_ac_plan_ms(ac->flat_ac) : 0.0;
+    /* a verify-bound plan (the compile handed the set to the filter kernels for that reason) is no candidate: on the texts
+     * that slow the filter down it is slower still (8000 patterns: 18-45 ms/GiB against 2.6-6.2, bench "skewed") */
+    est[SMH_ALGO_AC] = ac->alt_wm && ac->scan_cost > SMH_AC_ALT_ENGINE_COST ? 0.0 : smh_ac_plan_ms(ac);
+    est[SMH_ALGO_WM] = ac_filter_engine(ac) ? ac_filter_engine(ac)->scan_ms_est : 0.0;
+    est[SMH_ENGINE_AC_FLAT] = ac_flat_ms(ac);
 }
 static int ac_engine_now(struct smh_ac *ac)
 {
@@ -772,11 +795,19 @@ static int ac_engine_now(struct smh_ac *ac)
     return ac_engine_static(ac);
 }
 
+static int ac_prepare(struct smh_ac *ac, int variant);
+static int ac_flat_prepare(struct smh_ac *ac)
+{
+    int rc = SMH_OK;
+    for (struct smh_ac *p = ac->flat_ac; p && rc == SMH_OK; p = p->flat_next) rc = ac_prepare(p, SMH_VARIANT_TUNED);
+    return rc;
+}
+
 static int ac_prepare(struct smh_ac *ac, int variant)
 {
     const bool both = variant == SMH_VARIANT_TUNED && ac->engine_forced < 0 && ac_adaptive(ac);
     if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ALGO_WM && !both) return wm_prepare(ac_filter_engine(ac), variant);
-    if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_AC_FLAT && !both) return ac_prepare(ac->flat_ac, variant);
+    if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_AC_FLAT && !both) return ac_flat_prepare(ac);
     smh_ac_dev *d = NULL;
     int rc = ac_ensure_device(ac, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = ac_ensure_reference_tables(ac, d);
@@ -785,9 +816,8 @@ static int ac_prepare(struct smh_ac *ac, int variant)
         rc = ac_fill_cold(ac, d, V); /* the hash-verify handle's tables and the kernels' cold context */
     }
     if (rc == SMH_OK && both) { /* any of the engines may serve the next launch */
-        smh_wm_dev *wd = NULL;
-        if (ac->flex_wm) rc = wm_ensure_device(ac->flex_wm, &wd);
-        if (rc == SMH_OK && ac->flat_ac) rc = ac_prepare(ac->flat_ac, variant);
+        if (ac_filter_engine(ac)) rc = wm_prepare(ac_filter_engine(ac), variant);
+        if (rc == SMH_OK) rc = ac_flat_prepare(ac);
         smh_adapt_dev *A = NULL;
         if (rc == SMH_OK) rc = adapt_get(&ac->adapt, &A);
     }
@@ -847,6 +877,28 @@ static int ac_launch_own(struct smh_ac *ac, const unsigned char *d_text, uint64_
     return SMH_OK;
 }
 
+/* the parts of the text-independent engine one after the other into the same count; the first launch reports for all
+ * of them (its duration times the number of parts: a plain stride-1 scan runs at one speed whatever its table) */
+static int ac_flat_launch(struct smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream, smh_stats_arg SA)
+{
+    if (SA.st) SA.tag |= (unsigned int)(ac->flat_parts > 0 ? ac->flat_parts : 1) << 8;
+    for (struct smh_ac *p = ac->flat_ac; p; p = p->flat_next) {
+        const int rc = ac_launch_own(p, d_text, n, d_count, stream, SA);
+        if (rc != SMH_OK) return rc;
+        SA = smh_stats_arg{};
+    }
+    return SMH_OK;
+}
+
+/* the parts append to one output: distinct patterns of one length never share an END column */
+static int ac_flat_positions(struct smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                             uint64_t *d_cursor, void *stream)
+{
+    for (struct smh_ac *p = ac->flat_ac; p; p = p->flat_next)
+        if (const int rc = smh_ac_positions(p, d_text, n, d_positions, capacity, d_cursor, stream); rc != SMH_OK) return rc;
+    return SMH_OK;
+}
+
 extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count, int variant,
                            void *stream)
 {
@@ -870,7 +922,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         int engine = ac_engine_static(ac), rc;
         if (!ac_adaptive(ac)) {
             if (engine == SMH_ALGO_WM) return smh_wm_scan(ac_filter_engine(ac), d_text, n, d_count, SMH_VARIANT_TUNED, stream);
-            if (engine == SMH_ENGINE_AC_FLAT && ac->flat_ac) return ac_launch_own(ac->flat_ac, d_text, n, d_count, stream, smh_stats_arg{});
+            if (engine == SMH_ENGINE_AC_FLAT && ac->flat_ac) return ac_flat_launch(ac, d_text, n, d_count, stream, smh_stats_arg{});
             return ac_launch_own(ac, d_text, n, d_count, stream, smh_stats_arg{});
         }
         smh_adapt_dev *A = NULL;
@@ -885,7 +937,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         }
         const smh_stats_arg SA = adapt_arg(A, n, engine);
         if (engine == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), d_text, n, d_count, stream, SA, adapt_density(A, ac_filter_engine(ac)));
-        if (engine == SMH_ENGINE_AC_FLAT) return ac_launch_own(ac->flat_ac, d_text, n, d_count, stream, SA);
+        if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, d_text, n, d_count, stream, SA);
         return ac_launch_own(ac, d_text, n, d_count, stream, SA);
     }
     if (variant != SMH_VARIANT_TABLE) {
@@ -935,7 +987,7 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
     if (const int engine = ac_engine_now(ac); engine == SMH_ALGO_WM)
         return smh_wm_positions(ac_filter_engine(ac), d_text, n, d_positions, capacity, d_cursor, stream);
     else if (engine == SMH_ENGINE_AC_FLAT)
-        return smh_ac_positions(ac->flat_ac, d_text, n, d_positions, capacity, d_cursor, stream);
+        return ac_flat_positions(ac, d_text, n, d_positions, capacity, d_cursor, stream);
     smh_ac_dev *dv = NULL;
     int rc = ac_ensure_device(ac, &dv);
     if (rc != SMH_OK) return rc;
@@ -1251,6 +1303,12 @@ static int wm_engine_static(const struct smh_wm *wm)
     return wm->alt_ac ? SMH_ALGO_AC : SMH_ALGO_WM;
 }
 static struct smh_ac *wm_automaton_engine(const struct smh_wm *wm) { return wm->alt_ac ? wm->alt_ac : wm->flex_ac; }
+/* the automaton engine's estimate; 0 = kept for its text-independent parts only (wm_host.c, end of the compile) */
+static double wm_flex_ms(const struct smh_wm *wm)
+{
+    if (!wm->flex_ac) return 0.0;
+    return wm->alt_ac == wm->flex_ac || wm->flex_ac->scan_cost <= SMH_WM_FLEX_ENGINE_COST ? smh_ac_plan_ms(wm->flex_ac) : 0.0;
+}
 /* do this path's own kernels report (smh_stats.h)?  All but the pair lookup kernel (exact, m <= 8) */
 static bool wm_reports(const struct smh_wm *wm) { return wm->gram_table || !wm->pair_table; }
 static int wm_engine_now(struct smh_wm *wm)
@@ -1318,15 +1376,14 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
             if ((rc = adapt_get(&wm->adapt, &A)) != SMH_OK) return rc;
             adapt_poll(A);
             if (wm->flex_ac && wm->engine_forced < 0) {
-                const double est[SMH_ENGINES] = {smh_ac_plan_ms(wm->flex_ac), wm->scan_ms_est,
-                                                 wm->flex_ac->flat_ac ? smh_ac_plan_ms(wm->flex_ac->flat_ac) : 0.0};
+                const double est[SMH_ENGINES] = {wm_flex_ms(wm), wm->scan_ms_est, ac_flat_ms(wm->flex_ac)};
                 engine = adapt_choose(A, est, engine);
             } else {
                 A->engine = engine;
             }
         }
         if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine));
-        if (engine == SMH_ENGINE_AC_FLAT) return ac_launch_own(wm->flex_ac->flat_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine));
+        if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine));
         return wm_launch_own(wm, d_text, n, d_count, stream, adapt_arg(wm_reports(wm) ? A : NULL, n, engine), adapt_density(A, wm));
     }
     if (variant != SMH_VARIANT_TABLE) {
@@ -1353,8 +1410,7 @@ extern "C" int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out)
         smh_set_error("smh_wm_get_adapt: bad arguments (set struct_size = sizeof(smh_adapt_info))");
         return SMH_EINVAL;
     }
-    const double est[SMH_ENGINES] = {wm->flex_ac ? smh_ac_plan_ms(wm->flex_ac) : 0.0, wm->scan_ms_est,
-                                     wm->flex_ac && wm->flex_ac->flat_ac ? smh_ac_plan_ms(wm->flex_ac->flat_ac) : 0.0};
+    const double est[SMH_ENGINES] = {wm_flex_ms(wm), wm->scan_ms_est, wm->flex_ac ? ac_flat_ms(wm->flex_ac) : 0.0};
     const int adaptive = wm->flex_ac && wm->engine_forced < 0 && adapt_enabled();
     adapt_report(adapt_find(&wm->adapt), adaptive, wm_engine_static(wm), est, out);
     return SMH_OK;
@@ -1371,7 +1427,7 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
     if (const int engine = wm_engine_now(wm); engine == SMH_ALGO_AC)
         return smh_ac_positions(wm_automaton_engine(wm), d_text, n, d_positions, capacity, d_cursor, stream);
     else if (engine == SMH_ENGINE_AC_FLAT && wm->flex_ac && wm->flex_ac->flat_ac)
-        return smh_ac_positions(wm->flex_ac->flat_ac, d_text, n, d_positions, capacity, d_cursor, stream);
+        return ac_flat_positions(wm->flex_ac, d_text, n, d_positions, capacity, d_cursor, stream);
     smh_wm_dev *dv = NULL;
     int rc = wm_ensure_device(wm, &dv);
     if (rc != SMH_OK) return rc;

@@ -774,7 +774,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
      * leaves this path with a non-exact direct filter -- one LDS lookup per column plus the verify stage,
      * 2.4-2.6 TB/s -- while the automaton kernels, when the set's automaton fits LDS with next to no
      * candidates, run it at 3.5-3.6 TB/s.  Same count either way. */
-    if (alphabet <= 8 && !wm->filter_exact && !wm->pair_table && smh_alt_engine_depth == 0) {
+    if (alphabet <= 32 && !wm->filter_exact && !wm->pair_table && smh_alt_engine_depth == 0) {
         ++smh_alt_engine_depth;
         struct smh_ac *ac = smh_ac_compile_patterns(wm->pat_sorted, m, d, alphabet);
         --smh_alt_engine_depth;
@@ -784,7 +784,9 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         /* round 4: an automaton that is merely SLOWER on random text stays at hand -- a filter's speed is a property of the
          * text (survivors are verified one by one), the automaton's next to none, and the runtime follows what the launches
          * report (smh_runtime.hip "adaptive engine") */
-        if (ac && (wm->alt_ac == ac || (ac->fixed_length_ok && ac->scan_cost <= SMH_WM_FLEX_ENGINE_COST)))
+        /* ... and so does one that is out of the race itself but brought the text-independent engine along (the set as a few
+         * exact stride-1 automata, ac_host.c): that one is the floor under both */
+        if (ac && (wm->alt_ac == ac || (ac->fixed_length_ok && (ac->scan_cost <= SMH_WM_FLEX_ENGINE_COST || ac->flat_ac))))
             wm->flex_ac = ac;
         else
             smh_ac_free(ac);

@@ -24,7 +24,7 @@ VARIANT_TABLE = 1
 ALGO_AC = 0
 ALGO_WM = 1
 ENGINE_AC_FLAT = 2
-ENGINE_NAMES = {0: "automaton kernels", 1: "suffix-filter kernels", 2: "plain stride-1 automaton"}
+ENGINE_NAMES = {0: "automaton kernels", 1: "suffix-filter kernels", 2: "plain stride-1 automata"}
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int)
@@ -44,7 +44,7 @@ class AcInfo(C.Structure):
                 ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
                 ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32),
                 ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32), ("adaptive", C.c_uint32),
-                ("reserved", C.c_uint32 * 7)]
+                ("flat_parts", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class WmInfo(C.Structure):

@@ -159,7 +159,9 @@ typedef struct smh_ac_info {
     uint32_t adaptive;       /* 1: the handle holds both engines and no engine or plan is forced: scan_engine is where every
                               * device starts, and from then on the engine follows what the launches report about the text
                               * (smh_ac_get_adapt) */
-    uint32_t reserved[7];    /* zero; library 0.2 grew this struct -- later fields will come out of here */
+    uint32_t flat_parts;     /* launches of the text-independent engine (SMH_ENGINE_AC_FLAT): the set as that many exact stride-1
+                              * automata that each fit LDS whole, scanned one after the other; 0: the handle keeps none */
+    uint32_t reserved[6];    /* zero; library 0.2 grew this struct -- later fields will come out of here */
 } smh_ac_info;
 
 /* What the library has learned about the text it scans with a handle on the CURRENT device (round 4).  The engine that

@@ -150,3 +150,63 @@ def test_small_launches_and_disabled_adaptation(monkeypatch):
         assert _scan(ac, t, n) == want
     assert ac.adapt().reports == 0  # below 32 MiB a launch is mostly staging and tail: it reports nothing
     ac.close()
+
+
+PART_SETS = [(4, 1000, 32, S.CORPUS_DNA_REPEATS), (4, 3000, 16, S.CORPUS_UNIFORM), (20, 1000, 8, S.CORPUS_SKEWED), (4, 8000, 16, S.CORPUS_DNA_REPEATS)]
+
+
+@pytest.mark.parametrize("sigma,p,m,kind", PART_SETS)
+def test_text_independent_engine_is_kept_in_parts(sigma, p, m, kind):
+    """A set whose automaton does not fit LDS whole keeps the text-independent engine as SEVERAL exact stride-1 automata
+    (ac_host.c, end of the compile); a set that would need more than 16 keeps none, and neither does an exact plain plan."""
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, 1 << 24, 2, kind)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    info = ac.info()
+    assert 2 <= info.flat_parts <= 16 and info.adaptive == 1
+    assert ac.adapt().est_ms_per_gib[S.ENGINE_AC_FLAT] > 0.25 * info.flat_parts
+    ac.set_scan_engine(S.ENGINE_AC_FLAT)
+    assert ac.info().scan_engine == S.ENGINE_AC_FLAT
+    ac.close()
+    if sigma == 4:  # the Wu-Manber entry point holds the same engine through its automaton handle
+        wm = S.WmTables.from_patterns(pat, m, p, sigma)
+        assert wm.info().adaptive == 1 and wm.adapt().est_ms_per_gib[S.ENGINE_AC_FLAT] > 0.5
+        wm.close()
+    big = S.corpus_patterns(24, 20000, 7, 4, 42, 1 << 24, 2)
+    h = S.AcAutomaton.from_patterns(big, 24, 20000, 4)
+    assert h.info().flat_parts == 0
+    h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma,p,m,kind", PART_SETS)
+def test_parts_count_and_positions_equal_the_oracle(sigma, p, m, kind):
+    import torch
+    n = 12 << 20
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, kind)
+    t = _dev_text(n, sigma, kind)
+    host = t[:n].cpu().numpy()
+    want = O.oracle_ac(pat, m, p, sigma, host)[0]
+    assert want > 1000
+    handles = [S.AcAutomaton.from_patterns(pat, m, p, sigma)]
+    if sigma == 4:
+        handles.append(S.WmTables.from_patterns(pat, m, p, sigma))
+    for h in handles:
+        assert _scan(h, t, n) == want  # the compile's engine
+        h.set_scan_engine(S.ENGINE_AC_FLAT)
+        assert _scan(h, t, n) == want
+        assert _scan(h, t, n - 12345) == O.oracle_ac(pat, m, p, sigma, host[:n - 12345])[0]
+        cap = want + 8
+        out = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        cur = torch.zeros(1, dtype=torch.int64, device="cuda")
+        h.positions_device(t.data_ptr(), n, out.data_ptr(), cap, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(cur.item()) == want
+        got = np.sort(out[:want].cpu().numpy())
+        h.set_scan_engine(S.ALGO_WM)  # the filter kernels' positions: the same END columns
+        out2 = torch.zeros(cap, dtype=torch.int64, device="cuda")
+        cur.zero_()
+        h.positions_device(t.data_ptr(), n, out2.data_ptr(), cap, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(cur.item()) == want and np.array_equal(got, np.sort(out2[:want].cpu().numpy()))
+        assert len(np.unique(got)) == want  # distinct patterns of one length never share an END column
+        h.close()

@@ -40,7 +40,8 @@ def timed(h, text, reps):
 
 
 SETS = {"ac1000": ("ac", 4, 1000, (8, 16, 32)), "ac8000": ("ac", 4, 8000, (16, 32)), "wm_long": ("wm", 4, 1000, (16, 32)),
-        "wm_ascii": ("wm", 256, 100000, (8, 12, 20)), "protein": ("ac", 20, 1000, (8, 16))}
+        "wm_ascii": ("wm", 256, 100000, (8, 12, 20)), "protein": ("ac", 20, 1000, (8, 16)), "wm8000": ("wm", 4, 8000, (16, 32)),
+        "wm_protein": ("wm", 20, 1000, (8, 16)), "wm10000": ("wm", 4, 10000, (8, 12))}
 for kind in [int(k) for k in args.kinds.split(",")]:
     for name in args.sets.split(","):
         algo, sigma, p, lengths = SETS[name]
@@ -63,8 +64,6 @@ for kind in [int(k) for k in args.kinds.split(",")]:
                                  ms_per_gib=[round(x, 4) for x in ad.ms_per_gib], events_per_4k=[round(x, 3) for x in ad.events_per_4k],
                                  est=[round(x, 4) for x in ad.est_ms_per_gib], verify_density_x4096=round(ad.verify_density * 4096, 3))
             for eng, label in ((S.ALGO_AC, "automaton"), (S.ALGO_WM, "filter"), (S.ENGINE_AC_FLAT, "flat_automaton")):
-                if algo == "wm" and eng == S.ENGINE_AC_FLAT:
-                    continue
                 try:
                     h.set_scan_engine(eng)
                 except S.SmhError as e:
