@@ -176,6 +176,7 @@ struct smh_wm_launch {
     float gram_lane0;       /* pair form: columns per wave-chunk let through by the assumption made for lane 0 alone */
     int gram_planes;        /* pair form: planes J (2..15) */
     int gram_jb;            /* gram_kind 4 (grouped pairs, mixed-length sets): planes of the short-pattern group */
+    uint32_t sfx_slot_off, sfx_ent_off, sfx_pat_off; /* gram_kind 4: the verify stage's suffix index inside d_gram (byte offsets; 0 = none) */
     int verify_log2;
     const uint32_t *d_verify;
     const uint8_t *d_pat_sorted;

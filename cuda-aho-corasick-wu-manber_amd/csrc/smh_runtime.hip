@@ -1514,6 +1514,7 @@ static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes
     L.n_classes = n_classes; L.d_classes = sdv->d_classes;
     if (wm->gram_kind == SMH_GRAM_PAIR2) { /* grouped pair-gram filter over the full patterns (wm_host.c) */
         L.d_gram = sdv->d_gram; L.gram_kind = wm->gram_kind; L.gram_jb = wm->gram_jb;
+        L.sfx_slot_off = wm->sfx_slot_off; L.sfx_ent_off = wm->sfx_ent_off; L.sfx_pat_off = wm->sfx_pat_off;
     }
     if (po) {
         L.po = *po;

@@ -47,6 +47,11 @@ struct smh_wm_params {
                                           * value G (KIND 1, up to 15 planes); grouped pairs (KIND 4): G_A | G_B << 8 */
     int gram_jb;                         /* grouped pairs: planes of the short-pattern group, 0 = none; pair form: -1 = lane 0 keeps its assumption */
     int gram_planes;                     /* pair form (KIND 1): planes J (2..15), candidate = state bit J-1 clear */
+    /* grouped pairs: the verify stage's suffix index (HBM; wm_host.c smh_wm_build_gram_mixed), NULL = verify class by class */
+    const uint32_t *sfx_slot;            /* [65536] records of eight dwords by the code of the column's last eight symbols: next record + 1 (in
+                                          * sfx_ent), length (0 = empty), first dword of the pattern in sfx_pat, 0, its last 16 bytes END-aligned */
+    const uint32_t *sfx_ent;             /* overflow records, same layout */
+    const uint32_t *sfx_pat;             /* patterns END-aligned in whole dwords, zero-filled in front */
 };
 
 #define SMH_WM_MAX_CLASSES 32 /* distinct lengths of a mixed-length set scanned in one pass */
@@ -192,6 +197,82 @@ SMH_LANE uint32_t smh_wm_verify_any(const uint8_t *text, uint64_t e, const smh_w
     return cnt;
 }
 
+/* The number of DISTINCT patterns of a mixed-length set that end at column e, by the suffix index: the 32 bytes that end
+ * at e come in as nine aligned dwords requested together, the
+ * code of the last eight symbols picks the slot, and every entry of its chain is compared END-aligned, eight dwords at a
+ * time (a pattern longer than 32 bytes that agrees so far is finished byte by byte).  Two dependent trips to the index
+ * whatever the number of length classes.  ALL lanes of the wave call it (the chain loop and the positions append are
+ * wave-wide); `valid` = this lane holds a column; e >= 31 where valid. */
+SMH_LANE void smh_sfx_window(const uint32_t (&d)[9], uint32_t sh, uint32_t (&v)[8])
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        v[k] = __builtin_amdgcn_alignbit(d[k + 1], d[k], sh);
+#else
+        v[k] = (uint32_t)((((uint64_t)d[k + 1] << 32) | d[k]) >> sh);
+#endif
+    }
+}
+/* v[k] = bytes e-31+4k .. e-28+4k of the text */
+SMH_LANE uint32_t smh_wm_sfx_decide(const uint32_t (&v)[8], const uint8_t *text, uint64_t e, bool valid, const smh_wm_params &P, const smh_pos_out *po)
+{
+    /* bytes e-7 .. e are v[6], v[7]; oldest symbol in the highest bits, as wm_host.c packs the patterns' */
+    uint32_t code = 0;
+#pragma unroll
+    for (int k = 6; k < 8; ++k)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) code = (code << 2) | ((v[k] >> (8 * b)) & 3u);
+    const uint32_t *rec = valid ? P.sfx_slot + 8u * (size_t)code : nullptr;
+    uint32_t cnt = 0;
+    while (SMH_WAVE_ANY(rec != nullptr)) {
+        uint32_t hit = 0;
+        if (rec) {
+            const smh_u32x4 h = smh_load16(reinterpret_cast<const uint8_t *>(rec)), q = smh_load16(reinterpret_cast<const uint8_t *>(rec) + 16u);
+            const uint32_t next = h.v[0], L = h.v[1], nd = (L + 3u) >> 2;
+            const uint32_t front = 0xFFFFFFFFu << (8u * ((4u * nd - L) & 3u)); /* the bytes of the pattern's first dword that belong to it: the high ones */
+            uint32_t diff = L == 0u || e + 1u < (uint64_t)L ? 1u : 0u; /* an empty slot; no whole window of this length ends here */
+#pragma unroll
+            for (int j = 0; j < 4; ++j) /* the last 16 bytes, from the record itself */
+                if ((uint32_t)j < nd) {
+                    uint32_t t = v[7 - j];
+                    if ((uint32_t)j == nd - 1u) t &= front;
+                    diff |= t ^ q.v[3 - j];
+                }
+            if (!diff && nd > 4u) { /* a longer pattern whose end agrees: the rest of it */
+                const uint32_t *pp = P.sfx_pat + h.v[2];
+#pragma unroll
+                for (int j = 4; j < 8; ++j)
+                    if ((uint32_t)j < nd) {
+                        uint32_t t = v[7 - j];
+                        if ((uint32_t)j == nd - 1u) t &= front;
+                        diff |= t ^ pp[nd - 1u - (uint32_t)j];
+                    }
+                if (!diff && nd > 8u) {
+                    const uint8_t *pb = reinterpret_cast<const uint8_t *>(pp);
+                    for (uint32_t i = 32; i < L && !diff; ++i) diff = (uint32_t)(text[e - i] ^ pb[4u * nd - 1u - i]);
+                }
+            }
+            hit = diff == 0u ? 1u : 0u;
+            rec = next ? P.sfx_ent + 8u * (size_t)(next - 1u) : nullptr;
+        }
+        cnt += hit;
+        if (po) smh_append_bits(hit, e, *po);
+    }
+    return cnt;
+}
+SMH_LANE uint32_t smh_wm_verify_sfx(const uint8_t *text, uint64_t e, bool valid, const smh_wm_params &P, const smh_pos_out *po)
+{
+    const uint64_t s0 = valid ? e - 31u : 0u;
+    const uint32_t *al = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
+    const uint32_t sh = (uint32_t)(s0 & 3u) * 8u;
+    uint32_t d[9], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = al[j];
+    d[8] = al[sh ? 8 : 7]; /* an aligned window ends in d[7]: nothing past it is touched */
+    smh_sfx_window(d, sh, v);
+    return smh_wm_sfx_decide(v, text, e, valid, P, po);
+}
 /* block hash of the hashed filter: two 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 are
  * full-rate, v_mul_lo_u32 is not).  Keep in sync with smh_wm_block_hash in wm_host.c. */
 SMH_LANE uint32_t smh_wm_block_hash(uint32_t key)
@@ -460,10 +541,14 @@ SMH_LANE void smh_wm_drain(smh_wm_queue &Q, const uint8_t *text, const smh_wm_pa
     if (Q.count == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
     if (P.n_classes) {
-        /* mixed-length set: every surviving column is tried against each length class */
+        /* mixed-length set: every surviving column is looked up in the suffix index, or tried against each length class */
         for (uint32_t base = 0; base < Q.count; base += 64u) {
             const bool valid = base + lane < Q.count;
             const uint64_t e = valid ? Q.slots[base + lane] : Q.slots[0];
+            if (P.sfx_slot && !SMH_WAVE_ANY(valid && e < 31u)) {
+                Q.matches += smh_wm_verify_sfx(text, e, valid, P, Q.po);
+                continue;
+            }
             for (int c = 0; c < P.n_classes; ++c) {
                 const uint32_t hit = valid ? smh_wm_verify_class(text, e, P, c) : 0u;
                 Q.matches += hit;
@@ -501,6 +586,10 @@ SMH_LANE void smh_wm_drain(smh_wm_queue &, const uint8_t *, const smh_wm_params 
 SMH_LANE void smh_wm_emit(smh_wm_queue &Q, const uint8_t *text, const smh_wm_params &P, bool cond, uint64_t e)
 {
     if (!cond) return;
+    if (P.n_classes && P.sfx_slot && e >= 31u) {
+        Q.matches += smh_wm_verify_sfx(text, e, true, P, Q.po);
+        return;
+    }
     if (P.n_classes) {
         for (int c = 0; c < P.n_classes; ++c) {
             const uint32_t hit = smh_wm_verify_class(text, e, P, c);
@@ -1659,33 +1748,45 @@ SMH_LANE void smh_gram2_state_before(const uint8_t *text, uint64_t a, const uint
     }
 }
 
-/* bounds-checked path of the grouped form; only_class >= 0: that class alone (positions mode appends per class) */
-SMH_LANE uint32_t smh_wm_gram2_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const smh_wm_params &P,
-                                         uint64_t *match_mask = nullptr, int only_class = -1)
+/* bounds-checked path of the grouped form (the text's first and last chunks).  Wave-uniform -- all 64 lanes walk their 64
+ * columns in step, a lane past the text's end with nothing to do -- so that a candidate column is decided by the suffix
+ * index like the fast path's (wave-wide chain loop and positions append) instead of class by class: with 25 classes a
+ * candidate cost this path 25 window hashes, buckets and compares one after the other, ~50 us, and the wave that drew
+ * chunk 0 of the headline's mixed set (one candidate in every four steps somewhere among its lanes) ran 0.4 ms behind all
+ * the others -- the whole launch waited for it. */
+SMH_LANE uint32_t smh_wm_gram2_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const smh_wm_params &P, const smh_pos_out *po)
 {
-    if (match_mask) *match_mask = 0;
-    if (a >= n) return 0;
+    if (!SMH_WAVE_ANY(a < n)) return 0;
     uint64_t end = a + SMH_SEG;
     if (end > n) end = n;
-    uint32_t SA, SB, cnt = 0;
-    smh_gram2_state_before(text, a, P.gram_g7, SA, SB);
-    for (uint64_t e = a; e < end; ++e) {
-        uint32_t GA = 0u, GB = 0u; /* a column without a whole gram in front of it cannot be ruled out */
-        if (e + 1 >= 7u) {
-            uint32_t code = 0;
-            for (int i = 6; i >= 0; --i) code = (code << 2) | (text[e - (uint64_t)i] & 3u);
-            uint16_t g;
-            memcpy(&g, P.gram_g7 + 2u * code, 2);
-            GA = g & 0xFFu;
-            GB = g >> 8;
+    uint32_t SA = 0u, SB = 0u, cnt = 0;
+    if (a < n) smh_gram2_state_before(text, a, P.gram_g7, SA, SB);
+    for (uint32_t i = 0; i < SMH_SEG; ++i) {
+        const uint64_t e = a + i;
+        bool cand = false;
+        if (e < end) {
+            uint32_t GA = 0u, GB = 0u; /* a column without a whole gram in front of it cannot be ruled out */
+            if (e + 1 >= 7u) {
+                uint32_t code = 0;
+                for (int k = 6; k >= 0; --k) code = (code << 2) | (text[e - (uint64_t)k] & 3u);
+                uint16_t g;
+                memcpy(&g, P.gram_g7 + 2u * code, 2);
+                GA = g & 0xFFu;
+                GB = g >> 8;
+            }
+            SA = smh_gram_step(SA, GA);
+            SB = smh_gram_step(SB, GB);
+            cand = (!((SA >> 7) & 1u) || (P.gram_jb && !((SB >> (P.gram_jb - 1)) & 1u))) && e + 1 >= (uint64_t)P.m;
         }
-        SA = smh_gram_step(SA, GA);
-        SB = smh_gram_step(SB, GB);
-        const bool cand = !((SA >> 7) & 1u) || (P.gram_jb && !((SB >> (P.gram_jb - 1)) & 1u));
-        if (cand && e + 1 >= (uint64_t)P.m) {
-            const uint32_t hit = only_class >= 0 ? smh_wm_verify_class(text, e, P, only_class) : smh_wm_verify_any(text, e, P);
+        if (!SMH_WAVE_ANY(cand)) continue;
+        if (P.sfx_slot && n >= 64u && !SMH_WAVE_ANY(cand && e < 31u)) {
+            cnt += smh_wm_verify_sfx(text, e, cand, P, po);
+            continue;
+        }
+        for (int c = 0; c < P.n_classes; ++c) { /* a column in the text's first bytes, or no index: class by class */
+            const uint32_t hit = cand ? smh_wm_verify_class(text, e, P, c) : 0u;
             cnt += hit;
-            if (match_mask && hit) *match_mask |= 1ull << (e - a);
+            if (po) smh_append_bits(hit, e, *po);
         }
     }
     return cnt;
@@ -2094,15 +2195,7 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
         if (cur_fast) {
             smh_wm_gram_lane_fast<KIND, POS, STG, QD>(text, a, cur, cur_halo, tab, P, Q);
         } else if constexpr (KIND == 4) {
-            if (POS) { /* a column is appended once per length class that matches there */
-                uint64_t mm;
-                for (int c = 0; c < P.n_classes; ++c) {
-                    smh_wm_gram2_lane_slow(text, n, a, P, &mm, c);
-                    cnt += smh_append_bits(mm, a, *po);
-                }
-            } else {
-                cnt += smh_wm_gram2_lane_slow(text, n, a, P);
-            }
+            cnt += smh_wm_gram2_lane_slow(text, n, a, P, POS ? po : nullptr); /* positions: a column is appended once per pattern that ends there */
         } else if (POS) {
             uint64_t mm;
             smh_wm_gram_lane_slow<KIND>(text, n, a, tab, P, &mm);

@@ -510,6 +510,12 @@ extern "C" uint64_t emu_wm_scan_multi(const smh_wm *suffix, const smh_wm *const 
         P.classes = cls.data();
         P.gram_g7 = (const uint8_t *)suffix->gram_table + SMH_GRAM_BYTES;
         P.gram_jb = suffix->gram_jb;
+        if (suffix->sfx_slot_off && !(getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "sfx=0"))) { /* the verify stage's suffix index, as the launcher sets it */
+            const uint8_t *g = (const uint8_t *)suffix->gram_table;
+            P.sfx_slot = (const uint32_t *)(g + suffix->sfx_slot_off);
+            P.sfx_ent = (const uint32_t *)(g + suffix->sfx_ent_off);
+            P.sfx_pat = (const uint32_t *)(g + suffix->sfx_pat_off);
+        }
         const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
         total = 0;
         for (uint64_t t = 0; t < nthreads; ++t) {

@@ -299,6 +299,70 @@ def test_gpu_grouped_pair_gram_filter_on_random_dna_sets(seed, force, monkeypatc
     ps.close()
 
 
+def _nested_suffix_set(seed=5):
+    """patterns that share their LAST EIGHT symbols -- one slot of the verify stage's suffix index, a chain of records -- some
+    of them suffixes of others (several patterns end at one column), lengths on both sides of 16 and 32 symbols, a duplicate"""
+    rng = np.random.RandomState(seed)
+    n = 3 * 4096 + 777
+    text = rng.randint(0, 4, size=n).astype(np.uint8)
+    long = rng.randint(0, 4, size=45).astype(np.uint8)
+    pats = [long[45 - L:] for L in (8, 9, 12, 16, 17, 31, 32, 33, 40, 45)]       # nested: each a suffix of the next
+    other = rng.randint(0, 4, size=20).astype(np.uint8)
+    other[-8:] = long[-8:]                                                       # same slot, not nested
+    pats += [other, other[3:], other.copy(), rng.randint(0, 4, size=14).astype(np.uint8), rng.randint(0, 4, size=26).astype(np.uint8)]
+    for off in (0, 10, 500, 4096 - 45, 4096 - 20, 4096 + 30, 2 * 4096 - 3, n - 45):
+        text[off:off + 45] = long
+    for off in (100, 4096 - 9, 9000, n - 20):
+        text[off:off + 20] = other
+    text[3:3 + 12] = long[45 - 12:]                                              # a short one in the text's first bytes
+    text[7000:7000 + 14] = pats[-2]
+    text[7100:7100 + 26] = pats[-1]
+    patterns, lengths = np.concatenate(pats), np.array([len(q) for q in pats], dtype=np.uint32)
+    classes = cases.split_classes(patterns, lengths)
+    want_pos = np.sort(np.concatenate([O.positions_bruteforce(classes[L], L, len(classes[L]) // L, text) for L in sorted(classes)]))
+    return text, patterns, lengths, classes, want_pos
+
+
+@pytest.mark.parametrize("tune", ["grouped=force", "grouped=force,sfx=0"], ids=["suffix_index", "class_by_class"])
+def test_suffix_index_chains_nested_and_long_patterns(tune, monkeypatch):
+    text, patterns, lengths, classes, want_pos = _nested_suffix_set()
+    want = len(want_pos)
+    assert want > 50 and len(np.unique(want_pos)) < want  # several patterns end at one column
+    Lmin = min(classes)
+    off, suf = 0, []
+    for L in lengths:
+        suf.append(patterns[off + int(L) - Lmin:off + int(L)])
+        off += int(L)
+    suffix = S.WmTables.from_patterns(np.concatenate(suf), Lmin, len(lengths), 4)
+    handles = [S.WmTables.from_patterns(classes[L], L, len(classes[L]) // L, 4) for L in sorted(classes)]
+    monkeypatch.setenv("SMH_WM_TUNE", tune)
+    assert E.build_gram_mixed(suffix, patterns, lengths) == 0
+    assert E.wm_scan_multi(suffix, handles, text, None, 2) == want
+    total, got = E.wm_scan_multi(suffix, handles, text, want + 3, 3)
+    assert total == want and np.array_equal(np.sort(got).astype(np.int64), want_pos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tune", ["grouped=force", "grouped=force,sfx=0"], ids=["suffix_index", "class_by_class"])
+def test_gpu_suffix_index_chains_nested_and_long_patterns(tune, monkeypatch):
+    import torch
+    text, patterns, lengths, classes, want_pos = _nested_suffix_set()
+    want, n = len(want_pos), len(text)
+    monkeypatch.setenv("SMH_WM_TUNE", tune)
+    ps = S.PatternSet(patterns, lengths, 4, S.ALGO_WM)
+    assert ps.info().one_pass == 1
+    assert ps.count_host(text)[0] == want
+    dev = torch.device("cuda", 0)
+    d_text = torch.zeros(n + 64, dtype=torch.uint8, device=dev)
+    d_text[:n] = torch.from_numpy(text).to(dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    pos = torch.zeros(want + 3, dtype=torch.int64, device=dev)
+    ps.positions_device(d_text.data_ptr(), n, pos.data_ptr(), want + 3, cnt.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == want and np.array_equal(np.sort(pos[:want].cpu().numpy()), want_pos)
+    ps.close()
+
+
 def _wide_dna_set(p=2400, lo=8, hi=40, n=1 << 20, seed=77):
     """thousands of DNA patterns over a wide range of lengths: too many short ones for the grouped filter, too many
     nodes for one automaton in LDS"""
