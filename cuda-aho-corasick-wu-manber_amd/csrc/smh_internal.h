@@ -405,11 +405,12 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
  * get a gram filter at all (m = 5..7 had the 12-VALU blocked-Bloom test), m = 8 a better one; from ten grams on the set is
  * fuller than the planes and SMH_GRAM_BYTE wins.  Costs two VALU more per column than SMH_GRAM_BYTE (bit index, bit). */
 #define SMH_GRAM_FLAT 6
-/* candidates per column above which the grouped form is not used.  Round 4: 0.0005 -> 0.0045.  A candidate is now decided by the
+/* candidates per column above which the grouped form is not used.  Round 4: 0.0005 -> 0.002.  A candidate is now decided by the
  * suffix index (one 32-byte record, wm_host.c smh_wm_build_gram_mixed) instead of one window hash, bucket and compare per length
- * class; measured on 1 GiB (gpurun_out/r04_t): 40 patterns of each length 9..32 (0.0008 per column) 0.231 ms against the joined
- * automaton's 0.291, 8..32 (0.0039) 0.277 against 0.300, 100 of each length 8..16 (0.0099) 0.358 against 0.297 */
-#define SMH_PSET_GROUPED_DENSITY 0.0045
+ * class; measured on 1 GiB (profiles/r04_final/notes/mixed_grouped.log): 40 patterns of each length 9..32 (0.0008 per column)
+ * 0.231 ms against the joined automaton's 0.291, 10..32 (0.00016) 0.233 / 0.294; at 8..32 (0.0039) the two are level (0.273 /
+ * 0.293 in one order of measurement, 0.294 / 0.281 in the other), 100 of each length 8..16 (0.0099) 0.358 against 0.297 */
+#define SMH_PSET_GROUPED_DENSITY 0.002
 #define SMH_GRAM_PAIR2_SPLIT 14 /* patterns at least this long have all eight planes */
 #define SMH_GRAM_BYTES (128u * 1024u)
 /* 24-bit multiplier of the byte-gram index (v_mul_u32_u24).  Round 3: 0xD6E8FF instead of the golden-ratio constant
