@@ -643,6 +643,74 @@ static void adapt_report(const smh_adapt_dev *A, int adaptive, int engine_static
     out->verify_density = A->mode_density;
 }
 
+/* First look at a text (round 4).  The policy above needs a report to act on, so a handle's FIRST launch on a device runs the
+ * compile's choice whatever the text -- on the planted corpus the headline's m = 32 set through the hybrid image: 33 ms for one
+ * GiB that the plain stride-1 parts scan in 0.63.  The first tuned count launch of a handle on a device is synchronous anyway (its
+ * table set goes up with blocking copies), so when it is a long one (1 GiB or more) it looks first: a 1 MiB launch to get the
+ * engine's code and tables resident, then the text's first 256 MiB with a report, waited for.  Three times the estimate or more
+ * means the text is not of the kind the estimates were made on: the other engines scan the same piece (into a scratch count,
+ * twice each: the first launch of an engine runs cold) and the rest of the text goes to whichever measured best.  On ordinary
+ * text that is two short launches and one stream synchronisation more, once per handle and device.  launch(engine, text, n,
+ * count, SA) runs one engine; *done = the bytes whose END columns have been counted when the function returns. */
+#define SMH_FIRST_LOOK_BYTES (256ull << 20) /* a 64 MiB piece is 11 us of streaming: launch overhead and table staging made uniform text look hostile and the engines' figures noise */
+#define SMH_FIRST_LOOK_MIN_TEXT (1ull << 30)
+template <typename LAUNCH>
+static int adapt_first_look(smh_adapt_dev *A, const double est[SMH_ENGINES], int initial, int m, const unsigned char *d_text, uint64_t n,
+                            uint64_t *d_count, void *stream, LAUNCH &&launch, uint64_t *done)
+{
+    *done = 0;
+    if (A->engine >= 0 || n < SMH_FIRST_LOOK_MIN_TEXT || est[initial] <= 0) return SMH_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SMH_OK; }
+    int others = 0;
+    for (int o = 0; o < SMH_ENGINES; ++o) others += o != initial && est[o] > 0;
+    if (!others) return SMH_OK;
+    uint64_t *scratch = reinterpret_cast<uint64_t *>(&A->d_stats->pad[0]); /* device memory nobody else uses */
+    const uint64_t piece = SMH_FIRST_LOOK_BYTES + (uint64_t)(m - 1); /* END columns [m-1, piece) = the starts [0, 256 MiB) */
+    auto probe = [&](int engine, uint64_t *count, uint64_t bytes, bool report) -> int {
+        smh_stats_arg sa = {};
+        if (report) { sa.st = A->d_stats; sa.bytes = bytes; sa.tag = (unsigned int)engine; }
+        int rc = launch(engine, d_text, bytes, count, sa);
+        if (rc != SMH_OK) return rc;
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        adapt_poll(A);
+        return SMH_OK;
+    };
+    int rc;
+    A->engine = initial;
+    ++A->launches;
+    if ((rc = probe(initial, scratch, 1u << 20, false)) != SMH_OK) return rc; /* code and tables resident */
+    if ((rc = probe(initial, d_count, piece, true)) != SMH_OK) return rc;
+    *done = SMH_FIRST_LOOK_BYTES;
+    const double c0 = adapt_ms(A, initial);
+    if (A->n[initial] == 0 || c0 <= 3.0 * est[initial]) return SMH_OK;
+    if (initial != SMH_ENGINE_AC_FLAT && c0 / est[initial] > A->slow) A->slow = c0 / est[initial];
+    for (int o = SMH_ENGINES - 1; o >= 0; --o) { /* the text-independent parts first: the others may be as slow as the first */
+        if (o == initial || est[o] <= 0) continue;
+        if (o != SMH_ENGINE_AC_FLAT && adapt_ms(A, SMH_ENGINE_AC_FLAT) > 0 && est[o] * A->slow > 2.0 * adapt_ms(A, SMH_ENGINE_AC_FLAT)) continue; /* no chance */
+        for (int k = 0; k < 2; ++k)
+            if ((rc = probe(o, scratch, piece, true)) != SMH_OK) return rc;
+    }
+    int best = initial;
+    for (int o = 0; o < SMH_ENGINES; ++o)
+        if (A->n[o] > 0 && adapt_ms(A, o) * 1.03 < adapt_ms(A, best)) best = o;
+    if (best != initial && adapt_ms(A, initial) < 2.0 * adapt_ms(A, best)) {
+        /* a close call against a figure from the device's first busy milliseconds (clocks still ramping: DESIGN 6): the first
+         * engine gets its second launch like the others before it is judged */
+        if ((rc = probe(initial, scratch, piece, true)) != SMH_OK) return rc;
+        best = initial;
+        for (int o = 0; o < SMH_ENGINES; ++o)
+            if (A->n[o] > 0 && adapt_ms(A, o) * 1.03 < adapt_ms(A, best)) best = o;
+    }
+    if (best != initial) {
+        A->engine = best;
+        A->ref_valid = 0;
+        ++A->flips;
+    }
+    A->fresh = 0;
+    return SMH_OK;
+}
+
 /* ------------------------------------------------------------------ AC */
 static void ac_dev_free_one(smh_ac_dev *dev)
 {
@@ -931,6 +999,16 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         if (ac->engine_forced < 0) {
             double est[SMH_ENGINES];
             ac_estimates(ac, est);
+            uint64_t done = 0;
+            rc = adapt_first_look(A, est, engine, ac->m, d_text, n, d_count, stream,
+                                  [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
+                                      if (e == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), t, len, cnt, stream, sa, adapt_density(A, ac_filter_engine(ac)));
+                                      if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, t, len, cnt, stream, sa);
+                                      return ac_launch_own(ac, t, len, cnt, stream, sa);
+                                  }, &done);
+            if (rc != SMH_OK) return rc;
+            d_text += done; /* a multiple of 16 */
+            n -= done;
             engine = adapt_choose(A, est, engine);
         } else {
             A->engine = engine;
@@ -1377,6 +1455,16 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
             adapt_poll(A);
             if (wm->flex_ac && wm->engine_forced < 0) {
                 const double est[SMH_ENGINES] = {wm_flex_ms(wm), wm->scan_ms_est, ac_flat_ms(wm->flex_ac)};
+                uint64_t done = 0;
+                rc = adapt_first_look(A, est, engine, wm->m, d_text, n, d_count, stream,
+                                      [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
+                                          if (e == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), t, len, cnt, stream, sa);
+                                          if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, t, len, cnt, stream, sa);
+                                          return wm_launch_own(wm, t, len, cnt, stream, wm_reports(wm) ? sa : smh_stats_arg{}, adapt_density(A, wm));
+                                      }, &done);
+                if (rc != SMH_OK) return rc;
+                d_text += done;
+                n -= done;
                 engine = adapt_choose(A, est, engine);
             } else {
                 A->engine = engine;

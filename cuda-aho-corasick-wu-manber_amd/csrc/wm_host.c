@@ -825,7 +825,11 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
      * leaves this path with a non-exact direct filter -- one LDS lookup per column plus the verify stage,
      * 2.4-2.6 TB/s -- while the automaton kernels, when the set's automaton fits LDS with next to no
      * candidates, run it at 3.5-3.6 TB/s.  Same count either way. */
-    if (alphabet <= 32 && !wm->filter_exact && !wm->pair_table && smh_alt_engine_depth == 0) {
+    /* (alphabets 9..32 only for the sake of the text-independent parts: not when the set cannot fit SMH_FLAT_MAX_PARTS of them
+     * even if its patterns shared three symbols in four) */
+    const uint64_t flat_rows_cap = (uint64_t)SMH_FLAT_MAX_PARTS * (SMH_AC_LDS_BUDGET / ((uint64_t)alphabet * 2u));
+    if (alphabet <= 32 && (alphabet <= 8 || (uint64_t)d * (uint64_t)m <= 4u * flat_rows_cap) && !wm->filter_exact && !wm->pair_table &&
+        smh_alt_engine_depth == 0) {
         ++smh_alt_engine_depth;
         struct smh_ac *ac = smh_ac_compile_patterns(wm->pat_sorted, m, d, alphabet);
         --smh_alt_engine_depth;

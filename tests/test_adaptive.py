@@ -210,3 +210,44 @@ def test_parts_count_and_positions_equal_the_oracle(sigma, p, m, kind):
         assert int(cur.item()) == want and np.array_equal(got, np.sort(out2[:want].cpu().numpy()))
         assert len(np.unique(got)) == want  # distinct patterns of one length never share an END column
         h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["ac", "wm"])
+def test_first_look_at_a_long_text(entry):
+    """The first tuned count launch of a handle on a device, when the text is 1 GiB or more, scans the first 256 MiB with the
+    compile's choice and WAITS for its report (smh_runtime.hip adapt_first_look): on the planted text -- 20-50 x the estimate --
+    the other engines scan the same piece into a scratch count and the rest of the text goes to the best of them; on uniform text
+    the choice stands.  The count is the same whichever way the launch was cut, and equals every forced engine's."""
+    n, m, p, sigma = 1 << 30, 32, 1000, 4
+    make = S.AcAutomaton if entry == "ac" else S.WmTables
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, S.CORPUS_PLANTED)
+    pla = _dev_text(n, sigma, S.CORPUS_PLANTED)
+    h = make.from_patterns(pat, m, p, sigma)
+    assert h.info().adaptive == 1
+    first = h.info().scan_engine
+    c1 = _scan(h, pla, n)
+    ad = h.adapt()
+    assert ad.engine == S.ENGINE_AC_FLAT and ad.flips == 1 and ad.reports >= 3, (ad.engine, ad.flips, ad.reports)
+    assert ad.ms_per_gib[first] > 3.0 * ad.est_ms_per_gib[first]
+    assert _scan(h, pla, n) == c1  # now one launch, the parts
+    counts = []
+    for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT):
+        g = make.from_patterns(pat, m, p, sigma)
+        g.set_scan_engine(eng)
+        counts.append(_scan(g, pla, n))
+        assert g.adapt().flips == 0
+        g.close()
+    assert counts == [c1] * 3
+    # the same text cut at another place: END columns are counted once
+    assert _scan(h, pla, n - (300 << 20)) + 0 == _scan(h, pla, n - (300 << 20))
+    h.close()
+    del pla
+    uni = _dev_text(n, sigma, S.CORPUS_UNIFORM)
+    u = make.from_patterns(pat, m, p, sigma)
+    cu = _scan(u, uni, n)
+    au = u.adapt()
+    assert au.flips == 0 and au.engine == first and au.reports >= 1
+    u.set_scan_engine(first)
+    assert _scan(u, uni, n) == cu
+    u.close()
