@@ -144,6 +144,29 @@ def run(cases, seed, verbose=True):
                 torch.cuda.synchronize()
                 assert int(cur.item()) == wantset, (tag, "pset positions", algo, lens)
                 checks += 2
+                if algo == S.ALGO_WM and sigma == 4 and lens[0] >= 8:
+                    # the grouped pair-gram form forced whatever its candidate rate, its verify stage by the suffix index and
+                    # class by class: same count, same END columns
+                    ref = np.sort(out[:wantset].cpu().numpy())
+                    for tune in ("grouped=force", "grouped=force,sfx=0"):
+                        os.environ["SMH_WM_TUNE"] = tune
+                        try:
+                            pg = S.PatternSet(mpat, mlen, sigma, algo)
+                        finally:
+                            del os.environ["SMH_WM_TUNE"]
+                        os.environ["SMH_WM_TUNE"] = tune  # the launcher reads the knob too
+                        try:
+                            assert pg.count_host(text)[0] == wantset, (tag, "pset", tune, lens)
+                            cur.zero_()
+                            out.zero_()
+                            pg.positions_device(d_text.data_ptr(), len(text), out.data_ptr(), wantset + 4, cur.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+                            torch.cuda.synchronize()
+                        finally:
+                            del os.environ["SMH_WM_TUNE"]
+                        assert int(cur.item()) == wantset and np.array_equal(np.sort(out[:wantset].cpu().numpy()), ref), (tag, "pset positions", tune, lens)
+                        pg.close()
+                        checks += 2
         checks += 8
         if verbose:
             print(tag, "ok", flush=True)
