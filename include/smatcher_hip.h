@@ -119,9 +119,11 @@ void smh_shard_range(uint64_t n, int n_shards, int shard, int m, uint64_t *begin
 
 #define SMH_ALGO_AC 0
 #define SMH_ALGO_WM 1
-/* a third engine some Aho-Corasick handles keep (round 4): the automaton as a PLAIN stride-1 image with K = m in LDS -- one
- * lookup per symbol whatever the text -- beside a preferred hybrid stride-2 image, whose speed depends on how deep the text
- * keeps its lanes in the trie.  Only smh_ac_set_scan_engine and smh_adapt_info name it. */
+/* a third engine Aho-Corasick handles keep beside a text-dependent plan or engine (round 4): the automaton as PLAIN stride-1
+ * images with K = m in LDS -- one lookup per symbol whatever the text, no verify stage -- the whole set in one image when
+ * it fits, else the patterns cut into up to 16 runs whose own automata fit, scanned one after the other
+ * (smh_ac_info.flat_parts).  A hybrid image's speed depends on how deep the text keeps its lanes in the trie, a filter's on
+ * how many columns survive it; this engine's on nothing.  Only smh_*_set_scan_engine and smh_adapt_info name it. */
 #define SMH_ENGINE_AC_FLAT 2
 #define SMH_ENGINES 3
 
