@@ -737,11 +737,16 @@ def main():
                 h = (S.AcAutomaton if algo == "ac" else S.WmTables).from_patterns(pat, m, p, sigma)
                 launch = lambda: h.scan_device(ktext.data_ptr(), per_gpu, scnt.data_ptr(), S.VARIANT_TUNED, stream)
                 # adaptation: launches with a synchronisation behind each, so that each one's report is read before the next
-                seq = []
-                for _ in range(6):
+                seq, first_ms = [], None
+                for it in range(6):
                     scnt.zero_()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     launch()
+                    e1.record()
                     torch.cuda.synchronize()
+                    if it == 0:  # a fresh handle's first call on this text: table upload aside, the first look
+                        first_ms = e0.elapsed_time(e1)
                     seq.append(int(h.adapt().engine))
                 settled = next((i for i in range(len(seq)) if all(e == seq[-1] for e in seq[i:])), len(seq))
                 ms = sorted(timed(launch, 5, scnt))[2]
@@ -749,7 +754,7 @@ def main():
                 ad = h.adapt()
                 rec = dict(patterns=p, m=m, entry=algo, adaptive=int(h.info().adaptive), compiled_engine=S.ENGINE_NAMES[int(h.info().scan_engine)],
                            chosen=dict(engine=S.ENGINE_NAMES[int(ad.engine)], kernel_ms=round(ms, 4), **rate(per_gpu, ms), flips=int(ad.flips),
-                                       engines_per_launch=seq, launches_before_settled=settled,
+                                       engines_per_launch=seq, launches_before_settled=settled, first_launch_ms=round(first_ms, 3),
                                        events_per_4k=round(ad.events_per_4k[int(ad.engine)], 3)),
                            matches=matches)
                 forced, equal = {}, True
@@ -780,7 +785,9 @@ def main():
             sk[cname] = cobj
         out["skewed"] = dict(workload="the BASELINE pattern shapes on %d MiB of non-uniform text per corpus (csrc/corpus_gen.h), patterns sampled from "
                                       "the text; chosen = the entry point as compiled after 6 launches (the adaptive engine follows the launches' "
-                                      "reports), forced = smh_*_set_scan_engine with every engine the handle holds (the text-independent one = the set as "
+                                      "reports; first_launch_ms = the fresh handle's first scan of this text, device time: over 1 GiB or more it looks at the first 256 MiB "
+                                      "with the compile's choice and, when that runs 3x over its estimate, with the other engines, before the rest is launched), "
+                                      "forced = smh_*_set_scan_engine with every engine the handle holds (the text-independent one = the set as "
                                       "flat_parts exact stride-1 automata scanned one after the other); chosen_vs_best_forced = chosen / the fastest forced" % args.mib_per_gpu,
                              worst_chosen_vs_best_forced=round(worst_ratio, 3), **sk)
 

@@ -28,7 +28,7 @@ if isinstance(sk, dict):
         if not isinstance(sets, dict):
             continue
         for name, r in sets.items():
-            print("   ", corpus, name, "chosen:", r["chosen"]["engine"], r["chosen"]["kernel_ms"], "ms", r["chosen"]["hbm_frac"], "engines per launch", r["chosen"]["engines_per_launch"],
+            print("   ", corpus, name, "chosen:", r["chosen"]["engine"], r["chosen"]["kernel_ms"], "ms", r["chosen"]["hbm_frac"], "first launch", r["chosen"].get("first_launch_ms"), "ms; engines per launch", r["chosen"]["engines_per_launch"],
                   "| forced:", {k: v["kernel_ms"] for k, v in r["forced"].items()}, "| ratio", r.get("chosen_vs_best_forced"), "agree", r["engines_agree"])
 v = d.get("verified")
 if v:
