@@ -76,6 +76,12 @@ def run(cases, seed, verbose=True):
             positions(ac)
             ac.set_scan_engine(-1)
             checks += 2
+        if ac.info().flat_parts:  # the text-independent engine: the set as that many exact stride-1 automata, one launch each
+            ac.set_scan_engine(S.ENGINE_AC_FLAT)
+            assert ac.count_host(text)[0] == want, (tag, "ac flat parts", ac.info().flat_parts)
+            positions(ac)
+            ac.set_scan_engine(-1)
+            checks += 2
         plans = [(1, min(m, 33)), (1, max(1, m // 2)), (1, 2)]
         if sigma == 4:
             plans += [(2, min(m, 33)), (2, max(1, m // 2)), (3, min(m, 33) | (1 << 8)), (3, min(m, 33) | (3 << 8)),
@@ -95,6 +101,14 @@ def run(cases, seed, verbose=True):
             assert wm.count_host(text)[0] == want, (tag, "wm auto", wm.info().scan_engine)
             assert wm.count_host(text, S.VARIANT_TABLE)[0] == want, (tag, "wm table")
             positions(wm)
+            try:  # ... and through the Wu-Manber handle, when it keeps an automaton that brought parts along
+                wm.set_scan_engine(S.ENGINE_AC_FLAT)
+                assert wm.count_host(text)[0] == want, (tag, "wm flat parts")
+                positions(wm)
+                wm.set_scan_engine(-1)
+                checks += 2
+            except S.SmhError:
+                pass
             if wm.info().scan_engine == S.ALGO_AC:
                 wm.set_scan_engine(S.ALGO_WM)
                 assert wm.count_host(text)[0] == want, (tag, "wm own kernels")
