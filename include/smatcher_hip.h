@@ -205,7 +205,10 @@ int smh_ac_set_scan_engine(smh_ac *ac, int engine);
 /* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).
  * d_text must be 16-byte aligned; n may exceed 2^32.  A handle owns one candidate-queue workspace
  * per device: scans of the SAME handle must not overlap in time (use one stream per handle, or
- * one handle per stream). */
+ * one handle per stream).  The FIRST tuned scan of a handle on a device is not asynchronous: it uploads
+ * the handle's tables with blocking copies, and -- a handle with more than one engine (smh_ac_info.adaptive), a
+ * text of 1 GiB or more, no stream capture in progress -- it scans the first 256 MiB and waits for that launch's
+ * report before it commits the rest of the text to an engine (DESIGN.md 3.4 "first look"; SMH_ADAPT=0 turns it off). */
 int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_count,
                 int variant, void *stream);
 /* match positions (the reference only has commented-out printf's, ac/ac.c:217):
