@@ -106,3 +106,26 @@ def test_host_path_rate_and_flat_device_memory():
     S.lib.smh_host_path_release()
     assert torch.cuda.mem_get_info()[0] - free1 > (100 << 20)  # the two 64 MiB piece buffers went back
     ac.close()
+
+
+@pytest.mark.gpu
+def test_engine_flips_between_pieces_of_one_host_call():
+    """A hostile text through the host-pointer path: every 64 MiB piece is a launch that reports, so the engine changes in the
+    MIDDLE of one smh_ac_count_host call (the compile's choice for the first pieces, the plain stride-1 parts after): the count
+    is the forced engines' and the oracle's on a slice."""
+    n, m, p, sigma = 512 << 20, 32, 1000, 4
+    text = S.corpus_text(n, 42, sigma, 0, S.CORPUS_PLANTED)
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, S.CORPUS_PLANTED)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    assert ac.info().adaptive == 1 and ac.info().flat_parts >= 2
+    first = ac.info().scan_engine
+    got = ac.count_host(text)[0]
+    ad = ac.adapt()
+    assert ad.flips >= 1 and ad.engine == S.ENGINE_AC_FLAT and ad.reports >= 3, (ad.flips, ad.engine, ad.reports)
+    assert ad.ms_per_gib[first] > 3.0 * ad.est_ms_per_gib[first]
+    ac.set_scan_engine(S.ENGINE_AC_FLAT)
+    assert ac.count_host(text)[0] == got
+    ac.set_scan_engine(first)
+    assert ac.count_host(text[:96 << 20])[0] == O.oracle_ac(pat, m, p, sigma, text[:96 << 20])[0]
+    ac.close()
+    S.lib.smh_host_path_release()
