@@ -156,3 +156,31 @@ def test_table_sets_of_two_handles_are_built_side_by_side(monkeypatch):
     assert race([c, c]) == 1
     for h in (a, b, c):
         T.smh_wm_free(h)
+
+
+@pytest.mark.gpu
+def test_multi_device_shards_of_a_hostile_text():
+    """Two shards of 1 GiB of the planted text through the native path (rehearsed on one card when there is one): every
+    shard's first launch takes its first look and moves to the plain stride-1 parts on its own (the runtime keeps one
+    adaptive state per device and slot); totals and per-shard counts equal a forced engine's count of the same byte ranges."""
+    n_devices, m, p, sigma = 2, 32, 1000, 4
+    n = 2 << 30
+    text = S.corpus_text(n, 42, sigma, 0, S.CORPUS_PLANTED)
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, S.CORPUS_PLANTED)
+    share = S.device_count() < n_devices
+    mg = S.MultiGpu(n_devices, flags=S.MULTI_SHARE_DEVICE if share else 0)
+    mg.load_text(text, m - 1)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    total, per, secs = mg.ac_count(ac)
+    total2, per2, secs2 = mg.ac_count(ac)
+    assert (total2, list(per2)) == (total, list(per)) and secs2 < secs  # the second call runs the engine the first one settled on
+    ref = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    ref.set_scan_engine(S.ENGINE_AC_FLAT)
+    for r in range(n_devices):
+        b, e = S.shard_range(n, n_devices, r, m)
+        assert per[r] == ref.count_host(text[b:e])[0]
+    assert total == sum(per)
+    ref.close()
+    ac.close()
+    mg.close()
+    S.lib.smh_host_path_release()
