@@ -1086,6 +1086,14 @@ int smh_ac_set_scan_engine(smh_ac *ac, int engine)
     return SMH_OK;
 }
 
+struct smh_ac *smh_ac_flat_part(struct smh_ac *ac, int i)
+{
+    if (!ac || ac->magic != SMH_MAGIC_AC || i < 0) return NULL;
+    struct smh_ac *p = ac->flat_ac;
+    while (p && i-- > 0) p = p->flat_next;
+    return p;
+}
+
 void smh_ac_free(smh_ac *ac)
 {
     if (!ac) return;

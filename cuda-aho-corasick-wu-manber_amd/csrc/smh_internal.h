@@ -367,6 +367,9 @@ void smh_wm_host_free(struct smh_wm *wm);
 /* grouped pair-gram filter over the FULL patterns of a mixed-length set, attached to the set's suffix handle;
  * 0 = built (gram_kind == SMH_GRAM_PAIR2), 1 = not applicable / too many candidates, -1 = out of memory */
 int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns, const uint32_t *lengths, int p_size);
+/* part i of a handle's text-independent engine (smh_ac.flat_ac chain), NULL past the last: internal, bound for the tests --
+ * the CPU suite scans every part with the lane emulator and sums (tests/test_adaptive.py) */
+struct smh_ac *smh_ac_flat_part(struct smh_ac *ac, int i);
 void smh_wm_dev_free(struct smh_wm_dev *dev); /* smh_runtime.hip */
 int smh_wm_prepare_device(struct smh_wm *wm); /* smh_runtime.hip */
 int smh_dev_build_peak(int reset);            /* test hook: most table-set builds in flight together */

@@ -28,6 +28,23 @@ def ac_scan(ac, text, variant=S.VARIANT_TUNED, blocks=0):
     return int(_emu.emu_ac_scan(ac.h, text.ctypes.data_as(S.u8p), len(text), variant, blocks))
 
 
+# ---- the parts of a handle's text-independent engine (csrc/ac_host.c): internal entry point, bound for the tests
+S.lib.smh_ac_flat_part.restype = C.c_void_p
+S.lib.smh_ac_flat_part.argtypes = [C.c_void_p, C.c_int]
+
+
+def ac_scan_flat_parts(ac, text, blocks=0):
+    """-> (sum over the parts of the emulated scan of `text`, number of parts): what SMH_ENGINE_AC_FLAT launches one after the other"""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    total, i = 0, 0
+    while True:
+        part = S.lib.smh_ac_flat_part(ac.h, i)
+        if not part:
+            return total, i
+        total += int(_emu.emu_ac_scan(C.c_void_p(part), text.ctypes.data_as(S.u8p), len(text), S.VARIANT_TUNED, blocks))
+        i += 1
+
+
 def wm_scan(wm, text, variant=S.VARIANT_TUNED, blocks=0):
     text = np.ascontiguousarray(text, dtype=np.uint8)
     return int(_emu.emu_wm_scan(wm.h, text.ctypes.data_as(S.u8p), len(text), variant, blocks))

@@ -177,6 +177,21 @@ def test_text_independent_engine_is_kept_in_parts(sigma, p, m, kind):
     h.close()
 
 
+@pytest.mark.parametrize("sigma,p,m,kind", PART_SETS)
+def test_parts_partition_the_set_emulated(sigma, p, m, kind):
+    """every part scanned by the CPU lane emulator (the kernels' own lane code), summed: the oracle's count of the whole set --
+    no pattern lost or entered twice by the cut into runs"""
+    import emu_lib as E
+    n = 300_000
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, kind)
+    text = S.corpus_text(n, 42, sigma, 0, kind)
+    ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+    got, parts = E.ac_scan_flat_parts(ac, text, 2)
+    assert parts == ac.info().flat_parts >= 2
+    assert got == O.oracle_ac(pat, m, p, sigma, text)[0] > 0
+    ac.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("sigma,p,m,kind", PART_SETS)
 def test_parts_count_and_positions_equal_the_oracle(sigma, p, m, kind):
