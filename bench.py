@@ -720,7 +720,8 @@ def main():
     if not args.no_wm and not args.no_skewed and rank == 0 and world == 1:
         sk = {}
         corpora = [("dna_repeats", S.CORPUS_DNA_REPEATS, 4), ("dna_planted", S.CORPUS_PLANTED, 4),
-                   ("protein_skewed", S.CORPUS_SKEWED, 20), ("ascii_skewed", S.CORPUS_SKEWED, 256)]
+                   ("protein_skewed", S.CORPUS_SKEWED, 20), ("ascii_skewed", S.CORPUS_SKEWED, 256),
+                   ("protein_uniform", S.CORPUS_UNIFORM, 20)]  # the 20-letter alphabet on uniform text: no BASELINE configuration covers it
         shapes = {4: [("ac", AC_PATTERNS, 8), ("ac", AC_PATTERNS, 16), ("ac", AC_PATTERNS, 32), ("wm", WM_PATTERNS, WM_LENGTH),
                       ("ac", C4_PATTERNS, 16), ("ac", C4_PATTERNS, 32)],
                   20: [("ac", AC_PATTERNS, 8), ("ac", AC_PATTERNS, 16), ("wm", WM_PATTERNS, WM_LENGTH)],
@@ -783,8 +784,8 @@ def main():
                 cobj["%s_%d_m%d" % (algo, p, m)] = rec
                 h.close()
             sk[cname] = cobj
-        out["skewed"] = dict(workload="the BASELINE pattern shapes on %d MiB of non-uniform text per corpus (csrc/corpus_gen.h), patterns sampled from "
-                                      "the text; chosen = the entry point as compiled after 6 launches (the adaptive engine follows the launches' "
+        out["skewed"] = dict(workload="the BASELINE pattern shapes on %d MiB of non-uniform text per corpus (csrc/corpus_gen.h; protein_uniform: the 20-letter "
+                                      "alphabet on uniform text), patterns sampled from the text; chosen = the entry point as compiled after 6 launches (the adaptive engine follows the launches' "
                                       "reports; first_launch_ms = the fresh handle's first scan of this text, device time: over 1 GiB or more it looks at the first 256 MiB "
                                       "with the compile's choice and, when that runs 3x over its estimate, with the other engines, before the rest is launched), "
                                       "forced = smh_*_set_scan_engine with every engine the handle holds (the text-independent one = the set as "

@@ -846,7 +846,9 @@ static double ac_flat_ms(const struct smh_ac *ac)
 {
     double ms = 0.0;
     for (const struct smh_ac *p = ac->flat_ac; p; p = p->flat_next) ms += smh_ac_plan_ms(p);
-    return ms;
+    /* the plan model prices an exact stride-1 scan at 0.289 ms/GiB; the parts measure 0.25 each, a set's parts together 0.76-0.90
+     * of the sum (tools/est_check.py on 4- and 20-letter sets of 1 to 11 parts: profiles/r04_final/notes/est_check_*.log) */
+    return 0.87 * ms;
 }
 static void ac_estimates(const struct smh_ac *ac, double est[SMH_ENGINES])
 {
