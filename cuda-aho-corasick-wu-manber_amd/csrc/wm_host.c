@@ -671,7 +671,13 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         uint32_t w = code >> 5, b = 1u << (code & 31);
         if (!(direct[w] & b)) { direct[w] |= b; ++dset; }
     }
-    double direct_density = (double)dset / (double)(1ull << Td);
+    /* ... over the codes a text CAN produce: 4 symbols of a 20-letter alphabet fill 160 000 of the 2^20 five-bit codes, so
+     * 10 000 patterns pass 6 % of the columns, not the 0.95 % the bit count says (round 4: that set kept the direct filter,
+     * 1.02 ms/GiB measured against 0.51 estimated) */
+    double reach = 1.0;
+    for (int i = 0; i < Wd; ++i) reach *= (double)alphabet;
+    if (reach > (double)(1ull << Td)) reach = (double)(1ull << Td);
+    double direct_density = (double)dset / reach;
     int exact = (Wd == m);
     int Wh = 32 / bits;
     if (Wh > m) Wh = m;
