@@ -855,6 +855,21 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         else
             smh_ac_free(ac);
     }
+    /* (round 4) 4-letter sets of 9 or 10 symbols have the EXACT direct filter -- one LDS lookup per column, no verify stage,
+     * 0.28-0.32 ms/GiB whatever the set (tools/est_check.py) -- and no pair table (its index would be 2^20 / 2^22 entries).  While
+     * the set is small enough for an exact automaton image the automaton kernels run it at 0.16-0.26: same mirror-image choice
+     * as above, static (both engines are exact: nothing about the text could change it) */
+    if (alphabet == 4 && wm->filter_exact && !wm->pair_table && !wm->gram_table && m >= 9 && smh_alt_engine_depth == 0) {
+        wm->scan_ms_est = 0.30;
+        ++smh_alt_engine_depth;
+        struct smh_ac *ac = smh_ac_compile_patterns(wm->pat_sorted, m, d, alphabet);
+        --smh_alt_engine_depth;
+        if (ac && ac->fixed_length_ok && ac->scan_exact && !ac->scan_full_rows && smh_ac_plan_ms(ac) + 0.02 < wm->scan_ms_est) {
+            wm->alt_ac = ac; /* not flex_ac: nothing to adapt between two exact engines */
+        } else {
+            smh_ac_free(ac);
+        }
+    }
     return wm;
 
 oom:
