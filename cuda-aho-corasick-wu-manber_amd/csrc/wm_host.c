@@ -791,9 +791,14 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
          * un-pipelined round trip -- for 1 % of the windows; at two per pattern it was 7-14 % of them, which showed as
          * half of the verify stage's time once the first bucket's load was software-pipelined (gpurun_out/r02_aa) */
         int lg = ceil_log2_u32((uint32_t)d * 4u);
-        /* ... while the table stays within 1 MiB: beside the streaming text a 2 MiB table no longer lives in a 4 MiB L2
-         * (100 000 patterns: faster by 6 %, but 1.32x the algorithmic HBM traffic instead of 1.08x) */
-        if (((size_t)4 << lg) > ((size_t)1 << 20)) lg = ceil_log2_u32((uint32_t)d * 2u);
+        /* ... while the table stays within 2 MiB.  (Rounds 2-3 capped it at 1 MiB: beside the streaming text a 2 MiB table no
+         * longer lives in a 4 MiB L2 -- 100 000 patterns 6 % faster with it then, at 1.32x the algorithmic HBM traffic instead of
+         * 1.08x.  Round 4: with the windows from L2 and the first bucket's request pipelined across chunks, a full bucket's second,
+         * un-pipelined trip is what is left exposed -- 2.6 slots per pattern: 7 % of the windows, four: 1 % -- and the same
+         * 2 MiB table is 8-11 % faster, 100 000 byte patterns over 4 GiB 1.53 / 1.26 / 1.20 / 1.21 -> 1.42 / 1.15 / 1.08 / 1.07 ms
+         * at m = 5 / 8 / 12 / 20; 4 MiB: no better.  SMH_WM_TUNE="vt=1m" restores the old cap.) */
+        const size_t vt_cap = getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "vt=1m") ? (size_t)1 << 20 : (size_t)2 << 20;
+        if (((size_t)4 << lg) > vt_cap) lg = ceil_log2_u32((uint32_t)d * 2u);
         if (lg < 4) lg = 4;
         wm->verify_log2 = lg;
         size_t slots = (size_t)1 << lg;
