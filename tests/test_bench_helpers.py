@@ -47,3 +47,27 @@ def test_traffic_is_quoted_per_text_size_and_only_for_the_same_build(monkeypatch
     monkeypatch.setattr(bench, "kernel_build_id", lambda: "another build")
     got, src = bench.measured_traffic(_info(m=8, scan_dense=1), gib)
     assert got is None and "not quoted" in src
+
+
+def test_last_line_is_short_and_carries_roofline_and_cpu_baseline():
+    """The driver parses the LAST stdout line out of an 8 KB tail (round 4's 37.7 KB line came back as parsed = null): the
+    compact line built from a full round-4 record must stay under 4 KB, round-trip through json and hold both objects."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_final", "bench.json")))
+    line = bench.compact_line(rec, "bench_detail.json", "0" * 64)
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT == 4096
+    got = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in got, key
+    assert got["value"] == rec["value"] and got["ms_per_step"] == rec["ms_per_step"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(got["roofline"])
+    assert got["roofline"]["frac"] == rec["roofline"]["frac"] and got["roofline"]["automaton"]["frac"] == rec["roofline"]["automaton"]["frac"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(got["cpu_baseline"])
+    assert got["config"]["workload"] and "model" not in got["config"]
+    assert got["verified"]["all_equal"] is True and got["hbm_frac"]["wm_ascii"]["m5"] == rec["wm_ascii"]["m5"]["hbm_frac"]
+    # a record bloated far beyond anything bench.py writes still yields a parseable short line with the mandatory objects
+    fat = dict(rec)
+    fat["skewed"] = dict(rec["skewed"], **{"corpus%d" % i: rec["skewed"]["dna_repeats"] for i in range(200)})
+    fat["config"] = dict(rec["config"], workload="x" * 5000)
+    line = bench.compact_line(fat, "bench_detail.json", "0" * 64)
+    assert len(line) < 4096 and {"roofline", "cpu_baseline", "value"} <= set(json.loads(line))
