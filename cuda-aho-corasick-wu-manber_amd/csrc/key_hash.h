@@ -1,0 +1,70 @@
+/*
+ * csrc/key_hash.h -- the arithmetic the key engine's host builder (key_host.c) and its lane code (key_lane.h) share.
+ *
+ * The key engine (round 5) is the exact, single-pass, text-independent engine for sets of ONE pattern length m -- what
+ * the reference's API carries (smatcher.h:89-106) -- whose automaton does not fit LDS: the m-symbol window that ends at a
+ * column IS a number of m * bits bits (its KEY: oldest symbol in the highest bits), the pattern set is a set of at most a
+ * few ten thousand such numbers, and "does a pattern end here" is a membership test.  The set lives in LDS as a two-table
+ * cuckoo hash of the keys themselves -- every key sits in slot h1(key) of table 1 or slot h2(key) of table 2 -- so a
+ * column costs two independent LDS reads and two compares whatever the text and whatever the set: no filter, no verify
+ * stage, no survivors.  It answers the same question as ac/ac.c:207-219 does with one state per text symbol.
+ *
+ * Both hashes are built from 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 are full rate on gfx950, v_mul_lo_u32 is
+ * quarter rate).  A set whose keys do not place under the first pair of multipliers is retried under others.
+ */
+#ifndef SMH_KEY_HASH_H
+#define SMH_KEY_HASH_H
+
+#include <stdint.h>
+
+#define SMH_KEY_MAX_BITS 64  /* m * bits_per_symbol of the longest key */
+#define SMH_KEY_TRIES 24     /* multiplier pairs tried before the builder gives up */
+
+struct smh_key_params {
+    int m;
+    int bits;          /* per symbol: 2 (alphabet <= 4) .. 8 */
+    int wide;          /* 0: 32-bit keys (m * bits <= 32), 1: 64-bit keys */
+    uint32_t mask_lo, mask_hi; /* the key's bits in the rolling code */
+    uint32_t mul[4];   /* A1, B1, A2, B2: h_t = (f & 0xFFFFFF) * A_t + ((f >> 8) & 0xFFFFFF) * B_t  (mod 2^32) */
+    uint32_t fold[2];  /* wide keys: f = lo + (hi & 0xFFFFFF) * C + ((hi >> 8) & 0xFFFFFF) * D */
+    uint32_t slots;    /* per table; any number below 65536: slot_t = ((h_t & 0xFFFFFF) * slots) >> 24 (one v_mul_hi_u32_u24 with slots << 8: it takes the low 24 bits of h_t by itself) */
+    uint32_t base2;    /* byte offset of table 2 in the image (table 1 at 0) = slots * slot bytes */
+    uint32_t bytes;    /* the image: both tables, padded to 16 */
+};
+
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+#define SMH_KEY_FN __device__ __forceinline__
+SMH_KEY_FN uint32_t smh_key_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+/* the compiler does not form v_mul_hi_u32_u24 by itself (it takes the quarter-rate v_mul_hi_u32); b is wave-uniform */
+SMH_KEY_FN uint32_t smh_key_mulhi24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+#else
+#define SMH_KEY_FN static inline
+SMH_KEY_FN uint32_t smh_key_mul24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)); }
+SMH_KEY_FN uint32_t smh_key_mulhi24(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) >> 32); }
+#endif
+
+/* 64-bit key -> the 32 bits both hashes are taken from */
+SMH_KEY_FN uint32_t smh_key_fold(uint32_t lo, uint32_t hi, uint32_t c, uint32_t d)
+{
+    return lo + smh_key_mul24(hi, c) + smh_key_mul24(hi >> 8, d);
+}
+SMH_KEY_FN uint32_t smh_key_hash(uint32_t f, uint32_t g /* f >> 8 */, uint32_t a, uint32_t b)
+{
+    return smh_key_mul24(f, a) + smh_key_mul24(g, b);
+}
+/* byte offsets of the key's two slots in the image */
+SMH_KEY_FN void smh_key_slots(uint32_t f, const struct smh_key_params *K, uint32_t *o1, uint32_t *o2)
+{
+    const uint32_t g = f >> 8;
+    const uint32_t h1 = smh_key_hash(f, g, K->mul[0], K->mul[1]), h2 = smh_key_hash(f, g, K->mul[2], K->mul[3]);
+    const uint32_t ns = K->slots << 8, wsh = K->wide ? 3u : 2u;
+    *o1 = smh_key_mulhi24(h1, ns) << wsh;
+    *o2 = (smh_key_mulhi24(h2, ns) << wsh) + K->base2;
+}
+
+#endif

@@ -1,0 +1,197 @@
+/*
+ * csrc/key_lane.h -- lane code of the key engine (key_hash.h): what one lane does with its 64-byte text segment.
+ *
+ * A lane owns the 64 END columns of its segment.  It keeps the code of the last symbols in one or two registers
+ * (code = code << bits | symbol: one v_lshl_or, for 64-bit keys a v_alignbit in front of it), primed with the 16 * HP
+ * bytes in front of the segment -- the previous lane's last registers (DPP wave_shr:1), lane 0 the wave-uniform bytes
+ * in front of the wave-chunk -- and asks for every column: is the key (the code's low m * bits bits) in slot h1(key) of
+ * table 1 or slot h2(key) of table 2?  Two independent LDS reads per column, nothing that depends on what the text is or
+ * on what was found: ac/ac.c:207-219's loop with the state replaced by the window itself.
+ *
+ * Compiled for the GPU (key_kernels.hip) and, with SMH_HOST_EMU, for the CPU lane emulator (tests/emu).
+ */
+#ifndef SMH_KEY_LANE_H
+#define SMH_KEY_LANE_H
+
+#include "lane_common.h"
+#include "wm_lane.h" /* smh_prev_lane_word, smh_lds_u32x2 */
+#include "key_hash.h"
+
+struct smh_key_code { uint32_t lo, hi; };
+
+template <bool WIDE>
+SMH_LANE void smh_key_roll(smh_key_code &c, uint32_t sym, uint32_t bits)
+{
+    if constexpr (WIDE) {
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        c.hi = __builtin_amdgcn_alignbit(c.hi, c.lo, 32u - bits);
+#else
+        c.hi = (c.hi << bits) | (c.lo >> (32u - bits));
+#endif
+    }
+    c.lo = (c.lo << bits) | sym;
+}
+
+/* the key of code c and the byte offsets of its two slots in the image */
+struct smh_key_probe { uint32_t klo, khi, o1, o2; };
+template <bool WIDE>
+SMH_LANE smh_key_probe smh_key_address(const smh_key_code &c, const smh_key_params &K)
+{
+    smh_key_probe p;
+    p.klo = c.lo & K.mask_lo;
+    p.khi = WIDE ? (c.hi & K.mask_hi) : 0u;
+    const uint32_t f = WIDE ? smh_key_fold(p.klo, p.khi, K.fold[0], K.fold[1]) : p.klo;
+    const uint32_t g = f >> 8;
+    const uint32_t h1 = smh_key_hash(f, g, K.mul[0], K.mul[1]), h2 = smh_key_hash(f, g, K.mul[2], K.mul[3]);
+    const uint32_t ns = K.slots << 8;
+    p.o1 = smh_key_mulhi24(h1, ns) << (WIDE ? 3 : 2);
+    p.o2 = (smh_key_mulhi24(h2, ns) << (WIDE ? 3 : 2)) + K.base2;
+    return p;
+}
+/* the two slots' contents */
+struct smh_key_slots2 { uint32_t a0, a1, b0, b1; };
+template <bool WIDE>
+SMH_LANE smh_key_slots2 smh_key_read(const smh_key_probe &p, const void *tab)
+{
+    smh_key_slots2 r = {0u, 0u, 0u, 0u};
+    if constexpr (WIDE) {
+        smh_lds_u32x2(tab, p.o1, r.a0, r.a1);
+        smh_lds_u32x2(tab, p.o2, r.b0, r.b1);
+    } else {
+        r.a0 = smh_lds_u32(tab, p.o1);
+        r.b0 = smh_lds_u32(tab, p.o2);
+    }
+    return r;
+}
+template <bool WIDE>
+SMH_LANE uint32_t smh_key_decide(const smh_key_probe &p, const smh_key_slots2 &r)
+{
+    if constexpr (WIDE) return (((r.a0 ^ p.klo) | (r.a1 ^ p.khi)) == 0u || ((r.b0 ^ p.klo) | (r.b1 ^ p.khi)) == 0u) ? 1u : 0u;
+    return (r.a0 == p.klo || r.b0 == p.klo) ? 1u : 0u;
+}
+/* 1 when the window whose code is c is a pattern.  `tab` = the image (LDS offset 0 on the GPU). */
+template <bool WIDE>
+SMH_LANE uint32_t smh_key_test(const smh_key_code &c, const void *tab, const smh_key_params &K)
+{
+    const smh_key_probe p = smh_key_address<WIDE>(c, K);
+    return smh_key_decide<WIDE>(p, smh_key_read<WIDE>(p, tab));
+}
+
+/* fast path: the 64 END columns of the segment at a (a >= 16 * HP >= m - 1, a + 64 <= n); edge = the 16 * HP bytes in
+ * front of the wave-chunk (wave-uniform), what lane 0 primes with.  The columns go four at a time (one text dword): four
+ * keys and their eight slot addresses, eight LDS reads in flight together, then the eight compares. */
+template <bool WIDE, int HP, bool POS>
+SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&edge)[4 * HP],
+                                    const void *tab, const smh_key_params &K, const smh_pos_out *po)
+{
+    const uint32_t bits = (uint32_t)K.bits;
+    smh_key_code c = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4 * HP; ++q) {
+        const uint32_t pw = smh_prev_lane_word(w[16 - 4 * HP + q], edge[q], text, a - 16u * HP + 4u * q);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) smh_key_roll<WIDE>(c, smh_bfe(pw, 8u * k, bits), bits);
+    }
+    uint32_t cnt = 0, mlo = 0, mhi = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        smh_key_probe p[4];
+        smh_key_slots2 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            smh_key_roll<WIDE>(c, smh_bfe(w[q], 8u * k, bits), bits);
+            p[k] = smh_key_address<WIDE>(c, K);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = smh_key_read<WIDE>(p[k], tab);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t hit = smh_key_decide<WIDE>(p[k], r[k]);
+            if constexpr (POS) {
+                if (q < 8) mlo |= hit << (4 * q + k);
+                else mhi |= hit << (4 * (q - 8) + k);
+            } else {
+                cnt += hit;
+            }
+        }
+    }
+    if constexpr (POS) return smh_append_bits(((uint64_t)mhi << 32) | mlo, a, *po);
+    return cnt;
+}
+
+/* bounds-checked path: the END columns [max(a, m - 1), min(a + 64, n)) byte by byte from memory */
+template <bool WIDE>
+SMH_LANE uint32_t smh_key_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const void *tab, const smh_key_params &K,
+                                    uint64_t *match_mask = nullptr)
+{
+    if (match_mask) *match_mask = 0;
+    if (a >= n) return 0;
+    uint64_t end = a + SMH_SEG;
+    if (end > n) end = n;
+    uint64_t e0 = a;
+    if (e0 < (uint64_t)(K.m - 1)) e0 = (uint64_t)(K.m - 1);
+    if (e0 >= end) return 0;
+    const uint32_t bits = (uint32_t)K.bits, smask = (1u << bits) - 1u;
+    smh_key_code c = {0u, 0u};
+    uint32_t cnt = 0;
+    for (uint64_t i = e0 - (uint64_t)(K.m - 1); i < e0; ++i) smh_key_roll<WIDE>(c, text[i] & smask, bits);
+    for (uint64_t e = e0; e < end; ++e) {
+        smh_key_roll<WIDE>(c, text[e] & smask, bits);
+        const uint32_t hit = smh_key_test<WIDE>(c, tab, K);
+        cnt += hit;
+        if (match_mask && hit) *match_mask |= 1ull << (e - a);
+    }
+    return cnt;
+}
+
+template <bool WIDE, int HP, bool POS>
+SMH_LANE uint32_t smh_key_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n, const void *tab,
+                                 const smh_key_params &K, const smh_pos_out *po = nullptr)
+{
+    if (n < (uint64_t)K.m) return 0;
+    const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
+    const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
+    const uint32_t lane = (uint32_t)(gthread & 63u);
+    uint32_t cnt = 0;
+    uint32_t cur[16], edge[4 * HP];
+    /* chunk 0 has no text in front of it and columns without a whole window; the last chunk may end inside a segment */
+    auto is_fast = [&](uint64_t kk) { return kk >= 1 && kk < n_chunks && (kk + 1) * chunk_bytes <= n; };
+    auto load = [&](uint64_t kk) {
+        const uint64_t base = smh_uniform64(kk * chunk_bytes);
+        const uint8_t *p = text + base + (uint64_t)lane * SMH_SEG;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const smh_u32x4 t = smh_load16(p + 16u * q);
+            cur[4 * q + 0] = t.v[0];
+            cur[4 * q + 1] = t.v[1];
+            cur[4 * q + 2] = t.v[2];
+            cur[4 * q + 3] = t.v[3];
+        }
+#pragma unroll
+        for (int q = 0; q < HP; ++q) { /* the bytes in front of the wave-chunk, same address in every lane */
+            const smh_u32x4 t = smh_load16(text + base - 16u * (uint32_t)(HP - q));
+            edge[4 * q + 0] = t.v[0];
+            edge[4 * q + 1] = t.v[1];
+            edge[4 * q + 2] = t.v[2];
+            edge[4 * q + 3] = t.v[3];
+        }
+    };
+    uint64_t k = S.take(n_chunks);
+    while (k < n_chunks) {
+        const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
+        if (is_fast(k)) {
+            load(k);
+            cnt += smh_key_lane_fast<WIDE, HP, POS>(text, a, cur, edge, tab, K, po);
+        } else if (POS) {
+            uint64_t mm;
+            smh_key_lane_slow<WIDE>(text, n, a, tab, K, &mm);
+            cnt += smh_append_bits(mm, a, *po);
+        } else {
+            cnt += smh_key_lane_slow<WIDE>(text, n, a, tab, K);
+        }
+        k = S.take(n_chunks);
+    }
+    return cnt;
+}
+
+#endif

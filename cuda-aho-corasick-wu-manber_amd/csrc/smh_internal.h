@@ -159,6 +159,32 @@ void smh_adapt_dev_free(struct smh_adapt_dev *list); /* smh_runtime.hip */
 double smh_ac_plan_ms(const struct smh_ac *ac); /* ac_host.c: the plan model's estimate for the automaton kernels, ms per GiB */
 int smh_ac_prepare_device(struct smh_ac *ac); /* smh_runtime.hip: table set of the current device, no launch */
 
+/* ------------------------------------------------------------------ key engine (round 5; key_hash.h, key_host.c, key_lane.h)
+ * The distinct patterns of one length as a two-table cuckoo hash of their keys in LDS: one exact membership test per text
+ * column, no verify stage, a rate that depends neither on the text nor on the set.  Held by an automaton handle
+ * (smh_ac.keys) and by a Wu-Manber handle (smh_wm.keys) as SMH_ENGINE_KEYS whenever the set is one it takes. */
+#define SMH_MAGIC_KEYS 0x4b455953u /* "KEYS" */
+#include "key_hash.h"
+struct smh_keys_dev;
+struct smh_keys {
+    uint32_t magic;
+    int alphabet;
+    int m;
+    uint32_t n_keys;          /* distinct patterns */
+    struct smh_key_params P;
+    void *image;              /* P.bytes: table 1, table 2 */
+    double ms_est;            /* ms per GiB */
+    struct smh_keys_dev *dev; /* per device: the image in device memory (smh_runtime.hip) */
+};
+#define SMH_KEYS_LDS_BUDGET (156u * 1024u)
+#define SMH_KEYS_MS_NARROW 0.40 /* 32-bit keys; placeholders until measured */
+#define SMH_KEYS_MS_WIDE 0.55
+struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p_size, int alphabet, uint32_t lds_budget, const char **why);
+void smh_keys_free(struct smh_keys *k);
+int smh_keys_contains(const struct smh_keys *k, uint64_t key);
+int smh_keys_symbol_bits(int alphabet);
+void smh_keys_dev_free(struct smh_keys_dev *dev); /* smh_runtime.hip */
+
 /* ------------------------------------------------------------------ mixed-length automaton (acm_host.c)
  * One Aho-Corasick automaton with joined (suffix-closed) output COUNTS for a set of patterns of different
  * lengths, cut at depth K for LDS; see acm_host.c for the construction and acm_lane.h for the scan. */

@@ -12,6 +12,7 @@
 #include "wm_lane.h"
 #include "acm_lane.h"
 #include "corpus_gen.h"
+#include "key_hash.h"
 #include "smh_stats.h"
 
 #define SMH_BLOCK_THREADS 1024
@@ -209,6 +210,20 @@ struct smh_wm_table_launch {
 hipError_t smh_launch_wm_table(const smh_wm_table_launch &L, hipStream_t stream);
 hipError_t smh_launch_wm_positions(const smh_wm_table_launch &L, uint64_t *d_positions, uint64_t capacity,
                                    uint64_t *d_cursor, hipStream_t stream);
+
+struct smh_key_launch { /* key engine (key_kernels.hip) */
+    const uint8_t *d_text;
+    uint64_t n;
+    smh_key_params K;
+    const uint32_t *d_image; /* K.bytes */
+    uint64_t *d_count;
+    int n_cus;
+    int wg_per_cu;        /* 0 = the default (one) */
+    smh_pos_out po;       /* positions mode only */
+    smh_stats_arg stats;  /* st != NULL: the launch reports its duration (smh_stats.h) */
+};
+hipError_t smh_launch_keys(const smh_key_launch &L, hipStream_t stream);
+hipError_t smh_launch_keys_positions(const smh_key_launch &L, hipStream_t stream);
 
 hipError_t smh_launch_corpus_text(uint8_t *d_out, uint64_t n, uint64_t offset, uint64_t seed,
                                   int alphabet, hipStream_t stream);

@@ -1695,6 +1695,102 @@ extern "C" int smh_acm_scan(struct smh_acm *a, const unsigned char *d_text, uint
     return SMH_OK;
 }
 
+/* ------------------------------------------------------------------ key engine (key_host.c, key_kernels.hip) */
+struct smh_keys_dev {
+    int device;
+    smh_keys_dev *next;
+    void *d_image;
+};
+
+static void keys_dev_free_one(smh_keys_dev *dev)
+{
+    (void)hipFree(dev->d_image);
+    delete dev;
+}
+
+extern "C" void smh_keys_dev_free(struct smh_keys_dev *dev) /* the whole list */
+{
+    while (dev) {
+        smh_keys_dev *next = dev->next;
+        keys_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+static int keys_ensure_device(struct smh_keys *k, smh_keys_dev **out)
+{
+    return ensure_device_set<smh_keys_dev>(&k->dev, keys_dev_free_one, [&](smh_keys_dev *d) -> int {
+        return upload(&d->d_image, k->image, (size_t)k->P.bytes, 0);
+    }, out);
+}
+
+static int keys_wg_per_cu()
+{
+    static const int v = [] { const char *t = getenv("SMH_KEY_TUNE"); return t && strstr(t, "wg=") ? atoi(strstr(t, "wg=") + 3) : 0; }();
+    return v;
+}
+
+/* one launch over [d_text, d_text + n): END columns counted into *d_count, or appended to po */
+static int keys_launch(struct smh_keys *k, const unsigned char *d_text, uint64_t n, uint64_t *d_count, const smh_pos_out *po,
+                       void *stream, const smh_stats_arg &SA)
+{
+    if (n < (uint64_t)k->m) return SMH_OK;
+    int n_cus = 0, rc;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_keys_dev *dv = NULL;
+    if ((rc = keys_ensure_device(k, &dv)) != SMH_OK) return rc;
+    smh_key_launch L = {};
+    L.d_text = d_text; L.n = n; L.K = k->P; L.d_image = reinterpret_cast<const uint32_t *>(dv->d_image);
+    L.d_count = d_count; L.n_cus = n_cus; L.wg_per_cu = keys_wg_per_cu(); L.stats = SA;
+    if (po) {
+        L.po = *po;
+        HIP_TRY(smh_launch_keys_positions(L, (hipStream_t)stream));
+    } else {
+        HIP_TRY(smh_launch_keys(L, (hipStream_t)stream));
+    }
+    return SMH_OK;
+}
+
+extern "C" int smh_keys_scan(struct smh_keys *k, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream)
+{
+    if (!k || k->magic != SMH_MAGIC_KEYS || !d_count || (n && !d_text) || ((uintptr_t)d_text & 15u) != 0) {
+        smh_set_error("smh_keys_scan: bad arguments (the text must be 16-byte aligned)");
+        return SMH_EINVAL;
+    }
+    return keys_launch(k, d_text, n, d_count, NULL, stream, smh_stats_arg{});
+}
+
+extern "C" int smh_keys_positions(struct smh_keys *k, const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                                  uint64_t *d_cursor, void *stream)
+{
+    if (!k || k->magic != SMH_MAGIC_KEYS || !d_cursor || (capacity && !d_positions) || (n && !d_text) || ((uintptr_t)d_text & 15u) != 0) {
+        smh_set_error("smh_keys_positions: bad arguments (the text must be 16-byte aligned)");
+        return SMH_EINVAL;
+    }
+    const smh_pos_out po = {d_positions, capacity, d_cursor};
+    return keys_launch(k, d_text, n, NULL, &po, stream, smh_stats_arg{});
+}
+
+extern "C" int smh_keys_get_info(const struct smh_keys *k, smh_keys_info *out)
+{
+    if (!k || k->magic != SMH_MAGIC_KEYS || !out || out->struct_size != sizeof *out) {
+        smh_set_error("smh_keys_get_info: bad arguments (set struct_size = sizeof(smh_keys_info))");
+        return SMH_EINVAL;
+    }
+    out->alphabet = (uint32_t)k->alphabet; out->m = (uint32_t)k->m; out->keys = k->n_keys;
+    out->key_bits = (uint32_t)(k->P.m * k->P.bits); out->slot_bytes = k->P.wide ? 8u : 4u; out->slots = k->P.slots;
+    out->lds_bytes = k->P.bytes; out->est_ms_per_gib = k->ms_est;
+    return SMH_OK;
+}
+
+extern "C" struct smh_keys *smh_keys_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet)
+{
+    const char *why = "";
+    struct smh_keys *k = smh_keys_build(pattern_flat, m, p_size, alphabet, SMH_KEYS_LDS_BUDGET, &why);
+    if (!k) smh_set_error("smh_keys_compile_patterns: the key engine does not take this set (%s)", why);
+    return k;
+}
+
 /* ------------------------------------------------------------------ SH */
 struct smh_sh_dev {
     int device;

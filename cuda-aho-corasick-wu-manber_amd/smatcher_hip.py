@@ -24,7 +24,9 @@ VARIANT_TABLE = 1
 ALGO_AC = 0
 ALGO_WM = 1
 ENGINE_AC_FLAT = 2
-ENGINE_NAMES = {0: "automaton kernels", 1: "suffix-filter kernels", 2: "plain stride-1 automata"}
+ENGINE_KEYS = 3
+ENGINES = 4
+ENGINE_NAMES = {0: "automaton kernels", 1: "suffix-filter kernels", 2: "plain stride-1 automata", 3: "key table"}
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int)
@@ -60,8 +62,14 @@ class WmInfo(C.Structure):
 class AdaptInfo(C.Structure):
     """smh_adapt_info: what the adaptive engine knows about the text on the current device"""
     _fields_ = [("struct_size", C.c_uint32), ("adaptive", C.c_uint32), ("engine", C.c_uint32), ("flips", C.c_uint32),
-                ("reports", C.c_uint32), ("reserved", C.c_uint32), ("ms_per_gib", C.c_double * 3),
-                ("events_per_4k", C.c_double * 3), ("est_ms_per_gib", C.c_double * 3), ("verify_density", C.c_double)]
+                ("reports", C.c_uint32), ("reserved", C.c_uint32), ("ms_per_gib", C.c_double * ENGINES),
+                ("events_per_4k", C.c_double * ENGINES), ("est_ms_per_gib", C.c_double * ENGINES), ("verify_density", C.c_double)]
+
+
+class KeysInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("alphabet", C.c_uint32), ("m", C.c_uint32), ("keys", C.c_uint32),
+                ("key_bits", C.c_uint32), ("slot_bytes", C.c_uint32), ("slots", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("est_ms_per_gib", C.c_double)]
 
 
 class PsetInfo(C.Structure):
@@ -109,7 +117,8 @@ EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_dev
                "smh_ac_free", "smh_wm_compile", "smh_wm_compile_tables", "smh_wm_get_info", "smh_wm_set_scan_engine",
                "smh_wm_scan", "smh_wm_count_host", "smh_wm_free", "smh_pset_compile", "smh_pset_get_info",
                "smh_pset_get_class", "smh_pset_scan", "smh_pset_positions", "smh_pset_count_host",
-               "smh_pset_free", "smh_sh_compile_tables", "smh_sh_compile_patterns", "smh_sh_get_info",
+               "smh_pset_free", "smh_keys_compile_patterns", "smh_keys_get_info", "smh_keys_scan", "smh_keys_positions", "smh_keys_free",
+               "smh_sh_compile_tables", "smh_sh_compile_patterns", "smh_sh_get_info",
                "smh_sh_valid_bmbc", "smh_sh_scan", "smh_sh_count_host", "smh_sh_free", "smh_sbom_compile_tables",
                "smh_sbom_compile_patterns", "smh_sbom_get_info", "smh_sbom_scan", "smh_sbom_count_host", "smh_sbom_free",
                "smh_sog_compile_tables", "smh_sog_scan", "smh_sog_count_host", "smh_sog_free",
@@ -447,6 +456,42 @@ class WmTables:
     def close(self):
         if self.h:
             lib.smh_wm_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KeyTable:
+    """smh_keys handle: the key engine by itself (one exact hash-set lookup per text column)."""
+
+    def __init__(self, pat_flat, m, p, alphabet):
+        a, ptr = _u8(pat_flat)
+        lib.smh_keys_compile_patterns.restype = C.c_void_p
+        h = lib.smh_keys_compile_patterns(ptr, m, p, alphabet)
+        if not h:
+            raise SmhError("key engine: %s" % lib.smh_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def info(self):
+        out = KeysInfo(struct_size=C.sizeof(KeysInfo))
+        _check(lib.smh_keys_get_info(self.h, C.byref(out)), "smh_keys_get_info")
+        return out
+
+    def scan_device(self, d_text_ptr, n, d_count_ptr, stream=None):
+        _check(lib.smh_keys_scan(self.h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_void_p(d_count_ptr), C.c_void_p(stream or 0)), "smh_keys_scan")
+
+    def positions_device(self, d_text_ptr, n, d_positions_ptr, capacity, d_cursor_ptr, stream=None):
+        _check(lib.smh_keys_positions(self.h, C.c_void_p(d_text_ptr), C.c_uint64(n), C.c_void_p(d_positions_ptr), C.c_uint64(capacity),
+                                      C.c_void_p(d_cursor_ptr), C.c_void_p(stream or 0)), "smh_keys_positions")
+
+    def close(self):
+        if self.h:
+            lib.smh_keys_free.argtypes = [C.c_void_p]
+            lib.smh_keys_free(self.h)
             self.h = None
 
     def __del__(self):

@@ -125,7 +125,15 @@ void smh_shard_range(uint64_t n, int n_shards, int shard, int m, uint64_t *begin
  * (smh_ac_info.flat_parts).  A hybrid image's speed depends on how deep the text keeps its lanes in the trie, a filter's on
  * how many columns survive it; this engine's on nothing.  Only smh_*_set_scan_engine and smh_adapt_info name it. */
 #define SMH_ENGINE_AC_FLAT 2
-#define SMH_ENGINES 3
+/* a fourth engine (round 5), held by Aho-Corasick and Wu-Manber handles alike: the KEY engine.  All patterns of a run have
+ * ONE length m (smatcher.h:89-106), so the window that ends at a column is a number of m * bits bits and the set is a set
+ * of such numbers: it lives in LDS as a two-table cuckoo hash of the keys themselves and every column is one exact
+ * membership test -- two independent LDS reads, two compares -- in ONE pass, with no verify stage and a rate that depends
+ * neither on the text nor on the patterns.  Taken by sets with m * bits <= 64 (alphabet 4: m <= 32; 20 letters: m <= 12;
+ * bytes: m <= 8) whose keys fit 156 KiB of LDS at half load (about 18 000 keys of 32 bits, 9 000 of 64);
+ * smh_*_info.key_slots says whether the handle holds it. */
+#define SMH_ENGINE_KEYS 3
+#define SMH_ENGINES 4
 
 /* ---- Aho-Corasick ---- */
 typedef struct smh_ac smh_ac;
@@ -382,6 +390,29 @@ int smh_sbom_scan(smh_sbom *sb, const unsigned char *d_text, uint64_t n, uint64_
 int smh_sbom_count_host(smh_sbom *sb, const unsigned char *text, uint64_t n, int variant, uint64_t *count,
                         double *kernel_seconds);
 void smh_sbom_free(smh_sbom *sb);
+
+/* ---- the key engine by itself (round 5; what SMH_ENGINE_KEYS runs inside smh_ac / smh_wm handles) ----
+ * count = |{ e in [m-1, n) : text[e-m+1 .. e] in set(patterns) }|, the quantity of search_ac / search_wu (ac/ac.c:198-222,
+ * wu/wu.c:49-107), by an exact hash-set lookup per column.  NULL (smh_last_error says why) when the set is not one the
+ * engine takes: m * ceil(log2 alphabet) > 64, or more distinct patterns than two tables in LDS hold. */
+typedef struct smh_keys smh_keys;
+typedef struct smh_keys_info {
+    uint32_t struct_size;  /* in: sizeof(smh_keys_info) */
+    uint32_t alphabet, m;
+    uint32_t keys;         /* distinct patterns */
+    uint32_t key_bits;     /* m * bits per symbol */
+    uint32_t slot_bytes;   /* 4 or 8 */
+    uint32_t slots;        /* per table (two tables) */
+    uint32_t lds_bytes;    /* the image */
+    double est_ms_per_gib;
+} smh_keys_info;
+smh_keys *smh_keys_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
+int smh_keys_get_info(const smh_keys *k, smh_keys_info *out);
+/* asynchronous, same contract as smh_ac_scan (16-byte aligned device text, *d_count is added to) */
+int smh_keys_scan(smh_keys *k, const unsigned char *d_text, uint64_t n, uint64_t *d_count, void *stream);
+int smh_keys_positions(smh_keys *k, const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                       uint64_t *d_cursor, void *stream);
+void smh_keys_free(smh_keys *k);
 
 /* ---- pattern sets with mixed lengths ----
  * The reference API carries ONE pattern length per run (preproc_ac / preproc_wu take a single m;

@@ -589,3 +589,48 @@ extern "C" uint64_t emu_sog_scan(const smh_sog *sg, const uint8_t *text_in, uint
     }
     return result[0] == result[1] ? result[0] : ~0ull;
 }
+
+/* ------------------------------------------------------------------ key engine (csrc/key_lane.h) */
+#include "key_lane.h"
+template <bool WIDE, int HP>
+static uint64_t keys_grid(const smh_keys *k, const uint8_t *text, uint64_t n, uint64_t blocks, uint64_t *out, uint64_t capacity, uint64_t *cursor)
+{
+    const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
+    uint64_t total = 0;
+    smh_pos_out po{out, capacity, cursor};
+    for (uint64_t t = 0; t < nthreads; ++t) {
+        const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
+        if (cursor) smh_key_thread<WIDE, HP, true>(t, S, text, n, k->image, k->P, &po);
+        else total += smh_key_thread<WIDE, HP, false>(t, S, text, n, k->image, k->P, nullptr);
+    }
+    return cursor ? *cursor : total;
+}
+static uint64_t keys_any(const smh_keys *k, const uint8_t *text, uint64_t n, uint64_t blocks, uint64_t *out, uint64_t capacity, uint64_t *cursor)
+{
+    const bool hp2 = k->P.m - 1 > 16;
+    if (k->P.wide) return hp2 ? keys_grid<true, 2>(k, text, n, blocks, out, capacity, cursor) : keys_grid<true, 1>(k, text, n, blocks, out, capacity, cursor);
+    return hp2 ? keys_grid<false, 2>(k, text, n, blocks, out, capacity, cursor) : keys_grid<false, 1>(k, text, n, blocks, out, capacity, cursor);
+}
+/* count; the text once ending at and once starting behind a guard page (both results must agree: ~0 if not) */
+extern "C" uint64_t emu_keys_scan(const smh_keys *k, const uint8_t *text_in, uint64_t n, uint32_t blocks)
+{
+    if (n < (uint64_t)k->m) return 0;
+    if (!blocks) blocks = 3;
+    uint64_t result[2];
+    for (int mode = 0; mode < 2; ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        result[mode] = keys_any(k, g.text, n, blocks, nullptr, 0, nullptr);
+        guard_free(g);
+    }
+    return result[0] == result[1] ? result[0] : ~0ull;
+}
+extern "C" uint64_t emu_keys_positions(const smh_keys *k, const uint8_t *text_in, uint64_t n, uint64_t *out, uint64_t capacity, uint32_t blocks)
+{
+    if (n < (uint64_t)k->m) return 0;
+    if (!blocks) blocks = 2;
+    guarded g = guard_copy(text_in, n, 0);
+    uint64_t cursor = 0;
+    keys_any(k, g.text, n, blocks, out, capacity, &cursor);
+    guard_free(g);
+    return cursor;
+}

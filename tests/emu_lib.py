@@ -178,3 +178,21 @@ def sog_scan(sg, text, blocks=0):
     """the table-walking SOG lane code (sog_lane.h) over the handle's tables"""
     text = np.ascontiguousarray(text, dtype=np.uint8)
     return int(_emu.emu_sog_scan(sg.h, text.ctypes.data_as(S.u8p), len(text), blocks))
+
+
+_emu.emu_keys_scan.restype = C.c_uint64
+_emu.emu_keys_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.c_uint32]
+_emu.emu_keys_positions.restype = C.c_uint64
+_emu.emu_keys_positions.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32]
+
+
+def keys_scan(keys, text, blocks=0):
+    """the key engine's lane code (csrc/key_lane.h) over `text`; `keys` = smatcher_hip.KeyTable"""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    got = int(_emu.emu_keys_scan(keys.h, text.ctypes.data_as(S.u8p), len(text), blocks))
+    assert got != 0xFFFFFFFFFFFFFFFF, "the two guard-page placements of the text disagree"
+    return got
+
+
+def keys_positions(keys, text, capacity, blocks=0):
+    return _positions(_emu.emu_keys_positions, keys.h, text, capacity, blocks)

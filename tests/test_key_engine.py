@@ -1,0 +1,134 @@
+"""The key engine (round 5; csrc/key_hash.h, key_host.c, key_lane.h, key_kernels.hip): the patterns of ONE length as a two-table
+cuckoo hash of their keys in LDS, one exact membership test per text column.
+
+CPU: the host builder and the kernels' lane code (compiled for the CPU, tests/emu) against the oracle's search_ac restatement and
+a brute-force count on every alphabet / length class the engine takes, tiling edges included.  GPU (-m gpu): the real kernels
+through the C ABI against the same, the reference's golden vectors, and the engine forced inside smh_ac / smh_wm handles."""
+import numpy as np
+import pytest
+
+import emu_lib as E
+import oracle_lib as O
+import smatcher_hip as S
+
+# (alphabet, m, patterns): 32-bit keys, 64-bit keys, every symbol width, the halo classes (m - 1 <= 16 / <= 32), key widths that fill the slot
+SETS = [(4, 3, 10), (4, 8, 100), (4, 16, 1000), (4, 17, 300), (4, 32, 500), (2, 16, 40), (8, 10, 200), (8, 21, 100), (20, 6, 300),
+        (20, 8, 500), (20, 12, 200), (128, 4, 300), (128, 9, 100), (256, 3, 50), (256, 4, 1000), (256, 5, 400), (256, 8, 2000), (16, 16, 100)]
+
+
+def _text_and_patterns(sigma, m, p, n, seed=42):
+    text = O.gen_text(n, seed, sigma)
+    pat = O.gen_patterns_mixed(m, p, 7, sigma, seed, n, 2)  # every second pattern is a substring of the text
+    return text, pat
+
+
+@pytest.mark.parametrize("sigma,m,p", SETS)
+def test_builder_holds_exactly_the_set(sigma, m, p):
+    text, pat = _text_and_patterns(sigma, m, p, 1 << 14)
+    k = S.KeyTable(pat, m, p, sigma)
+    info = k.info()
+    pats = np.asarray(pat, dtype=np.uint8).reshape(p, m)
+    assert info.keys == len({bytes(r) for r in pats})
+    assert info.key_bits == m * max(2, int(np.ceil(np.log2(sigma)))) and info.slot_bytes == (8 if info.key_bits > 32 else 4)
+    assert info.keys <= 0.485 * 2 * info.slots and info.lds_bytes <= 156 * 1024
+    k.close()
+
+
+@pytest.mark.parametrize("sigma,m,p", SETS)
+def test_lane_code_counts_what_search_ac_counts(sigma, m, p):
+    # 3 wave-chunks and a ragged tail: chunk 0 and the last chunk take the bounds-checked path, the middle one the register path
+    n = 3 * 4096 + 1234
+    text, pat = _text_and_patterns(sigma, m, p, n)
+    want = O.count_bruteforce(pat, m, p, text)
+    assert want > 0
+    k = S.KeyTable(pat, m, p, sigma)
+    assert E.keys_scan(k, text) == want
+    assert E.keys_scan(k, text, blocks=1) == want
+    k.close()
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 63, 64, 65, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 12289])
+def test_text_length_edges(n):
+    sigma, m, p = 4, 8, 64
+    text, pat = _text_and_patterns(sigma, m, p, max(n, 64))
+    text = text[:n]
+    k = S.KeyTable(pat, m, p, sigma)
+    assert E.keys_scan(k, text) == O.count_bruteforce(pat, m, p, text)
+    k.close()
+
+
+def test_matches_across_every_lane_and_chunk_boundary():
+    """a text that is ONE pattern repeated: every column from m - 1 on ends a match, across segment, wave-chunk and workgroup edges"""
+    for sigma, m in ((4, 16), (4, 32), (256, 8), (20, 12)):
+        unit = O.gen_text(m, 5, sigma)
+        text = np.tile(unit, (5 * 4096) // m + 2)[:5 * 4096 + 77]
+        rot = np.concatenate([np.roll(unit, -r) for r in range(m)])  # all rotations of the unit
+        k = S.KeyTable(rot, m, m, sigma)
+        assert E.keys_scan(k, text) == len(text) - m + 1 == O.count_bruteforce(rot, m, m, text)
+        k.close()
+
+
+def test_agrees_with_the_restated_search_ac_and_search_wu():
+    for sigma, m, p in ((4, 8, 100), (4, 16, 300), (256, 8, 200)):
+        text, pat = _text_and_patterns(sigma, m, p, 1 << 15)
+        want, _ = O.oracle_ac(pat, m, p, sigma, text)
+        k = S.KeyTable(pat, m, p, sigma)
+        assert E.keys_scan(k, text) == want
+        if sigma in (4, 256):
+            assert O.oracle_wu(pat, m, p, sigma, text)[0] == want
+        k.close()
+
+
+def test_positions_are_the_end_columns():
+    sigma, m, p, n = 4, 12, 200, 3 * 4096 + 100
+    text, pat = _text_and_patterns(sigma, m, p, n)
+    want = np.asarray(O.positions_bruteforce(pat, m, p, text), dtype=np.uint64)
+    k = S.KeyTable(pat, m, p, sigma)
+    total, got = E.keys_positions(k, text, len(want) + 8)
+    assert total == len(want) and np.array_equal(np.sort(got), np.sort(want))
+    k.close()
+
+
+def test_a_key_that_fills_its_slot_never_matches_a_free_slot():
+    """m * bits == 32 / 64: every slot value is a possible key, so free slots hold keys that hash elsewhere -- a text made of exactly
+    those filler values must count nothing"""
+    for sigma, m in ((4, 16), (256, 4), (4, 32), (256, 8)):
+        pat = O.gen_patterns(m, 3, 11, sigma)
+        k = S.KeyTable(pat, m, 3, sigma)
+        bits = 2 if sigma == 4 else 8
+        fillers = []
+        for v in range(64):  # the builder's fillers are small numbers
+            sym = [(v >> (bits * (m - 1 - i))) & ((1 << bits) - 1) if bits * (m - 1 - i) < 64 else 0 for i in range(m)]
+            fillers.append(np.asarray(sym, dtype=np.uint8))
+        text = np.concatenate(fillers * 40)
+        assert E.keys_scan(k, text) == O.count_bruteforce(pat, m, 3, text)
+        k.close()
+
+
+def test_sets_the_engine_does_not_take():
+    with pytest.raises(S.SmhError, match="64"):
+        S.KeyTable(O.gen_patterns(33, 10, 7, 4), 33, 10, 4)
+    with pytest.raises(S.SmhError, match="64"):
+        S.KeyTable(O.gen_patterns(9, 10, 7, 256), 9, 10, 256)
+    with pytest.raises(S.SmhError, match="LDS"):
+        S.KeyTable(O.gen_patterns(8, 30000, 7, 256), 8, 30000, 256)
+    S.KeyTable(O.gen_patterns(32, 8000, 7, 4), 32, 8000, 4).close()   # BASELINE configs[3]'s longest set fits
+    S.KeyTable(O.gen_patterns(16, 16000, 7, 4), 16, 16000, 4).close()
+
+
+def test_golden_vectors_of_the_reference_through_the_lane_code():
+    """the counts the reference's own search_ac produced (tests/golden/ref_vectors.json), every vector the engine takes"""
+    import json
+    import os
+    import cases
+    vectors = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.json")))
+    taken = 0
+    for v in vectors:
+        if v["m"] * max(2, int(np.ceil(np.log2(v["sigma"])))) > 64 or v["n"] > 130000:
+            continue
+        text, pat = cases.build(v)
+        k = S.KeyTable(pat, v["m"], v["p"], v["sigma"])
+        assert E.keys_scan(k, text, blocks=1) == v["count_ac"], v["name"]
+        k.close()
+        taken += 1
+    assert taken > 90
