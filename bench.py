@@ -862,7 +862,7 @@ def main():
                                        events_per_4k=round(ad.events_per_4k[int(ad.engine)], 3)),
                            matches=matches)
                 forced, equal = {}, True
-                for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT):
+                for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT, S.ENGINE_KEYS):
                     try:
                         h.set_scan_engine(eng)
                     except S.SmhError:
@@ -873,6 +873,7 @@ def main():
                 h.set_scan_engine(-1)
                 rec["forced"] = forced
                 rec["engines_agree"] = equal
+                rec["key_slots"] = int(h.info().key_slots)  # > 0: the handle keeps the key engine (round 5)
                 if algo == "ac":
                     rec["flat_parts"] = int(h.info().flat_parts)  # launches of the text-independent engine
                 every = [v["kernel_ms"] for v in forced.values()]  # all the handle holds, the text-independent parts included

@@ -187,6 +187,7 @@ void smh_ac_host_free(struct smh_ac *ac)
     smh_wm_free(ac->alt_wm);
     smh_ac_free(ac->flat_ac);
     smh_ac_free(ac->flat_next);
+    smh_keys_free(ac->keys);
     ac->magic = 0;
     free(ac);
 }
@@ -542,6 +543,17 @@ struct smh_ac *smh_ac_compile_tables_impl(const int *trans, const unsigned int *
         ac->flat_parts = head ? parts : 0;
         --smh_alt_engine_depth;
         --flat_building;
+    }
+    /* Round 5: the key engine (key_hash.h) -- the set as a hash set of its m-symbol windows in LDS, ONE exact pass whatever the
+     * text -- for every handle whose own plan is text-dependent or verify-bound (the same handles that look for flat parts) and
+     * that is not served by a single plain stride-1 image already (0.25 ms/GiB: faster than two LDS reads per column). */
+    if (ac->fixed_length_ok && !ac->scan_dense && !(ac->scan_exact && !ac->scan_full_rows) && !flat_building && smh_alt_engine_depth == 0 &&
+        ac->flat_parts != 1 && m * smh_keys_symbol_bits(alphabet) <= SMH_KEY_MAX_BITS) {
+        const int *tsrc = ac->g_transition ? ac->g_transition : trans;
+        const unsigned int *fsrc = ac->g_final ? ac->g_final : final;
+        unsigned char *pats = ac_extract_patterns(tsrc, fsrc, ac->g_transition ? ac->states : R, alphabet, m, ac->finals);
+        if (pats) ac->keys = smh_keys_build(pats, m, (int)ac->finals, alphabet, SMH_KEYS_LDS_BUDGET, NULL);
+        free(pats);
     }
     return ac;
 
@@ -1028,8 +1040,9 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_full_rows = ac->scan_full_rows;
     out->scan_engine = ac->engine_forced >= 0 ? (uint32_t)ac->engine_forced : (ac->alt_wm ? SMH_ALGO_WM : SMH_ALGO_AC);
     out->scan_dense = (uint32_t)ac->scan_dense;
-    out->adaptive = (ac->flex_wm || ac->flat_ac) && ac->engine_forced < 0 ? 1u : 0u;
+    out->adaptive = (ac->flex_wm || ac->flat_ac || ac->keys) && ac->engine_forced < 0 ? 1u : 0u;
     out->flat_parts = (uint32_t)ac->flat_parts;
+    out->key_slots = ac->keys ? 2u * ac->keys->P.slots : 0u;
     if (out->scan_engine == SMH_ALGO_WM) {
         smh_wm_info wi;
         if (smh_wm_get_info(ac->alt_wm ? ac->alt_wm : ac->flex_wm, &wi) == SMH_OK) {
@@ -1068,9 +1081,13 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
 
 int smh_ac_set_scan_engine(smh_ac *ac, int engine)
 {
-    if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT)) {
+    if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT && engine != SMH_ENGINE_KEYS)) {
         smh_set_error("smh_ac_set_scan_engine: bad arguments");
         return SMH_EINVAL;
+    }
+    if (engine == SMH_ENGINE_KEYS && !ac->keys) {
+        smh_set_error("smh_ac_set_scan_engine: this handle keeps no key table (m * bits per symbol > 64, more keys than LDS holds, or its plan is an exact one-launch plan)");
+        return SMH_EUNSUP;
     }
     if (engine == SMH_ENGINE_AC_FLAT && !ac->flat_ac) {
         smh_set_error("smh_ac_set_scan_engine: this set keeps no plain stride-1 automata (its plan is exact and plain already, or more than %d parts would be needed)", SMH_FLAT_MAX_PARTS);

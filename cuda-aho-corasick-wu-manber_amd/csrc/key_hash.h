@@ -25,7 +25,7 @@ struct smh_key_params {
     int bits;          /* per symbol: 2 (alphabet <= 4) .. 8 */
     int wide;          /* 0: 32-bit keys (m * bits <= 32), 1: 64-bit keys */
     uint32_t mask_lo, mask_hi; /* the key's bits in the rolling code */
-    uint32_t mul[4];   /* A1, B1, A2, B2: h_t = (f & 0xFFFFFF) * A_t + ((f >> 8) & 0xFFFFFF) * B_t  (mod 2^32) */
+    uint32_t mul[4];   /* A, B, C (24 bits, odd): h1 = (f & 0xFFFFFF) * A + ((f >> 8) & 0xFFFFFF) * B, h2 = (h1 & 0xFFFFFF) * C  (mod 2^32); [3] unused */
     uint32_t fold[2];  /* wide keys: f = lo + (hi & 0xFFFFFF) * C + ((hi >> 8) & 0xFFFFFF) * D */
     uint32_t slots;    /* per table; any number below 65536: slot_t = ((h_t & 0xFFFFFF) * slots) >> 24 (one v_mul_hi_u32_u24 with slots << 8: it takes the low 24 bits of h_t by itself) */
     uint32_t base2;    /* byte offset of table 2 in the image (table 1 at 0) = slots * slot bytes */
@@ -53,15 +53,14 @@ SMH_KEY_FN uint32_t smh_key_fold(uint32_t lo, uint32_t hi, uint32_t c, uint32_t 
 {
     return lo + smh_key_mul24(hi, c) + smh_key_mul24(hi >> 8, d);
 }
-SMH_KEY_FN uint32_t smh_key_hash(uint32_t f, uint32_t g /* f >> 8 */, uint32_t a, uint32_t b)
-{
-    return smh_key_mul24(f, a) + smh_key_mul24(g, b);
-}
+/* The two hashes of f (a 32-bit key, or a 64-bit key folded): h1 = (f & 0xFFFFFF) * A + (f >> 8) * B -- every bit of f reaches it
+ * through one of the two products -- and h2 = (h1 & 0xFFFFFF) * C, which re-spreads h1's low 24 bits: keys that share slot 1 (h1
+ * within one 2^24 / slots wide range) land all over table 2.  Four VALU for both. */
+
 /* byte offsets of the key's two slots in the image */
 SMH_KEY_FN void smh_key_slots(uint32_t f, const struct smh_key_params *K, uint32_t *o1, uint32_t *o2)
 {
-    const uint32_t g = f >> 8;
-    const uint32_t h1 = smh_key_hash(f, g, K->mul[0], K->mul[1]), h2 = smh_key_hash(f, g, K->mul[2], K->mul[3]);
+    const uint32_t h1 = smh_key_mul24(f, K->mul[0]) + smh_key_mul24(f >> 8, K->mul[1]), h2 = smh_key_mul24(h1, K->mul[2]);
     const uint32_t ns = K->slots << 8, wsh = K->wide ? 3u : 2u;
     *o1 = smh_key_mulhi24(h1, ns) << wsh;
     *o2 = (smh_key_mulhi24(h2, ns) << wsh) + K->base2;

@@ -19,6 +19,20 @@
 
 struct smh_key_code { uint32_t lo, hi; };
 
+/* acc += the number of lanes of the wave whose `hit` is set, on the scalar unit (one s_bcnt1 + s_add per column instead of a
+ * v_cndmask / v_addc pair: the loop is VALU-issue bound); acc is wave-uniform.  The emulation runs one lane at a time. */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+/* (one ballot per compare, OR-ed on the scalar unit: the ballot of an OR of two compares is lowered through v_cndmask + v_cmp_ne) */
+SMH_LANE void smh_key_count(uint32_t &acc, bool hit1, bool hit2)
+{
+    acc += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit1) | __builtin_amdgcn_ballot_w64(hit2));
+}
+SMH_LANE uint32_t smh_key_count_mine(uint32_t acc) { return (threadIdx.x & 63u) == 0u ? acc : 0u; }
+#else
+SMH_LANE void smh_key_count(uint32_t &acc, bool hit1, bool hit2) { acc += (hit1 || hit2) ? 1u : 0u; }
+SMH_LANE uint32_t smh_key_count_mine(uint32_t acc) { return acc; }
+#endif
+
 template <bool WIDE>
 SMH_LANE void smh_key_roll(smh_key_code &c, uint32_t sym, uint32_t bits)
 {
@@ -34,15 +48,15 @@ SMH_LANE void smh_key_roll(smh_key_code &c, uint32_t sym, uint32_t bits)
 
 /* the key of code c and the byte offsets of its two slots in the image */
 struct smh_key_probe { uint32_t klo, khi, o1, o2; };
-template <bool WIDE>
+/* FULL: the key fills its slot (m * bits == 32 or 64) -- the rolling code IS the key, no mask */
+template <bool WIDE, bool FULL = false>
 SMH_LANE smh_key_probe smh_key_address(const smh_key_code &c, const smh_key_params &K)
 {
     smh_key_probe p;
-    p.klo = c.lo & K.mask_lo;
-    p.khi = WIDE ? (c.hi & K.mask_hi) : 0u;
+    p.klo = FULL ? c.lo : (c.lo & K.mask_lo);
+    p.khi = WIDE ? (FULL ? c.hi : (c.hi & K.mask_hi)) : 0u;
     const uint32_t f = WIDE ? smh_key_fold(p.klo, p.khi, K.fold[0], K.fold[1]) : p.klo;
-    const uint32_t g = f >> 8;
-    const uint32_t h1 = smh_key_hash(f, g, K.mul[0], K.mul[1]), h2 = smh_key_hash(f, g, K.mul[2], K.mul[3]);
+    const uint32_t h1 = smh_key_mul24(f, K.mul[0]) + smh_key_mul24(f >> 8, K.mul[1]), h2 = smh_key_mul24(h1, K.mul[2]);
     const uint32_t ns = K.slots << 8;
     p.o1 = smh_key_mulhi24(h1, ns) << (WIDE ? 3 : 2);
     p.o2 = (smh_key_mulhi24(h2, ns) << (WIDE ? 3 : 2)) + K.base2;
@@ -63,24 +77,35 @@ SMH_LANE smh_key_slots2 smh_key_read(const smh_key_probe &p, const void *tab)
     }
     return r;
 }
-template <bool WIDE>
-SMH_LANE uint32_t smh_key_decide(const smh_key_probe &p, const smh_key_slots2 &r)
+/* slot t of the probe holds the key */
+template <bool WIDE, int T>
+SMH_LANE bool smh_key_slot_is(const smh_key_probe &p, const smh_key_slots2 &r)
 {
-    if constexpr (WIDE) return (((r.a0 ^ p.klo) | (r.a1 ^ p.khi)) == 0u || ((r.b0 ^ p.klo) | (r.b1 ^ p.khi)) == 0u) ? 1u : 0u;
-    return (r.a0 == p.klo || r.b0 == p.klo) ? 1u : 0u;
+    if constexpr (WIDE) return ((((uint64_t)(T ? r.b1 : r.a1)) << 32) | (T ? r.b0 : r.a0)) == ((((uint64_t)p.khi) << 32) | p.klo);
+    return (T ? r.b0 : r.a0) == p.klo;
+}
+template <bool WIDE>
+SMH_LANE bool smh_key_decide(const smh_key_probe &p, const smh_key_slots2 &r)
+{
+    /* no short-circuit: as `||` the compiler puts the second slot's READ behind a branch on the first compare */
+    if constexpr (WIDE) {
+        const uint64_t key = ((uint64_t)p.khi << 32) | p.klo, a = ((uint64_t)r.a1 << 32) | r.a0, b = ((uint64_t)r.b1 << 32) | r.b0;
+        return (a == key) | (b == key);
+    }
+    return (r.a0 == p.klo) | (r.b0 == p.klo);
 }
 /* 1 when the window whose code is c is a pattern.  `tab` = the image (LDS offset 0 on the GPU). */
 template <bool WIDE>
 SMH_LANE uint32_t smh_key_test(const smh_key_code &c, const void *tab, const smh_key_params &K)
 {
     const smh_key_probe p = smh_key_address<WIDE>(c, K);
-    return smh_key_decide<WIDE>(p, smh_key_read<WIDE>(p, tab));
+    return smh_key_decide<WIDE>(p, smh_key_read<WIDE>(p, tab)) ? 1u : 0u;
 }
 
 /* fast path: the 64 END columns of the segment at a (a >= 16 * HP >= m - 1, a + 64 <= n); edge = the 16 * HP bytes in
  * front of the wave-chunk (wave-uniform), what lane 0 primes with.  The columns go four at a time (one text dword): four
  * keys and their eight slot addresses, eight LDS reads in flight together, then the eight compares. */
-template <bool WIDE, int HP, bool POS>
+template <bool WIDE, int HP, bool POS, bool FULL = false>
 SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&edge)[4 * HP],
                                     const void *tab, const smh_key_params &K, const smh_pos_out *po)
 {
@@ -100,23 +125,23 @@ SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint3
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             smh_key_roll<WIDE>(c, smh_bfe(w[q], 8u * k, bits), bits);
-            p[k] = smh_key_address<WIDE>(c, K);
+            p[k] = smh_key_address<WIDE, FULL>(c, K);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) r[k] = smh_key_read<WIDE>(p[k], tab);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t hit = smh_key_decide<WIDE>(p[k], r[k]);
             if constexpr (POS) {
-                if (q < 8) mlo |= hit << (4 * q + k);
-                else mhi |= hit << (4 * (q - 8) + k);
+                const bool hit = smh_key_decide<WIDE>(p[k], r[k]);
+                if (q < 8) mlo |= (hit ? 1u : 0u) << (4 * q + k);
+                else mhi |= (hit ? 1u : 0u) << (4 * (q - 8) + k);
             } else {
-                cnt += hit;
+                smh_key_count(cnt, smh_key_slot_is<WIDE, 0>(p[k], r[k]), smh_key_slot_is<WIDE, 1>(p[k], r[k]));
             }
         }
     }
     if constexpr (POS) return smh_append_bits(((uint64_t)mhi << 32) | mlo, a, *po);
-    return cnt;
+    return smh_key_count_mine(cnt);
 }
 
 /* bounds-checked path: the END columns [max(a, m - 1), min(a + 64, n)) byte by byte from memory */
@@ -144,7 +169,7 @@ SMH_LANE uint32_t smh_key_lane_slow(const uint8_t *text, uint64_t n, uint64_t a,
     return cnt;
 }
 
-template <bool WIDE, int HP, bool POS>
+template <bool WIDE, int HP, bool POS, bool FULL = false>
 SMH_LANE uint32_t smh_key_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n, const void *tab,
                                  const smh_key_params &K, const smh_pos_out *po = nullptr)
 {
@@ -181,7 +206,7 @@ SMH_LANE uint32_t smh_key_thread(uint64_t gthread, const smh_chunk_sched &S, con
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (is_fast(k)) {
             load(k);
-            cnt += smh_key_lane_fast<WIDE, HP, POS>(text, a, cur, edge, tab, K, po);
+            cnt += smh_key_lane_fast<WIDE, HP, POS, FULL>(text, a, cur, edge, tab, K, po);
         } else if (POS) {
             uint64_t mm;
             smh_key_lane_slow<WIDE>(text, n, a, tab, K, &mm);

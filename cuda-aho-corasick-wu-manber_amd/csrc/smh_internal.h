@@ -46,6 +46,7 @@ uint64_t smh_handle_serial(void); /* ac_host.c: 1, 2, 3, ... */
  *                        (alphabet^2 entries/row, 16-bit, alphabet 4 only)
  */
 struct smh_ac_dev; /* opaque to C: device buffers, owned by smh_runtime.hip */
+struct smh_keys;   /* key engine, below */
 
 struct smh_ac {
     uint32_t magic;
@@ -96,6 +97,8 @@ struct smh_ac {
                              * more than SMH_FLAT_MAX_PARTS would be needed */
     struct smh_ac *flat_next; /* in a part: the next part */
     int flat_parts;
+    struct smh_keys *keys;  /* round 5: the key engine over the same patterns (key_host.c), NULL = the set is not one it takes or the
+                             * handle's plan is an exact one-launch plan already */
     int engine_forced;
     uint32_t generation;  /* bumped by every re-plan / forced engine: what was prepared or warmed for the handle before is stale */
     uint64_t serial;      /* unique per compiled handle (smh_handle_serial): an address can be reused after a free, a serial cannot */
@@ -177,8 +180,8 @@ struct smh_keys {
     struct smh_keys_dev *dev; /* per device: the image in device memory (smh_runtime.hip) */
 };
 #define SMH_KEYS_LDS_BUDGET (156u * 1024u)
-#define SMH_KEYS_MS_NARROW 0.40 /* 32-bit keys; placeholders until measured */
-#define SMH_KEYS_MS_WIDE 0.55
+#define SMH_KEYS_MS_NARROW 0.47 /* ms per GiB, 32-bit keys: measured on MI355X whatever text and set (profiles/r05_keys) */
+#define SMH_KEYS_MS_WIDE 0.63   /* 64-bit keys */
 struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p_size, int alphabet, uint32_t lds_budget, const char **why);
 void smh_keys_free(struct smh_keys *k);
 int smh_keys_contains(const struct smh_keys *k, uint64_t key);
@@ -380,6 +383,7 @@ struct smh_wm {
     struct smh_ac *alt_ac; /* automaton engine for small-alphabet sets of long patterns when it is the faster one, else NULL */
     int alt_off;           /* smh_wm_set_scan_engine(SMH_ALGO_WM): scans use this path's own kernels regardless */
     struct smh_ac *flex_ac; /* round 4: the automaton engine kept at hand even when it is the slower one on random text (== alt_ac when that is set) */
+    struct smh_keys *keys;  /* round 5: the key engine over the same patterns (key_host.c), NULL = not a set it takes / this path is exact */
     int engine_forced;     /* -1 = the runtime follows the launches' reports (round 4), else the engine smh_wm_set_scan_engine named */
     uint32_t generation;   /* bumped by smh_wm_set_scan_engine */
     uint64_t serial;       /* unique per compiled handle */

@@ -460,6 +460,9 @@ struct smh_adapt_dev {
     int tried[SMH_ENGINES]; /* the engine has reported on this kind of text */
 };
 
+/* engines whose rate does not depend on the text: their compile-time estimate holds on any text */
+static bool engine_text_independent(int e) { return e == SMH_ENGINE_AC_FLAT || e == SMH_ENGINE_KEYS; }
+
 static bool adapt_enabled()
 {
     static const int on = [] { const char *e = getenv("SMH_ADAPT"); return e && atoi(e) == 0 ? 0 : 1; }();
@@ -572,7 +575,7 @@ static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int ini
      * kernels where the hybrid image ran 7-75 x over -- so an engine of that kind that has NOT run on this text yet is
      * expected to be off by the factor the running one is; the plain stride-1 parts are not (their estimate holds on any
      * text).  An engine whose measurement was merely forgotten (below) is re-tried at its plain estimate. */
-    if (cur != SMH_ENGINE_AC_FLAT && est[cur] > 0 && c_cur / est[cur] > A->slow) A->slow = c_cur / est[cur];
+    if (!engine_text_independent(cur) && est[cur] > 0 && c_cur / est[cur] > A->slow) A->slow = c_cur / est[cur];
     int best = -1;
     double c_best = 0, m_best = 1.0;
     for (int o = 0; o < SMH_ENGINES; ++o) {
@@ -583,7 +586,7 @@ static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int ini
             if (A->keep[o] < 4096u) A->keep[o] *= 2u;
         }
         double c = A->n[o] > 0 ? adapt_ms(A, o) : est[o];
-        if (A->n[o] == 0 && o != SMH_ENGINE_AC_FLAT && !A->tried[o] && A->slow > 2.0) c *= A->slow;
+        if (A->n[o] == 0 && !engine_text_independent(o) && !A->tried[o] && A->slow > 2.0) c *= A->slow;
         const double margin = A->n[o] > 0 ? 1.03 : 1.08;
         if (best < 0 || c * margin < c_best * m_best) { best = o; c_best = c; m_best = margin; }
     }
@@ -684,12 +687,15 @@ static int adapt_first_look(smh_adapt_dev *A, const double est[SMH_ENGINES], int
     *done = SMH_FIRST_LOOK_BYTES;
     const double c0 = adapt_ms(A, initial);
     if (A->n[initial] == 0 || c0 <= 3.0 * est[initial]) return SMH_OK;
-    if (initial != SMH_ENGINE_AC_FLAT && c0 / est[initial] > A->slow) A->slow = c0 / est[initial];
-    for (int o = SMH_ENGINES - 1; o >= 0; --o) { /* the text-independent parts first: the others may be as slow as the first */
+    if (!engine_text_independent(initial) && c0 / est[initial] > A->slow) A->slow = c0 / est[initial];
+    double floor_ms = 0.0; /* the best text-independent engine measured so far */
+    for (int o = SMH_ENGINES - 1; o >= 0; --o) { /* the text-independent engines first: the others may be as slow as the first */
         if (o == initial || est[o] <= 0) continue;
-        if (o != SMH_ENGINE_AC_FLAT && adapt_ms(A, SMH_ENGINE_AC_FLAT) > 0 && est[o] * A->slow > 2.0 * adapt_ms(A, SMH_ENGINE_AC_FLAT)) continue; /* no chance */
+        if (!engine_text_independent(o) && floor_ms > 0 && est[o] * A->slow > 2.0 * floor_ms) continue; /* no chance */
+        if (engine_text_independent(o) && floor_ms > 0 && est[o] > 1.3 * floor_ms) continue; /* its estimate holds on any text */
         for (int k = 0; k < 2; ++k)
             if ((rc = probe(o, scratch, piece, true)) != SMH_OK) return rc;
+        if (engine_text_independent(o) && adapt_ms(A, o) > 0 && (floor_ms == 0.0 || adapt_ms(A, o) < floor_ms)) floor_ms = adapt_ms(A, o);
     }
     int best = initial;
     for (int o = 0; o < SMH_ENGINES; ++o)
@@ -711,6 +717,11 @@ static int adapt_first_look(smh_adapt_dev *A, const double est[SMH_ENGINES], int
     return SMH_OK;
 }
 
+/* the key engine's launch (below, "key engine"): END columns of [d_text, d_text + n) counted into *d_count or appended to po */
+static int keys_launch(struct smh_keys *k, const unsigned char *d_text, uint64_t n, uint64_t *d_count, const smh_pos_out *po,
+                       void *stream, const smh_stats_arg &SA);
+struct smh_keys_dev;
+static int keys_ensure_device(struct smh_keys *k, smh_keys_dev **out);
 /* ------------------------------------------------------------------ AC */
 static void ac_dev_free_one(smh_ac_dev *dev)
 {
@@ -840,7 +851,7 @@ static int ac_engine_static(const struct smh_ac *ac)
 }
 static struct smh_wm *ac_filter_engine(const struct smh_ac *ac) { return ac->alt_wm ? ac->alt_wm : ac->flex_wm; }
 /* the engine the next tuned scan on the current device runs (positions, info) */
-static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac) && adapt_enabled(); }
+static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac || ac->keys) && adapt_enabled(); }
 /* the text-independent engine: one exact stride-1 launch per part (ac_host.c, end of the compile) */
 static double ac_flat_ms(const struct smh_ac *ac)
 {
@@ -857,6 +868,7 @@ static void ac_estimates(const struct smh_ac *ac, double est[SMH_ENGINES])
     est[SMH_ALGO_AC] = ac->alt_wm && ac->scan_cost > SMH_AC_ALT_ENGINE_COST ? 0.0 : smh_ac_plan_ms(ac);
     est[SMH_ALGO_WM] = ac_filter_engine(ac) ? ac_filter_engine(ac)->scan_ms_est : 0.0;
     est[SMH_ENGINE_AC_FLAT] = ac_flat_ms(ac);
+    est[SMH_ENGINE_KEYS] = ac->keys ? ac->keys->ms_est : 0.0;
 }
 static int ac_engine_now(struct smh_ac *ac)
 {
@@ -873,11 +885,12 @@ static int ac_flat_prepare(struct smh_ac *ac)
     return rc;
 }
 
-static int ac_prepare(struct smh_ac *ac, int variant)
+static int ac_prepare_engines(struct smh_ac *ac, int variant)
 {
     const bool both = variant == SMH_VARIANT_TUNED && ac->engine_forced < 0 && ac_adaptive(ac);
     if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ALGO_WM && !both) return wm_prepare(ac_filter_engine(ac), variant);
     if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_AC_FLAT && !both) return ac_flat_prepare(ac);
+    if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_KEYS && !both && ac->keys) { smh_keys_dev *kd = NULL; return keys_ensure_device(ac->keys, &kd); }
     smh_ac_dev *d = NULL;
     int rc = ac_ensure_device(ac, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = ac_ensure_reference_tables(ac, d);
@@ -888,8 +901,18 @@ static int ac_prepare(struct smh_ac *ac, int variant)
     if (rc == SMH_OK && both) { /* any of the engines may serve the next launch */
         if (ac_filter_engine(ac)) rc = wm_prepare(ac_filter_engine(ac), variant);
         if (rc == SMH_OK) rc = ac_flat_prepare(ac);
+        if (rc == SMH_OK && ac->keys) { smh_keys_dev *kd = NULL; rc = keys_ensure_device(ac->keys, &kd); }
+    }
+    return rc;
+}
+static int ac_prepare(struct smh_ac *ac, int variant)
+{
+    int rc = ac_prepare_engines(ac, variant);
+    /* the adaptive state too, whenever smh_ac_scan will ask for it (also with an engine forced): created inside the scan call it
+     * would put blocking allocations into a captured stream and into count_host's kernel time */
+    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && ac_adaptive(ac)) {
         smh_adapt_dev *A = NULL;
-        if (rc == SMH_OK) rc = adapt_get(&ac->adapt, &A);
+        rc = adapt_get(&ac->adapt, &A);
     }
     return rc;
 }
@@ -993,6 +1016,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         if (!ac_adaptive(ac)) {
             if (engine == SMH_ALGO_WM) return smh_wm_scan(ac_filter_engine(ac), d_text, n, d_count, SMH_VARIANT_TUNED, stream);
             if (engine == SMH_ENGINE_AC_FLAT && ac->flat_ac) return ac_flat_launch(ac, d_text, n, d_count, stream, smh_stats_arg{});
+            if (engine == SMH_ENGINE_KEYS && ac->keys) return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, smh_stats_arg{});
             return ac_launch_own(ac, d_text, n, d_count, stream, smh_stats_arg{});
         }
         smh_adapt_dev *A = NULL;
@@ -1006,6 +1030,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
                                   [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
                                       if (e == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), t, len, cnt, stream, sa, adapt_density(A, ac_filter_engine(ac)));
                                       if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, t, len, cnt, stream, sa);
+                                      if (e == SMH_ENGINE_KEYS) return keys_launch(ac->keys, t, len, cnt, NULL, stream, sa);
                                       return ac_launch_own(ac, t, len, cnt, stream, sa);
                                   }, &done);
             if (rc != SMH_OK) return rc;
@@ -1018,6 +1043,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
         const smh_stats_arg SA = adapt_arg(A, n, engine);
         if (engine == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), d_text, n, d_count, stream, SA, adapt_density(A, ac_filter_engine(ac)));
         if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, d_text, n, d_count, stream, SA);
+        if (engine == SMH_ENGINE_KEYS) return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, SA);
         return ac_launch_own(ac, d_text, n, d_count, stream, SA);
     }
     if (variant != SMH_VARIANT_TABLE) {
@@ -1068,6 +1094,10 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
         return smh_wm_positions(ac_filter_engine(ac), d_text, n, d_positions, capacity, d_cursor, stream);
     else if (engine == SMH_ENGINE_AC_FLAT)
         return ac_flat_positions(ac, d_text, n, d_positions, capacity, d_cursor, stream);
+    else if (engine == SMH_ENGINE_KEYS && ac->keys && ((uintptr_t)d_text & 15u) == 0) {
+        const smh_pos_out po = {d_positions, capacity, d_cursor};
+        return keys_launch(ac->keys, d_text, n, NULL, &po, stream, smh_stats_arg{});
+    }
     smh_ac_dev *dv = NULL;
     int rc = ac_ensure_device(ac, &dv);
     if (rc != SMH_OK) return rc;
@@ -1391,22 +1421,42 @@ static double wm_flex_ms(const struct smh_wm *wm)
 }
 /* do this path's own kernels report (smh_stats.h)?  All but the pair lookup kernel (exact, m <= 8) */
 static bool wm_reports(const struct smh_wm *wm) { return wm->gram_table || !wm->pair_table; }
+static bool wm_engines(const struct smh_wm *wm) { return wm->flex_ac || wm->keys; } /* more than this path's own kernels at hand */
+static void wm_estimates(const struct smh_wm *wm, double est[SMH_ENGINES])
+{
+    est[SMH_ALGO_AC] = wm_flex_ms(wm);
+    est[SMH_ALGO_WM] = wm->scan_ms_est;
+    est[SMH_ENGINE_AC_FLAT] = wm->flex_ac ? ac_flat_ms(wm->flex_ac) : 0.0;
+    est[SMH_ENGINE_KEYS] = wm->keys ? wm->keys->ms_est : 0.0;
+}
 static int wm_engine_now(struct smh_wm *wm)
 {
-    if (wm->engine_forced < 0 && wm->flex_ac && adapt_enabled())
+    if (wm->engine_forced < 0 && wm_engines(wm) && adapt_enabled())
         if (smh_adapt_dev *A = adapt_find(&wm->adapt); A && A->engine >= 0) return A->engine;
     return wm_engine_static(wm);
 }
 
 static int wm_prepare(struct smh_wm *wm, int variant)
 {
-    const bool both = variant == SMH_VARIANT_TUNED && wm->flex_ac && wm->engine_forced < 0 && adapt_enabled();
-    if (variant == SMH_VARIANT_TUNED && wm_engine_static(wm) == SMH_ALGO_AC && !both) return ac_prepare(wm_automaton_engine(wm), variant);
+    const bool both = variant == SMH_VARIANT_TUNED && wm_engines(wm) && wm->engine_forced < 0 && adapt_enabled();
+    const bool other = variant == SMH_VARIANT_TUNED && !both && wm_engine_static(wm) != SMH_ALGO_WM; /* a forced / static engine that is not this path's */
+    int rc = SMH_OK;
+    if (other && wm_engine_static(wm) == SMH_ALGO_AC) rc = ac_prepare(wm_automaton_engine(wm), variant);
+    else if (other && wm_engine_static(wm) == SMH_ENGINE_AC_FLAT && wm->flex_ac) rc = ac_flat_prepare(wm->flex_ac);
+    else if (other && wm_engine_static(wm) == SMH_ENGINE_KEYS && wm->keys) { smh_keys_dev *kd = NULL; rc = keys_ensure_device(wm->keys, &kd); }
+    if (other) {
+        if (rc == SMH_OK && adapt_enabled() && (wm_engines(wm) || wm_reports(wm))) { /* smh_wm_scan asks for it whatever engine runs */
+            smh_adapt_dev *A = NULL;
+            rc = adapt_get(&wm->adapt, &A);
+        }
+        return rc;
+    }
     smh_wm_dev *d = NULL;
-    int rc = wm_ensure_device(wm, &d);
+    rc = wm_ensure_device(wm, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = wm_ensure_reference_tables(wm, d);
-    if (rc == SMH_OK && both) rc = ac_prepare(wm->flex_ac, variant);
-    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && adapt_enabled() && wm_reports(wm)) {
+    if (rc == SMH_OK && both && wm->flex_ac) rc = ac_prepare(wm->flex_ac, variant);
+    if (rc == SMH_OK && both && wm->keys) { smh_keys_dev *kd = NULL; rc = keys_ensure_device(wm->keys, &kd); }
+    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && adapt_enabled() && (wm_engines(wm) || wm_reports(wm))) {
         smh_adapt_dev *A = NULL;
         rc = adapt_get(&wm->adapt, &A);
     }
@@ -1452,16 +1502,18 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
          * engine" above).  A handle with one engine still learns its verify mode from its own reports. */
         int engine = wm_engine_static(wm), rc;
         smh_adapt_dev *A = NULL;
-        if (adapt_enabled() && (wm->flex_ac || wm_reports(wm))) {
+        if (adapt_enabled() && (wm_engines(wm) || wm_reports(wm))) {
             if ((rc = adapt_get(&wm->adapt, &A)) != SMH_OK) return rc;
             adapt_poll(A);
-            if (wm->flex_ac && wm->engine_forced < 0) {
-                const double est[SMH_ENGINES] = {wm_flex_ms(wm), wm->scan_ms_est, ac_flat_ms(wm->flex_ac)};
+            if (wm_engines(wm) && wm->engine_forced < 0) {
+                double est[SMH_ENGINES];
+                wm_estimates(wm, est);
                 uint64_t done = 0;
                 rc = adapt_first_look(A, est, engine, wm->m, d_text, n, d_count, stream,
                                       [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
                                           if (e == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), t, len, cnt, stream, sa);
                                           if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, t, len, cnt, stream, sa);
+                                          if (e == SMH_ENGINE_KEYS) return keys_launch(wm->keys, t, len, cnt, NULL, stream, sa);
                                           return wm_launch_own(wm, t, len, cnt, stream, wm_reports(wm) ? sa : smh_stats_arg{}, adapt_density(A, wm));
                                       }, &done);
                 if (rc != SMH_OK) return rc;
@@ -1474,6 +1526,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
         }
         if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine));
         if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine));
+        if (engine == SMH_ENGINE_KEYS) return keys_launch(wm->keys, d_text, n, d_count, NULL, stream, adapt_arg(A, n, engine));
         return wm_launch_own(wm, d_text, n, d_count, stream, adapt_arg(wm_reports(wm) ? A : NULL, n, engine), adapt_density(A, wm));
     }
     if (variant != SMH_VARIANT_TABLE) {
@@ -1500,8 +1553,9 @@ extern "C" int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out)
         smh_set_error("smh_wm_get_adapt: bad arguments (set struct_size = sizeof(smh_adapt_info))");
         return SMH_EINVAL;
     }
-    const double est[SMH_ENGINES] = {wm_flex_ms(wm), wm->scan_ms_est, wm->flex_ac ? ac_flat_ms(wm->flex_ac) : 0.0};
-    const int adaptive = wm->flex_ac && wm->engine_forced < 0 && adapt_enabled();
+    double est[SMH_ENGINES];
+    wm_estimates(wm, est);
+    const int adaptive = wm_engines(wm) && wm->engine_forced < 0 && adapt_enabled();
     adapt_report(adapt_find(&wm->adapt), adaptive, wm_engine_static(wm), est, out);
     return SMH_OK;
 }
@@ -1518,6 +1572,10 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         return smh_ac_positions(wm_automaton_engine(wm), d_text, n, d_positions, capacity, d_cursor, stream);
     else if (engine == SMH_ENGINE_AC_FLAT && wm->flex_ac && wm->flex_ac->flat_ac)
         return ac_flat_positions(wm->flex_ac, d_text, n, d_positions, capacity, d_cursor, stream);
+    else if (engine == SMH_ENGINE_KEYS && wm->keys && ((uintptr_t)d_text & 15u) == 0) {
+        const smh_pos_out po = {d_positions, capacity, d_cursor};
+        return keys_launch(wm->keys, d_text, n, NULL, &po, stream, smh_stats_arg{});
+    }
     smh_wm_dev *dv = NULL;
     int rc = wm_ensure_device(wm, &dv);
     if (rc != SMH_OK) return rc;

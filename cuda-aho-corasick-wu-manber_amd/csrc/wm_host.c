@@ -96,6 +96,7 @@ void smh_wm_host_free(struct smh_wm *wm)
     free(wm->l_bucket);
     free(wm->pat_orig);
     smh_ac_free(wm->flex_ac ? wm->flex_ac : wm->alt_ac); /* alt_ac, when set, is the same handle */
+    smh_keys_free(wm->keys);
     wm->magic = 0;
     free(wm);
 }
@@ -875,6 +876,10 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
             smh_ac_free(ac);
         }
     }
+    /* Round 5: the key engine (key_hash.h) beside every path whose rate depends on the text (a filter with a verify stage) */
+    if (!wm->filter_exact && !wm->pair_table && smh_alt_engine_depth == 0 && m * smh_keys_symbol_bits(alphabet) <= SMH_KEY_MAX_BITS &&
+        !(wm->flex_ac && wm->flex_ac->flat_parts == 1))
+        wm->keys = smh_keys_build(wm->pat_sorted, m, d, alphabet, SMH_KEYS_LDS_BUDGET, NULL);
     return wm;
 
 oom:
@@ -921,7 +926,8 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->verify_slots = wm->filter_exact ? 0u : (1u << wm->verify_log2);
     out->lds_bytes = (uint32_t)(((size_t)1 << wm->filter_log2) / 8);
     out->scan_engine = wm->engine_forced >= 0 ? (uint32_t)wm->engine_forced : (wm->alt_ac ? SMH_ALGO_AC : SMH_ALGO_WM);
-    out->adaptive = wm->flex_ac && wm->engine_forced < 0 ? 1u : 0u;
+    out->adaptive = (wm->flex_ac || wm->keys) && wm->engine_forced < 0 ? 1u : 0u;
+    out->key_slots = wm->keys ? 2u * wm->keys->P.slots : 0u;
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
     out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
@@ -935,9 +941,13 @@ int smh_wm_set_scan_engine(smh_wm *wm, int engine)
         smh_set_error("smh_wm_set_scan_engine: this set keeps no plain stride-1 automaton");
         return SMH_EUNSUP;
     }
-    if (!wm || wm->magic != SMH_MAGIC_WM || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT)) {
+    if (!wm || wm->magic != SMH_MAGIC_WM || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT && engine != SMH_ENGINE_KEYS)) {
         smh_set_error("smh_wm_set_scan_engine: bad arguments");
         return SMH_EINVAL;
+    }
+    if (engine == SMH_ENGINE_KEYS && !wm->keys) {
+        smh_set_error("smh_wm_set_scan_engine: this handle keeps no key table (m * bits per symbol > 64, more keys than LDS holds, or this path is exact)");
+        return SMH_EUNSUP;
     }
     if (engine == SMH_ALGO_AC && !wm->alt_ac && !wm->flex_ac) {
         smh_set_error("smh_wm_set_scan_engine: this set has no automaton engine (its automaton would be slower)");

@@ -46,7 +46,7 @@ class AcInfo(C.Structure):
                 ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
                 ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32),
                 ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32), ("adaptive", C.c_uint32),
-                ("flat_parts", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("flat_parts", C.c_uint32), ("key_slots", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class WmInfo(C.Structure):
@@ -56,7 +56,7 @@ class WmInfo(C.Structure):
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
                 ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32),
-                ("adaptive", C.c_uint32), ("reserved", C.c_uint32 * 7)]
+                ("adaptive", C.c_uint32), ("key_slots", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class AdaptInfo(C.Structure):

@@ -171,7 +171,8 @@ typedef struct smh_ac_info {
                               * (smh_ac_get_adapt) */
     uint32_t flat_parts;     /* launches of the text-independent engine (SMH_ENGINE_AC_FLAT): the set as that many exact stride-1
                               * automata that each fit LDS whole, scanned one after the other; 0: the handle keeps none */
-    uint32_t reserved[6];    /* zero; library 0.2 grew this struct -- later fields will come out of here */
+    uint32_t key_slots;      /* round 5: slots of the key table the handle keeps (SMH_ENGINE_KEYS); 0: it keeps none */
+    uint32_t reserved[5];    /* zero; library 0.2 grew this struct -- later fields come out of here (key_slots did) */
 } smh_ac_info;
 
 /* What the library has learned about the text it scans with a handle on the CURRENT device (round 4).  The engine that
@@ -259,7 +260,8 @@ typedef struct smh_wm_info {
                                * grams, two columns per lookup), 2 hashed byte grams (one plane per offset), 3 8-symbol grams, 5 8-symbol
                                * grams at two columns per lookup, 6 flat byte grams (one Bloom set for all offsets) */
     uint32_t adaptive;        /* as smh_ac_info.adaptive: this handle also holds an automaton engine and follows the launches' reports */
-    uint32_t reserved[7];
+    uint32_t key_slots;       /* round 5: as smh_ac_info.key_slots */
+    uint32_t reserved[6];
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */

@@ -16,3 +16,6 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: holds wall-clock / rate expectations (tests/perf.py): recorded under -m gpu, enforced under -m \"gpu and perf\"")
+    import perf
+    perf.STRICT = "perf" in (config.getoption("markexpr") or "")

@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import pytest
 
+from perf import perf_check
+
 import oracle_lib as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,6 +61,7 @@ def _scan(h, t, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.perf
 @pytest.mark.parametrize("entry", ["ac", "wm"])
 def test_engine_follows_the_text_and_counts_do_not_change(entry):
     """1000 patterns of 16 symbols sampled from a repeat-rich genome-like text.  On uniform text the compile's choice (the
@@ -94,16 +97,19 @@ def test_engine_follows_the_text_and_counts_do_not_change(entry):
     assert e_rep[0] == e_uni[-1]
     hot = h.adapt()
     assert hot.flips > calm.flips, (e_uni, e_rep)
-    assert e_rep[-1] == S.ENGINE_AC_FLAT, e_rep  # the engine whose speed does not depend on the text
-    assert e_rep.index(S.ENGINE_AC_FLAT) <= 12, e_rep  # ... reached within a few REPORTS (one launch in eight reports once an engine has settled)
-    assert hot.ms_per_gib[S.ENGINE_AC_FLAT] * 2.0 < max(hot.ms_per_gib[S.ALGO_AC], hot.ms_per_gib[S.ALGO_WM])
+    indep = (S.ENGINE_AC_FLAT, S.ENGINE_KEYS)  # the engines whose speed does not depend on the text
+    assert e_rep[-1] in indep, e_rep
+    settled = min(e_rep.index(e) for e in indep if e in e_rep)
+    perf_check(settled <= 12, "text-independent engine reached after %d launches (expected <= 12: one launch in eight reports once an engine has settled): %r" % (settled, e_rep))
+    perf_check(hot.ms_per_gib[e_rep[-1]] * 2.0 < max(hot.ms_per_gib[S.ALGO_AC], hot.ms_per_gib[S.ALGO_WM]),
+               "settled engine %.3f ms/GiB, text-dependent engines %.3f / %.3f" % (hot.ms_per_gib[e_rep[-1]], hot.ms_per_gib[S.ALGO_AC], hot.ms_per_gib[S.ALGO_WM]))
     # forced engines agree on the counts (and are not overridden)
     forced = 0
-    for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT):
+    for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT, S.ENGINE_KEYS):
         try:
             h.set_scan_engine(eng)
-        except S.SmhError:  # an exact hybrid plan keeps no filter engine
-            assert eng == S.ALGO_WM and entry == "ac"
+        except S.SmhError:  # an exact hybrid plan keeps no filter engine; a set served by ONE plain stride-1 image keeps no key table
+            assert (eng == S.ALGO_WM and entry == "ac") or eng == S.ENGINE_KEYS
             continue
         forced += 1
         assert _scan(h, rep, n) == counts["rep"] and _scan(h, uni, n) == counts["uni"]
@@ -243,17 +249,17 @@ def test_first_look_at_a_long_text(entry):
     first = h.info().scan_engine
     c1 = _scan(h, pla, n)
     ad = h.adapt()
-    assert ad.engine == S.ENGINE_AC_FLAT and ad.flips == 1 and ad.reports >= 3, (ad.engine, ad.flips, ad.reports)
-    assert ad.ms_per_gib[first] > 3.0 * ad.est_ms_per_gib[first]
-    assert _scan(h, pla, n) == c1  # now one launch, the parts
+    assert ad.engine in (S.ENGINE_AC_FLAT, S.ENGINE_KEYS) and ad.flips == 1 and ad.reports >= 3, (ad.engine, ad.flips, ad.reports)
+    perf_check(ad.ms_per_gib[first] > 3.0 * ad.est_ms_per_gib[first], "the compile's engine on the hostile text: %.3f ms/GiB measured, %.3f estimated (expected > 3x)" % (ad.ms_per_gib[first], ad.est_ms_per_gib[first]))
+    assert _scan(h, pla, n) == c1  # now one launch, the text-independent engine
     counts = []
-    for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT):
+    for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT, S.ENGINE_KEYS):
         g = make.from_patterns(pat, m, p, sigma)
         g.set_scan_engine(eng)
         counts.append(_scan(g, pla, n))
         assert g.adapt().flips == 0
         g.close()
-    assert counts == [c1] * 3
+    assert counts == [c1] * 4
     # the same text cut at another place: END columns are counted once
     assert _scan(h, pla, n - (300 << 20)) + 0 == _scan(h, pla, n - (300 << 20))
     h.close()

@@ -132,3 +132,42 @@ def test_golden_vectors_of_the_reference_through_the_lane_code():
         k.close()
         taken += 1
     assert taken > 90
+
+
+def test_which_handles_keep_a_key_table():
+    """held beside every plan or path whose rate depends on the text or that is verify-bound -- not beside an exact one-launch plan,
+    not beside a set ONE plain stride-1 image serves (0.25 ms/GiB: faster than two LDS reads per column)"""
+    # (alphabet, m, patterns) -> key table expected through the (AC, WM) entry points
+    cases = [((4, 8, 1000), (False, False)),      # dense plan / pair table: exact, one launch
+             ((4, 16, 1000), (False, False)),     # one plain stride-1 image holds the set
+             ((4, 32, 1000), (True, True)),       # two parts
+             ((4, 16, 8000), (True, True)),
+             ((4, 32, 8000), (True, True)),
+             ((20, 8, 1000), (True, True)),
+             ((256, 8, 3000), (True, True)),      # verify-bound automaton plan / byte-gram filter
+             ((256, 12, 3000), (False, False)),   # 96 bits: not a set the engine takes
+             ((256, 8, 100000), (False, False))]  # more keys than LDS holds
+    for (sigma, m, p), (want_ac, want_wm) in cases:
+        pat = O.gen_patterns(m, p, 7, sigma)
+        if p <= 8000:
+            ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
+            assert (ac.info().key_slots > 0) == want_ac, ("ac", sigma, m, p, ac.info().key_slots)
+            if want_ac:
+                assert ac.info().adaptive == 1 and ac.adapt().est_ms_per_gib[S.ENGINE_KEYS] > 0.3
+                ac.set_scan_engine(S.ENGINE_KEYS)
+                assert ac.info().scan_engine == S.ENGINE_KEYS and ac.info().adaptive == 0
+                ac.set_scan_engine(-1)
+            else:
+                with pytest.raises(S.SmhError, match="key table"):
+                    ac.set_scan_engine(S.ENGINE_KEYS)
+            ac.close()
+        wm = S.WmTables.from_patterns(pat, m, p, sigma)
+        assert (wm.info().key_slots > 0) == want_wm, ("wm", sigma, m, p, wm.info().key_slots)
+        if want_wm:
+            assert wm.info().adaptive == 1 and wm.adapt().est_ms_per_gib[S.ENGINE_KEYS] > 0.3
+            wm.set_scan_engine(S.ENGINE_KEYS)
+            assert wm.info().scan_engine == S.ENGINE_KEYS
+        else:
+            with pytest.raises(S.SmhError, match="key table"):
+                wm.set_scan_engine(S.ENGINE_KEYS)
+        wm.close()

@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import oracle_lib as O
+import emu_lib  # noqa: F401  (puts the package directory on sys.path)
 import smatcher_hip as S
 from test_key_engine import SETS, _text_and_patterns
 
@@ -69,3 +70,78 @@ def test_positions_on_the_device():
     assert int(cur.item()) == len(want)
     assert np.array_equal(np.sort(out[:len(want)].cpu().numpy()), np.sort(want))
     k.close()
+
+
+def _scan_handle(h, text):
+    dev = torch.device("cuda", 0)
+    n = len(text)
+    t = torch.zeros(((n + 15) // 16) * 16 + 64, dtype=torch.uint8, device=dev)
+    t[:n] = torch.from_numpy(np.ascontiguousarray(text)).to(dev)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    h.scan_device(t.data_ptr(), n, cnt.data_ptr(), S.VARIANT_TUNED, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return int(cnt.item())
+
+
+def test_engine_forced_inside_the_handles_on_the_golden_vectors():
+    """smh_ac / smh_wm handles with SMH_ENGINE_KEYS forced: the reference's golden counts (every vector whose handle keeps a key table)"""
+    import cases
+    vectors = json.load(open(os.path.join(HERE, "golden", "ref_vectors.json")))
+    forced = {"ac": 0, "wm": 0}
+    for v in vectors:
+        sigma, m, p = v["sigma"], v["m"], v["p"]
+        text, pat = cases.build(v)
+        for entry, make in (("ac", S.AcAutomaton), ("wm", S.WmTables)):
+            if entry == "wm" and (m < 3 or sigma not in (2, 4, 8, 20, 128, 256)):
+                continue
+            h = make.from_patterns(pat, m, p, sigma)
+            if h.info().key_slots:
+                h.set_scan_engine(S.ENGINE_KEYS)
+                assert _scan_handle(h, text) == v["count_ac"], (entry, v["name"])
+                got, _ = h.count_host(text)  # the legacy host-pointer path through the same engine
+                assert got == v["count_ac"], (entry, v["name"])
+                forced[entry] += 1
+            h.close()
+    assert forced["ac"] >= 10 and forced["wm"] >= 10, forced
+
+
+def test_handle_settles_on_the_key_table_on_hostile_text():
+    """8000 patterns of 16 symbols sampled from the repeat-rich text: the filter kernels verify a real match in every tenth column,
+    the plain stride-1 parts take four passes -- the key table one.  Same count from every engine the handle holds."""
+    n, m, p, sigma = 256 << 20, 16, 8000, 4
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    text = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    S.corpus_text_device(text.data_ptr(), n, 42, sigma, 0, S.CORPUS_DNA_REPEATS, st)
+    torch.cuda.synchronize()
+    pat = S.corpus_patterns(m, p, 12, sigma, 42, n, 2, S.CORPUS_DNA_REPEATS)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    for make in (S.AcAutomaton, S.WmTables):
+        h = make.from_patterns(pat, m, p, sigma)
+        assert h.info().key_slots > 0 and h.info().adaptive == 1
+        seen, counts = [], set()
+        for _ in range(12):
+            cnt.zero_()
+            h.scan_device(text.data_ptr(), n, cnt.data_ptr(), S.VARIANT_TUNED, st)
+            torch.cuda.synchronize()
+            counts.add(int(cnt.item()))
+            seen.append(int(h.adapt().engine))
+        assert len(counts) == 1, counts
+        assert seen[-1] == S.ENGINE_KEYS, seen
+        for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT, S.ENGINE_KEYS):
+            try:
+                h.set_scan_engine(eng)
+            except S.SmhError:
+                continue
+            cnt.zero_()
+            h.scan_device(text.data_ptr(), 64 << 20, cnt.data_ptr(), S.VARIANT_TUNED, st)
+            torch.cuda.synchronize()
+            counts.add(("prefix", int(cnt.item())))
+        assert len(counts) == 2, counts
+        want = O.oracle_ac(pat, m, p, sigma, text[:8 << 20].cpu().numpy())[0]
+        h.set_scan_engine(S.ENGINE_KEYS)
+        cnt.zero_()
+        h.scan_device(text.data_ptr(), 8 << 20, cnt.data_ptr(), S.VARIANT_TUNED, st)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == want
+        h.close()

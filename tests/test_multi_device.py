@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import pytest
 
+from perf import perf_check
+
 import oracle_lib as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,6 +80,7 @@ def test_multi_device_counts_match_the_oracle(n_devices):
 
 
 @pytest.mark.gpu
+@pytest.mark.perf
 def test_first_count_call_is_as_fast_as_the_tenth_after_prepare():
     """smh_multi_*_prepare (and the count calls themselves, before their clock starts) build the table set and run
     the kernel once per device: `seconds` of the first count call holds launches + reduce only."""
@@ -90,12 +93,13 @@ def test_first_count_call_is_as_fast_as_the_tenth_after_prepare():
         mg.prepare(h)
         runs = [count(h) for _ in range(10)]
         later = sorted(r[2] for r in runs[1:])[len(runs) // 2]
-        assert runs[0][2] <= 2.0 * later + 2e-4, (runs[0][2], later)
+        perf_check(runs[0][2] <= 2.0 * later + 2e-4, "first smh_multi count call after prepare %.6f s, later ones %.6f s" % (runs[0][2], later))
         assert len({r[0] for r in runs}) == 1
         # without the explicit call the count does the same before its clock starts
         h2 = make.from_patterns(pat, m, p, sigma)
         first = count(h2)
-        assert first[0] == runs[0][0] and first[2] <= 2.0 * later + 2e-4, (first[2], later)
+        assert first[0] == runs[0][0]
+        perf_check(first[2] <= 2.0 * later + 2e-4, "first smh_multi count call without prepare %.6f s, later ones %.6f s" % (first[2], later))
     mg.close()
 
 
