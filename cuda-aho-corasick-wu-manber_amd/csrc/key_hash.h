@@ -19,16 +19,22 @@
 
 #define SMH_KEY_MAX_BITS 64  /* m * bits_per_symbol of the longest key */
 #define SMH_KEY_TRIES 24     /* multiplier pairs tried before the builder gives up */
+#define SMH_KEY_QUOT_BITS 42 /* longest quotient key: 2^10 padding slots per table */
 
 struct smh_key_params {
     int m;
     int bits;          /* per symbol: 2 (alphabet <= 4) .. 8 */
-    int wide;          /* 0: 32-bit keys (m * bits <= 32), 1: 64-bit keys */
+    int wide;          /* key class: 0 = 32-bit keys (m * bits <= 32) in 4-byte slots; 1 = 64-bit keys in 8-byte slots; 2 = QUOTIENT keys
+                        * of 33..42 bits in 4-byte slots: the slot holds the key's low 32 bits x, the high bits y (< 2^10) are ADDED
+                        * to the slot number -- slot_t = s_t(x) + y, tables padded by 2^(bits - 32) slots -- so that "slot s_t(x) + y
+                        * holds x" says the whole key is there (a stored key (x', y') sits at s_t(x') + y': x' = x makes the slot
+                        * numbers differ by y' - y) */
     uint32_t mask_lo, mask_hi; /* the key's bits in the rolling code */
     uint32_t mul[4];   /* A, B, C (24 bits, odd): h1 = (f & 0xFFFFFF) * A + ((f >> 8) & 0xFFFFFF) * B, h2 = (h1 & 0xFFFFFF) * C  (mod 2^32); [3] unused */
     uint32_t fold[2];  /* wide keys: f = lo + (hi & 0xFFFFFF) * C + ((hi >> 8) & 0xFFFFFF) * D */
     uint32_t slots;    /* per table; any number below 65536: slot_t = ((h_t & 0xFFFFFF) * slots) >> 24 (one v_mul_hi_u32_u24 with slots << 8: it takes the low 24 bits of h_t by itself) */
-    uint32_t base2;    /* byte offset of table 2 in the image (table 1 at 0) = slots * slot bytes */
+    uint32_t pad;      /* quotient keys: extra slots behind each table's `slots` (2^(m * bits - 32)), else 0 */
+    uint32_t base2;    /* byte offset of table 2 in the image (table 1 at 0) = (slots + pad) * slot bytes */
     uint32_t bytes;    /* the image: both tables, padded to 16 */
 };
 
@@ -57,13 +63,14 @@ SMH_KEY_FN uint32_t smh_key_fold(uint32_t lo, uint32_t hi, uint32_t c, uint32_t 
  * through one of the two products -- and h2 = (h1 & 0xFFFFFF) * C, which re-spreads h1's low 24 bits: keys that share slot 1 (h1
  * within one 2^24 / slots wide range) land all over table 2.  Four VALU for both. */
 
-/* byte offsets of the key's two slots in the image */
-SMH_KEY_FN void smh_key_slots(uint32_t f, const struct smh_key_params *K, uint32_t *o1, uint32_t *o2)
+/* byte offsets of a key's two slots in the image; f = the 32 bits the hashes are taken from (the key, a wide key folded, a quotient
+ * key's low half), y = a quotient key's high bits (else 0) */
+SMH_KEY_FN void smh_key_slots(uint32_t f, uint32_t y, const struct smh_key_params *K, uint32_t *o1, uint32_t *o2)
 {
     const uint32_t h1 = smh_key_mul24(f, K->mul[0]) + smh_key_mul24(f >> 8, K->mul[1]), h2 = smh_key_mul24(h1, K->mul[2]);
-    const uint32_t ns = K->slots << 8, wsh = K->wide ? 3u : 2u;
-    *o1 = smh_key_mulhi24(h1, ns) << wsh;
-    *o2 = (smh_key_mulhi24(h2, ns) << wsh) + K->base2;
+    const uint32_t ns = K->slots << 8, wsh = K->wide == 1 ? 3u : 2u;
+    *o1 = (smh_key_mulhi24(h1, ns) + y) << wsh;
+    *o2 = ((smh_key_mulhi24(h2, ns) + y) << wsh) + K->base2;
 }
 
 #endif

@@ -40,24 +40,25 @@ static int cmp_u64(const void *a, const void *b)
 
 static uint32_t key_f(uint64_t key, const struct smh_key_params *K)
 {
-    return K->wide ? smh_key_fold((uint32_t)key, (uint32_t)(key >> 32), K->fold[0], K->fold[1]) : (uint32_t)key;
+    return K->wide == 1 ? smh_key_fold((uint32_t)key, (uint32_t)(key >> 32), K->fold[0], K->fold[1]) : (uint32_t)key;
 }
+static uint32_t key_y(uint64_t key, const struct smh_key_params *K) { return K->wide == 2 ? (uint32_t)(key >> 32) : 0u; }
 
 /* both slots of a key as indices into slot_of[]: [0, N) = table 1, [N, 2N) = table 2 */
 static void key_slot_ids(uint64_t key, const struct smh_key_params *K, uint32_t *s1, uint32_t *s2)
 {
-    const uint32_t wsh = K->wide ? 3u : 2u;
+    const uint32_t wsh = K->wide == 1 ? 3u : 2u;
     uint32_t o1, o2;
-    smh_key_slots(key_f(key, K), K, &o1, &o2);
+    smh_key_slots(key_f(key, K), key_y(key, K), K, &o1, &o2);
     *s1 = o1 >> wsh;
-    *s2 = K->slots + ((o2 - K->base2) >> wsh);
+    *s2 = K->slots + K->pad + ((o2 - K->base2) >> wsh);
 }
 
 /* place every key in one of its two slots (random-walk cuckoo insertion); slot contents are indices into keys[] + 1,
  * 0 = free.  0 = some key could not be placed under these multipliers. */
 static int cuckoo_place(const uint64_t *keys, uint32_t n, const struct smh_key_params *K, uint32_t *slot_of /* [2 * slots] */)
 {
-    memset(slot_of, 0, sizeof(uint32_t) * 2u * K->slots);
+    memset(slot_of, 0, sizeof(uint32_t) * 2u * (K->slots + K->pad));
     for (uint32_t i = 0; i < n; ++i) {
         uint32_t cur = i + 1, s1, s2;
         key_slot_ids(keys[i], K, &s1, &s2);
@@ -116,24 +117,28 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
     memset(&K, 0, sizeof K);
     K.m = m;
     K.bits = bits;
-    K.wide = m * bits > 32;
     const int kb = m * bits;
+    K.wide = kb <= 32 ? 0 : (kb <= SMH_KEY_QUOT_BITS ? 2 : 1);
+    K.pad = K.wide == 2 ? 1u << (kb - 32) : 0u;
     K.mask_lo = kb >= 32 ? 0xFFFFFFFFu : (1u << kb) - 1u;
     K.mask_hi = kb <= 32 ? 0u : (kb >= 64 ? 0xFFFFFFFFu : (1u << (kb - 32)) - 1u);
-    const uint32_t W = K.wide ? 8u : 4u;
+    const uint32_t W = K.wide == 1 ? 8u : 4u;
     /* slots per table: 42 % full when LDS allows, never more than 48.5 % (two-choice cuckoo places up to 50 %) */
     uint32_t N = (uint32_t)((double)n / (2.0 * 0.42)) + 1u;
-    const uint32_t cap = (lds_budget / (2u * W)) & ~1u;
+    const uint32_t cap = ((lds_budget / (2u * W)) - K.pad) & ~1u;
     if (N > cap) N = cap;
     if (N < 16u) N = 16u;
+    if (N < 4u * K.pad) N = 4u * K.pad; /* quotient keys: a free slot's filler must hash outside the pad slots in front of it -- possible only while the table is longer than its padding */
+    if (N > cap) { free(keys); *why = "more keys than two tables in LDS hold"; return NULL; }
     if (N > 65535u) N = 65535u;
     if ((double)n > 0.485 * 2.0 * (double)N) { free(keys); *why = "more keys than two tables in LDS hold"; return NULL; }
     N = (N + 1u) & ~1u; /* table 2 starts 8-byte aligned */
     K.slots = N;
-    K.base2 = N * W;
-    K.bytes = (2u * N * W + 15u) & ~15u;
+    K.base2 = (N + K.pad) * W;
+    K.bytes = (2u * (N + K.pad) * W + 15u) & ~15u;
+    const uint32_t T = N + K.pad; /* slots of one table in the image */
 
-    uint32_t *slot_of = (uint32_t *)malloc(sizeof(uint32_t) * 2u * (size_t)N);
+    uint32_t *slot_of = (uint32_t *)malloc(sizeof(uint32_t) * 2u * (size_t)T);
     struct smh_keys *k = (struct smh_keys *)calloc(1, sizeof *k);
     unsigned char *image = (unsigned char *)calloc(1, K.bytes);
     if (!slot_of || !k || !image) { free(keys); free(slot_of); free(k); free(image); *why = "out of memory"; return NULL; }
@@ -145,27 +150,32 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
         placed = cuckoo_place(keys, n, &K, slot_of);
     }
     if (!placed) { free(keys); free(slot_of); free(k); free(image); *why = "no cuckoo placement found"; return NULL; }
-    /* the image.  A free slot holds a value that can never be read as a match: a pattern with a bit outside the key's mask
-     * when there is one; when the key fills the slot (m * bits == 32 or 64), a key that does not hash to this slot. */
-    const int full = kb == 32 || kb == 64;
-    for (uint32_t s = 0; s < 2u * N; ++s) {
+    /* the image.  A free slot holds a value that can never be read as a match: a value with a bit outside the key's mask
+     * when there is one; when the stored part fills the slot (m * bits == 32 or 64; a quotient key's low half), one that no
+     * probe landing on this slot carries -- a key that does not hash to it (whatever its high bits, for quotient keys). */
+    const int full = kb == 32 || kb == 64 || K.wide == 2;
+    int filled = 1;
+    for (uint32_t s = 0; s < 2u * T && filled; ++s) {
         uint64_t v;
         if (slot_of[s]) {
             v = keys[slot_of[s] - 1];
         } else if (!full) {
             v = ~0ull;
         } else {
-            for (v = 0;; ++v) {
+            for (v = 0; v < (1u << 16); ++v) {
                 uint32_t s1, s2;
-                key_slot_ids(v, &K, &s1, &s2);
-                if ((s < N ? s1 : s2) != s) break;
+                key_slot_ids(v, &K, &s1, &s2); /* v < 2^32: high bits 0, so s_t = the slot of y = 0; probes with this x land on s_t .. s_t + pad - 1 */
+                const uint32_t mine = s < T ? s1 : s2;
+                if (K.wide == 2 ? (s < mine || s >= mine + K.pad) : mine != s) break;
             }
+            if (v == (1u << 16)) filled = 0; /* (cannot happen while slots > pad: one value in slots / (slots - pad) qualifies) */
         }
-        if (K.wide) memcpy(image + 8u * (size_t)s, &v, 8);
+        if (K.wide == 1) memcpy(image + 8u * (size_t)s, &v, 8);
         else { const uint32_t v32 = (uint32_t)v; memcpy(image + 4u * (size_t)s, &v32, 4); }
     }
     free(slot_of);
     free(keys);
+    if (!filled) { free(k); free(image); *why = "no filler for a free slot"; return NULL; }
     k->magic = SMH_MAGIC_KEYS;
     k->alphabet = alphabet;
     k->m = m;
@@ -173,7 +183,7 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
     k->P = K;
     k->image = image;
     /* one column = key roll + two hashes + two LDS reads + two compares whatever text and set (measured on MI355X, round 5) */
-    k->ms_est = K.wide ? SMH_KEYS_MS_WIDE : SMH_KEYS_MS_NARROW;
+    k->ms_est = K.wide == 1 ? SMH_KEYS_MS_WIDE : SMH_KEYS_MS_NARROW;
     return k;
 }
 
@@ -181,9 +191,9 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
 int smh_keys_contains(const struct smh_keys *k, uint64_t key)
 {
     uint32_t o1, o2;
-    smh_key_slots(key_f(key, &k->P), &k->P, &o1, &o2);
+    smh_key_slots(key_f(key, &k->P), key_y(key, &k->P), &k->P, &o1, &o2);
     const unsigned char *im = (const unsigned char *)k->image;
-    if (k->P.wide) {
+    if (k->P.wide == 1) {
         uint64_t a, b;
         memcpy(&a, im + o1, 8);
         memcpy(&b, im + o2, 8);

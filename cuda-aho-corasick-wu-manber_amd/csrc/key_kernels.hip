@@ -13,7 +13,7 @@
 #include "key_lane.h"
 #include "smh_stats.h"
 
-template <bool WIDE, int HP, bool POS, bool FULL>
+template <int KC, int HP, bool POS, bool FULL>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void key_kernel(const uint8_t *__restrict__ text, uint64_t n,
                                                                const uint32_t *__restrict__ image_g, smh_key_params K,
                                                                uint64_t *count, smh_pos_out po, smh_stats_arg SA)
@@ -28,14 +28,14 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void key_kernel(const uint8_t *_
     smh_stats_stash(S.ctr_off, SA);
     __syncthreads();
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t cnt = smh_key_thread<WIDE, HP, POS, FULL>(gthread, S, text, n, smh_lds, K, &po);
+    const uint32_t cnt = smh_key_thread<KC, HP, POS, FULL>(gthread, S, text, n, smh_lds, K, &po);
     if constexpr (!POS) smh_block_finish(cnt, count, smh_lds, S.ctr_off, n, 0u); /* positions mode: the cursor is the count */
 }
 
-template <bool WIDE, int HP, bool POS, bool FULL>
+template <int KC, int HP, bool POS, bool FULL>
 static hipError_t launch(const smh_key_launch &L, hipStream_t stream)
 {
-    auto kern = key_kernel<WIDE, HP, POS, FULL>;
+    auto kern = key_kernel<KC, HP, POS, FULL>;
     const uint32_t lds = (L.K.bytes < SMH_LDS_MIN ? SMH_LDS_MIN : L.K.bytes) + 16u + SMH_SCHED_LDS;
     static smh_attr_cache cache;
     int per_cu = 0;
@@ -60,10 +60,11 @@ static hipError_t launch_any(const smh_key_launch &L, hipStream_t stream)
     const bool hp2 = L.K.m - 1 > 16;
     const int kb = L.K.m * L.K.bits;
     /* the key fills its slot (alphabet 4: m = 16 / m = 32, the BASELINE lengths): no mask per column; counting kernels only */
-    if (!POS && kb == 64) return hp2 ? launch<true, 2, POS, true>(L, stream) : launch<true, 1, POS, true>(L, stream);
-    if (!POS && kb == 32) return hp2 ? launch<false, 2, POS, true>(L, stream) : launch<false, 1, POS, true>(L, stream);
-    if (L.K.wide) return hp2 ? launch<true, 2, POS, false>(L, stream) : launch<true, 1, POS, false>(L, stream);
-    return hp2 ? launch<false, 2, POS, false>(L, stream) : launch<false, 1, POS, false>(L, stream);
+    if (!POS && kb == 64) return hp2 ? launch<1, 2, POS, true>(L, stream) : launch<1, 1, POS, true>(L, stream);
+    if (!POS && kb == 32) return hp2 ? launch<0, 2, POS, true>(L, stream) : launch<0, 1, POS, true>(L, stream);
+    if (L.K.wide == 2) return hp2 ? launch<2, 2, POS, false>(L, stream) : launch<2, 1, POS, false>(L, stream); /* quotient keys */
+    if (L.K.wide == 1) return hp2 ? launch<1, 2, POS, false>(L, stream) : launch<1, 1, POS, false>(L, stream);
+    return hp2 ? launch<0, 2, POS, false>(L, stream) : launch<0, 1, POS, false>(L, stream);
 }
 
 hipError_t smh_launch_keys(const smh_key_launch &L, hipStream_t stream) { return launch_any<false>(L, stream); }

@@ -33,10 +33,12 @@ SMH_LANE void smh_key_count(uint32_t &acc, bool hit1, bool hit2) { acc += (hit1 
 SMH_LANE uint32_t smh_key_count_mine(uint32_t acc) { return acc; }
 #endif
 
-template <bool WIDE>
+/* KC = the key class (smh_key_params.wide): 0 = 32-bit keys, 1 = 64-bit keys in 8-byte slots, 2 = quotient keys (33..42 bits,
+ * the low 32 in a 4-byte slot, the high bits added to the slot number) */
+template <int KC>
 SMH_LANE void smh_key_roll(smh_key_code &c, uint32_t sym, uint32_t bits)
 {
-    if constexpr (WIDE) {
+    if constexpr (KC != 0) {
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         c.hi = __builtin_amdgcn_alignbit(c.hi, c.lo, 32u - bits);
 #else
@@ -49,26 +51,31 @@ SMH_LANE void smh_key_roll(smh_key_code &c, uint32_t sym, uint32_t bits)
 /* the key of code c and the byte offsets of its two slots in the image */
 struct smh_key_probe { uint32_t klo, khi, o1, o2; };
 /* FULL: the key fills its slot (m * bits == 32 or 64) -- the rolling code IS the key, no mask */
-template <bool WIDE, bool FULL = false>
+template <int KC, bool FULL = false>
 SMH_LANE smh_key_probe smh_key_address(const smh_key_code &c, const smh_key_params &K)
 {
     smh_key_probe p;
-    p.klo = FULL ? c.lo : (c.lo & K.mask_lo);
-    p.khi = WIDE ? (FULL ? c.hi : (c.hi & K.mask_hi)) : 0u;
-    const uint32_t f = WIDE ? smh_key_fold(p.klo, p.khi, K.fold[0], K.fold[1]) : p.klo;
+    p.klo = FULL || KC == 2 ? c.lo : (c.lo & K.mask_lo);
+    p.khi = KC != 0 ? (FULL ? c.hi : (c.hi & K.mask_hi)) : 0u;
+    const uint32_t f = KC == 1 ? smh_key_fold(p.klo, p.khi, K.fold[0], K.fold[1]) : p.klo;
     const uint32_t h1 = smh_key_mul24(f, K.mul[0]) + smh_key_mul24(f >> 8, K.mul[1]), h2 = smh_key_mul24(h1, K.mul[2]);
     const uint32_t ns = K.slots << 8;
-    p.o1 = smh_key_mulhi24(h1, ns) << (WIDE ? 3 : 2);
-    p.o2 = (smh_key_mulhi24(h2, ns) << (WIDE ? 3 : 2)) + K.base2;
+    if constexpr (KC == 2) { /* the key's high bits move the slot (one v_add_lshl per table instead of the shift) */
+        p.o1 = (smh_key_mulhi24(h1, ns) + p.khi) << 2;
+        p.o2 = ((smh_key_mulhi24(h2, ns) + p.khi) << 2) + K.base2;
+    } else {
+        p.o1 = smh_key_mulhi24(h1, ns) << (KC == 1 ? 3 : 2);
+        p.o2 = (smh_key_mulhi24(h2, ns) << (KC == 1 ? 3 : 2)) + K.base2;
+    }
     return p;
 }
 /* the two slots' contents */
 struct smh_key_slots2 { uint32_t a0, a1, b0, b1; };
-template <bool WIDE>
+template <int KC>
 SMH_LANE smh_key_slots2 smh_key_read(const smh_key_probe &p, const void *tab)
 {
     smh_key_slots2 r = {0u, 0u, 0u, 0u};
-    if constexpr (WIDE) {
+    if constexpr (KC == 1) {
         smh_lds_u32x2(tab, p.o1, r.a0, r.a1);
         smh_lds_u32x2(tab, p.o2, r.b0, r.b1);
     } else {
@@ -78,34 +85,34 @@ SMH_LANE smh_key_slots2 smh_key_read(const smh_key_probe &p, const void *tab)
     return r;
 }
 /* slot t of the probe holds the key */
-template <bool WIDE, int T>
+template <int KC, int T>
 SMH_LANE bool smh_key_slot_is(const smh_key_probe &p, const smh_key_slots2 &r)
 {
-    if constexpr (WIDE) return ((((uint64_t)(T ? r.b1 : r.a1)) << 32) | (T ? r.b0 : r.a0)) == ((((uint64_t)p.khi) << 32) | p.klo);
+    if constexpr (KC == 1) return ((((uint64_t)(T ? r.b1 : r.a1)) << 32) | (T ? r.b0 : r.a0)) == ((((uint64_t)p.khi) << 32) | p.klo);
     return (T ? r.b0 : r.a0) == p.klo;
 }
-template <bool WIDE>
+template <int KC>
 SMH_LANE bool smh_key_decide(const smh_key_probe &p, const smh_key_slots2 &r)
 {
     /* no short-circuit: as `||` the compiler puts the second slot's READ behind a branch on the first compare */
-    if constexpr (WIDE) {
+    if constexpr (KC == 1) {
         const uint64_t key = ((uint64_t)p.khi << 32) | p.klo, a = ((uint64_t)r.a1 << 32) | r.a0, b = ((uint64_t)r.b1 << 32) | r.b0;
         return (a == key) | (b == key);
     }
     return (r.a0 == p.klo) | (r.b0 == p.klo);
 }
 /* 1 when the window whose code is c is a pattern.  `tab` = the image (LDS offset 0 on the GPU). */
-template <bool WIDE>
+template <int KC>
 SMH_LANE uint32_t smh_key_test(const smh_key_code &c, const void *tab, const smh_key_params &K)
 {
-    const smh_key_probe p = smh_key_address<WIDE>(c, K);
-    return smh_key_decide<WIDE>(p, smh_key_read<WIDE>(p, tab)) ? 1u : 0u;
+    const smh_key_probe p = smh_key_address<KC>(c, K);
+    return smh_key_decide<KC>(p, smh_key_read<KC>(p, tab)) ? 1u : 0u;
 }
 
 /* fast path: the 64 END columns of the segment at a (a >= 16 * HP >= m - 1, a + 64 <= n); edge = the 16 * HP bytes in
  * front of the wave-chunk (wave-uniform), what lane 0 primes with.  The columns go four at a time (one text dword): four
  * keys and their eight slot addresses, eight LDS reads in flight together, then the eight compares. */
-template <bool WIDE, int HP, bool POS, bool FULL = false>
+template <int KC, int HP, bool POS, bool FULL = false>
 SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&edge)[4 * HP],
                                     const void *tab, const smh_key_params &K, const smh_pos_out *po)
 {
@@ -115,7 +122,7 @@ SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint3
     for (int q = 0; q < 4 * HP; ++q) {
         const uint32_t pw = smh_prev_lane_word(w[16 - 4 * HP + q], edge[q], text, a - 16u * HP + 4u * q);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) smh_key_roll<WIDE>(c, smh_bfe(pw, 8u * k, bits), bits);
+        for (int k = 0; k < 4; ++k) smh_key_roll<KC>(c, smh_bfe(pw, 8u * k, bits), bits);
     }
     uint32_t cnt = 0, mlo = 0, mhi = 0;
 #pragma unroll
@@ -124,19 +131,19 @@ SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint3
         smh_key_slots2 r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            smh_key_roll<WIDE>(c, smh_bfe(w[q], 8u * k, bits), bits);
-            p[k] = smh_key_address<WIDE, FULL>(c, K);
+            smh_key_roll<KC>(c, smh_bfe(w[q], 8u * k, bits), bits);
+            p[k] = smh_key_address<KC, FULL>(c, K);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) r[k] = smh_key_read<WIDE>(p[k], tab);
+        for (int k = 0; k < 4; ++k) r[k] = smh_key_read<KC>(p[k], tab);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if constexpr (POS) {
-                const bool hit = smh_key_decide<WIDE>(p[k], r[k]);
+                const bool hit = smh_key_decide<KC>(p[k], r[k]);
                 if (q < 8) mlo |= (hit ? 1u : 0u) << (4 * q + k);
                 else mhi |= (hit ? 1u : 0u) << (4 * (q - 8) + k);
             } else {
-                smh_key_count(cnt, smh_key_slot_is<WIDE, 0>(p[k], r[k]), smh_key_slot_is<WIDE, 1>(p[k], r[k]));
+                smh_key_count(cnt, smh_key_slot_is<KC, 0>(p[k], r[k]), smh_key_slot_is<KC, 1>(p[k], r[k]));
             }
         }
     }
@@ -145,7 +152,7 @@ SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint3
 }
 
 /* bounds-checked path: the END columns [max(a, m - 1), min(a + 64, n)) byte by byte from memory */
-template <bool WIDE>
+template <int KC>
 SMH_LANE uint32_t smh_key_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const void *tab, const smh_key_params &K,
                                     uint64_t *match_mask = nullptr)
 {
@@ -159,17 +166,17 @@ SMH_LANE uint32_t smh_key_lane_slow(const uint8_t *text, uint64_t n, uint64_t a,
     const uint32_t bits = (uint32_t)K.bits, smask = (1u << bits) - 1u;
     smh_key_code c = {0u, 0u};
     uint32_t cnt = 0;
-    for (uint64_t i = e0 - (uint64_t)(K.m - 1); i < e0; ++i) smh_key_roll<WIDE>(c, text[i] & smask, bits);
+    for (uint64_t i = e0 - (uint64_t)(K.m - 1); i < e0; ++i) smh_key_roll<KC>(c, text[i] & smask, bits);
     for (uint64_t e = e0; e < end; ++e) {
-        smh_key_roll<WIDE>(c, text[e] & smask, bits);
-        const uint32_t hit = smh_key_test<WIDE>(c, tab, K);
+        smh_key_roll<KC>(c, text[e] & smask, bits);
+        const uint32_t hit = smh_key_test<KC>(c, tab, K);
         cnt += hit;
         if (match_mask && hit) *match_mask |= 1ull << (e - a);
     }
     return cnt;
 }
 
-template <bool WIDE, int HP, bool POS, bool FULL = false>
+template <int KC, int HP, bool POS, bool FULL = false>
 SMH_LANE uint32_t smh_key_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n, const void *tab,
                                  const smh_key_params &K, const smh_pos_out *po = nullptr)
 {
@@ -206,13 +213,13 @@ SMH_LANE uint32_t smh_key_thread(uint64_t gthread, const smh_chunk_sched &S, con
         const uint64_t a = smh_uniform64(k * chunk_bytes) + (uint64_t)lane * SMH_SEG;
         if (is_fast(k)) {
             load(k);
-            cnt += smh_key_lane_fast<WIDE, HP, POS, FULL>(text, a, cur, edge, tab, K, po);
+            cnt += smh_key_lane_fast<KC, HP, POS, FULL>(text, a, cur, edge, tab, K, po);
         } else if (POS) {
             uint64_t mm;
-            smh_key_lane_slow<WIDE>(text, n, a, tab, K, &mm);
+            smh_key_lane_slow<KC>(text, n, a, tab, K, &mm);
             cnt += smh_append_bits(mm, a, *po);
         } else {
-            cnt += smh_key_lane_slow<WIDE>(text, n, a, tab, K);
+            cnt += smh_key_lane_slow<KC>(text, n, a, tab, K);
         }
         k = S.take(n_chunks);
     }

@@ -1836,7 +1836,7 @@ extern "C" int smh_keys_get_info(const struct smh_keys *k, smh_keys_info *out)
         return SMH_EINVAL;
     }
     out->alphabet = (uint32_t)k->alphabet; out->m = (uint32_t)k->m; out->keys = k->n_keys;
-    out->key_bits = (uint32_t)(k->P.m * k->P.bits); out->slot_bytes = k->P.wide ? 8u : 4u; out->slots = k->P.slots;
+    out->key_bits = (uint32_t)(k->P.m * k->P.bits); out->slot_bytes = k->P.wide == 1 ? 8u : 4u; out->slots = k->P.slots;
     out->lds_bytes = k->P.bytes; out->est_ms_per_gib = k->ms_est;
     return SMH_OK;
 }

@@ -592,7 +592,7 @@ extern "C" uint64_t emu_sog_scan(const smh_sog *sg, const uint8_t *text_in, uint
 
 /* ------------------------------------------------------------------ key engine (csrc/key_lane.h) */
 #include "key_lane.h"
-template <bool WIDE, int HP, bool FULL>
+template <int KC, int HP, bool FULL>
 static uint64_t keys_grid(const smh_keys *k, const uint8_t *text, uint64_t n, uint64_t blocks, uint64_t *out, uint64_t capacity, uint64_t *cursor)
 {
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
@@ -600,8 +600,8 @@ static uint64_t keys_grid(const smh_keys *k, const uint8_t *text, uint64_t n, ui
     smh_pos_out po{out, capacity, cursor};
     for (uint64_t t = 0; t < nthreads; ++t) {
         const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
-        if (cursor) smh_key_thread<WIDE, HP, true, false>(t, S, text, n, k->image, k->P, &po);
-        else total += smh_key_thread<WIDE, HP, false, FULL>(t, S, text, n, k->image, k->P, nullptr);
+        if (cursor) smh_key_thread<KC, HP, true, false>(t, S, text, n, k->image, k->P, &po);
+        else total += smh_key_thread<KC, HP, false, FULL>(t, S, text, n, k->image, k->P, nullptr);
     }
     return cursor ? *cursor : total;
 }
@@ -609,10 +609,11 @@ static uint64_t keys_any(const smh_keys *k, const uint8_t *text, uint64_t n, uin
 {
     const bool hp2 = k->P.m - 1 > 16;
     const int kb = k->P.m * k->P.bits; /* as key_kernels.hip launch_any: keys that fill their slot run the instantiation without the mask */
-    if (kb == 64) return hp2 ? keys_grid<true, 2, true>(k, text, n, blocks, out, capacity, cursor) : keys_grid<true, 1, true>(k, text, n, blocks, out, capacity, cursor);
-    if (kb == 32) return hp2 ? keys_grid<false, 2, true>(k, text, n, blocks, out, capacity, cursor) : keys_grid<false, 1, true>(k, text, n, blocks, out, capacity, cursor);
-    if (k->P.wide) return hp2 ? keys_grid<true, 2, false>(k, text, n, blocks, out, capacity, cursor) : keys_grid<true, 1, false>(k, text, n, blocks, out, capacity, cursor);
-    return hp2 ? keys_grid<false, 2, false>(k, text, n, blocks, out, capacity, cursor) : keys_grid<false, 1, false>(k, text, n, blocks, out, capacity, cursor);
+    if (kb == 64) return hp2 ? keys_grid<1, 2, true>(k, text, n, blocks, out, capacity, cursor) : keys_grid<1, 1, true>(k, text, n, blocks, out, capacity, cursor);
+    if (kb == 32) return hp2 ? keys_grid<0, 2, true>(k, text, n, blocks, out, capacity, cursor) : keys_grid<0, 1, true>(k, text, n, blocks, out, capacity, cursor);
+    if (k->P.wide == 2) return hp2 ? keys_grid<2, 2, false>(k, text, n, blocks, out, capacity, cursor) : keys_grid<2, 1, false>(k, text, n, blocks, out, capacity, cursor);
+    if (k->P.wide == 1) return hp2 ? keys_grid<1, 2, false>(k, text, n, blocks, out, capacity, cursor) : keys_grid<1, 1, false>(k, text, n, blocks, out, capacity, cursor);
+    return hp2 ? keys_grid<0, 2, false>(k, text, n, blocks, out, capacity, cursor) : keys_grid<0, 1, false>(k, text, n, blocks, out, capacity, cursor);
 }
 /* count; the text once ending at and once starting behind a guard page (both results must agree: ~0 if not) */
 extern "C" uint64_t emu_keys_scan(const smh_keys *k, const uint8_t *text_in, uint64_t n, uint32_t blocks)

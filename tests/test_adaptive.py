@@ -126,10 +126,12 @@ def test_engine_follows_the_text_and_counts_do_not_change(entry):
 def test_verify_mode_follows_measured_survivors():
     """8000 patterns of 16 symbols: on uniform text ~1.4 survivors per 4 KiB (verified in registers); on the planted text
     -- one of the patterns recurs in every 64-byte cell -- over 60: the launcher is handed the measured rate and takes the
-    staged verify.  Same counts either way, and SMH_WM_TUNE can still force each mode."""
+    staged verify.  Same counts either way, and SMH_WM_TUNE can still force each mode.  (The filter kernels are forced: left to
+    itself the handle leaves them on the planted text for its text-independent engines -- the key table since round 5.)"""
     n, m, p, sigma = 64 << 20, 16, 8000, 4
     pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2, S.CORPUS_PLANTED)
     wm = S.WmTables.from_patterns(pat, m, p, sigma)
+    wm.set_scan_engine(S.ALGO_WM)
     uni, pla = _dev_text(n, sigma, S.CORPUS_UNIFORM), _dev_text(n, sigma, S.CORPUS_PLANTED)
     want_uni = O.oracle_ac(pat, m, p, sigma, uni[:n].cpu().numpy())[0]
     want_pla = O.oracle_ac(pat, m, p, sigma, pla[:n].cpu().numpy())[0]

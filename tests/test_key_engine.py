@@ -12,7 +12,8 @@ import oracle_lib as O
 import smatcher_hip as S
 
 # (alphabet, m, patterns): 32-bit keys, 64-bit keys, every symbol width, the halo classes (m - 1 <= 16 / <= 32), key widths that fill the slot
-SETS = [(4, 3, 10), (4, 8, 100), (4, 16, 1000), (4, 17, 300), (4, 32, 500), (2, 16, 40), (8, 10, 200), (8, 21, 100), (20, 6, 300),
+SETS = [(4, 17, 1200), (4, 20, 300), (4, 21, 5000), (20, 7, 400), (20, 8, 10000), (256, 5, 3000), (128, 5, 100), (128, 6, 200), (8, 14, 700),  # quotient keys (33..42 bits)
+        (4, 3, 10), (4, 8, 100), (4, 16, 1000), (4, 17, 300), (4, 32, 500), (2, 16, 40), (8, 10, 200), (8, 21, 100), (20, 6, 300),
         (20, 8, 500), (20, 12, 200), (128, 4, 300), (128, 9, 100), (256, 3, 50), (256, 4, 1000), (256, 5, 400), (256, 8, 2000), (16, 16, 100)]
 
 
@@ -29,7 +30,7 @@ def test_builder_holds_exactly_the_set(sigma, m, p):
     info = k.info()
     pats = np.asarray(pat, dtype=np.uint8).reshape(p, m)
     assert info.keys == len({bytes(r) for r in pats})
-    assert info.key_bits == m * max(2, int(np.ceil(np.log2(sigma)))) and info.slot_bytes == (8 if info.key_bits > 32 else 4)
+    assert info.key_bits == m * max(2, int(np.ceil(np.log2(sigma)))) and info.slot_bytes == (8 if info.key_bits > 42 else 4)  # 33..42 bits: quotient keys
     assert info.keys <= 0.485 * 2 * info.slots and info.lds_bytes <= 156 * 1024
     k.close()
 
@@ -59,7 +60,7 @@ def test_text_length_edges(n):
 
 def test_matches_across_every_lane_and_chunk_boundary():
     """a text that is ONE pattern repeated: every column from m - 1 on ends a match, across segment, wave-chunk and workgroup edges"""
-    for sigma, m in ((4, 16), (4, 32), (256, 8), (20, 12)):
+    for sigma, m in ((4, 16), (4, 32), (256, 8), (20, 12), (20, 8), (4, 19), (256, 5)):
         unit = O.gen_text(m, 5, sigma)
         text = np.tile(unit, (5 * 4096) // m + 2)[:5 * 4096 + 77]
         rot = np.concatenate([np.roll(unit, -r) for r in range(m)])  # all rotations of the unit
@@ -92,14 +93,16 @@ def test_positions_are_the_end_columns():
 def test_a_key_that_fills_its_slot_never_matches_a_free_slot():
     """m * bits == 32 / 64: every slot value is a possible key, so free slots hold keys that hash elsewhere -- a text made of exactly
     those filler values must count nothing"""
-    for sigma, m in ((4, 16), (256, 4), (4, 32), (256, 8)):
+    for sigma, m in ((4, 16), (256, 4), (4, 32), (256, 8), (256, 5), (4, 20), (20, 8)):
         pat = O.gen_patterns(m, 3, 11, sigma)
         k = S.KeyTable(pat, m, 3, sigma)
-        bits = 2 if sigma == 4 else 8
+        bits = {4: 2, 20: 5, 256: 8}[sigma]
         fillers = []
-        for v in range(64):  # the builder's fillers are small numbers
+        # the builder's fillers are small numbers; quotient keys: any high bits in front of them
+        for v in list(range(64)) + ([(y << 32) | x for y in (1, 2, 3, (1 << (bits * m - 32)) - 1) for x in range(16)] if 32 < bits * m <= 42 else []):
             sym = [(v >> (bits * (m - 1 - i))) & ((1 << bits) - 1) if bits * (m - 1 - i) < 64 else 0 for i in range(m)]
-            fillers.append(np.asarray(sym, dtype=np.uint8))
+            if max(sym) < sigma:
+                fillers.append(np.asarray(sym, dtype=np.uint8))
         text = np.concatenate(fillers * 40)
         assert E.keys_scan(k, text) == O.count_bruteforce(pat, m, 3, text)
         k.close()
@@ -112,6 +115,7 @@ def test_sets_the_engine_does_not_take():
         S.KeyTable(O.gen_patterns(9, 10, 7, 256), 9, 10, 256)
     with pytest.raises(S.SmhError, match="LDS"):
         S.KeyTable(O.gen_patterns(8, 30000, 7, 256), 8, 30000, 256)
+    S.KeyTable(O.gen_patterns(8, 16000, 7, 20), 8, 16000, 20).close()   # 40-bit keys as quotient keys in 4-byte slots: twice the 64-bit capacity
     S.KeyTable(O.gen_patterns(32, 8000, 7, 4), 32, 8000, 4).close()   # BASELINE configs[3]'s longest set fits
     S.KeyTable(O.gen_patterns(16, 16000, 7, 4), 16, 16000, 4).close()
 

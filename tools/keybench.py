@@ -26,7 +26,7 @@ def timed(launch, reps=9):
 
 
 CORP = [("uniform", S.CORPUS_UNIFORM), ("repeats", S.CORPUS_DNA_REPEATS), ("planted", S.CORPUS_PLANTED), ("skewed", S.CORPUS_SKEWED)]
-SETS = [(4, 16, 8000), (4, 32, 8000), (4, 16, 1000), (4, 12, 16000), (20, 8, 1000), (20, 12, 5000), (256, 8, 5000), (256, 4, 10000)]
+SETS = [(4, 16, 8000), (4, 32, 8000), (4, 20, 8000), (20, 8, 10000), (20, 12, 5000), (256, 8, 5000), (256, 5, 10000)]
 for sigma, m, p in SETS:
     for cname, kind in CORP:
         if (kind == S.CORPUS_DNA_REPEATS and sigma != 4) or (kind == S.CORPUS_SKEWED and sigma == 4):
