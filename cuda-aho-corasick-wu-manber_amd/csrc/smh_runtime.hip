@@ -422,57 +422,15 @@ static int upload(void **d, const void *h, size_t bytes, size_t pad)
     return SMH_OK;
 }
 
-/* ------------------------------------------------------------------ adaptive engine (round 4; smh_stats.h)
- * A handle that holds several engines -- an automaton with a depth-cut or hybrid plan, the suffix-filter kernels over
- * the same patterns (smh_ac.flex_wm / smh_wm.flex_ac), the plain stride-1 automaton (smh_ac.flat_ac) -- starts with the
- * one its compile estimated fastest on random text and then follows the launches' own reports: every count launch of
- * 32 MiB or more publishes its duration (device clock, one workgroup's prologue to its last chunk) and the number of
- * columns it had to verify (a sample of eight workgroups, scaled: smh_stats.h).  Before the NEXT launch the host compares, per GiB, the running engine's measured time
- * (the better of its last two reports: an engine's first launch on a device runs cold) with the best of the others
- * (measured on this text, else the compile's estimate) and switches when that is clearly better -- after the first
- * report when a launch of 256 MiB or more ran four times slower than estimated, else after the second.  What was measured of an
- * engine that is not running is forgotten, so that it is tried again, when the running engine's events per 4 KiB move by
- * a factor of two (another kind of text) and after 32 reports of the others -- 64, 128, ... 4096 when it keeps losing.  The
- * filter kernels' verify mode (in registers / staged) follows the measured survivors per chunk the same way.  Not every
- * launch reports (adapt_arg: a report costs its launch 2-4 us).  Nothing here synchronises: a launch that has not finished has simply not reported yet.  SMH_ADAPT=0 in the environment
- * (read once) turns all of it off; a forced engine or plan is never overridden. */
-struct smh_adapt_dev {
-    int device;
-    smh_adapt_dev *next;
-    smh_scan_stats *d_stats;
-    unsigned long long *h_rec; /* pinned host record the last workgroup of a launch writes (SMH_STATS_HOST_WORDS) */
-    unsigned int seen;
-    int engine;            /* the kernels that run next; -1 before the first launch */
-    int fresh;             /* a report of the running engine arrived since the last decision */
-    double last[SMH_ENGINES][2]; /* per engine: ms per GiB of its last two reports, [0] the newer */
-    int n[SMH_ENGINES];    /* reports held (0..2); 0 = not measured on this text */
-    uint32_t age[SMH_ENGINES]; /* reports of other engines since */
-    uint32_t keep[SMH_ENGINES]; /* reports of other engines after which the engine's measurement is forgotten: 32, doubling
-                                 * every time it is (an engine that keeps losing is tried ever more rarely), back to 32 when it wins */
-    double sig[SMH_ENGINES]; /* events per 4 KiB at the engine's last report */
-    unsigned long long last_bytes; /* text length of the newest report */
-    double ref_sig;
-    int ref_valid;
-    uint32_t reports, flips;
-    uint32_t launches;     /* tuned count launches of the handle on this device */
-    double mode_density;   /* survivors per column handed to the gram launcher (< 0: the compile's estimate so far) */
-    double slow;           /* the most a text-dependent engine has run over its estimate on this kind of text (>= 1) */
-    int tried[SMH_ENGINES]; /* the engine has reported on this kind of text */
-};
-
-/* engines whose rate does not depend on the text: their compile-time estimate holds on any text */
-static bool engine_text_independent(int e) { return e == SMH_ENGINE_AC_FLAT || e == SMH_ENGINE_KEYS; }
-
-static bool adapt_enabled()
-{
-    static const int on = [] { const char *e = getenv("SMH_ADAPT"); return e && atoi(e) == 0 ? 0 : 1; }();
-    return on != 0;
-}
+#include "smh_adapt.h" /* the adaptive engine: state, polling, policy (no HIP calls; also built for the CPU by tools/tsan_adapt.cpp) */
 
 static void adapt_free_one(smh_adapt_dev *a)
 {
+    if (a->order_ev) (void)hipEventDestroy((hipEvent_t)a->order_ev);
     (void)hipFree(a->d_stats);
+    (void)hipFree(a->d_scratch);
     if (a->h_rec) (void)hipHostFree(a->h_rec);
+    delete a->mu;
     delete a;
 }
 
@@ -491,12 +449,16 @@ static int adapt_get(smh_adapt_dev **head, smh_adapt_dev **out)
         a->engine = -1;
         a->mode_density = -1.0;
         a->slow = 1.0;
-        HIP_TRY(hipHostMalloc((void **)&a->h_rec, SMH_STATS_HOST_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
-        memset(a->h_rec, 0, SMH_STATS_HOST_WORDS * sizeof(unsigned long long));
-        smh_scan_stats init = {};
-        init.host = a->h_rec; /* pinned host memory has one address on both sides */
+        a->mu = new std::mutex();
+        const size_t rec_bytes = SMH_STATS_SLOTS * SMH_STATS_HOST_WORDS * sizeof(unsigned long long);
+        HIP_TRY(hipHostMalloc((void **)&a->h_rec, rec_bytes, hipHostMallocDefault));
+        memset(a->h_rec, 0, rec_bytes);
+        smh_scan_stats init[SMH_STATS_SLOTS] = {};
+        for (unsigned int i = 0; i < SMH_STATS_SLOTS; ++i) init[i].host = a->h_rec + i * SMH_STATS_HOST_WORDS; /* pinned host memory has one address on both sides */
         HIP_TRY(hipMalloc((void **)&a->d_stats, sizeof init));
-        HIP_TRY(hipMemcpy(a->d_stats, &init, sizeof init, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(a->d_stats, init, sizeof init, hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc((void **)&a->d_scratch, 64));
+        HIP_TRY(hipMemset(a->d_scratch, 0, 64));
         return SMH_OK;
     }, out);
 }
@@ -512,138 +474,40 @@ static smh_adapt_dev *adapt_find(smh_adapt_dev *const *head)
     return NULL;
 }
 
-static double adapt_ms(const smh_adapt_dev *A, int e)
+/* Launches of ONE handle are ordered on the device, also across streams (round 5).  A handle owns per-device workspaces -- the
+ * depth-cut automaton kernels' candidate queue, the report slots -- and its measured rates are only its own while its launches do
+ * not run beside each other.  Same stream as the previous launch: in order anyway, nothing to do, nothing recorded (the
+ * single-stream caller pays nothing).  The first time a second stream shows up nothing was recorded behind the earlier launches:
+ * one hipDeviceSynchronize, once per handle and device.  From then on every launch records an event behind itself and a launch
+ * on another stream than the previous one waits for it on the device (the host never blocks).  Not inside a stream capture.
+ * Called with A->mu held. */
+static int adapt_order_before(smh_adapt_dev *A, void *stream)
 {
-    if (A->n[e] == 0) return 0.0;
-    return A->n[e] == 1 || A->last[e][0] < A->last[e][1] ? A->last[e][0] : A->last[e][1];
-}
-
-#define SMH_ADAPT_MIN_BYTES (32ull << 20) /* smaller launches are mostly table staging and tail: not a rate */
-#define SMH_ADAPT_FIXED_TICKS 400.0        /* 4 us of every launch are table staging and the last wave's tail whatever the text's length: taken off before a duration becomes a rate */
-static void adapt_poll(smh_adapt_dev *A)
-{
-    volatile unsigned long long *h = A->h_rec;
-    const unsigned int seq = (unsigned int)h[0];
-    if (seq == A->seen) return;
-    const unsigned long long ev = h[1], ticks = h[2], bytes = h[3], tag = h[4], seq2 = h[5], sum = h[6];
-    /* the record is written without a fence between data and flag: it validates itself */
-    if ((unsigned int)seq2 != seq || (unsigned int)h[0] != seq || sum != (ev ^ ticks ^ bytes ^ tag ^ (unsigned long long)seq)) return;
-    A->seen = seq;
-    const int e = (int)(tag & 3u);
-    if (bytes < SMH_ADAPT_MIN_BYTES || ticks == 0 || e >= SMH_ENGINES) return;
-    A->last[e][1] = A->last[e][0];
-    double t = (double)ticks - SMH_ADAPT_FIXED_TICKS;
-    if (t < 0.25 * (double)ticks) t = 0.25 * (double)ticks;
-    const double launches = (double)(((tag >> 8) & 0xFFu) ? ((tag >> 8) & 0xFFu) : 1u); /* the first of that many equal launches reported (ac_flat_launch) */
-    A->last[e][0] = launches * t * 1e-5 * (double)(1ull << 30) / (double)bytes; /* 100 MHz ticks -> ms per GiB */
-    A->last_bytes = bytes;
-    if (A->n[e] < 2) ++A->n[e];
-    A->tried[e] = 1;
-    A->sig[e] = (double)ev * 4096.0 / (double)bytes;
-    A->age[e] = 0;
-    for (int o = 0; o < SMH_ENGINES; ++o)
-        if (o != e) ++A->age[o];
-    ++A->reports;
-    if (e == A->engine) A->fresh = 1;
-}
-
-/* which engine runs the next launch; est[e] = the compile's estimate in ms per GiB, <= 0: the handle has no such engine */
-static int adapt_choose(smh_adapt_dev *A, const double est[SMH_ENGINES], int initial)
-{
-    if (A->engine < 0) { A->engine = initial; return initial; }
-    if (!A->fresh) return A->engine;
-    A->fresh = 0;
-    const int cur = A->engine;
-    const double c_cur = adapt_ms(A, cur);
-    if (c_cur <= 0) return cur;
-    /* a first report runs cold: wait for the second -- unless a launch of 256 MiB or more took four times what was estimated */
-    if (A->n[cur] < 2 && !(est[cur] > 0 && c_cur > 4.0 * est[cur] && A->last_bytes >= (256ull << 20))) return cur;
-    if (!A->ref_valid) {
-        A->ref_sig = A->sig[cur];
-        A->ref_valid = 1;
-    } else {
-        const double a = A->sig[cur], b = A->ref_sig;
-        if (fabs(a - b) > 0.05 && (a > 2.0 * b || b > 2.0 * a)) { /* another kind of text: what the others did on the old one says nothing */
-            for (int o = 0; o < SMH_ENGINES; ++o)
-                if (o != cur) A->n[o] = 0, A->tried[o] = 0;
-            A->ref_sig = a;
-            A->slow = 1.0;
-        }
+    A->unordered = 0;
+    if (!A->have_stream || A->last_stream == stream) return SMH_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        A->unordered = 1;
+        return SMH_OK;
     }
-    /* An estimate is a rate on random text.  Text that slows one text-dependent engine (survivors to verify, lanes deep in
-     * compact rows) slows the other for the same reason -- measured on the non-uniform corpora 5-30 x for the filter
-     * kernels where the hybrid image ran 7-75 x over -- so an engine of that kind that has NOT run on this text yet is
-     * expected to be off by the factor the running one is; the plain stride-1 parts are not (their estimate holds on any
-     * text).  An engine whose measurement was merely forgotten (below) is re-tried at its plain estimate. */
-    if (!engine_text_independent(cur) && est[cur] > 0 && c_cur / est[cur] > A->slow) A->slow = c_cur / est[cur];
-    int best = -1;
-    double c_best = 0, m_best = 1.0;
-    for (int o = 0; o < SMH_ENGINES; ++o) {
-        if (o == cur || est[o] <= 0) continue;
-        if (A->keep[o] == 0) A->keep[o] = 32u;
-        if (A->n[o] > 0 && A->age[o] >= A->keep[o]) { /* the race is re-run now and then: the text may have changed in a way the running engine's events do not show */
-            A->n[o] = 0;
-            if (A->keep[o] < 4096u) A->keep[o] *= 2u;
-        }
-        double c = A->n[o] > 0 ? adapt_ms(A, o) : est[o];
-        if (A->n[o] == 0 && !engine_text_independent(o) && !A->tried[o] && A->slow > 2.0) c *= A->slow;
-        const double margin = A->n[o] > 0 ? 1.03 : 1.08;
-        if (best < 0 || c * margin < c_best * m_best) { best = o; c_best = c; m_best = margin; }
+    if (!A->multi_stream) {
+        HIP_TRY(hipDeviceSynchronize());
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        A->order_ev = (void *)ev;
+        A->multi_stream = 1;
+        return SMH_OK;
     }
-    if (best >= 0 && c_best * m_best < c_cur) {
-        A->engine = best;
-        A->n[best] = 0; /* a fresh series for the engine that takes over */
-        if (c_best * 1.5 < c_cur) A->keep[best] = 32u;
-        A->ref_valid = 0;
-        ++A->flips;
-    }
-    return A->engine;
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)A->order_ev, 0));
+    return SMH_OK;
 }
-
-/* surviving columns per text column the gram launcher should plan its verify mode for: the compile's estimate until
- * the filter kernels have reported from this text, then what they measured -- replaced only when it moves by more than a
- * quarter, so that a rate near one of the launcher's thresholds does not flip the kernel instance from launch to launch */
-static float adapt_density(smh_adapt_dev *A, const struct smh_wm *wm)
+static int adapt_order_after(smh_adapt_dev *A, void *stream)
 {
-    if (!A) return (float)wm->gram_density;
-    if (A->mode_density < 0) A->mode_density = wm->gram_density;
-    if (A->n[SMH_ALGO_WM] > 0) {
-        const double meas = A->sig[SMH_ALGO_WM] / 4096.0, old = A->mode_density;
-        if (fabs(meas - old) > 0.25 * (meas > old ? meas : old)) A->mode_density = meas;
-    }
-    return (float)A->mode_density;
-}
-
-/* A report costs its launch 2-4 us (the reporting workgroups' atomics, the record's trip to host memory before the kernel
- * may end: measured 1-3 % on the 175 us headline scans), so not every launch reports: the first four of a handle on a
- * device, every launch while the running engine's series is incomplete (a decision is pending), then every eighth. */
-static smh_stats_arg adapt_arg(smh_adapt_dev *A, uint64_t n, int engine)
-{
-    smh_stats_arg sa = {};
-    if (!A) return sa;
-    const uint32_t k = A->launches++;
-    if (k < 4u || (engine >= 0 && engine < SMH_ENGINES && A->n[engine] < 2) || (k & 7u) == 0u) {
-        sa.st = A->d_stats;
-        sa.bytes = n;
-        sa.tag = (unsigned int)engine;
-    }
-    return sa;
-}
-
-static void adapt_report(const smh_adapt_dev *A, int adaptive, int engine_static, const double est[SMH_ENGINES], smh_adapt_info *out)
-{
-    const uint32_t size = out->struct_size;
-    memset(out, 0, sizeof *out);
-    out->struct_size = size;
-    out->adaptive = (uint32_t)adaptive;
-    out->engine = (uint32_t)(adaptive && A && A->engine >= 0 ? A->engine : engine_static);
-    for (int e = 0; e < SMH_ENGINES; ++e) out->est_ms_per_gib[e] = est[e];
-    out->verify_density = -1.0;
-    if (!A) return;
-    out->flips = A->flips;
-    out->reports = A->reports;
-    for (int e = 0; e < SMH_ENGINES; ++e) { out->ms_per_gib[e] = adapt_ms(A, e); out->events_per_4k[e] = A->sig[e]; }
-    out->verify_density = A->mode_density;
+    A->last_stream = stream;
+    A->have_stream = 1;
+    if (A->multi_stream && !A->unordered) HIP_TRY(hipEventRecord((hipEvent_t)A->order_ev, (hipStream_t)stream));
+    return SMH_OK;
 }
 
 /* First look at a text (round 4).  The policy above needs a report to act on, so a handle's FIRST launch on a device runs the
@@ -662,17 +526,19 @@ static int adapt_first_look(smh_adapt_dev *A, const double est[SMH_ENGINES], int
                             uint64_t *d_count, void *stream, LAUNCH &&launch, uint64_t *done)
 {
     *done = 0;
-    if (A->engine >= 0 || n < SMH_FIRST_LOOK_MIN_TEXT || est[initial] <= 0) return SMH_OK;
+    /* (gated on "no report held yet", not on "no launch yet": a short warm-up scan -- smh_multi_*_prepare's 16 KiB one -- sets the
+     * engine without telling anything about the text) */
+    if (A->reports > 0 || n < SMH_FIRST_LOOK_MIN_TEXT || est[initial] <= 0) return SMH_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return SMH_OK; }
     int others = 0;
     for (int o = 0; o < SMH_ENGINES; ++o) others += o != initial && est[o] > 0;
     if (!others) return SMH_OK;
-    uint64_t *scratch = reinterpret_cast<uint64_t *>(&A->d_stats->pad[0]); /* device memory nobody else uses */
+    uint64_t *scratch = A->d_scratch; /* device memory nobody else reads */
     const uint64_t piece = SMH_FIRST_LOOK_BYTES + (uint64_t)(m - 1); /* END columns [m-1, piece) = the starts [0, 256 MiB) */
     auto probe = [&](int engine, uint64_t *count, uint64_t bytes, bool report) -> int {
         smh_stats_arg sa = {};
-        if (report) { sa.st = A->d_stats; sa.bytes = bytes; sa.tag = (unsigned int)engine; }
+        if (report) sa = adapt_slot(A, bytes, engine, false);
         int rc = launch(engine, d_text, bytes, count, sa);
         if (rc != SMH_OK) return rc;
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -851,6 +717,8 @@ static int ac_engine_static(const struct smh_ac *ac)
 }
 static struct smh_wm *ac_filter_engine(const struct smh_ac *ac) { return ac->alt_wm ? ac->alt_wm : ac->flex_wm; }
 /* the engine the next tuned scan on the current device runs (positions, info) */
+/* a handle with per-device state shared by its launches: several engines (reports, rates) or a candidate-queue workspace */
+static bool ac_needs_state(const struct smh_ac *ac) { return ac->flex_wm || ac->flat_ac || ac->keys || (!ac->scan_exact && !ac->scan_dense); }
 static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac || ac->keys) && adapt_enabled(); }
 /* the text-independent engine: one exact stride-1 launch per part (ac_host.c, end of the compile) */
 static double ac_flat_ms(const struct smh_ac *ac)
@@ -873,7 +741,10 @@ static void ac_estimates(const struct smh_ac *ac, double est[SMH_ENGINES])
 static int ac_engine_now(struct smh_ac *ac)
 {
     if (ac->engine_forced < 0 && ac_adaptive(ac))
-        if (smh_adapt_dev *A = adapt_find(&ac->adapt); A && A->engine >= 0) return A->engine;
+        if (smh_adapt_dev *A = adapt_find(&ac->adapt)) {
+            std::lock_guard<std::mutex> lock(*A->mu);
+            if (A->engine >= 0) return A->engine;
+        }
     return ac_engine_static(ac);
 }
 
@@ -910,7 +781,7 @@ static int ac_prepare(struct smh_ac *ac, int variant)
     int rc = ac_prepare_engines(ac, variant);
     /* the adaptive state too, whenever smh_ac_scan will ask for it (also with an engine forced): created inside the scan call it
      * would put blocking allocations into a captured stream and into count_host's kernel time */
-    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && ac_adaptive(ac)) {
+    if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && ac_needs_state(ac)) {
         smh_adapt_dev *A = NULL;
         rc = adapt_get(&ac->adapt, &A);
     }
@@ -1013,38 +884,47 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
     if (variant == SMH_VARIANT_TUNED) {
         /* engine choice: ac_host.c, end of the compile; with both engines at hand, what the launches report (above) */
         int engine = ac_engine_static(ac), rc;
-        if (!ac_adaptive(ac)) {
+        auto launch_static = [&]() -> int {
             if (engine == SMH_ALGO_WM) return smh_wm_scan(ac_filter_engine(ac), d_text, n, d_count, SMH_VARIANT_TUNED, stream);
             if (engine == SMH_ENGINE_AC_FLAT && ac->flat_ac) return ac_flat_launch(ac, d_text, n, d_count, stream, smh_stats_arg{});
             if (engine == SMH_ENGINE_KEYS && ac->keys) return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, smh_stats_arg{});
             return ac_launch_own(ac, d_text, n, d_count, stream, smh_stats_arg{});
-        }
+        };
+        if (!ac_needs_state(ac)) return launch_static(); /* one exact plan, no workspace, nothing to adapt: launches may overlap freely */
         smh_adapt_dev *A = NULL;
         if ((rc = adapt_get(&ac->adapt, &A)) != SMH_OK) return rc;
-        adapt_poll(A);
-        if (ac->engine_forced < 0) {
-            double est[SMH_ENGINES];
-            ac_estimates(ac, est);
-            uint64_t done = 0;
-            rc = adapt_first_look(A, est, engine, ac->m, d_text, n, d_count, stream,
-                                  [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
-                                      if (e == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), t, len, cnt, stream, sa, adapt_density(A, ac_filter_engine(ac)));
-                                      if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, t, len, cnt, stream, sa);
-                                      if (e == SMH_ENGINE_KEYS) return keys_launch(ac->keys, t, len, cnt, NULL, stream, sa);
-                                      return ac_launch_own(ac, t, len, cnt, stream, sa);
-                                  }, &done);
-            if (rc != SMH_OK) return rc;
-            d_text += done; /* a multiple of 16 */
-            n -= done;
-            engine = adapt_choose(A, est, engine);
-        } else {
-            A->engine = engine;
-        }
-        const smh_stats_arg SA = adapt_arg(A, n, engine);
-        if (engine == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), d_text, n, d_count, stream, SA, adapt_density(A, ac_filter_engine(ac)));
-        if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, d_text, n, d_count, stream, SA);
-        if (engine == SMH_ENGINE_KEYS) return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, SA);
-        return ac_launch_own(ac, d_text, n, d_count, stream, SA);
+        std::lock_guard<std::mutex> adapt_lock(*A->mu); /* poll, choice, slot and launch of one handle happen one at a time (smh_stats.h SMH_STATS_SLOTS) */
+        if ((rc = adapt_order_before(A, stream)) != SMH_OK) return rc;
+        rc = [&]() -> int {
+            int rc;
+            if (!ac_adaptive(ac)) return launch_static();
+            adapt_poll(A);
+            if (ac->engine_forced < 0) {
+                double est[SMH_ENGINES];
+                ac_estimates(ac, est);
+                uint64_t done = 0;
+                rc = adapt_first_look(A, est, engine, ac->m, d_text, n, d_count, stream,
+                                      [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
+                                          if (e == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), t, len, cnt, stream, sa, adapt_density(A, ac_filter_engine(ac)));
+                                          if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, t, len, cnt, stream, sa);
+                                          if (e == SMH_ENGINE_KEYS) return keys_launch(ac->keys, t, len, cnt, NULL, stream, sa);
+                                          return ac_launch_own(ac, t, len, cnt, stream, sa);
+                                      }, &done);
+                if (rc != SMH_OK) return rc;
+                d_text += done; /* a multiple of 16 */
+                n -= done;
+                engine = adapt_choose(A, est, engine);
+            } else {
+                A->engine = engine;
+            }
+            const smh_stats_arg SA = adapt_arg(A, n, engine, stream);
+            if (engine == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), d_text, n, d_count, stream, SA, adapt_density(A, ac_filter_engine(ac)));
+            if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, d_text, n, d_count, stream, SA);
+            if (engine == SMH_ENGINE_KEYS) return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, SA);
+            return ac_launch_own(ac, d_text, n, d_count, stream, SA);
+        }();
+        const int rc_after = adapt_order_after(A, stream);
+        return rc != SMH_OK ? rc : rc_after;
     }
     if (variant != SMH_VARIANT_TABLE) {
         smh_set_error("smh_ac_scan: unknown variant %d", variant);
@@ -1074,10 +954,15 @@ extern "C" int smh_ac_get_adapt(smh_ac *ac, smh_adapt_info *out)
     ac_estimates(ac, est);
     if (!ac->flex_wm && ac->alt_wm) est[SMH_ALGO_WM] = ac->alt_wm->scan_ms_est;
     const int adaptive = ac->engine_forced < 0 && ac_adaptive(ac);
-    adapt_report(ac_adaptive(ac) ? adapt_find(&ac->adapt) : NULL, adaptive, ac_engine_static(ac), est, out);
+    smh_adapt_dev *A = ac_adaptive(ac) ? adapt_find(&ac->adapt) : NULL;
+    std::unique_lock<std::mutex> lock;
+    if (A) lock = std::unique_lock<std::mutex>(*A->mu);
+    adapt_report(A, adaptive, ac_engine_static(ac), est, out);
     return SMH_OK;
 }
 
+static int ac_positions_impl(smh_ac *ac, int engine, const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                             uint64_t *d_cursor, void *stream);
 extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_t n, uint64_t *d_positions,
                                 uint64_t capacity, uint64_t *d_cursor, void *stream)
 {
@@ -1085,12 +970,27 @@ extern "C" int smh_ac_positions(smh_ac *ac, const unsigned char *d_text, uint64_
         smh_set_error("smh_ac_positions: bad arguments");
         return SMH_EINVAL;
     }
+    if (!ac_needs_state(ac)) return ac_positions_impl(ac, ac_engine_static(ac), d_text, n, d_positions, capacity, d_cursor, stream);
+    /* ordered behind the handle's other launches on this device (adapt_order_before): the depth-cut kernels' queue workspace is shared */
+    smh_adapt_dev *A = NULL;
+    int rc = adapt_get(&ac->adapt, &A);
+    if (rc != SMH_OK) return rc;
+    const int engine = ac_engine_now(ac); /* (takes A->mu itself) */
+    std::lock_guard<std::mutex> adapt_lock(*A->mu);
+    if ((rc = adapt_order_before(A, stream)) != SMH_OK) return rc;
+    rc = ac_positions_impl(ac, engine, d_text, n, d_positions, capacity, d_cursor, stream);
+    const int rc_after = adapt_order_after(A, stream);
+    return rc != SMH_OK ? rc : rc_after;
+}
+static int ac_positions_impl(smh_ac *ac, int engine, const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                             uint64_t *d_cursor, void *stream)
+{
     if (!ac->fixed_length_ok) {
         smh_set_error("smh_ac_positions: patterns are not all of length m");
         return SMH_EUNSUP;
     }
     if (n < (uint64_t)ac->m) return SMH_OK;
-    if (const int engine = ac_engine_now(ac); engine == SMH_ALGO_WM)
+    if (engine == SMH_ALGO_WM)
         return smh_wm_positions(ac_filter_engine(ac), d_text, n, d_positions, capacity, d_cursor, stream);
     else if (engine == SMH_ENGINE_AC_FLAT)
         return ac_flat_positions(ac, d_text, n, d_positions, capacity, d_cursor, stream);
@@ -1432,7 +1332,10 @@ static void wm_estimates(const struct smh_wm *wm, double est[SMH_ENGINES])
 static int wm_engine_now(struct smh_wm *wm)
 {
     if (wm->engine_forced < 0 && wm_engines(wm) && adapt_enabled())
-        if (smh_adapt_dev *A = adapt_find(&wm->adapt); A && A->engine >= 0) return A->engine;
+        if (smh_adapt_dev *A = adapt_find(&wm->adapt)) {
+            std::lock_guard<std::mutex> lock(*A->mu);
+            if (A->engine >= 0) return A->engine;
+        }
     return wm_engine_static(wm);
 }
 
@@ -1502,32 +1405,42 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
          * engine" above).  A handle with one engine still learns its verify mode from its own reports. */
         int engine = wm_engine_static(wm), rc;
         smh_adapt_dev *A = NULL;
+        std::unique_lock<std::mutex> adapt_lock; /* held to the end of the call: poll, choice, slot and launch of one handle one at a time */
         if (adapt_enabled() && (wm_engines(wm) || wm_reports(wm))) {
             if ((rc = adapt_get(&wm->adapt, &A)) != SMH_OK) return rc;
-            adapt_poll(A);
-            if (wm_engines(wm) && wm->engine_forced < 0) {
-                double est[SMH_ENGINES];
-                wm_estimates(wm, est);
-                uint64_t done = 0;
-                rc = adapt_first_look(A, est, engine, wm->m, d_text, n, d_count, stream,
-                                      [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
-                                          if (e == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), t, len, cnt, stream, sa);
-                                          if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, t, len, cnt, stream, sa);
-                                          if (e == SMH_ENGINE_KEYS) return keys_launch(wm->keys, t, len, cnt, NULL, stream, sa);
-                                          return wm_launch_own(wm, t, len, cnt, stream, wm_reports(wm) ? sa : smh_stats_arg{}, adapt_density(A, wm));
-                                      }, &done);
-                if (rc != SMH_OK) return rc;
-                d_text += done;
-                n -= done;
-                engine = adapt_choose(A, est, engine);
-            } else {
-                A->engine = engine;
-            }
+            adapt_lock = std::unique_lock<std::mutex>(*A->mu);
+            if ((rc = adapt_order_before(A, stream)) != SMH_OK) return rc; /* launches of one handle: ordered on the device also across streams */
         }
-        if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine));
-        if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine));
-        if (engine == SMH_ENGINE_KEYS) return keys_launch(wm->keys, d_text, n, d_count, NULL, stream, adapt_arg(A, n, engine));
-        return wm_launch_own(wm, d_text, n, d_count, stream, adapt_arg(wm_reports(wm) ? A : NULL, n, engine), adapt_density(A, wm));
+        rc = [&]() -> int {
+            int rc;
+            if (A) {
+                adapt_poll(A);
+                if (wm_engines(wm) && wm->engine_forced < 0) {
+                    double est[SMH_ENGINES];
+                    wm_estimates(wm, est);
+                    uint64_t done = 0;
+                    rc = adapt_first_look(A, est, engine, wm->m, d_text, n, d_count, stream,
+                                          [&](int e, const unsigned char *t, uint64_t len, uint64_t *cnt, const smh_stats_arg &sa) -> int {
+                                              if (e == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), t, len, cnt, stream, sa);
+                                              if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, t, len, cnt, stream, sa);
+                                              if (e == SMH_ENGINE_KEYS) return keys_launch(wm->keys, t, len, cnt, NULL, stream, sa);
+                                              return wm_launch_own(wm, t, len, cnt, stream, wm_reports(wm) ? sa : smh_stats_arg{}, adapt_density(A, wm));
+                                          }, &done);
+                    if (rc != SMH_OK) return rc;
+                    d_text += done;
+                    n -= done;
+                    engine = adapt_choose(A, est, engine);
+                } else {
+                    A->engine = engine;
+                }
+            }
+            if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine, stream));
+            if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine, stream));
+            if (engine == SMH_ENGINE_KEYS) return keys_launch(wm->keys, d_text, n, d_count, NULL, stream, adapt_arg(A, n, engine, stream));
+            return wm_launch_own(wm, d_text, n, d_count, stream, adapt_arg(wm_reports(wm) ? A : NULL, n, engine, stream), adapt_density(A, wm));
+        }();
+        const int rc_after = A ? adapt_order_after(A, stream) : SMH_OK;
+        return rc != SMH_OK ? rc : rc_after;
     }
     if (variant != SMH_VARIANT_TABLE) {
         smh_set_error("smh_wm_scan: unknown variant %d", variant);
@@ -1556,7 +1469,10 @@ extern "C" int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out)
     double est[SMH_ENGINES];
     wm_estimates(wm, est);
     const int adaptive = wm_engines(wm) && wm->engine_forced < 0 && adapt_enabled();
-    adapt_report(adapt_find(&wm->adapt), adaptive, wm_engine_static(wm), est, out);
+    smh_adapt_dev *A = adapt_find(&wm->adapt);
+    std::unique_lock<std::mutex> lock;
+    if (A) lock = std::unique_lock<std::mutex>(*A->mu);
+    adapt_report(A, adaptive, wm_engine_static(wm), est, out);
     return SMH_OK;
 }
 

@@ -17,20 +17,26 @@
 
 #include <stdint.h>
 
-struct smh_scan_stats { /* device memory, one per (handle, device); zero */
-    unsigned long long ticket; /* low 16 bits: reporting workgroups done; above: their events */
+struct smh_scan_stats { /* device memory, SMH_STATS_SLOTS per (handle, device); zero */
+    unsigned long long ticket; /* bits 0..15: reporting workgroups done; 16..47: their events; 48..63: the sum of their launches' nonces */
     unsigned int seq, pad0;
-    unsigned long long *host; /* SMH_STATS_HOST_WORDS words of pinned host memory: seq, events, ticks, bytes, tag, seq, checksum */
+    unsigned long long *host; /* SMH_STATS_HOST_WORDS words of pinned host memory: seq, events, ticks, bytes, tag | nonce << 32, seq, checksum */
     unsigned long long pad[5];
 };
 #define SMH_STATS_HOST_WORDS 8
 #define SMH_STATS_SAMPLE 8u /* workgroups of a launch that report (blockIdx.x below this) */
+/* Round 5: launches of ONE handle may overlap (two streams, two host threads: the extended API allows it, the reference's
+ * globals did not, smatcher.h:71-73).  Every reporting launch takes the next of SMH_STATS_SLOTS blocks (its own ticket, its own
+ * host record) and carries a 12-bit nonce that its workgroups add into the ticket's top bits: the workgroup that completes a
+ * ticket publishes only when the sum says all of the ticket's workgroups belonged to ITS launch -- more than SMH_STATS_SLOTS
+ * reporting launches in flight at once then lose their reports instead of mixing them. */
+#define SMH_STATS_SLOTS 4u
 
 struct smh_stats_arg { /* kernel argument; st == NULL: the launch reports nothing */
-    smh_scan_stats *st;
+    smh_scan_stats *st;   /* the launch's slot */
     unsigned long long bytes;
-    unsigned int tag;
-    unsigned int pad;
+    unsigned int tag;     /* engine | launches that share this report << 8 | slot << 16 | rate unreliable << 20 (smh_runtime.hip adapt_arg) */
+    unsigned int nonce;   /* 1..4095 */
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -46,6 +52,7 @@ __device__ __forceinline__ void smh_stats_stash(uint32_t ctr_off, const smh_stat
         *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 8u) = t;
         *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 16u) = on ? (unsigned long long)(uintptr_t)A.st : 0ull;
         *reinterpret_cast<__attribute__((address_space(3))) unsigned int *>(ctr_off + 24u) = A.tag;
+        *reinterpret_cast<__attribute__((address_space(3))) unsigned int *>(ctr_off + 28u) = A.nonce;
     }
 }
 
@@ -57,22 +64,24 @@ __device__ __forceinline__ void smh_stats_stash(uint32_t ctr_off, const smh_stat
  * 64-bit add.  The last of them publishes the sample's events scaled to the grid and ITS OWN duration (start of its
  * prologue to here) to the host record.  The record carries its sequence number twice and a checksum instead of a
  * system-scope fence between data and flag (a PCIe round trip at the end of the kernel). */
-__device__ __forceinline__ void smh_stats_commit(smh_scan_stats *st, unsigned int tag, unsigned long long bytes, uint64_t t_start, uint64_t events)
+__device__ __forceinline__ void smh_stats_commit(smh_scan_stats *st, unsigned int tag, unsigned int nonce, unsigned long long bytes, uint64_t t_start, uint64_t events)
 {
     const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
     const unsigned int reporting = gridDim.x < SMH_STATS_SAMPLE ? gridDim.x : SMH_STATS_SAMPLE;
-    const unsigned long long old = atomicAdd(&st->ticket, ((unsigned long long)events << 16) | 1ull);
+    const unsigned long long nn = nonce & 0xFFFu;
+    const unsigned long long old = atomicAdd(&st->ticket, (nn << 48) | ((unsigned long long)(events & 0xFFFFFFFFull) << 16) | 1ull);
     if ((unsigned int)(old & 0xFFFFu) + 1u == reporting) {
         atomicExch(&st->ticket, 0ull);
-        const unsigned long long e = ((old >> 16) + events) * gridDim.x / reporting;
-        const unsigned int seq = ++st->seq; /* this thread alone, launches of a handle do not overlap */
-        const unsigned long long ticks = t_end - t_start;
+        if ((old >> 48) + nn != nn * reporting) return; /* another launch's workgroups are in this ticket: no report (smh_stats.h SMH_STATS_SLOTS) */
+        const unsigned long long e = (((old >> 16) & 0xFFFFFFFFull) + events) * gridDim.x / reporting;
+        const unsigned int seq = ++st->seq; /* this thread alone: the ticket was this launch's */
+        const unsigned long long ticks = t_end - t_start, tagw = (unsigned long long)tag | (nn << 32);
         volatile unsigned long long *h = st->host;
         h[1] = e;
         h[2] = ticks;
         h[3] = bytes;
-        h[4] = tag;
-        h[6] = e ^ ticks ^ bytes ^ (unsigned long long)tag ^ (unsigned long long)seq;
+        h[4] = tagw;
+        h[6] = e ^ ticks ^ bytes ^ tagw ^ (unsigned long long)seq;
         h[5] = seq;
         h[0] = seq;
     }
@@ -91,11 +100,12 @@ __device__ __forceinline__ void smh_block_finish(uint32_t cnt, uint64_t *count, 
         wave_events += __shfl_down(wave_events, off, 64);
     }
     unsigned long long t_start = 0, st_bits = 0;
-    unsigned int tag = 0;
+    unsigned int tag = 0, nonce = 0;
     if (threadIdx.x == 0) { /* before the reduction below reuses the front of LDS (a tiny table's counter sits there) */
         t_start = *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 8u);
         st_bits = *reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>(ctr_off + 16u);
         tag = *reinterpret_cast<__attribute__((address_space(3))) unsigned int *>(ctr_off + 24u);
+        nonce = *reinterpret_cast<__attribute__((address_space(3))) unsigned int *>(ctr_off + 28u);
     }
     __syncthreads();
     uint32_t *part = reinterpret_cast<uint32_t *>(lds);
@@ -115,7 +125,7 @@ __device__ __forceinline__ void smh_block_finish(uint32_t cnt, uint64_t *count, 
         }
         if (threadIdx.x == 0) {
             if (v && count) atomicAdd((unsigned long long *)count, (unsigned long long)v);
-            if (st_bits) smh_stats_commit(reinterpret_cast<smh_scan_stats *>((uintptr_t)st_bits), tag, bytes, t_start, ev);
+            if (st_bits) smh_stats_commit(reinterpret_cast<smh_scan_stats *>((uintptr_t)st_bits), tag, nonce, bytes, t_start, ev);
         }
     }
 }

@@ -212,9 +212,17 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth);
  * is off; -1 restores the compile's choice and the adaptive engine */
 int smh_ac_set_scan_engine(smh_ac *ac, int engine);
 /* asynchronous: adds the number of matches in d_text[0, n) to *d_count (device uint64).
- * d_text must be 16-byte aligned; n may exceed 2^32.  A handle owns one candidate-queue workspace
- * per device: scans of the SAME handle must not overlap in time (use one stream per handle, or
- * one handle per stream).  The FIRST tuned scan of a handle on a device is not asynchronous: it uploads
+ * d_text must be 16-byte aligned; n may exceed 2^32.
+ * Threads and streams (round 5; the reference is single-threaded with global state, smatcher.h:71-73): the scan, positions and
+ * count_host calls of ONE handle may be issued from several host threads and on several streams.  A handle owns per-device
+ * state -- the depth-cut kernels' candidate queue, the report slots of the adaptive engine -- so the library (i) serialises the
+ * host side of those calls per handle and device with a mutex and (ii) ORDERS the handle's launches on the device: a launch on
+ * another stream than the handle's previous one first waits (hipStreamWaitEvent, the host does not block) for that one.  The same
+ * stream as before costs nothing; the first change of stream costs one hipDeviceSynchronize, once per handle and device.  Launches
+ * of DIFFERENT handles are independent.  Exceptions: inside a stream capture no ordering is applied (capture a handle on one
+ * stream only); smh_pset handles and SMH_ADAPT=0 processes keep the old rule -- scans of the same handle must not overlap.
+ * smh_*_free must not run beside any other call on the handle.
+ * The FIRST tuned scan of a handle on a device is not asynchronous: it uploads
  * the handle's tables with blocking copies, and -- a handle with more than one engine (smh_ac_info.adaptive), a
  * text of 1 GiB or more, no stream capture in progress -- it scans the first 256 MiB and waits for that launch's
  * report before it commits the rest of the text to an engine (DESIGN.md 3.4 "first look"; SMH_ADAPT=0 turns it off). */
