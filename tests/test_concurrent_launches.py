@@ -26,7 +26,7 @@ def test_adaptive_state_machine_is_tsan_clean_on_the_cpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("entry", ["ac", "wm"])
 def test_two_threads_two_streams_one_handle(entry):
-    n, m, p, sigma, launches = 64 << 20, 16, 1000, 4, 50
+    n, m, p, sigma, launches = 256 << 20, 16, 1000, 4, 50  # (launches long enough for their rate to mean something: tests/test_adaptive.py uses the same size)
     dev = torch.device("cuda", 0)
     texts = {}
     for name, kind in (("uniform", S.CORPUS_UNIFORM), ("repeats", S.CORPUS_DNA_REPEATS)):
