@@ -200,6 +200,8 @@ def compact_line(out, detail_path=None, detail_sha=None):
         optional.append(("rehearsal", str(out["rehearsal"])[:120]))
     if "wall_s" in out:
         optional.append(("wall_s", out["wall_s"]))
+    if "phases_s" in out:
+        optional.append(("phases_s", out["phases_s"]))
     if detail_path:
         line["detail"] = dict(path=detail_path, sha256=detail_sha)
     kept = list(optional)
@@ -255,6 +257,9 @@ class Cpu:
         # every rank of an N-rank job checks its own shard: an equal share of the threads each, at most 64
         self.cores = max(1, min(self.host_threads // max(world, 1), 64))
         self.pool = ThreadPoolExecutor(self.cores)
+        # the all-cores baseline (N = 1 only) is not capped: every thread this process may run on
+        self.all_cores = max(1, self.host_threads)
+        self._all_pool = None
         self.kind = "reference" if O.have_ref() else "port"
         self.model = cpu_model()
 
@@ -290,17 +295,21 @@ class Cpu:
         """The reference search fanned out by byte range with an m-1 halo -- its own MPI decomposition
         (main.c:467-477) with threads for ranks; time = the slowest shard's search_ac per set, summed."""
         O, n, ok, secs, wall0 = self.O, len(text), True, 0.0, time.perf_counter()
+        from concurrent.futures import ThreadPoolExecutor
+        self._all_pool = self._all_pool or ThreadPoolExecutor(self.all_cores)
         for m, pat in pats.items():
-            ranges = [O.shard_range(n, self.cores, r, m) for r in range(self.cores)]
-            parts = list(self.pool.map(lambda be: O.ref_ac(pat, m, p, sigma, text[be[0]:be[1]]), ranges))
+            ranges = [O.shard_range(n, self.all_cores, r, m) for r in range(self.all_cores)]
+            parts = list(self._all_pool.map(lambda be: O.ref_ac(pat, m, p, sigma, text[be[0]:be[1]]), ranges))
             ok = ok and sum(q[0] for q in parts) == want[m]
             secs += max(q[3] for q in parts)
         return secs, ok, time.perf_counter() - wall0
 
     def wm_all_cores_reference(self, pat, m, p, sigma, text, want):
         O, n = self.O, len(text)
-        ranges = [O.shard_range(n, self.cores, r, m) for r in range(self.cores)]
-        parts = list(self.pool.map(lambda be: O.ref_wu(pat, m, p, sigma, text[be[0]:be[1]], flat=True), ranges))
+        from concurrent.futures import ThreadPoolExecutor
+        self._all_pool = self._all_pool or ThreadPoolExecutor(self.all_cores)
+        ranges = [O.shard_range(n, self.all_cores, r, m) for r in range(self.all_cores)]
+        parts = list(self._all_pool.map(lambda be: O.ref_wu(pat, m, p, sigma, text[be[0]:be[1]], flat=True), ranges))
         return max(q[3] for q in parts), sum(q[0] for q in parts) == want
 
     # --- verification (restated search, tables built once and shared by the threads) ---
@@ -433,6 +442,12 @@ def main():
                     help="rehearsal of the N > 1 control flow on ONE card: every rank uses device 0, process group over gloo")
     args = ap.parse_args()
     wall_t0 = time.perf_counter()
+    phases, phase_t = {}, [wall_t0]
+
+    def mark(name):  # wall seconds of the phase that just ended (rank 0's clock)
+        now = time.perf_counter()
+        phases[name] = round(phases.get(name, 0.0) + now - phase_t[0], 1)
+        phase_t[0] = now
 
     if args.steps < 1 or args.warmup < 0:
         raise SystemExit("bench.py: --steps must be >= 1 and --warmup >= 0")
@@ -518,6 +533,7 @@ def main():
         gbs = nbytes / (ms * 1e-3) / 1e9
         return dict(GBps=round(gbs, 1), Gbit_s=round(8 * gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4))
 
+    mark('start (imports, process group)')
     # ---- pattern sets (host) and compiled automata
     pats = {m: S.corpus_patterns(m, AC_PATTERNS, PAT_SEED, SIGMA, TEXT_SEED, n_total, 2) for m in AC_LENGTHS}
     acs = {m: S.AcAutomaton.from_patterns(pats[m], m, AC_PATTERNS, SIGMA) for m in AC_LENGTHS}
@@ -586,6 +602,7 @@ def main():
     mean = lambda xs: sum(xs) / len(xs) if xs else 0.0
     all_kern_ms = sharded.gather_objects({m: mean(kern_ms[m]) for m in AC_LENGTHS})  # [rank][m]
 
+    mark('headline (compile, text, timed steps)')
     out = None
     # every rank: (name, algorithm, patterns, m, p, sigma, device text, shard length, gpu count, scan(ptr, n) -> count)
     verify = []
@@ -771,6 +788,7 @@ def main():
         out["mixed_8_32"] = dict(workload="BASELINE configs[1] read as ONE set: 1000 patterns, 40 of each length 8..32, same text, "
                                           "scanned in one pass; count = sum over length classes of the reference's count", **mobj)
 
+    mark('side measurements (stream read, positions, WM, automaton, mixed)')
     # ---- the 32 GB configurations: every rank scans ITS 4 GiB byte range (+ halo) of one (N x 4 GiB) text
     if not args.no_wm:
         def shard_config(label, algo, sigma, lengths, p, seed, workload):
@@ -818,6 +836,7 @@ def main():
                      "WM: the remaining lengths of BASELINE configs[4]'s 5-20 sweep that sit at filter-form boundaries, m=%s; verified on "
                      "the first 512 MiB + the last 64 MiB of the shard" % "/".join(str(m) for m in C5_MORE_LENGTHS))
 
+    mark('32 GB configurations (configs[3], configs[4], more lengths)')
     # ---- text that is NOT i.i.d. uniform (round 4): the BASELINE pattern shapes on genome-like / protein-like / natural-language-like
     #      text and on a text in which one pattern recurs every 64 columns, patterns sampled from those texts; N = 1
     if not args.no_wm and not args.no_skewed and rank == 0 and world == 1:
@@ -896,6 +915,7 @@ def main():
                                       "flat_parts exact stride-1 automata scanned one after the other); chosen_vs_best_forced = chosen / the fastest forced" % args.mib_per_gpu,
                              worst_chosen_vs_best_forced=round(worst_ratio, 3), **sk)
 
+    mark('skewed corpora')
     # ---- the table-walking kernels (cuda_*1/2: the reference's tables walked as given) on a 64 MiB prefix, N = 1
     if not args.no_wm and rank == 0 and world == 1:
         tn = min(64 << 20, per_gpu)
@@ -921,6 +941,7 @@ def main():
         out["table_kernels"] = dict(workload="the reference-layout tables walked as given (latency-bound by design), m=8 set of %d "
                                              "patterns, first %d MiB of the same text; all five counts equal" % (AC_PATTERNS, tn >> 20), **tk)
 
+    mark('table kernels')
     # ---- the same workloads through the native one-process path (smh_multi_*): a CHILD process of rank 0 drives all N
     #      devices while the ranks wait in the c10d store with their GPUs idle
     if not args.no_multi and not args.share_device:
@@ -952,6 +973,7 @@ def main():
                 raise SystemExit("smh_multi leg failed: %s" % leg.get("error", "no totals to compare"))
         sharded.host_barrier("smh_multi_after")
 
+    mark('smh_multi leg')
     # ---- bit-exact verification of every count above, every rank its own shards; CPU baselines at N = 1
     parity_ok = True
     if not args.no_cpu:
@@ -1006,6 +1028,7 @@ def main():
                                                               % ((verify_budget >> 20) - 64)),
                                    seconds=round(secs, 1), all_equal=all_equal, counts=merged)
 
+    mark('verification')
     if rank == 0 and world == 1 and not args.no_cpu:
         sample = min(args.cpu_sample_mib << 20, per_gpu)
         host_text = text[:per_gpu].cpu().numpy()
@@ -1048,21 +1071,23 @@ def main():
         S.lib.smh_host_path_release()
         if cpu.kind == "reference":
             secs, ok, wall = cpu.ac_all_cores_reference(pats, AC_PATTERNS, SIGMA, prefix, cpu_counts)
-            allc = dict(value=round(8.0 * sample * len(pats) / secs / 1e9, 3), unit="Gbit/s", cores=cpu.cores, kind="reference",
+            allc = dict(value=round(8.0 * sample * len(pats) / secs / 1e9, 3), unit="Gbit/s", cores=cpu.all_cores, kind="reference",
                         cpu=cpu.model, host_cpus=cpu.host_cpus, counts_match=ok,
-                        sample="same sample as byte-range shards (main.c:467-477) on %d threads; time = slowest shard's search_ac "
-                               "per set, summed (%.2f s; %.1f s wall with preproc_ac repeated per shard as every MPI rank of the "
-                               "reference does)" % (cpu.cores, secs, wall))
+                        sample="same sample as byte-range shards (main.c:467-477) on %d threads = every thread this process may run on "
+                               "(%d CPUs in the machine); time = slowest shard's search_ac per set, summed (%.2f s; %.1f s wall with "
+                               "preproc_ac repeated per shard as every MPI rank of the reference does)" % (cpu.all_cores, cpu.host_cpus, secs, wall))
             if wpat is not None:
                 wsecs, wok = cpu.wm_all_cores_reference(wpat, WM_LENGTH, WM_PATTERNS, SIGMA, host_text[:wsample], wcnt)
                 allc["wm"] = dict(value=round(8.0 * wsample / wsecs / 1e9, 3), unit="Gbit/s", counts_match=wok,
-                                  sample="search_wu2, the WM sample as %d byte-range shards, slowest shard %.2f s" % (cpu.cores, wsecs))
+                                  sample="search_wu2, the WM sample as %d byte-range shards, slowest shard %.2f s" % (cpu.all_cores, wsecs))
                 ok = ok and wok
             out["cpu_baseline_all_cores"] = allc
             parity_ok = parity_ok and ok
 
     if rank == 0:
+        mark("cpu baselines, host-pointer path")
         out["wall_s"] = round(time.perf_counter() - wall_t0, 1)
+        out["phases_s"] = phases
         emit(out)
     if world > 1:
         dist.barrier()
