@@ -432,7 +432,7 @@ def main():
     ap.add_argument("--cpu-wm-sample-mib", type=int, default=16, help="prefix the serial search_wu2 baseline runs on")
     ap.add_argument("--shard-mib", type=int, default=4096, help="per-GPU shard of the 32 GB configurations (configs[3], [4])")
     ap.add_argument("--verify-mib", type=int, default=-1,
-                    help="MiB of every 4 GiB shard the CPU recounts (head + last 64 MiB); 0 = all of it; default: all at N = 1, 512 at N > 1")
+                    help="MiB of every 4 GiB shard the CPU recounts (head + last 64 MiB); 0 = all of it; default: all at N = 1; at N > 1 8 MiB per host thread of the rank, 128..512")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baselines and the verification")
     ap.add_argument("--no-wm", action="store_true", help="skip the side configurations (WM, configs[3], configs[4])")
     ap.add_argument("--no-multi", action="store_true", help="skip the one-process smh_multi leg")
@@ -485,7 +485,10 @@ def main():
     per_gpu = args.mib_per_gpu << 20
     n_total = per_gpu * world
     shard = args.shard_mib << 20
-    verify_budget = (args.verify_mib << 20) if args.verify_mib >= 0 else (0 if world == 1 else 512 << 20)
+    # N > 1: what a rank's share of the host threads recounts in about a minute per 32 GB configuration -- 8 MiB per thread,
+    # 128..512 MiB of every 4 GiB shard (6 ranks on one box: 153 s of wall at 512 MiB, 149 s of it this; profiles/r05_final/rehearse6*)
+    auto_mib = max(128, min(512, 8 * max(1, len(os.sched_getaffinity(0)) // max(world, 1))))
+    verify_budget = (args.verify_mib << 20) if args.verify_mib >= 0 else (0 if world == 1 else auto_mib << 20)
     stream = torch.cuda.current_stream().cuda_stream
     ev = lambda: torch.cuda.Event(enable_timing=True)
 
@@ -881,7 +884,7 @@ def main():
                                        events_per_4k=round(ad.events_per_4k[int(ad.engine)], 3)),
                            matches=matches)
                 forced, equal = {}, True
-                for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT, S.ENGINE_KEYS):
+                for eng in (S.ALGO_AC, S.ALGO_WM, S.ENGINE_AC_FLAT, S.ENGINE_KEYS, S.ENGINE_HASH):
                     try:
                         h.set_scan_engine(eng)
                     except S.SmhError:
@@ -893,6 +896,8 @@ def main():
                 rec["forced"] = forced
                 rec["engines_agree"] = equal
                 rec["key_slots"] = int(h.info().key_slots)  # > 0: the handle keeps the key engine (round 5)
+                if algo == "wm":
+                    rec["hash_slots"] = int(h.info().hash_slots)  # > 0: ... the window-hash engine
                 if algo == "ac":
                     rec["flat_parts"] = int(h.info().flat_parts)  # launches of the text-independent engine
                 every = [v["kernel_ms"] for v in forced.values()]  # all the handle holds, the text-independent parts included

@@ -1,0 +1,68 @@
+/*
+ * csrc/hash_engine.h -- the arithmetic shared by the window-hash engine's host builder (hash_host.c) and its lane code
+ * (hash_lane.h).
+ *
+ * The window-hash engine (round 5) is the filter engine for sets too large for the key engine (key_hash.h) on text that defeats
+ * q-gram filters: 100 000 byte patterns sampled from natural-language-like text let half of all columns through a 3-byte-gram
+ * filter (bench.py skewed.ascii_skewed: 2000 surviving columns per 4 KiB), because the text's common grams ARE the patterns'
+ * grams.  A filter keyed on the WHOLE m-byte window has no such dependence: its false-positive rate is the load of its table
+ * whatever the text.
+ *   stage 1 (LDS, every column): a polynomial hash of the window rolled along the text -- h = h * B + in - out * B^m mod 2^24,
+ *           two v_mad_u32_u24 -- indexes a blocked Bloom filter, two bits in one 32-bit word (ds_read_b32): 100 000 keys in 2^20
+ *           bits let ~4 % of non-matching columns through.
+ *   stage 2 (L2 / Infinity Cache, surviving columns, compacted per wave): the window's aligned dwords are requested from global
+ *           memory (streamed microseconds ago), hashed again with the verify stage's multiply-xorshift, and BOTH of the window's
+ *           slots in a two-table cuckoo hash of the PATTERNS THEMSELVES (16 or 32 bytes per slot, zero-padded) are compared with
+ *           it in registers: two dependent round trips for every surviving column, true match or not -- no tag, no third trip to
+ *           the pattern array (wm_lane.h smh_wm_probe_from pays one for every true match, and on such text one column in twenty
+ *           is a true match).
+ * Exact: a column counts when its window equals a stored pattern (what wu/wu.c:88's memcmp decides).
+ */
+#ifndef SMH_HASH_ENGINE_H
+#define SMH_HASH_ENGINE_H
+
+#include <stdint.h>
+
+#define SMH_HASH_BASE 0x5BD1E9u    /* B: odd, 24 bits */
+#define SMH_HASH_MAX_M 32          /* the window's dwords: nine aligned ones cover 33 bytes at any alignment */
+#define SMH_HASH_MIN_M 4
+
+struct smh_hash_params {
+    int m;
+    uint32_t neg_bm;       /* 2^24 - B^m mod 2^24: h += out * neg_bm removes the byte that leaves the window */
+    uint32_t bloom_shift;  /* byte address of the window's filter word = (h >> bloom_shift) & bloom_mask */
+    uint32_t bloom_mask;   /* (words - 1) << 2 */
+    uint32_t bloom_bytes;  /* LDS image: 2^15 words at most */
+    uint32_t slots;        /* per pattern table (two tables) */
+    uint32_t seed;         /* of the slot hashes: the builder retries with another one when the patterns do not place */
+    uint32_t slot_dwords;  /* 4 (m <= 16) or 8 */
+};
+
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+#define SMH_HASH_FN __device__ __forceinline__
+SMH_HASH_FN uint32_t smh_hash_mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+#else
+#define SMH_HASH_FN static inline
+SMH_HASH_FN uint32_t smh_hash_mad24(uint32_t a, uint32_t b, uint32_t c) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) + c; }
+#endif
+
+/* one byte enters the rolling hash (only its low 24 bits mean anything) */
+SMH_HASH_FN uint32_t smh_hash_in(uint32_t h, uint32_t byte) { return smh_hash_mad24(h, SMH_HASH_BASE, byte); }
+/* ... and the byte m places back leaves it */
+SMH_HASH_FN uint32_t smh_hash_out(uint32_t h, uint32_t byte, uint32_t neg_bm) { return smh_hash_mad24(byte, neg_bm, h); }
+/* the window's two filter bits: bit (h & 31) and bit ((h >> 5) & 31) of the word at byte address (h >> shift) & mask */
+SMH_HASH_FN uint32_t smh_hash_word_addr(uint32_t h, uint32_t shift, uint32_t mask) { return (h >> shift) & mask; }
+
+/* the two slots of a window whose verify-stage hash (wm_lane.h smh_wm_tag_dwords == wm_host.c smh_wm_tag) is `tag` */
+SMH_HASH_FN uint32_t smh_hash_mulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+SMH_HASH_FN void smh_hash_slots(uint32_t tag, uint32_t seed, uint32_t slots, uint32_t *s1, uint32_t *s2)
+{
+    uint32_t t1 = (tag ^ seed) * 0x9E3779B1u;
+    t1 ^= t1 >> 15;
+    uint32_t t2 = (tag + seed) * 0x85EBCA6Bu;
+    t2 ^= t2 >> 13;
+    *s1 = smh_hash_mulhi(t1 * 0x2C1B3C6Du, slots);
+    *s2 = slots + smh_hash_mulhi(t2 * 0xC2B2AE35u, slots);
+}
+
+#endif

@@ -1,0 +1,150 @@
+/*
+ * csrc/hash_host.c -- host builder of the window-hash engine (hash_engine.h): the Bloom filter of the patterns' rolling hashes
+ * (LDS image) and the two-table cuckoo hash of the patterns themselves (device memory), for the distinct patterns of one length.
+ * Replaces, for the sets it takes, wu/wu.c:109-149's SHIFT / PREFIX tables and the memcmp of wu/wu.c:88.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "smh_internal.h"
+#include "hash_engine.h"
+
+static uint32_t hash_tag(const unsigned char *p, int m) /* == wm_host.c smh_wm_tag == wm_lane.h smh_wm_tag_dwords */
+{
+    uint32_t h = 0x811C9DC5u;
+    for (int j = 0; j < (m + 3) / 4; ++j) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4 && 4 * j + b < m; ++b) v |= (uint32_t)p[4 * j + b] << (8 * b);
+        h = (h ^ v) * 0x9E3779B1u;
+        h ^= h >> 15;
+    }
+    return h;
+}
+
+static uint32_t hash_roll(const unsigned char *p, int m)
+{
+    uint32_t h = 0;
+    for (int i = 0; i < m; ++i) h = smh_hash_in(h, p[i]);
+    return h & 0xFFFFFFu;
+}
+
+void smh_hash_free(struct smh_hashes *k)
+{
+    if (!k) return;
+    smh_hash_dev_free(k->dev);
+    free(k->bloom);
+    free(k->table);
+    free(k);
+}
+
+/* patterns: `distinct` DISTINCT patterns of m bytes each, back to back.  NULL: not a set the engine takes / out of memory. */
+struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int distinct, const char **why)
+{
+    const char *dummy;
+    if (!why) why = &dummy;
+    *why = "";
+    if (m < SMH_HASH_MIN_M || m > SMH_HASH_MAX_M || distinct < 1) { *why = "pattern length outside 4..32"; return NULL; }
+    if ((uint32_t)distinct > (1u << 20)) { *why = "more than 2^20 patterns"; return NULL; }
+    struct smh_hashes *k = (struct smh_hashes *)calloc(1, sizeof *k);
+    if (!k) { *why = "out of memory"; return NULL; }
+    struct smh_hash_params P;
+    memset(&P, 0, sizeof P);
+    P.m = m;
+    uint32_t bm = 1;
+    for (int i = 0; i < m; ++i) bm = (uint32_t)(((uint64_t)bm * SMH_HASH_BASE) & 0xFFFFFFu);
+    P.neg_bm = (0x1000000u - bm) & 0xFFFFFFu;
+    /* filter: 10 bits per key when LDS allows, 2^15 words (128 KiB) at most, 2^8 at least */
+    int wl = 8;
+    while (wl < 15 && (32u << wl) < 10u * (uint32_t)distinct) ++wl;
+    P.bloom_shift = (uint32_t)(24 - wl - 2);
+    P.bloom_mask = ((1u << wl) - 1u) << 2;
+    P.bloom_bytes = 4u << wl;
+    P.slot_dwords = m <= 16 ? 4u : 8u;
+    uint32_t N = (uint32_t)((double)distinct / (2.0 * 0.42)) + 8u;
+    P.slots = N;
+    k->bloom = (uint32_t *)calloc(1, P.bloom_bytes);
+    const size_t slot_bytes = 4u * (size_t)P.slot_dwords;
+    k->table_bytes = 2u * (size_t)N * slot_bytes;
+    k->table = (unsigned char *)calloc(1, k->table_bytes + 64);
+    uint32_t *slot_of = (uint32_t *)calloc(2u * (size_t)N, sizeof(uint32_t));
+    if (!k->bloom || !k->table || !slot_of) { free(slot_of); smh_hash_free(k); *why = "out of memory"; return NULL; }
+    for (int j = 0; j < distinct; ++j) {
+        const uint32_t h = hash_roll(patterns + (size_t)j * (size_t)m, m);
+        uint32_t *w = k->bloom + (smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask) >> 2);
+        *w |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+    }
+    uint64_t set = 0;
+    for (uint32_t i = 0; i < P.bloom_bytes / 4u; ++i) set += (uint64_t)__builtin_popcount(k->bloom[i]);
+    /* a non-matching window passes when both of its bits are set: about (bits set / bits)^2, a little more for the uneven words */
+    const double load = (double)set / (8.0 * (double)P.bloom_bytes);
+    k->pass_rate = 1.15 * load * load;
+    /* cuckoo placement of the patterns (random walk, as key_host.c); a set that does not place -- a few hundred patterns form a
+     * component with more keys than slots now and then -- is retried under another seed */
+    int ok = 0;
+    for (uint32_t attempt = 0; attempt < 16u && !ok; ++attempt) {
+    P.seed = attempt * 0x7F4A7C15u;
+    memset(slot_of, 0, sizeof(uint32_t) * 2u * (size_t)N);
+    ok = 1;
+    for (int j = 0; j < distinct && ok; ++j) {
+        uint32_t cur = (uint32_t)j + 1, s1, s2;
+        smh_hash_slots(hash_tag(patterns + (size_t)j * (size_t)m, m), P.seed, N, &s1, &s2);
+        if (!slot_of[s1]) { slot_of[s1] = cur; continue; }
+        if (!slot_of[s2]) { slot_of[s2] = cur; continue; }
+        uint32_t pos = (j & 1) ? s2 : s1;
+        int done = 0;
+        for (uint32_t kicks = 0; kicks < 2000u && !done; ++kicks) {
+            const uint32_t out = slot_of[pos];
+            slot_of[pos] = cur;
+            if (!out) { done = 1; break; }
+            cur = out;
+            smh_hash_slots(hash_tag(patterns + (size_t)(cur - 1) * (size_t)m, m), P.seed, N, &s1, &s2);
+            pos = pos == s1 ? s2 : s1;
+        }
+        ok = done;
+    }
+    }
+    if (!ok) { free(slot_of); smh_hash_free(k); *why = "no cuckoo placement found"; return NULL; }
+    /* slots: the pattern zero-padded to the slot; a free slot holds a string whose own slots lie elsewhere, so that no
+     * window that is looked up here can equal it */
+    for (uint32_t s = 0; s < 2u * N; ++s) {
+        unsigned char *dst = k->table + (size_t)s * slot_bytes;
+        if (slot_of[s]) {
+            memcpy(dst, patterns + (size_t)(slot_of[s] - 1) * (size_t)m, (size_t)m);
+            continue;
+        }
+        unsigned char f[SMH_HASH_MAX_M];
+        for (uint32_t v = 0;; ++v) {
+            memset(f, 0, sizeof f);
+            memcpy(f, &v, 4);
+            uint32_t s1, s2;
+            smh_hash_slots(hash_tag(f, m), P.seed, N, &s1, &s2);
+            if (s1 != s && s2 != s) break;
+        }
+        memcpy(dst, f, (size_t)m);
+    }
+    free(slot_of);
+    k->magic = SMH_MAGIC_HASHES;
+    k->m = m;
+    k->distinct = (uint32_t)distinct;
+    k->P = P;
+    /* scan 0.36 ms/GiB (eleven VALU and one LDS read per column) + two round trips per surviving column: measured (round 5) */
+    k->ms_est = SMH_HASHES_MS_SCAN + SMH_HASHES_MS_PER_SURVIVOR * 4096.0 * k->pass_rate;
+    return k;
+}
+
+/* the engine's two tests on the host (tests): does the window pass the filter / is it a stored pattern */
+int smh_hash_filter_passes(const struct smh_hashes *k, const unsigned char *window)
+{
+    const uint32_t h = hash_roll(window, k->m);
+    const uint32_t w = k->bloom[smh_hash_word_addr(h, k->P.bloom_shift, k->P.bloom_mask) >> 2];
+    return (int)((w >> (h & 31u)) & (w >> ((h >> 5) & 31u)) & 1u);
+}
+int smh_hash_contains(const struct smh_hashes *k, const unsigned char *window)
+{
+    uint32_t s1, s2;
+    smh_hash_slots(hash_tag(window, k->m), k->P.seed, k->P.slots, &s1, &s2);
+    const size_t sb = 4u * (size_t)k->P.slot_dwords;
+    unsigned char pad[SMH_HASH_MAX_M];
+    memset(pad, 0, sizeof pad);
+    memcpy(pad, window, (size_t)k->m);
+    return memcmp(k->table + s1 * sb, pad, sb) == 0 || memcmp(k->table + s2 * sb, pad, sb) == 0;
+}

@@ -47,6 +47,7 @@ uint64_t smh_handle_serial(void); /* ac_host.c: 1, 2, 3, ... */
  */
 struct smh_ac_dev; /* opaque to C: device buffers, owned by smh_runtime.hip */
 struct smh_keys;   /* key engine, below */
+struct smh_hashes; /* window-hash engine, below */
 
 struct smh_ac {
     uint32_t magic;
@@ -187,6 +188,33 @@ void smh_keys_free(struct smh_keys *k);
 int smh_keys_contains(const struct smh_keys *k, uint64_t key);
 int smh_keys_symbol_bits(int alphabet);
 void smh_keys_dev_free(struct smh_keys_dev *dev); /* smh_runtime.hip */
+
+/* ------------------------------------------------------------------ window-hash engine (round 5; hash_engine.h, hash_host.c, hash_lane.h)
+ * A Bloom filter of the WHOLE window's rolling hash in LDS -- a pass rate that does not depend on the text -- and the patterns
+ * themselves in a two-table cuckoo hash in device memory: the filter engine for byte sets too large for the key engine, kept
+ * by a Wu-Manber handle as SMH_ENGINE_HASH. */
+#define SMH_MAGIC_HASHES 0x48415348u /* "HASH" */
+#include "hash_engine.h"
+struct smh_hash_dev;
+struct smh_hashes {
+    uint32_t magic;
+    int m;
+    uint32_t distinct;
+    struct smh_hash_params P;
+    uint32_t *bloom;        /* P.bloom_bytes: the LDS image */
+    unsigned char *table;   /* 2 * P.slots slots of 4 * P.slot_dwords bytes */
+    uint64_t table_bytes;
+    double pass_rate;       /* non-matching columns the filter lets through */
+    double ms_est;          /* ms per GiB on text without matches */
+    struct smh_hash_dev *dev;
+};
+#define SMH_HASHES_MS_SCAN 0.36
+#define SMH_HASHES_MS_PER_SURVIVOR 0.0017 /* ms per GiB per surviving column in 4 KiB */
+struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int distinct, const char **why);
+void smh_hash_free(struct smh_hashes *k);
+int smh_hash_filter_passes(const struct smh_hashes *k, const unsigned char *window);
+int smh_hash_contains(const struct smh_hashes *k, const unsigned char *window);
+void smh_hash_dev_free(struct smh_hash_dev *dev); /* smh_runtime.hip */
 
 /* ------------------------------------------------------------------ mixed-length automaton (acm_host.c)
  * One Aho-Corasick automaton with joined (suffix-closed) output COUNTS for a set of patterns of different
@@ -384,6 +412,7 @@ struct smh_wm {
     int alt_off;           /* smh_wm_set_scan_engine(SMH_ALGO_WM): scans use this path's own kernels regardless */
     struct smh_ac *flex_ac; /* round 4: the automaton engine kept at hand even when it is the slower one on random text (== alt_ac when that is set) */
     struct smh_keys *keys;  /* round 5: the key engine over the same patterns (key_host.c), NULL = not a set it takes / this path is exact */
+    struct smh_hashes *hashes; /* round 5: the window-hash engine (hash_host.c) for byte-like sets the key engine does not take, else NULL */
     int engine_forced;     /* -1 = the runtime follows the launches' reports (round 4), else the engine smh_wm_set_scan_engine named */
     uint32_t generation;   /* bumped by smh_wm_set_scan_engine */
     uint64_t serial;       /* unique per compiled handle */

@@ -13,6 +13,7 @@
 #include "acm_lane.h"
 #include "corpus_gen.h"
 #include "key_hash.h"
+#include "hash_lane.h"
 #include "smh_stats.h"
 
 #define SMH_BLOCK_THREADS 1024
@@ -224,6 +225,17 @@ struct smh_key_launch { /* key engine (key_kernels.hip) */
 };
 hipError_t smh_launch_keys(const smh_key_launch &L, hipStream_t stream);
 hipError_t smh_launch_keys_positions(const smh_key_launch &L, hipStream_t stream);
+
+struct smh_hash_launch { /* window-hash engine (hash_kernels.hip) */
+    smh_hash_ctx C;          /* text, n, parameters, pattern table (device pointers) */
+    const uint32_t *d_bloom; /* C.P.bloom_bytes: the LDS image */
+    uint64_t *d_count;
+    int n_cus;
+    smh_pos_out po;          /* positions mode only */
+    smh_stats_arg stats;     /* st != NULL: the launch reports its surviving columns and its duration (smh_stats.h) */
+};
+hipError_t smh_launch_hash(const smh_hash_launch &L, hipStream_t stream);
+hipError_t smh_launch_hash_positions(const smh_hash_launch &L, hipStream_t stream);
 
 hipError_t smh_launch_corpus_text(uint8_t *d_out, uint64_t n, uint64_t offset, uint64_t seed,
                                   int alphabet, hipStream_t stream);

@@ -588,6 +588,11 @@ static int keys_launch(struct smh_keys *k, const unsigned char *d_text, uint64_t
                        void *stream, const smh_stats_arg &SA);
 struct smh_keys_dev;
 static int keys_ensure_device(struct smh_keys *k, smh_keys_dev **out);
+/* the window-hash engine's launch (below) */
+static int hash_launch(struct smh_hashes *k, const unsigned char *d_text, uint64_t n, uint64_t *d_count, const smh_pos_out *po,
+                       void *stream, const smh_stats_arg &SA);
+struct smh_hash_dev;
+static int hash_ensure_device(struct smh_hashes *k, smh_hash_dev **out);
 /* ------------------------------------------------------------------ AC */
 static void ac_dev_free_one(smh_ac_dev *dev)
 {
@@ -737,6 +742,7 @@ static void ac_estimates(const struct smh_ac *ac, double est[SMH_ENGINES])
     est[SMH_ALGO_WM] = ac_filter_engine(ac) ? ac_filter_engine(ac)->scan_ms_est : 0.0;
     est[SMH_ENGINE_AC_FLAT] = ac_flat_ms(ac);
     est[SMH_ENGINE_KEYS] = ac->keys ? ac->keys->ms_est : 0.0;
+    est[SMH_ENGINE_HASH] = 0.0; /* Wu-Manber handles only */
 }
 static int ac_engine_now(struct smh_ac *ac)
 {
@@ -1321,13 +1327,14 @@ static double wm_flex_ms(const struct smh_wm *wm)
 }
 /* do this path's own kernels report (smh_stats.h)?  All but the pair lookup kernel (exact, m <= 8) */
 static bool wm_reports(const struct smh_wm *wm) { return wm->gram_table || !wm->pair_table; }
-static bool wm_engines(const struct smh_wm *wm) { return wm->flex_ac || wm->keys; } /* more than this path's own kernels at hand */
+static bool wm_engines(const struct smh_wm *wm) { return wm->flex_ac || wm->keys || wm->hashes; } /* more than this path's own kernels at hand */
 static void wm_estimates(const struct smh_wm *wm, double est[SMH_ENGINES])
 {
     est[SMH_ALGO_AC] = wm_flex_ms(wm);
     est[SMH_ALGO_WM] = wm->scan_ms_est;
     est[SMH_ENGINE_AC_FLAT] = wm->flex_ac ? ac_flat_ms(wm->flex_ac) : 0.0;
     est[SMH_ENGINE_KEYS] = wm->keys ? wm->keys->ms_est : 0.0;
+    est[SMH_ENGINE_HASH] = wm->hashes ? wm->hashes->ms_est : 0.0;
 }
 static int wm_engine_now(struct smh_wm *wm)
 {
@@ -1347,6 +1354,7 @@ static int wm_prepare(struct smh_wm *wm, int variant)
     if (other && wm_engine_static(wm) == SMH_ALGO_AC) rc = ac_prepare(wm_automaton_engine(wm), variant);
     else if (other && wm_engine_static(wm) == SMH_ENGINE_AC_FLAT && wm->flex_ac) rc = ac_flat_prepare(wm->flex_ac);
     else if (other && wm_engine_static(wm) == SMH_ENGINE_KEYS && wm->keys) { smh_keys_dev *kd = NULL; rc = keys_ensure_device(wm->keys, &kd); }
+    else if (other && wm_engine_static(wm) == SMH_ENGINE_HASH && wm->hashes) { smh_hash_dev *hd = NULL; rc = hash_ensure_device(wm->hashes, &hd); }
     if (other) {
         if (rc == SMH_OK && adapt_enabled() && (wm_engines(wm) || wm_reports(wm))) { /* smh_wm_scan asks for it whatever engine runs */
             smh_adapt_dev *A = NULL;
@@ -1359,6 +1367,7 @@ static int wm_prepare(struct smh_wm *wm, int variant)
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = wm_ensure_reference_tables(wm, d);
     if (rc == SMH_OK && both && wm->flex_ac) rc = ac_prepare(wm->flex_ac, variant);
     if (rc == SMH_OK && both && wm->keys) { smh_keys_dev *kd = NULL; rc = keys_ensure_device(wm->keys, &kd); }
+    if (rc == SMH_OK && both && wm->hashes) { smh_hash_dev *hd = NULL; rc = hash_ensure_device(wm->hashes, &hd); }
     if (rc == SMH_OK && variant == SMH_VARIANT_TUNED && adapt_enabled() && (wm_engines(wm) || wm_reports(wm))) {
         smh_adapt_dev *A = NULL;
         rc = adapt_get(&wm->adapt, &A);
@@ -1424,6 +1433,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
                                               if (e == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), t, len, cnt, stream, sa);
                                               if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, t, len, cnt, stream, sa);
                                               if (e == SMH_ENGINE_KEYS) return keys_launch(wm->keys, t, len, cnt, NULL, stream, sa);
+                                              if (e == SMH_ENGINE_HASH) return hash_launch(wm->hashes, t, len, cnt, NULL, stream, sa);
                                               return wm_launch_own(wm, t, len, cnt, stream, wm_reports(wm) ? sa : smh_stats_arg{}, adapt_density(A, wm));
                                           }, &done);
                     if (rc != SMH_OK) return rc;
@@ -1437,6 +1447,7 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
             if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine, stream));
             if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine, stream));
             if (engine == SMH_ENGINE_KEYS) return keys_launch(wm->keys, d_text, n, d_count, NULL, stream, adapt_arg(A, n, engine, stream));
+            if (engine == SMH_ENGINE_HASH) return hash_launch(wm->hashes, d_text, n, d_count, NULL, stream, adapt_arg(A, n, engine, stream));
             return wm_launch_own(wm, d_text, n, d_count, stream, adapt_arg(wm_reports(wm) ? A : NULL, n, engine, stream), adapt_density(A, wm));
         }();
         const int rc_after = A ? adapt_order_after(A, stream) : SMH_OK;
@@ -1491,6 +1502,9 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
     else if (engine == SMH_ENGINE_KEYS && wm->keys && ((uintptr_t)d_text & 15u) == 0) {
         const smh_pos_out po = {d_positions, capacity, d_cursor};
         return keys_launch(wm->keys, d_text, n, NULL, &po, stream, smh_stats_arg{});
+    } else if (engine == SMH_ENGINE_HASH && wm->hashes && ((uintptr_t)d_text & 15u) == 0) {
+        const smh_pos_out po = {d_positions, capacity, d_cursor};
+        return hash_launch(wm->hashes, d_text, n, NULL, &po, stream, smh_stats_arg{});
     }
     smh_wm_dev *dv = NULL;
     int rc = wm_ensure_device(wm, &dv);
@@ -1763,6 +1777,59 @@ extern "C" struct smh_keys *smh_keys_compile_patterns(const unsigned char *patte
     struct smh_keys *k = smh_keys_build(pattern_flat, m, p_size, alphabet, SMH_KEYS_LDS_BUDGET, &why);
     if (!k) smh_set_error("smh_keys_compile_patterns: the key engine does not take this set (%s)", why);
     return k;
+}
+
+/* ------------------------------------------------------------------ window-hash engine (hash_host.c, hash_kernels.hip) */
+struct smh_hash_dev {
+    int device;
+    smh_hash_dev *next;
+    void *d_bloom;
+    void *d_table;
+};
+
+static void hash_dev_free_one(smh_hash_dev *dev)
+{
+    (void)hipFree(dev->d_bloom);
+    (void)hipFree(dev->d_table);
+    delete dev;
+}
+
+extern "C" void smh_hash_dev_free(struct smh_hash_dev *dev) /* the whole list */
+{
+    while (dev) {
+        smh_hash_dev *next = dev->next;
+        hash_dev_free_one(dev);
+        dev = next;
+    }
+}
+
+static int hash_ensure_device(struct smh_hashes *k, smh_hash_dev **out)
+{
+    return ensure_device_set<smh_hash_dev>(&k->dev, hash_dev_free_one, [&](smh_hash_dev *d) -> int {
+        int rc = upload(&d->d_bloom, k->bloom, (size_t)k->P.bloom_bytes, 0);
+        if (rc != SMH_OK) return rc;
+        return upload(&d->d_table, k->table, (size_t)k->table_bytes, 64);
+    }, out);
+}
+
+static int hash_launch(struct smh_hashes *k, const unsigned char *d_text, uint64_t n, uint64_t *d_count, const smh_pos_out *po,
+                       void *stream, const smh_stats_arg &SA)
+{
+    if (n < (uint64_t)k->m) return SMH_OK;
+    int n_cus = 0, rc;
+    if ((rc = current_cus(&n_cus)) != SMH_OK) return rc;
+    smh_hash_dev *dv = NULL;
+    if ((rc = hash_ensure_device(k, &dv)) != SMH_OK) return rc;
+    smh_hash_launch L = {};
+    L.C.text = d_text; L.C.n = n; L.C.P = k->P; L.C.table = reinterpret_cast<const uint8_t *>(dv->d_table);
+    L.d_bloom = reinterpret_cast<const uint32_t *>(dv->d_bloom); L.d_count = d_count; L.n_cus = n_cus; L.stats = SA;
+    if (po) {
+        L.po = *po;
+        HIP_TRY(smh_launch_hash_positions(L, (hipStream_t)stream));
+    } else {
+        HIP_TRY(smh_launch_hash(L, (hipStream_t)stream));
+    }
+    return SMH_OK;
 }
 
 /* ------------------------------------------------------------------ SH */

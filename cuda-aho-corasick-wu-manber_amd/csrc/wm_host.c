@@ -97,6 +97,7 @@ void smh_wm_host_free(struct smh_wm *wm)
     free(wm->pat_orig);
     smh_ac_free(wm->flex_ac ? wm->flex_ac : wm->alt_ac); /* alt_ac, when set, is the same handle */
     smh_keys_free(wm->keys);
+    smh_hash_free(wm->hashes);
     wm->magic = 0;
     free(wm);
 }
@@ -880,6 +881,10 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
     if (!wm->filter_exact && !wm->pair_table && smh_alt_engine_depth == 0 && m * smh_keys_symbol_bits(alphabet) <= SMH_KEY_MAX_BITS &&
         !(wm->flex_ac && wm->flex_ac->flat_parts == 1))
         wm->keys = smh_keys_build(wm->pat_sorted, m, d, alphabet, SMH_KEYS_LDS_BUDGET, NULL);
+    /* ... and where the key engine does not take the set (more keys than LDS holds, m * bits > 64), byte-like alphabets get the
+     * window-hash engine (hash_engine.h): a filter whose pass rate does not depend on the text either */
+    if (!wm->keys && !wm->filter_exact && !wm->pair_table && smh_alt_engine_depth == 0 && alphabet > 4 && m >= SMH_HASH_MIN_M && m <= SMH_HASH_MAX_M)
+        wm->hashes = smh_hash_build(wm->pat_sorted, m, d, NULL);
     return wm;
 
 oom:
@@ -926,8 +931,9 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->verify_slots = wm->filter_exact ? 0u : (1u << wm->verify_log2);
     out->lds_bytes = (uint32_t)(((size_t)1 << wm->filter_log2) / 8);
     out->scan_engine = wm->engine_forced >= 0 ? (uint32_t)wm->engine_forced : (wm->alt_ac ? SMH_ALGO_AC : SMH_ALGO_WM);
-    out->adaptive = (wm->flex_ac || wm->keys) && wm->engine_forced < 0 ? 1u : 0u;
+    out->adaptive = (wm->flex_ac || wm->keys || wm->hashes) && wm->engine_forced < 0 ? 1u : 0u;
     out->key_slots = wm->keys ? 2u * wm->keys->P.slots : 0u;
+    out->hash_slots = wm->hashes ? 2u * wm->hashes->P.slots : 0u;
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
     out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
@@ -941,9 +947,13 @@ int smh_wm_set_scan_engine(smh_wm *wm, int engine)
         smh_set_error("smh_wm_set_scan_engine: this set keeps no plain stride-1 automaton");
         return SMH_EUNSUP;
     }
-    if (!wm || wm->magic != SMH_MAGIC_WM || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT && engine != SMH_ENGINE_KEYS)) {
+    if (!wm || wm->magic != SMH_MAGIC_WM || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT && engine != SMH_ENGINE_KEYS && engine != SMH_ENGINE_HASH)) {
         smh_set_error("smh_wm_set_scan_engine: bad arguments");
         return SMH_EINVAL;
+    }
+    if (engine == SMH_ENGINE_HASH && !wm->hashes) {
+        smh_set_error("smh_wm_set_scan_engine: this handle keeps no window-hash engine (it keeps a key table, its path is exact, or m is outside 4..32)");
+        return SMH_EUNSUP;
     }
     if (engine == SMH_ENGINE_KEYS && !wm->keys) {
         smh_set_error("smh_wm_set_scan_engine: this handle keeps no key table (m * bits per symbol > 64, more keys than LDS holds, or this path is exact)");

@@ -25,8 +25,9 @@ ALGO_AC = 0
 ALGO_WM = 1
 ENGINE_AC_FLAT = 2
 ENGINE_KEYS = 3
-ENGINES = 4
-ENGINE_NAMES = {0: "automaton kernels", 1: "suffix-filter kernels", 2: "plain stride-1 automata", 3: "key table"}
+ENGINE_HASH = 4
+ENGINES = 5
+ENGINE_NAMES = {0: "automaton kernels", 1: "suffix-filter kernels", 2: "plain stride-1 automata", 3: "key table", 4: "window-hash filter"}
 
 u8p = C.POINTER(C.c_uint8)
 i32p = C.POINTER(C.c_int)
@@ -56,7 +57,7 @@ class WmInfo(C.Structure):
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
                 ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32),
-                ("adaptive", C.c_uint32), ("key_slots", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+                ("adaptive", C.c_uint32), ("key_slots", C.c_uint32), ("hash_slots", C.c_uint32), ("reserved", C.c_uint32 * 5)]
 
 
 class AdaptInfo(C.Structure):

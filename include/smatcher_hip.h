@@ -133,7 +133,13 @@ void smh_shard_range(uint64_t n, int n_shards, int shard, int m, uint64_t *begin
  * bytes: m <= 8) whose keys fit 156 KiB of LDS at half load (about 18 000 keys of 32 bits, 9 000 of 64);
  * smh_*_info.key_slots says whether the handle holds it. */
 #define SMH_ENGINE_KEYS 3
-#define SMH_ENGINES 4
+/* a fifth engine (round 5), held by Wu-Manber handles over byte-like alphabets whose set the key engine does not take (too many
+ * patterns, m * bits > 64): the WINDOW-HASH engine.  A Bloom filter of the rolling hash of the WHOLE m-byte window in LDS -- its
+ * false-positive rate is the table's load (about 4 % at 100 000 patterns) whatever the text, where a q-gram filter passes every
+ * column whose grams are common in the text -- and the patterns themselves in a two-table cuckoo hash in device memory: a
+ * surviving column costs two dependent round trips (window, both slots), true match or not.  4 <= m <= 32. */
+#define SMH_ENGINE_HASH 4
+#define SMH_ENGINES 5
 
 /* ---- Aho-Corasick ---- */
 typedef struct smh_ac smh_ac;
@@ -269,7 +275,8 @@ typedef struct smh_wm_info {
                                * grams at two columns per lookup, 6 flat byte grams (one Bloom set for all offsets) */
     uint32_t adaptive;        /* as smh_ac_info.adaptive: this handle also holds an automaton engine and follows the launches' reports */
     uint32_t key_slots;       /* round 5: as smh_ac_info.key_slots */
-    uint32_t reserved[6];
+    uint32_t hash_slots;      /* round 5: slots of the window-hash engine's pattern table (SMH_ENGINE_HASH); 0: the handle keeps none */
+    uint32_t reserved[5];
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */

@@ -638,3 +638,37 @@ extern "C" uint64_t emu_keys_positions(const smh_keys *k, const uint8_t *text_in
     guard_free(g);
     return cursor;
 }
+
+/* ------------------------------------------------------------------ window-hash engine (csrc/hash_lane.h) */
+#include "hash_lane.h"
+/* count (out == NULL) or positions of a Wu-Manber handle's window-hash engine; ~0 = the handle keeps none */
+extern "C" uint64_t emu_hash_scan(const smh_wm *wm, const uint8_t *text_in, uint64_t n, uint64_t *out, uint64_t capacity, uint32_t blocks,
+                                  uint64_t *events_out)
+{
+    const smh_hashes *k = wm->hashes;
+    if (!k) return ~0ull;
+    if (n < (uint64_t)k->m) return 0;
+    if (!blocks) blocks = 3;
+    uint64_t result[2] = {0, 0}, cursor = 0, events = 0;
+    for (int mode = 0; mode < (out ? 1 : 2); ++mode) {
+        guarded g = guard_copy(text_in, n, mode);
+        smh_hash_ctx C;
+        C.text = g.text; C.n = n; C.P = k->P; C.table = k->table;
+        smh_pos_out po{out, capacity, &cursor};
+        const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
+        uint64_t total = 0;
+        events = 0;
+        for (uint64_t t = 0; t < nthreads; ++t) {
+            const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
+            uint32_t ev = 0;
+            if (out) smh_hash_thread<true>(t, S, C, k->bloom, nullptr, &po, &ev);
+            else total += smh_hash_thread<false>(t, S, C, k->bloom, nullptr, nullptr, &ev);
+            events += ev;
+        }
+        result[mode] = total;
+        guard_free(g);
+    }
+    if (events_out) *events_out = events;
+    if (out) return cursor;
+    return result[0] == result[1] ? result[0] : ~0ull - 1;
+}

@@ -196,3 +196,24 @@ def keys_scan(keys, text, blocks=0):
 
 def keys_positions(keys, text, capacity, blocks=0):
     return _positions(_emu.emu_keys_positions, keys.h, text, capacity, blocks)
+
+
+_emu.emu_hash_scan.restype = C.c_uint64
+_emu.emu_hash_scan.argtypes = [C.c_void_p, S.u8p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+
+
+def hash_scan(wm, text, blocks=0):
+    """-> (count, columns that passed the filter) by the window-hash engine's lane code (csrc/hash_lane.h) of a WmTables handle"""
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    ev = C.c_uint64(0)
+    got = int(_emu.emu_hash_scan(wm.h, text.ctypes.data_as(S.u8p), len(text), None, 0, blocks, C.byref(ev)))
+    assert got != 0xFFFFFFFFFFFFFFFF, "the handle keeps no window-hash engine"
+    assert got != 0xFFFFFFFFFFFFFFFE, "the two guard-page placements of the text disagree"
+    return got, int(ev.value)
+
+
+def hash_positions(wm, text, capacity, blocks=0):
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    out = np.zeros(max(capacity, 1), dtype=np.uint64)
+    total = int(_emu.emu_hash_scan(wm.h, text.ctypes.data_as(S.u8p), len(text), out.ctypes.data_as(C.POINTER(C.c_uint64)), capacity, blocks, None))
+    return total, out[:min(total, capacity)]

@@ -40,13 +40,13 @@ int main(int argc, char **argv)
     A.h_rec = rec.data();
     A.d_stats = blocks.data();
     for (unsigned i = 0; i < SMH_STATS_SLOTS; ++i) blocks[i].host = rec.data() + i * SMH_STATS_HOST_WORDS;
-    const double est[SMH_ENGINES] = {0.20, 0.18, 0.55, 0.40};
+    const double est[SMH_ENGINES] = {0.20, 0.18, 0.55, 0.40, 0.0};
     /* the text turns hostile half way: the filter engine's rate collapses, the text-independent ones hold */
     auto rate = [&](int engine, int step) { return step < 100 ? est[engine] : (engine == SMH_ALGO_AC ? 6.0 : engine == SMH_ALGO_WM ? 3.0 : est[engine]); };
     struct smh_wm wm;
     memset(&wm, 0, sizeof wm);
     wm.gram_density = 0.001;
-    int engines_seen[SMH_ENGINES] = {0, 0, 0, 0};
+    int engines_seen[SMH_ENGINES] = {0, 0, 0, 0, 0};
     std::mutex seen_mu;
     auto worker = [&](int id) {
         void *stream = (void *)(uintptr_t)(0x1000 + id);
