@@ -12,8 +12,8 @@
  *           bits let ~4 % of non-matching columns through.
  *   stage 2 (L2 / Infinity Cache, surviving columns, compacted per wave): the window's aligned dwords are requested from global
  *           memory (streamed microseconds ago), hashed again with the verify stage's multiply-xorshift, and BOTH of the window's
- *           slots in a two-table cuckoo hash of the PATTERNS THEMSELVES (16 or 32 bytes per slot, zero-padded) are compared with
- *           it in registers: two dependent round trips for every surviving column, true match or not -- no tag, no third trip to
+ *           buckets (two slots each) in a two-table cuckoo hash of the PATTERNS THEMSELVES (zero-padded to whole dwords) are compared
+ *           with it in registers: two dependent round trips for every surviving column, true match or not -- no tag, no third trip to
  *           the pattern array (wm_lane.h smh_wm_probe_from pays one for every true match, and on such text one column in twenty
  *           is a true match).
  * Exact: a column counts when its window equals a stored pattern (what wu/wu.c:88's memcmp decides).
@@ -33,9 +33,12 @@ struct smh_hash_params {
     uint32_t bloom_shift;  /* byte address of the window's filter word = (h >> bloom_shift) & bloom_mask */
     uint32_t bloom_mask;   /* (words - 1) << 2 */
     uint32_t bloom_bytes;  /* LDS image: 2^15 words at most */
-    uint32_t slots;        /* per pattern table (two tables) */
+    uint32_t slots;        /* BUCKETS per pattern table (two tables); a bucket = two slots back to back: 85 % of the slots hold a pattern,
+                            * where one-slot buckets place 42 % -- half the table, and the probes are random 128-byte line fills of
+                            * a table that should stay in L2 */
     uint32_t seed;         /* of the slot hashes: the builder retries with another one when the patterns do not place */
-    uint32_t slot_dwords;  /* 4 (m <= 16) or 8 */
+    uint32_t slot_dwords;  /* (m + 3) / 4: a slot is the pattern zero-padded to whole dwords, slots back to back (a table that is a third smaller
+                            * than with 16 / 32-byte slots stays in L2 that much better: the probes are random 128-byte line fills) */
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)

@@ -58,14 +58,15 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
     P.bloom_shift = (uint32_t)(24 - wl - 2);
     P.bloom_mask = ((1u << wl) - 1u) << 2;
     P.bloom_bytes = 4u << wl;
-    P.slot_dwords = m <= 16 ? 4u : 8u;
-    uint32_t N = (uint32_t)((double)distinct / (2.0 * 0.42)) + 8u;
+    P.slot_dwords = ((uint32_t)m + 3u) / 4u;
+    /* buckets of two slots, two tables: 4 N slots for `distinct` patterns at 82 % */
+    uint32_t N = (uint32_t)((double)distinct / (4.0 * 0.82)) + 4u;
     P.slots = N;
     k->bloom = (uint32_t *)calloc(1, P.bloom_bytes);
     const size_t slot_bytes = 4u * (size_t)P.slot_dwords;
-    k->table_bytes = 2u * (size_t)N * slot_bytes;
+    k->table_bytes = 4u * (size_t)N * slot_bytes;
     k->table = (unsigned char *)calloc(1, k->table_bytes + 64);
-    uint32_t *slot_of = (uint32_t *)calloc(2u * (size_t)N, sizeof(uint32_t));
+    uint32_t *slot_of = (uint32_t *)calloc(4u * (size_t)N, sizeof(uint32_t)); /* [2 * bucket + slot], buckets of table 2 behind table 1's */
     if (!k->bloom || !k->table || !slot_of) { free(slot_of); smh_hash_free(k); *why = "out of memory"; return NULL; }
     for (int j = 0; j < distinct; ++j) {
         const uint32_t h = hash_roll(patterns + (size_t)j * (size_t)m, m);
@@ -74,59 +75,63 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
     }
     uint64_t set = 0;
     for (uint32_t i = 0; i < P.bloom_bytes / 4u; ++i) set += (uint64_t)__builtin_popcount(k->bloom[i]);
-    /* a non-matching window passes when both of its bits are set: about (bits set / bits)^2, a little more for the uneven words */
+    /* a non-matching window passes when both of its bits are set: about (bits set / bits)^2, more for the uneven words (measured
+     * 5.2 % at 100 000 patterns where the plain square says 3.0 %) */
     const double load = (double)set / (8.0 * (double)P.bloom_bytes);
-    k->pass_rate = 1.15 * load * load;
-    /* cuckoo placement of the patterns (random walk, as key_host.c); a set that does not place -- a few hundred patterns form a
-     * component with more keys than slots now and then -- is retried under another seed */
+    k->pass_rate = 1.7 * load * load;
+    /* cuckoo placement of the patterns (random walk); a set that does not place is retried under another seed */
     int ok = 0;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
     for (uint32_t attempt = 0; attempt < 16u && !ok; ++attempt) {
-    P.seed = attempt * 0x7F4A7C15u;
-    memset(slot_of, 0, sizeof(uint32_t) * 2u * (size_t)N);
-    ok = 1;
-    for (int j = 0; j < distinct && ok; ++j) {
-        uint32_t cur = (uint32_t)j + 1, s1, s2;
-        smh_hash_slots(hash_tag(patterns + (size_t)j * (size_t)m, m), P.seed, N, &s1, &s2);
-        if (!slot_of[s1]) { slot_of[s1] = cur; continue; }
-        if (!slot_of[s2]) { slot_of[s2] = cur; continue; }
-        uint32_t pos = (j & 1) ? s2 : s1;
-        int done = 0;
-        for (uint32_t kicks = 0; kicks < 2000u && !done; ++kicks) {
-            const uint32_t out = slot_of[pos];
-            slot_of[pos] = cur;
-            if (!out) { done = 1; break; }
-            cur = out;
-            smh_hash_slots(hash_tag(patterns + (size_t)(cur - 1) * (size_t)m, m), P.seed, N, &s1, &s2);
-            pos = pos == s1 ? s2 : s1;
+        P.seed = attempt * 0x7F4A7C15u;
+        memset(slot_of, 0, sizeof(uint32_t) * 4u * (size_t)N);
+        ok = 1;
+        for (int j = 0; j < distinct && ok; ++j) {
+            uint32_t cur = (uint32_t)j + 1;
+            int done = 0;
+            for (uint32_t kicks = 0; kicks < 4000u && !done; ++kicks) {
+                uint32_t b1, b2;
+                smh_hash_slots(hash_tag(patterns + (size_t)(cur - 1) * (size_t)m, m), P.seed, N, &b1, &b2);
+                const uint32_t cand[4] = {2u * b1, 2u * b1 + 1u, 2u * b2, 2u * b2 + 1u};
+                for (int c = 0; c < 4 && !done; ++c)
+                    if (!slot_of[cand[c]]) { slot_of[cand[c]] = cur; done = 1; }
+                if (done) break;
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                const uint32_t victim = cand[(rng >> 33) & 3u];
+                const uint32_t out = slot_of[victim];
+                slot_of[victim] = cur;
+                cur = out;
+            }
+            ok = done;
         }
-        ok = done;
-    }
     }
     if (!ok) { free(slot_of); smh_hash_free(k); *why = "no cuckoo placement found"; return NULL; }
-    /* slots: the pattern zero-padded to the slot; a free slot holds a string whose own slots lie elsewhere, so that no
+    /* slots: the pattern zero-padded to the slot; a free slot holds a string whose own buckets are other ones, so that no
      * window that is looked up here can equal it */
-    for (uint32_t s = 0; s < 2u * N; ++s) {
-        unsigned char *dst = k->table + (size_t)s * slot_bytes;
+    for (uint32_t s = 0; s < 4u * N; ++s) {
+        unsigned char f[SMH_HASH_MAX_M + 4];
+        memset(f, 0, sizeof f);
         if (slot_of[s]) {
-            memcpy(dst, patterns + (size_t)(slot_of[s] - 1) * (size_t)m, (size_t)m);
-            continue;
+            memcpy(f, patterns + (size_t)(slot_of[s] - 1) * (size_t)m, (size_t)m);
+        } else {
+            for (uint32_t v = 0;; ++v) {
+                memset(f, 0, sizeof f);
+                memcpy(f, &v, 4);
+                uint32_t b1, b2;
+                smh_hash_slots(hash_tag(f, m), P.seed, N, &b1, &b2);
+                if (b1 != s / 2u && b2 != s / 2u) break;
+            }
         }
-        unsigned char f[SMH_HASH_MAX_M];
-        for (uint32_t v = 0;; ++v) {
-            memset(f, 0, sizeof f);
-            memcpy(f, &v, 4);
-            uint32_t s1, s2;
-            smh_hash_slots(hash_tag(f, m), P.seed, N, &s1, &s2);
-            if (s1 != s && s2 != s) break;
-        }
-        memcpy(dst, f, (size_t)m);
+        /* the bucket's two slots interleaved dword by dword: slot k's dword j at dword 2 j + k of the bucket */
+        unsigned char *bucket = k->table + (size_t)(s / 2u) * 2u * slot_bytes;
+        for (uint32_t j = 0; j < P.slot_dwords; ++j) memcpy(bucket + 4u * (2u * j + (s & 1u)), f + 4u * j, 4);
     }
     free(slot_of);
     k->magic = SMH_MAGIC_HASHES;
     k->m = m;
     k->distinct = (uint32_t)distinct;
     k->P = P;
-    /* scan 0.36 ms/GiB (eleven VALU and one LDS read per column) + two round trips per surviving column: measured (round 5) */
+    /* scan 0.43 ms/GiB (twelve VALU and one LDS read per column) + two round trips per surviving column: measured (round 5) */
     k->ms_est = SMH_HASHES_MS_SCAN + SMH_HASHES_MS_PER_SURVIVOR * 4096.0 * k->pass_rate;
     return k;
 }
@@ -143,8 +148,14 @@ int smh_hash_contains(const struct smh_hashes *k, const unsigned char *window)
     uint32_t s1, s2;
     smh_hash_slots(hash_tag(window, k->m), k->P.seed, k->P.slots, &s1, &s2);
     const size_t sb = 4u * (size_t)k->P.slot_dwords;
-    unsigned char pad[SMH_HASH_MAX_M];
+    unsigned char pad[SMH_HASH_MAX_M + 4];
     memset(pad, 0, sizeof pad);
     memcpy(pad, window, (size_t)k->m);
-    return memcmp(k->table + s1 * sb, pad, sb) == 0 || memcmp(k->table + s2 * sb, pad, sb) == 0;
+    for (uint32_t slot = 0; slot < 4u; ++slot) {
+        const unsigned char *bucket = k->table + (size_t)(slot < 2u ? s1 : s2) * 2u * sb;
+        int same = 1;
+        for (uint32_t j = 0; j < k->P.slot_dwords && same; ++j) same = memcmp(bucket + 4u * (2u * j + (slot & 1u)), pad + 4u * j, 4) == 0;
+        if (same) return 1;
+    }
+    return 0;
 }

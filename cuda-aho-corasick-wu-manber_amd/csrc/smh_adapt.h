@@ -63,8 +63,10 @@ struct smh_adapt_dev {
     int tried[SMH_ENGINES]; /* the engine has reported on this kind of text */
 };
 
-/* engines whose rate does not depend on the text: their compile-time estimate holds on any text */
-static bool engine_text_independent(int e) { return e == SMH_ENGINE_AC_FLAT || e == SMH_ENGINE_KEYS; }
+/* engines whose rate does not depend on the text: their compile-time estimate holds on any text.  (The window-hash engine's filter
+ * rate does not; it verifies the true matches, two round trips each -- its estimate holds within a small factor while matches are
+ * a few per cent of the columns, where a q-gram filter's is off by the 5-30 x the policy otherwise assumes.) */
+static bool engine_text_independent(int e) { return e == SMH_ENGINE_AC_FLAT || e == SMH_ENGINE_KEYS || e == SMH_ENGINE_HASH; }
 
 static bool adapt_enabled()
 {

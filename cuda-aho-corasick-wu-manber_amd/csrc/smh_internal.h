@@ -208,8 +208,8 @@ struct smh_hashes {
     double ms_est;          /* ms per GiB on text without matches */
     struct smh_hash_dev *dev;
 };
-#define SMH_HASHES_MS_SCAN 0.36
-#define SMH_HASHES_MS_PER_SURVIVOR 0.0017 /* ms per GiB per surviving column in 4 KiB */
+#define SMH_HASHES_MS_SCAN 0.43
+#define SMH_HASHES_MS_PER_SURVIVOR 0.0020 /* ms per GiB per surviving column in 4 KiB: 100 000 patterns of 12 bytes, 213 per 4 KiB on uniform text 0.87 ms/GiB against 0.43 with the survivors dropped (profiles/r05_final/notes) */
 struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int distinct, const char **why);
 void smh_hash_free(struct smh_hashes *k);
 int smh_hash_filter_passes(const struct smh_hashes *k, const unsigned char *window);

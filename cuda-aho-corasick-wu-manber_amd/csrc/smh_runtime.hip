@@ -1822,6 +1822,8 @@ static int hash_launch(struct smh_hashes *k, const unsigned char *d_text, uint64
     if ((rc = hash_ensure_device(k, &dv)) != SMH_OK) return rc;
     smh_hash_launch L = {};
     L.C.text = d_text; L.C.n = n; L.C.P = k->P; L.C.table = reinterpret_cast<const uint8_t *>(dv->d_table);
+    static const uint32_t drop = [] { const char *t = getenv("SMH_HASH_TUNE"); return t && strstr(t, "drop=1") ? 1u : 0u; }();
+    L.C.drop = drop;
     L.d_bloom = reinterpret_cast<const uint32_t *>(dv->d_bloom); L.d_count = d_count; L.n_cus = n_cus; L.stats = SA;
     if (po) {
         L.po = *po;

@@ -933,7 +933,7 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->scan_engine = wm->engine_forced >= 0 ? (uint32_t)wm->engine_forced : (wm->alt_ac ? SMH_ALGO_AC : SMH_ALGO_WM);
     out->adaptive = (wm->flex_ac || wm->keys || wm->hashes) && wm->engine_forced < 0 ? 1u : 0u;
     out->key_slots = wm->keys ? 2u * wm->keys->P.slots : 0u;
-    out->hash_slots = wm->hashes ? 2u * wm->hashes->P.slots : 0u;
+    out->hash_slots = wm->hashes ? 4u * wm->hashes->P.slots : 0u; /* two tables of two-slot buckets */
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
     out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);

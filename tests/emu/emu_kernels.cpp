@@ -653,7 +653,7 @@ extern "C" uint64_t emu_hash_scan(const smh_wm *wm, const uint8_t *text_in, uint
     for (int mode = 0; mode < (out ? 1 : 2); ++mode) {
         guarded g = guard_copy(text_in, n, mode);
         smh_hash_ctx C;
-        C.text = g.text; C.n = n; C.P = k->P; C.table = k->table;
+        C.text = g.text; C.n = n; C.P = k->P; C.table = k->table; C.drop = 0;
         smh_pos_out po{out, capacity, &cursor};
         const uint64_t nthreads = (uint64_t)blocks * EMU_BLOCK_THREADS;
         uint64_t total = 0;
@@ -661,8 +661,12 @@ extern "C" uint64_t emu_hash_scan(const smh_wm *wm, const uint8_t *text_in, uint
         for (uint64_t t = 0; t < nthreads; ++t) {
             const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
             uint32_t ev = 0;
-            if (out) smh_hash_thread<true>(t, S, C, k->bloom, nullptr, &po, &ev);
-            else total += smh_hash_thread<false>(t, S, C, k->bloom, nullptr, nullptr, &ev);
+            switch ((k->m + 3) / 4) { /* as hash_kernels.hip launch_nd */
+#define EMU_HASH_ND(ND) case ND: if (out) smh_hash_thread<true, ND>(t, S, C, k->bloom, nullptr, &po, &ev); else total += smh_hash_thread<false, ND>(t, S, C, k->bloom, nullptr, nullptr, &ev); break;
+            EMU_HASH_ND(1) EMU_HASH_ND(2) EMU_HASH_ND(3) EMU_HASH_ND(4) EMU_HASH_ND(5) EMU_HASH_ND(6) EMU_HASH_ND(7)
+            default: if (out) smh_hash_thread<true, 8>(t, S, C, k->bloom, nullptr, &po, &ev); else total += smh_hash_thread<false, 8>(t, S, C, k->bloom, nullptr, nullptr, &ev); break;
+#undef EMU_HASH_ND
+            }
             events += ev;
         }
         result[mode] = total;
