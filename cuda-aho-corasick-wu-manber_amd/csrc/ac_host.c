@@ -1040,9 +1040,13 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_full_rows = ac->scan_full_rows;
     out->scan_engine = ac->engine_forced >= 0 ? (uint32_t)ac->engine_forced : (ac->alt_wm ? SMH_ALGO_WM : SMH_ALGO_AC);
     out->scan_dense = (uint32_t)ac->scan_dense;
-    out->adaptive = (ac->flex_wm || ac->flat_ac || ac->keys) && ac->engine_forced < 0 ? 1u : 0u;
     out->flat_parts = (uint32_t)ac->flat_parts;
     out->key_slots = ac->keys ? 2u * ac->keys->P.slots : 0u;
+    {
+        const struct smh_wm *fw = ac->alt_wm ? ac->alt_wm : ac->flex_wm;
+        out->hash_slots = fw && fw->hashes && !ac->keys ? 4u * fw->hashes->P.slots : 0u;
+    }
+    out->adaptive = (ac->flex_wm || ac->flat_ac || ac->keys || out->hash_slots) && ac->engine_forced < 0 ? 1u : 0u;
     if (out->scan_engine == SMH_ALGO_WM) {
         smh_wm_info wi;
         if (smh_wm_get_info(ac->alt_wm ? ac->alt_wm : ac->flex_wm, &wi) == SMH_OK) {
@@ -1081,9 +1085,13 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
 
 int smh_ac_set_scan_engine(smh_ac *ac, int engine)
 {
-    if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT && engine != SMH_ENGINE_KEYS)) {
+    if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT && engine != SMH_ENGINE_KEYS && engine != SMH_ENGINE_HASH)) {
         smh_set_error("smh_ac_set_scan_engine: bad arguments");
         return SMH_EINVAL;
+    }
+    if (engine == SMH_ENGINE_HASH && !((ac->alt_wm && ac->alt_wm->hashes) || (ac->flex_wm && ac->flex_wm->hashes))) {
+        smh_set_error("smh_ac_set_scan_engine: this handle keeps no window-hash engine (alphabet 4, a key table, an exact plan, or m outside 4..32)");
+        return SMH_EUNSUP;
     }
     if (engine == SMH_ENGINE_KEYS && !ac->keys) {
         smh_set_error("smh_ac_set_scan_engine: this handle keeps no key table (m * bits per symbol > 64, more keys than LDS holds, or its plan is an exact one-launch plan)");

@@ -723,8 +723,13 @@ static int ac_engine_static(const struct smh_ac *ac)
 static struct smh_wm *ac_filter_engine(const struct smh_ac *ac) { return ac->alt_wm ? ac->alt_wm : ac->flex_wm; }
 /* the engine the next tuned scan on the current device runs (positions, info) */
 /* a handle with per-device state shared by its launches: several engines (reports, rates) or a candidate-queue workspace */
-static bool ac_needs_state(const struct smh_ac *ac) { return ac->flex_wm || ac->flat_ac || ac->keys || (!ac->scan_exact && !ac->scan_dense); }
-static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac || ac->keys) && adapt_enabled(); }
+static struct smh_hashes *ac_hashes(const struct smh_ac *ac)
+{
+    const struct smh_wm *fw = ac->alt_wm ? ac->alt_wm : ac->flex_wm;
+    return fw && !ac->keys ? fw->hashes : NULL;
+}
+static bool ac_needs_state(const struct smh_ac *ac) { return ac->flex_wm || ac->flat_ac || ac->keys || ac_hashes(ac) || (!ac->scan_exact && !ac->scan_dense); }
+static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac || ac->keys || ac_hashes(ac)) && adapt_enabled(); }
 /* the text-independent engine: one exact stride-1 launch per part (ac_host.c, end of the compile) */
 static double ac_flat_ms(const struct smh_ac *ac)
 {
@@ -742,7 +747,8 @@ static void ac_estimates(const struct smh_ac *ac, double est[SMH_ENGINES])
     est[SMH_ALGO_WM] = ac_filter_engine(ac) ? ac_filter_engine(ac)->scan_ms_est : 0.0;
     est[SMH_ENGINE_AC_FLAT] = ac_flat_ms(ac);
     est[SMH_ENGINE_KEYS] = ac->keys ? ac->keys->ms_est : 0.0;
-    est[SMH_ENGINE_HASH] = 0.0; /* Wu-Manber handles only */
+    /* the window-hash engine of the handle's filter engine (byte-like alphabets), unless the handle has a key table of its own */
+    est[SMH_ENGINE_HASH] = ac_hashes(ac) ? ac_hashes(ac)->ms_est : 0.0;
 }
 static int ac_engine_now(struct smh_ac *ac)
 {
@@ -768,6 +774,7 @@ static int ac_prepare_engines(struct smh_ac *ac, int variant)
     if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ALGO_WM && !both) return wm_prepare(ac_filter_engine(ac), variant);
     if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_AC_FLAT && !both) return ac_flat_prepare(ac);
     if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_KEYS && !both && ac->keys) { smh_keys_dev *kd = NULL; return keys_ensure_device(ac->keys, &kd); }
+    if (variant == SMH_VARIANT_TUNED && ac_engine_static(ac) == SMH_ENGINE_HASH && !both && ac_hashes(ac)) { smh_hash_dev *hd = NULL; return hash_ensure_device(ac_hashes(ac), &hd); }
     smh_ac_dev *d = NULL;
     int rc = ac_ensure_device(ac, &d);
     if (rc == SMH_OK && variant == SMH_VARIANT_TABLE) rc = ac_ensure_reference_tables(ac, d);
@@ -779,6 +786,7 @@ static int ac_prepare_engines(struct smh_ac *ac, int variant)
         if (ac_filter_engine(ac)) rc = wm_prepare(ac_filter_engine(ac), variant);
         if (rc == SMH_OK) rc = ac_flat_prepare(ac);
         if (rc == SMH_OK && ac->keys) { smh_keys_dev *kd = NULL; rc = keys_ensure_device(ac->keys, &kd); }
+        if (rc == SMH_OK && ac_hashes(ac)) { smh_hash_dev *hd = NULL; rc = hash_ensure_device(ac_hashes(ac), &hd); }
     }
     return rc;
 }
@@ -894,6 +902,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
             if (engine == SMH_ALGO_WM) return smh_wm_scan(ac_filter_engine(ac), d_text, n, d_count, SMH_VARIANT_TUNED, stream);
             if (engine == SMH_ENGINE_AC_FLAT && ac->flat_ac) return ac_flat_launch(ac, d_text, n, d_count, stream, smh_stats_arg{});
             if (engine == SMH_ENGINE_KEYS && ac->keys) return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, smh_stats_arg{});
+            if (engine == SMH_ENGINE_HASH && ac_hashes(ac)) return hash_launch(ac_hashes(ac), d_text, n, d_count, NULL, stream, smh_stats_arg{});
             return ac_launch_own(ac, d_text, n, d_count, stream, smh_stats_arg{});
         };
         if (!ac_needs_state(ac)) return launch_static(); /* one exact plan, no workspace, nothing to adapt: launches may overlap freely */
@@ -914,6 +923,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
                                           if (e == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), t, len, cnt, stream, sa, adapt_density(A, ac_filter_engine(ac)));
                                           if (e == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, t, len, cnt, stream, sa);
                                           if (e == SMH_ENGINE_KEYS) return keys_launch(ac->keys, t, len, cnt, NULL, stream, sa);
+                                          if (e == SMH_ENGINE_HASH) return hash_launch(ac_hashes(ac), t, len, cnt, NULL, stream, sa);
                                           return ac_launch_own(ac, t, len, cnt, stream, sa);
                                       }, &done);
                 if (rc != SMH_OK) return rc;
@@ -927,6 +937,7 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
             if (engine == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), d_text, n, d_count, stream, SA, adapt_density(A, ac_filter_engine(ac)));
             if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, d_text, n, d_count, stream, SA);
             if (engine == SMH_ENGINE_KEYS) return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, SA);
+            if (engine == SMH_ENGINE_HASH) return hash_launch(ac_hashes(ac), d_text, n, d_count, NULL, stream, SA);
             return ac_launch_own(ac, d_text, n, d_count, stream, SA);
         }();
         const int rc_after = adapt_order_after(A, stream);
@@ -1003,6 +1014,9 @@ static int ac_positions_impl(smh_ac *ac, int engine, const unsigned char *d_text
     else if (engine == SMH_ENGINE_KEYS && ac->keys && ((uintptr_t)d_text & 15u) == 0) {
         const smh_pos_out po = {d_positions, capacity, d_cursor};
         return keys_launch(ac->keys, d_text, n, NULL, &po, stream, smh_stats_arg{});
+    } else if (engine == SMH_ENGINE_HASH && ac_hashes(ac) && ((uintptr_t)d_text & 15u) == 0) {
+        const smh_pos_out po = {d_positions, capacity, d_cursor};
+        return hash_launch(ac_hashes(ac), d_text, n, NULL, &po, stream, smh_stats_arg{});
     }
     smh_ac_dev *dv = NULL;
     int rc = ac_ensure_device(ac, &dv);

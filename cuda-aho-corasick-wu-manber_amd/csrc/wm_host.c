@@ -883,7 +883,8 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         wm->keys = smh_keys_build(wm->pat_sorted, m, d, alphabet, SMH_KEYS_LDS_BUDGET, NULL);
     /* ... and where the key engine does not take the set (more keys than LDS holds, m * bits > 64), byte-like alphabets get the
      * window-hash engine (hash_engine.h): a filter whose pass rate does not depend on the text either */
-    if (!wm->keys && !wm->filter_exact && !wm->pair_table && smh_alt_engine_depth == 0 && alphabet > 4 && m >= SMH_HASH_MIN_M && m <= SMH_HASH_MAX_M)
+    /* (also for the handle an automaton handle keeps as its filter engine -- depth 1 --: that handle runs it as ITS fifth engine) */
+    if (!wm->keys && !wm->filter_exact && !wm->pair_table && smh_alt_engine_depth <= 1 && alphabet > 4 && m >= SMH_HASH_MIN_M && m <= SMH_HASH_MAX_M)
         wm->hashes = smh_hash_build(wm->pat_sorted, m, d, NULL);
     return wm;
 

@@ -47,7 +47,7 @@ class AcInfo(C.Structure):
                 ("scan_depth", C.c_uint32), ("scan_stride", C.c_uint32), ("scan_exact", C.c_uint32),
                 ("scan_full_rows", C.c_uint32), ("scan_engine", C.c_uint32), ("scan_dense", C.c_uint32),
                 ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32), ("adaptive", C.c_uint32),
-                ("flat_parts", C.c_uint32), ("key_slots", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("flat_parts", C.c_uint32), ("key_slots", C.c_uint32), ("hash_slots", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class WmInfo(C.Structure):

@@ -178,7 +178,8 @@ typedef struct smh_ac_info {
     uint32_t flat_parts;     /* launches of the text-independent engine (SMH_ENGINE_AC_FLAT): the set as that many exact stride-1
                               * automata that each fit LDS whole, scanned one after the other; 0: the handle keeps none */
     uint32_t key_slots;      /* round 5: slots of the key table the handle keeps (SMH_ENGINE_KEYS); 0: it keeps none */
-    uint32_t reserved[5];    /* zero; library 0.2 grew this struct -- later fields come out of here (key_slots did) */
+    uint32_t hash_slots;     /* round 5: slots of the window-hash engine's pattern table (SMH_ENGINE_HASH; byte-like alphabets without a key table); 0: none */
+    uint32_t reserved[4];    /* zero; library 0.2 grew this struct -- later fields come out of here (key_slots, hash_slots did) */
 } smh_ac_info;
 
 /* What the library has learned about the text it scans with a handle on the CURRENT device (round 4).  The engine that
