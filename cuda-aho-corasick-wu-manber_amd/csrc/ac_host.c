@@ -1042,10 +1042,7 @@ int smh_ac_get_info(const smh_ac *ac, smh_ac_info *out)
     out->scan_dense = (uint32_t)ac->scan_dense;
     out->flat_parts = (uint32_t)ac->flat_parts;
     out->key_slots = ac->keys ? 2u * ac->keys->P.slots : 0u;
-    {
-        const struct smh_wm *fw = ac->alt_wm ? ac->alt_wm : ac->flex_wm;
-        out->hash_slots = fw && fw->hashes && !ac->keys ? 4u * fw->hashes->P.slots : 0u;
-    }
+    out->hash_slots = smh_ac_hash_engine(ac) ? 4u * smh_ac_hash_engine(ac)->P.slots : 0u;
     out->adaptive = (ac->flex_wm || ac->flat_ac || ac->keys || out->hash_slots) && ac->engine_forced < 0 ? 1u : 0u;
     if (out->scan_engine == SMH_ALGO_WM) {
         smh_wm_info wi;
@@ -1083,13 +1080,20 @@ int smh_ac_set_scan_plan(smh_ac *ac, int stride, int depth)
     return SMH_OK;
 }
 
+/* the window-hash engine an automaton handle runs as SMH_ENGINE_HASH: its filter engine's, unless it has a key table of its own */
+struct smh_hashes *smh_ac_hash_engine(const struct smh_ac *ac)
+{
+    const struct smh_wm *fw = ac->alt_wm ? ac->alt_wm : ac->flex_wm;
+    return fw && !ac->keys ? fw->hashes : NULL;
+}
+
 int smh_ac_set_scan_engine(smh_ac *ac, int engine)
 {
     if (!ac || ac->magic != SMH_MAGIC_AC || (engine != -1 && engine != SMH_ALGO_WM && engine != SMH_ALGO_AC && engine != SMH_ENGINE_AC_FLAT && engine != SMH_ENGINE_KEYS && engine != SMH_ENGINE_HASH)) {
         smh_set_error("smh_ac_set_scan_engine: bad arguments");
         return SMH_EINVAL;
     }
-    if (engine == SMH_ENGINE_HASH && !((ac->alt_wm && ac->alt_wm->hashes) || (ac->flex_wm && ac->flex_wm->hashes))) {
+    if (engine == SMH_ENGINE_HASH && !smh_ac_hash_engine(ac)) {
         smh_set_error("smh_ac_set_scan_engine: this handle keeps no window-hash engine (alphabet 4, a key table, an exact plan, or m outside 4..32)");
         return SMH_EUNSUP;
     }

@@ -91,8 +91,9 @@ static void adapt_poll_slot(smh_adapt_dev *A, unsigned int slot)
     /* the record is written without a fence between data and flag: it validates itself */
     if ((unsigned int)seq2 != seq || (unsigned int)h[0] != seq || sum != (ev ^ ticks ^ bytes ^ tagw ^ (unsigned long long)seq)) return;
     A->seen[slot] = seq;
-    const unsigned int tag = (unsigned int)tagw, nonce = (unsigned int)(tagw >> 32);
-    if (nonce != A->slot_nonce[slot]) return; /* a launch that lost its slot to a later one (more than SMH_STATS_SLOTS in flight) */
+    /* (a record is one launch's whatever launch holds the slot by now -- the device publishes only tickets whose workgroups all
+     * carried the same nonce -- so a caller that queues launches far ahead of the device still gets its reports, late) */
+    const unsigned int tag = (unsigned int)tagw;
     const int e = (int)(tag & 0xFFu);
     if (bytes < SMH_ADAPT_MIN_BYTES || ticks == 0 || e >= SMH_ENGINES) return;
     A->sig[e] = (double)ev * 4096.0 / (double)bytes;

@@ -160,6 +160,7 @@ extern _Thread_local int smh_alt_engine_depth;
 void smh_ac_dev_free(struct smh_ac_dev *dev); /* smh_runtime.hip */
 struct smh_adapt_dev;
 void smh_adapt_dev_free(struct smh_adapt_dev *list); /* smh_runtime.hip */
+struct smh_hashes *smh_ac_hash_engine(const struct smh_ac *ac); /* ac_host.c: what the handle runs as SMH_ENGINE_HASH, or NULL */
 double smh_ac_plan_ms(const struct smh_ac *ac); /* ac_host.c: the plan model's estimate for the automaton kernels, ms per GiB */
 int smh_ac_prepare_device(struct smh_ac *ac); /* smh_runtime.hip: table set of the current device, no launch */
 

@@ -723,11 +723,7 @@ static int ac_engine_static(const struct smh_ac *ac)
 static struct smh_wm *ac_filter_engine(const struct smh_ac *ac) { return ac->alt_wm ? ac->alt_wm : ac->flex_wm; }
 /* the engine the next tuned scan on the current device runs (positions, info) */
 /* a handle with per-device state shared by its launches: several engines (reports, rates) or a candidate-queue workspace */
-static struct smh_hashes *ac_hashes(const struct smh_ac *ac)
-{
-    const struct smh_wm *fw = ac->alt_wm ? ac->alt_wm : ac->flex_wm;
-    return fw && !ac->keys ? fw->hashes : NULL;
-}
+static struct smh_hashes *ac_hashes(const struct smh_ac *ac) { return smh_ac_hash_engine(ac); }
 static bool ac_needs_state(const struct smh_ac *ac) { return ac->flex_wm || ac->flat_ac || ac->keys || ac_hashes(ac) || (!ac->scan_exact && !ac->scan_dense); }
 static bool ac_adaptive(const struct smh_ac *ac) { return (ac->flex_wm || ac->flat_ac || ac->keys || ac_hashes(ac)) && adapt_enabled(); }
 /* the text-independent engine: one exact stride-1 launch per part (ac_host.c, end of the compile) */
@@ -974,6 +970,7 @@ extern "C" int smh_ac_get_adapt(smh_ac *ac, smh_adapt_info *out)
     smh_adapt_dev *A = ac_adaptive(ac) ? adapt_find(&ac->adapt) : NULL;
     std::unique_lock<std::mutex> lock;
     if (A) lock = std::unique_lock<std::mutex>(*A->mu);
+    if (A) adapt_poll(A); /* what the launches finished so far have published */
     adapt_report(A, adaptive, ac_engine_static(ac), est, out);
     return SMH_OK;
 }
@@ -1497,6 +1494,7 @@ extern "C" int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out)
     smh_adapt_dev *A = adapt_find(&wm->adapt);
     std::unique_lock<std::mutex> lock;
     if (A) lock = std::unique_lock<std::mutex>(*A->mu);
+    if (A) adapt_poll(A);
     adapt_report(A, adaptive, wm_engine_static(wm), est, out);
     return SMH_OK;
 }
