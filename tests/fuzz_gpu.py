@@ -82,6 +82,13 @@ def run(cases, seed, verbose=True):
             positions(ac)
             ac.set_scan_engine(-1)
             checks += 2
+        for eng, slots in ((S.ENGINE_KEYS, ac.info().key_slots), (S.ENGINE_HASH, ac.info().hash_slots)):  # round 5: the key table / the window-hash engine
+            if slots:
+                ac.set_scan_engine(eng)
+                assert ac.count_host(text)[0] == want, (tag, "ac engine", eng)
+                positions(ac)
+                ac.set_scan_engine(-1)
+                checks += 2
         plans = [(1, min(m, 33)), (1, max(1, m // 2)), (1, 2)]
         if sigma == 4:
             plans += [(2, min(m, 33)), (2, max(1, m // 2)), (3, min(m, 33) | (1 << 8)), (3, min(m, 33) | (3 << 8)),
@@ -109,6 +116,13 @@ def run(cases, seed, verbose=True):
                 checks += 2
             except S.SmhError:
                 pass
+            for eng, slots in ((S.ENGINE_KEYS, wm.info().key_slots), (S.ENGINE_HASH, wm.info().hash_slots)):
+                if slots:
+                    wm.set_scan_engine(eng)
+                    assert wm.count_host(text)[0] == want, (tag, "wm engine", eng)
+                    positions(wm)
+                    wm.set_scan_engine(-1)
+                    checks += 2
             if wm.info().scan_engine == S.ALGO_AC:
                 wm.set_scan_engine(S.ALGO_WM)
                 assert wm.count_host(text)[0] == want, (tag, "wm own kernels")

@@ -37,7 +37,7 @@ def load(path, counter):
             if r["Counter_Name"] != counter:
                 continue
             name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
-            if not any(k in name for k in ("ac_dfa", "wm_block", "wm_pair", "wm_gram", "acm_kernel", "ac_table", "wm_table", "stream_read")):
+            if not any(k in name for k in ("ac_dfa", "wm_block", "wm_pair", "wm_gram", "acm_kernel", "ac_table", "wm_table", "stream_read", "key_kernel", "hash_kernel")):
                 continue
             agg.setdefault(name, []).append(float(r["Counter_Value"]))
     return agg
