@@ -9,7 +9,7 @@ import csv
 import glob
 import sys
 
-KEEP = ("ac_dfa", "wm_block", "wm_pair", "wm_gram", "acm_kernel", "ac_table", "wm_table", "stream_read")
+KEEP = ("ac_dfa", "wm_block", "wm_pair", "wm_gram", "acm_kernel", "key_kernel", "hash_kernel", "ac_table", "wm_table", "stream_read")
 
 
 def main():
