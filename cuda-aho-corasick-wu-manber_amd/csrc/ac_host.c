@@ -35,7 +35,7 @@ void smh_set_error(const char *fmt, ...)
 
 const char *smh_last_error(void) { return g_err; }
 _Thread_local int smh_alt_engine_depth = 0;
-const char *smh_version(void) { return "mi355x-smatcher 0.2 (gfx950)"; }
+const char *smh_version(void) { return "mi355x-smatcher 0.3 (gfx950)"; }
 
 uint64_t smh_handle_serial(void)
 {

@@ -358,6 +358,11 @@ struct smh_wm {
     double filter_density; /* fraction of windows expected to pass on uniform text */
     int verify_log2;      /* slots = 1 << verify_log2; 0 slots when exact */
     uint32_t *verify;     /* 2 words per slot: tag, pattern index + 1 (0 = empty) */
+    /* round 5: the same entries as a two-table cuckoo hash of two-slot buckets, 82 % full (100 000 patterns: 0.5 MB instead of the
+     * 2 MiB above) -- what the pipelined probes of the byte-gram kernels read: random 16-byte probes fill 128-byte lines, and a table
+     * that does not stay in L2 beside the streaming text cost them 1.6-1.95 x the algorithmic HBM traffic.  NULL for small sets. */
+    uint32_t *verify_ck;  /* 4 * ck_buckets entries: bucket b of table t at 2 * (t * ck_buckets + b) */
+    uint32_t ck_buckets, ck_seed;
     unsigned char *pat_sorted; /* distinct * m */
     /* pair filter (alphabet 4, m <= 8, exact): indexed by the code i of NINE consecutive symbols (18 bits, oldest
      * symbol highest).  The seven oldest symbols select the dword pair_table[i >> 4]; inside it the newest two

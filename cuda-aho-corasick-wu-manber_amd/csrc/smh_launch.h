@@ -181,6 +181,8 @@ struct smh_wm_launch {
     uint32_t sfx_slot_off, sfx_ent_off, sfx_pat_off; /* gram_kind 4: the verify stage's suffix index inside d_gram (byte offsets; 0 = none) */
     int verify_log2;
     const uint32_t *d_verify;
+    const uint32_t *d_verify_ck; /* the cuckoo form of the verify entries (smh_internal.h), else NULL */
+    uint32_t ck_buckets, ck_seed;
     const uint8_t *d_pat_sorted;
     uint64_t *d_queue; /* smh_wm_max_blocks * 16 waves * SMH_WM_QCAP columns (NULL when exact) */
     uint64_t *d_count;

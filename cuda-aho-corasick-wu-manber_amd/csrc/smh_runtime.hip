@@ -59,6 +59,7 @@ struct smh_wm_dev {
     uint32_t *d_gram;
     uint64_t *d_queue;
     uint32_t *d_verify;
+    uint32_t *d_verify_ck;
     uint8_t *d_pat_sorted;
     uint16_t *d_shift;
     uint32_t *d_bucket_off;
@@ -1257,6 +1258,7 @@ static void wm_dev_free_one(smh_wm_dev *dev)
     (void)hipFree(dev->d_gram);
     (void)hipFree(dev->d_queue);
     (void)hipFree(dev->d_verify);
+    (void)hipFree(dev->d_verify_ck);
     (void)hipFree(dev->d_pat_sorted);
     (void)hipFree(dev->d_shift);
     (void)hipFree(dev->d_bucket_off);
@@ -1285,6 +1287,7 @@ static int wm_ensure_device(struct smh_wm *wm, smh_wm_dev **out)
         if (wm->gram_table && (rc = upload((void **)&d->d_gram, wm->gram_table, wm->gram_bytes, 0)) != SMH_OK) return rc;
         if (wm->verify) {
             if ((rc = upload((void **)&d->d_verify, wm->verify, ((size_t)1 << wm->verify_log2) * 4, 0)) != SMH_OK) return rc;
+            if (wm->verify_ck && (rc = upload((void **)&d->d_verify_ck, wm->verify_ck, (size_t)wm->ck_buckets * 16u, 16)) != SMH_OK) return rc;
         }
         {
             /* distinct patterns, each zero-padded to whole dwords (the verify stage compares dwords) */
@@ -1398,7 +1401,7 @@ static int wm_launch_own(struct smh_wm *wm, const unsigned char *d_text, uint64_
     smh_wm_launch L = {};
     L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
     L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
-    L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
+    L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify; L.d_verify_ck = dv->d_verify_ck; L.ck_buckets = wm->ck_buckets; L.ck_seed = wm->ck_seed;
     L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind; L.gram_density = density < 0 ? (float)wm->gram_density : density; L.gram_lane0 = (float)wm->gram_lane0; L.gram_planes = wm->gram_planes;
     if (wm->gram_kind == SMH_GRAM_FLAT) L.gram_jb = wm->gram_jb; /* 1: two bits per gram */
     L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
@@ -1529,7 +1532,7 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         smh_wm_launch L = {};
         L.d_text = d_text; L.n = n; L.m = wm->m; L.bits = wm->bits_per_symbol; L.block_symbols = wm->block_symbols;
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
-        L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify;
+        L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify; L.d_verify_ck = dv->d_verify_ck; L.ck_buckets = wm->ck_buckets; L.ck_seed = wm->ck_seed;
         L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind; L.gram_density = (float)wm->gram_density; L.gram_lane0 = (float)wm->gram_lane0; L.gram_planes = wm->gram_planes;
         if (wm->gram_kind == SMH_GRAM_FLAT) L.gram_jb = wm->gram_jb;
         L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = NULL; L.n_cus = n_cus;

@@ -20,6 +20,7 @@
  *     (up to the whole pattern), so its SHIFT == 0 test actually filters.
  */
 #include "smh_internal.h"
+#include "hash_engine.h" /* smh_hash_slots */
 #include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
@@ -90,6 +91,7 @@ void smh_wm_host_free(struct smh_wm *wm)
     free(wm->pair_table);
     free(wm->gram_table);
     free(wm->verify);
+    free(wm->verify_ck);
     free(wm->pat_sorted);
     free(wm->l_shift);
     free(wm->l_bucket_off);
@@ -823,6 +825,47 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
         }
     }
 
+    /* ---- the verify entries once more as a cuckoo hash (smh_internal.h verify_ck): sets whose table above exceeds 512 KiB ---- */
+    if (((size_t)4 << wm->verify_log2) > ((size_t)512 << 10)) {
+        const uint32_t NB = (uint32_t)((double)d / (4.0 * 0.82)) + 4u;
+        uint32_t *ck = (uint32_t *)calloc(4u * (size_t)NB, sizeof(uint32_t));
+        if (!ck) goto oom;
+        int ok = 0;
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        uint32_t seed = 0;
+        for (uint32_t attempt = 0; attempt < 16u && !ok; ++attempt) {
+            seed = attempt * 0x7F4A7C15u;
+            memset(ck, 0, sizeof(uint32_t) * 4u * (size_t)NB);
+            ok = 1;
+            for (int j = 0; j < d && ok; ++j) {
+                uint32_t cur = (uint32_t)j + 1u; /* entries are placed as pattern numbers and encoded below */
+                int done = 0;
+                for (uint32_t kicks = 0; kicks < 4000u && !done; ++kicks) {
+                    uint32_t b1, b2;
+                    smh_hash_slots(smh_wm_tag(wm->pat_sorted + (size_t)(cur - 1u) * m, m), seed, NB, &b1, &b2);
+                    const uint32_t cand[4] = {2u * b1, 2u * b1 + 1u, 2u * b2, 2u * b2 + 1u};
+                    for (int c = 0; c < 4 && !done; ++c)
+                        if (!ck[cand[c]]) { ck[cand[c]] = cur; done = 1; }
+                    if (done) break;
+                    rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                    const uint32_t victim = cand[(rng >> 33) & 3u], out = ck[victim];
+                    ck[victim] = cur;
+                    cur = out;
+                }
+                ok = done;
+            }
+        }
+        if (ok) {
+            for (uint32_t i = 0; i < 4u * NB; ++i)
+                if (ck[i]) ck[i] = ((smh_wm_tag(wm->pat_sorted + (size_t)(ck[i] - 1u) * m, m) & 0xFFFu) << 20) | ck[i];
+            wm->verify_ck = ck;
+            wm->ck_buckets = NB;
+            wm->ck_seed = seed;
+        } else {
+            free(ck); /* the bucket table above serves */
+        }
+    }
+
     /* ---- gram filter: taken when this path would otherwise scan with a NON-exact filter and the gram filter
      *      lets fewer columns through (it also costs less per column: one lookup per two columns on the
      *      4-letter alphabet, no hash arithmetic beyond one 24-bit multiply on byte symbols) ---- */
@@ -935,6 +978,7 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->adaptive = (wm->flex_ac || wm->keys || wm->hashes) && wm->engine_forced < 0 ? 1u : 0u;
     out->key_slots = wm->keys ? 2u * wm->keys->P.slots : 0u;
     out->hash_slots = wm->hashes ? 4u * wm->hashes->P.slots : 0u; /* two tables of two-slot buckets */
+    out->verify_ck_slots = wm->verify_ck ? 4u * wm->ck_buckets : 0u;
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
     out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);

@@ -24,6 +24,7 @@
 #define SMH_WM_LANE_H
 
 #include "lane_common.h"
+#include "hash_engine.h" /* smh_hash_slots: the cuckoo form of the verify table */
 
 #define SMH_WM_HASH_MUL 0x9E3779B1u /* == SMH_HASH_MUL in smh_internal.h */
 #define SMH_GRAM_MUL_DEV 0xD6E8FFu  /* == SMH_GRAM_MUL in smh_internal.h */
@@ -52,6 +53,11 @@ struct smh_wm_params {
                                           * sfx_ent), length (0 = empty), first dword of the pattern in sfx_pat, 0, its last 16 bytes END-aligned */
     const uint32_t *sfx_ent;             /* overflow records, same layout */
     const uint32_t *sfx_pat;             /* patterns END-aligned in whole dwords, zero-filled in front */
+    /* round 5: the verify entries as a two-table cuckoo hash of two-slot buckets (smh_internal.h verify_ck), NULL = none: what the
+     * PIPELINED probes read (smh_wm_pend_issue / _finish: staged verify with PIPE, windows from L2) -- both of a window's buckets are
+     * requested together, four entries as before, and there is no "bucket full, try the next" trip */
+    const uint32_t *verify_ck;
+    uint32_t ck_buckets, ck_seed;
 };
 
 #define SMH_WM_MAX_CLASSES 32 /* distinct lengths of a mixed-length set scanned in one pass */
@@ -122,6 +128,42 @@ SMH_LANE uint32_t smh_wm_probe(const uint8_t *text, uint64_t e, uint32_t tag, co
     return smh_wm_probe_from(text, e, tag, P, false, smh_u32x4{{0, 0, 0, 0}});
 }
 
+/* the cuckoo form (P.verify_ck): the window's four candidate entries -- two buckets of two -- as one smh_u32x4 */
+SMH_LANE smh_u32x4 smh_wm_ck_load(uint32_t tag, const smh_wm_params &P)
+{
+    uint32_t b1, b2;
+    smh_hash_slots(tag, P.ck_seed, P.ck_buckets, &b1, &b2);
+    smh_u32x4 q;
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    typedef uint32_t v2a __attribute__((ext_vector_type(2), aligned(8)));
+    const v2a a = *reinterpret_cast<const v2a *>(P.verify_ck + 2u * (size_t)b1), b = *reinterpret_cast<const v2a *>(P.verify_ck + 2u * (size_t)b2);
+    q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y;
+#else
+    q.v[0] = P.verify_ck[2u * (size_t)b1]; q.v[1] = P.verify_ck[2u * (size_t)b1 + 1u];
+    q.v[2] = P.verify_ck[2u * (size_t)b2]; q.v[3] = P.verify_ck[2u * (size_t)b2 + 1u];
+#endif
+    return q;
+}
+/* ... and the decision over them: an entry whose 12 tag bits agree is compared with the text (as smh_wm_probe_from) */
+SMH_LANE uint32_t smh_wm_ck_decide(const uint8_t *text, uint64_t e, uint32_t tag, const smh_wm_params &P, const smh_u32x4 &q4)
+{
+    const uint64_t s0 = e + 1 - (uint64_t)P.m;
+    const uint32_t *aligned = reinterpret_cast<const uint32_t *>(text + (s0 & ~(uint64_t)3));
+    const uint32_t shift_bits = (uint32_t)(s0 & 3u) * 8u;
+    const int nd = (P.m + 3) >> 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t slot = q4.v[k];
+        if (slot != 0 && (slot >> 20) == (tag & 0xFFFu)) {
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(P.pat_sorted) + (uint64_t)((slot & 0xFFFFFu) - 1) * (uint32_t)nd;
+            uint32_t diff = 0;
+            for (int j = 0; j < nd; ++j) diff |= q[j] ^ smh_window_dword(aligned, shift_bits, j, P.m);
+            if (diff == 0) return 1;
+        }
+    }
+    return 0;
+}
+
 /* device HASH/PREFIX stage: is text[e-m+1 .. e] one of the patterns?  Three dependent memory
  * phases (window dwords, one table slot, pattern dwords) instead of byte loops.  Kept small on
  * purpose: it is inlined into the scan kernel and must not raise its register pressure. */
@@ -185,6 +227,7 @@ SMH_LANE uint32_t smh_wm_verify_class(const uint8_t *text, uint64_t e, const smh
     Pc.m = k.m;
     Pc.verify_log2 = k.verify_log2;
     Pc.verify = k.verify;
+    Pc.verify_ck = nullptr; /* (the cuckoo form belongs to the suffix handle's own pattern set) */
     Pc.pat_sorted = k.pat_sorted;
     return smh_wm_verify(text, e, Pc);
 }
@@ -646,7 +689,8 @@ SMH_LANE void smh_wm_pend_issue(smh_wm_queue &Q, const smh_wm_params &P)
         return;
     }
     if (Q.pend_n == 0 || Q.pend_loaded) return;
-    Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
+    if (P.verify_ck) Q.pend_q = smh_wm_ck_load(Q.pend_tag, P); /* wave-uniform */
+    else Q.pend_q = smh_load16(reinterpret_cast<const uint8_t *>(P.verify) + 16u * (uint64_t)smh_wm_first_bucket(Q.pend_tag, P));
     Q.pend_loaded = 1u;
 }
 /* decide the pending columns; all 64 lanes must call it */
@@ -659,7 +703,8 @@ SMH_LANE void smh_wm_pend_finish(smh_wm_queue &Q, const uint8_t *text, const smh
     }
     if (Q.pend_n == 0) return;
     const bool mine = (threadIdx.x & 63u) < Q.pend_n;
-    const uint32_t r = smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
+    const uint32_t r = P.verify_ck ? smh_wm_ck_decide(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u ? Q.pend_q : smh_wm_ck_load(Q.pend_tag, P))
+                                   : smh_wm_probe_from(text, Q.pend_e, Q.pend_tag, P, Q.pend_loaded != 0u, Q.pend_q);
     Q.matches += mine ? r : 0u;
     if (Q.po) smh_append_bits(mine ? r : 0u, Q.pend_e, *Q.po);
     Q.pend_n = 0u;
@@ -909,7 +954,8 @@ SMH_LANE void smh_wm_l2_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t, 
         const uint64_t e = a + (uint64_t)__builtin_ctzll(msk);
         uint32_t d[MAXD + 1];
         const uint32_t sh = smh_wm_l2_request<MAXD>(text, e, P.m, d, false);
-        const uint32_t hit = smh_wm_probe(text, e, smh_wm_tag_dwords<MAXD>(d, sh, P.m), P);
+        const uint32_t tag = smh_wm_tag_dwords<MAXD>(d, sh, P.m);
+        const uint32_t hit = P.verify_ck ? smh_wm_ck_decide(text, e, tag, P, smh_wm_ck_load(tag, P)) : smh_wm_probe(text, e, tag, P);
         Q.matches += hit;
         if (hit && Q.po) smh_append_bits(1u, e, *Q.po);
         msk &= msk - 1u;

@@ -57,7 +57,7 @@ class WmInfo(C.Structure):
                 ("filter_exact", C.c_uint32), ("filter_hashed", C.c_uint32),
                 ("verify_slots", C.c_uint32), ("lds_bytes", C.c_uint32), ("scan_engine", C.c_uint32),
                 ("gram_planes", C.c_uint32), ("verify_in_registers", C.c_uint32), ("gram_kind", C.c_uint32),
-                ("adaptive", C.c_uint32), ("key_slots", C.c_uint32), ("hash_slots", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("adaptive", C.c_uint32), ("key_slots", C.c_uint32), ("hash_slots", C.c_uint32), ("verify_ck_slots", C.c_uint32), ("reserved", C.c_uint32 * 4)]
 
 
 class AdaptInfo(C.Structure):

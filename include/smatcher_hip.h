@@ -277,7 +277,9 @@ typedef struct smh_wm_info {
     uint32_t adaptive;        /* as smh_ac_info.adaptive: this handle also holds an automaton engine and follows the launches' reports */
     uint32_t key_slots;       /* round 5: as smh_ac_info.key_slots */
     uint32_t hash_slots;      /* round 5: slots of the window-hash engine's pattern table (SMH_ENGINE_HASH); 0: the handle keeps none */
-    uint32_t reserved[5];
+    uint32_t verify_ck_slots; /* round 5: > 0: the verify entries also exist as a cuckoo hash of that many slots (sets whose bucket table
+                               * exceeds 512 KiB), which the pipelined probes of the filter kernels read */
+    uint32_t reserved[4];
 } smh_wm_info;
 
 /* from patterns; the reference-layout SHIFT / PREFIX tables are built internally */

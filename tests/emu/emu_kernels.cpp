@@ -232,6 +232,7 @@ static uint64_t wm_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, uint6
     P.classes = g_emu_classes;
     P.verify_log2 = wm->verify_log2;
     P.verify = wm->verify;
+    P.verify_ck = wm->verify_ck; P.ck_buckets = wm->ck_buckets; P.ck_seed = wm->ck_seed;
     /* distinct patterns zero-padded to whole dwords, as smh_runtime.hip uploads them */
     const size_t row = (size_t)((wm->m + 3) / 4) * 4;
     std::vector<uint8_t> padded((size_t)wm->distinct * row + 16, 0);
@@ -252,6 +253,7 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     P.bits = wm->bits_per_symbol;
     P.verify_log2 = wm->verify_log2;
     P.verify = wm->verify;
+    P.verify_ck = wm->verify_ck; P.ck_buckets = wm->ck_buckets; P.ck_seed = wm->ck_seed;
     const size_t row = (size_t)((wm->m + 3) / 4) * 4;
     std::vector<uint8_t> padded((size_t)wm->distinct * row + 16, 0);
     for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);

@@ -262,3 +262,25 @@ def test_dense_plan(m, p):
     assert ac.info().scan_dense == chosen
     with pytest.raises(S.SmhError):
         S.AcAutomaton.from_patterns(rng.randint(0, sigma, size=9 * 10).astype(np.uint8), 9, 10, sigma).set_scan_plan(4, 0)
+
+
+def test_cuckoo_form_of_the_verify_table():
+    """sets whose four-slots-per-pattern bucket table exceeds 512 KiB also keep their verify entries as a two-table cuckoo hash
+    (82 % full), which the pipelined probes read (csrc/wm_lane.h smh_wm_ck_*): same counts as the bucket table's, on uniform text
+    and on text made of the patterns themselves"""
+    import smatcher_hip as S
+    sigma, p = 256, 40000
+    for m in (8, 12, 20):
+        pat = O.gen_patterns(m, p, 7, sigma)
+        wm = S.WmTables.from_patterns(pat, m, p, sigma)
+        info = wm.info()
+        assert info.verify_ck_slots >= info.distinct and info.verify_ck_slots * 4 < info.verify_slots * 4 / 2, (info.verify_ck_slots, info.verify_slots)
+        wm.set_scan_engine(S.ALGO_WM)
+        text = np.concatenate([O.gen_text(3 * 4096 + 100, 9, sigma), pat[:m * 3000], O.gen_text(5000, 10, sigma)])
+        want = O.count_bruteforce(pat, m, p, text)
+        assert want >= 3000
+        assert E.wm_scan(wm, text) == want
+        wm.close()
+    small = S.WmTables.from_patterns(O.gen_patterns(8, 3000, 7, 256), 8, 3000, 256)
+    assert small.info().verify_ck_slots == 0
+    small.close()
