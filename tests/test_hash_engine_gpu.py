@@ -114,3 +114,23 @@ def test_handle_settles_on_it_on_natural_language_like_text():
         assert pre == {O.oracle_wu(pat, m, p, sigma, text[:chk].cpu().numpy())[0]}
         wm.close()
         del text
+
+
+def test_cuckoo_form_of_the_verify_table_on_the_device(monkeypatch):
+    """SMH_WM_TUNE="ck=1": the filter kernels' pipelined probes read the verify entries from the two-table cuckoo hash instead of the
+    bucket table (csrc/wm_lane.h smh_wm_ck_*; opt-in: it trades 0-8 % of time for 1.06x instead of 1.5-1.95x HBM traffic)"""
+    sigma, p, n = 256, 40000, (4 << 20) + 77
+    for m in (5, 8, 12, 20):
+        pat = O.gen_patterns(m, p, 7, sigma)
+        text = O.gen_text(n, 9, sigma)
+        text[100000:100000 + m * 2000] = pat[:m * 2000]  # 2000 patterns back to back: true matches through the cuckoo probe
+        want = O.oracle_wu(pat, m, p, sigma, text)[0]
+        assert want >= 2000
+        wm = S.WmTables.from_patterns(pat, m, p, sigma)
+        assert wm.info().verify_ck_slots > 0
+        wm.set_scan_engine(S.ALGO_WM)
+        monkeypatch.setenv("SMH_WM_TUNE", "ck=1")
+        assert _scan(wm, text) == want, m
+        monkeypatch.delenv("SMH_WM_TUNE")
+        assert _scan(wm, text) == want, m
+        wm.close()
