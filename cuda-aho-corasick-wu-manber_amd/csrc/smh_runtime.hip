@@ -844,6 +844,11 @@ static int ac_launch_own(struct smh_ac *ac, const unsigned char *d_text, uint64_
                       * test treats every compact row as deep (conservative, see ac_lane.h) */
         for (int i = 0; i < SMH_AC_DF_LEN; ++i)
             if (L.df.v[i] > L.full_rows) L.df.v[i] = L.full_rows;
+    /* development knob SMH_AC_TUNE="nohalo=1": no lane ever counts as deep enough for a halo step, so the scan does NONE of its
+     * K - 1 warm-up steps -- counts are wrong; the launch time is the bound on what shrinking the halo share could buy
+     * (profiles/r05_final/notes/ab_automaton_halo.log) */
+    if (const char *t = getenv("SMH_AC_TUNE"); t && strstr(t, "nohalo=1"))
+        for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = 0xFFFFFFFFu;
     L.d_count = d_count; L.n_cus = n_cus;
     L.V.pos.out = NULL; L.V.pos.capacity = 0; L.V.pos.cursor = NULL;
     L.d_wave_times = g_wave_trace;
