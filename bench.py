@@ -40,7 +40,9 @@ Extra objects on the JSON line (every one of them at every N unless it says othe
   cpu_baseline*          N = 1 only (rank 0): the reference's own compiled search_ac / search_wu2 (oracle/_ref;
                          the oracle port when absent), one thread and all cores, on bounded prefixes
   stream_read            what a pure streaming read of the same 1 GiB reaches in this run (best of five variants)
-  skewed                 N = 1 only (round 4): the BASELINE pattern shapes on text that is NOT i.i.d. uniform -- a genome-like
+  (the LAST stdout line is a compact record of < 4 KB -- metric, value, roofline, cpu_baseline, one number per configuration;
+   everything below is in bench_detail.json next to this file, path + sha256 on the line: compact_line / emit)
+  skewed                 N = 1 only (round 4; round 5: with the key table and the window-hash filter among the engines): the BASELINE pattern shapes on text that is NOT i.i.d. uniform -- a genome-like
                          DNA text with repeats / tandem repeats / poly-A runs, a protein-like 20-symbol text, a natural-language-
                          like 256-symbol text, and a text in which one planted pattern recurs every 64 columns (csrc/corpus_gen.h;
                          the reference's own data: main.c:39-109), patterns sampled from those texts.  Per set: the entry point as

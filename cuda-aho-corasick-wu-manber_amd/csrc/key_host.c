@@ -183,7 +183,7 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
     k->P = K;
     k->image = image;
     /* one column = key roll + two hashes + two LDS reads + two compares whatever text and set (measured on MI355X, round 5) */
-    k->ms_est = K.wide == 1 ? SMH_KEYS_MS_WIDE : SMH_KEYS_MS_NARROW;
+    k->ms_est = K.wide == 1 ? SMH_KEYS_MS_WIDE : (K.wide == 2 ? SMH_KEYS_MS_QUOT : SMH_KEYS_MS_NARROW);
     return k;
 }
 
