@@ -959,7 +959,7 @@ def main():
                    "--shard-mib", str(args.shard_mib)] + (["--no-wm"] if args.no_wm else [])
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
             try:
-                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
                 line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
                 leg = json.loads(line[-1]) if r.returncode == 0 and line else {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
             except (subprocess.TimeoutExpired, OSError, ValueError) as e:
@@ -975,9 +975,12 @@ def main():
             if agree and not all(agree.values()):
                 print(json.dumps(out))
                 raise SystemExit("PARITY FAILURE: smh_multi totals differ from the per-rank totals: %r" % agree)
-            if "error" in leg or not agree:  # a leg that did not run is not a leg that agreed (--no-multi skips it on purpose)
-                print(json.dumps(out))
-                raise SystemExit("smh_multi leg failed: %s" % leg.get("error", "no totals to compare"))
+            if "error" in leg or not agree:
+                # a leg that did not run is not a leg that agreed: the record says so ("error", totals_equal false on the compact
+                # line) -- but the per-rank measurement above is complete and verified by itself, so the run goes on.  (Until round 5
+                # this ended the run: the first launch on a real N-GPU node would have lost its headline to a side leg.)
+                leg.setdefault("error", "no totals to compare")
+                print("bench.py: smh_multi leg did not run: %s" % leg["error"], file=sys.stderr)
         sharded.host_barrier("smh_multi_after")
 
     mark('smh_multi leg')

@@ -157,5 +157,13 @@ def host_barrier(tag, timeout_s=1800.0):
             if time.time() > deadline:
                 raise RuntimeError("host_barrier(%s): timed out" % tag)
             time.sleep(0.02)
+        # rank 0 may be the process that SERVES the store (init_method tcp://, mp.spawn): it must not go on -- and perhaps tear the
+        # process group down -- while another rank is still inside a poll above ("Connection reset by peer", seen once in a few
+        # runs of tests/test_distributed_cpu.py).  So every rank signs out and rank 0 leaves last.
+        store.add(tag + "/left", 1)
+        while dist.get_rank() == 0 and store.add(tag + "/left", 0) < dist.get_world_size():
+            if time.time() > deadline:
+                raise RuntimeError("host_barrier(%s): timed out waiting for the ranks to leave" % tag)
+            time.sleep(0.005)
     except (AttributeError, NotImplementedError):
         dist.barrier()
