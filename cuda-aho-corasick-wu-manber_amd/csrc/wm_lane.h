@@ -907,23 +907,20 @@ SMH_LANE void smh_wm_l2_step(smh_wm_queue &Q, const uint8_t *text, uint64_t chun
         smh_wm_pend_issue<false>(Q, P);
     }
     if (!take || Q.count == 0) return;
+    /* the queue holds END columns (64-bit), of this chunk and of earlier ones (smh_wm_l2_columns): the LAST 64 of them are
+     * taken, one per lane; what lies in front of them stays for the next step */
     const uint32_t lane = threadIdx.x & 63u, cnt = Q.count;
-    const uint32_t *offs = reinterpret_cast<const uint32_t *>(Q.slots);
-    /* a lane without an entry re-requests entry 0 (a valid address; its answer is dropped) */
-    Q.pa_e = chunk_base + offs[lane < cnt ? lane : 0u];
+    const uint32_t n_take = cnt < 64u ? cnt : 64u, first = cnt - n_take;
+    /* a lane without an entry re-requests the first one taken (a valid address; its answer is dropped) */
+    Q.pa_e = Q.slots[first + (lane < n_take ? lane : 0u)];
     uint32_t d[MAXD + 1];
-    Q.pa_sh = smh_wm_l2_request<MAXD>(text, Q.pa_e, P.m, d, chunk_base + 4096u + 4u * (MAXD + 1) <= Q.pa_limit);
+    /* wave-uniform: 40 bytes from every window's first dword on lie inside the text (the first dword is at or below the column) */
+    const bool wide = MAXD == 9 && !SMH_WAVE_ANY(Q.pa_e + 44u > Q.pa_limit);
+    Q.pa_sh = smh_wm_l2_request<MAXD>(text, Q.pa_e, P.m, d, wide);
 #pragma unroll
     for (int j = 0; j <= MAXD; ++j) Q.pa_w[j] = d[j];
-    Q.pa_n = cnt < 64u ? cnt : 64u;
-    if (cnt > 64u) { /* the overflow of a dense chunk is decided at once (three dependent round trips: rare by the filter's design) */
-        const bool h1 = lane + 64u < cnt;
-        const uint64_t e1 = chunk_base + offs[h1 ? lane + 64u : 0u];
-        const uint32_t r1 = smh_wm_verify(text, e1, P);
-        Q.matches += h1 ? r1 : 0u;
-        if (Q.po) smh_append_bits(h1 ? r1 : 0u, e1, *Q.po);
-    }
-    Q.count = 0u;
+    Q.pa_n = n_take;
+    Q.count = first;
 }
 
 /* the surviving columns `msk` (bit b = column a + b) of a lane's segment in the wave-chunk at chunk_base */
@@ -933,17 +930,26 @@ SMH_LANE void smh_wm_l2_columns(smh_wm_queue &Q, const uint8_t *text, uint64_t c
     if (!SMH_WAVE_ANY(msk != 0)) return;
     if (Q.st_min == 0xFFFFFFFFu) return; /* development knob: survivors dropped (smh_wm_stage_columns) */
     do {
-        if (Q.count + 64u > SMH_WM_QCAP) smh_wm_l2_step<MAXD>(Q, text, chunk_base, P, true); /* 128 queued: take them now */
+        if (Q.count + 64u > SMH_WM_QCAP) smh_wm_l2_step<MAXD>(Q, text, chunk_base, P, true); /* more than 64 queued: take 64 now */
         const bool have = msk != 0;
         const uint32_t b = have ? (uint32_t)__builtin_ctzll(msk) : 0u;
         const uint64_t mask = __ballot(have);
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (have) reinterpret_cast<uint32_t *>(Q.slots)[Q.count + before] = (uint32_t)(a - chunk_base) + b;
+        if (have) Q.slots[Q.count + before] = a + b;
         Q.count += (uint32_t)__popcll(mask);
         Q.events += have ? 1u : 0u;
         msk &= msk - 1u;
     } while (SMH_WAVE_ANY(msk != 0));
-    smh_wm_l2_step<MAXD>(Q, text, chunk_base, P, true);
+    /* Round 5: a step costs the wave the same instructions whether 27 of its lanes hold a column or 64 (window request, hash,
+     * bucket request, four tag compares: about a quarter of the kernel's vector instructions at 27 survivors per chunk, taken
+     * after every chunk).  So the columns wait in the queue -- as END columns, not chunk offsets -- until st_min (48) of them
+     * are there, about every second chunk on uniform text; a chunk that takes nothing still moves the pipeline on
+     * (smh_wm_gram_thread), and the end of the wave's work empties the queue.  100 000 byte patterns, 4 GiB: m = 8 1.249 -> 1.207 ms,
+     * m = 20 1.203 -> 1.141, m = 12 and 5 within 1 %; vector instructions per column 6.45 -> 5.80 (profiles/r05_final/notes/
+     * ab_verify_pipeline.log, which also holds what did NOT pay: one 16-byte window request instead of six 4-byte ones, and the
+     * next chunk's text prefetched in front of the step -- the cost of a survivor is its two scattered lines, not their order). */
+    if (Q.st_min == 0xFFFFFFFEu) { Q.count = 0; return; } /* development knob "stmin=-2": survivors queued, then dropped */
+    if (Q.count >= Q.st_min) smh_wm_l2_step<MAXD>(Q, text, chunk_base, P, true);
 }
 #else
 /* CPU emulation (one lane at a time): the same window request and hash, decided at once */
@@ -2271,7 +2277,8 @@ SMH_LANE uint32_t smh_wm_gram_thread(uint64_t gthread, const smh_chunk_sched &S,
     }
     if constexpr (RV) smh_wm_pend_finish_rv(Q, text, P);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
-    else if constexpr (smh_stg_l2(STG)) { /* run the pipeline dry */
+    else if constexpr (smh_stg_l2(STG)) { /* empty the queue, then run the pipeline dry */
+        while (Q.count) smh_wm_l2_step<smh_stg_l2_maxd(STG)>(Q, text, 0, P, true);
         smh_wm_l2_step<smh_stg_l2_maxd(STG)>(Q, text, 0, P, false);
         smh_wm_l2_step<smh_stg_l2_maxd(STG)>(Q, text, 0, P, false);
     } else if (STG > 0) smh_wm_pend_finish<false>(Q, text, P);
