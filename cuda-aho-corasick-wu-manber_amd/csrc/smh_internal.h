@@ -479,7 +479,10 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
  * class; measured on 1 GiB (profiles/r04_final/notes/mixed_grouped.log): 40 patterns of each length 9..32 (0.0008 per column)
  * 0.231 ms against the joined automaton's 0.291, 10..32 (0.00016) 0.233 / 0.294; at 8..32 (0.0039) the two are level (0.273 /
  * 0.293 in one order of measurement, 0.294 / 0.281 in the other), 100 of each length 8..16 (0.0099) 0.358 against 0.297 */
-#define SMH_PSET_GROUPED_DENSITY 0.002
+/* Round 5: 0.002 -> 0.003 with the split of the two groups chosen per set (wm_host.c smh_wm_build_gram_mixed): 40 patterns of
+ * each length 8..32 now give 0.0022 candidates per column (split at 11; 0.0039 at the fixed 14) and 0.248 ms against the
+ * automaton's 0.286 and the old split's 0.274 (gpurun_out/ab_split.log -> profiles/r05_final/notes/ab_mixed_split.log) */
+#define SMH_PSET_GROUPED_DENSITY 0.003
 #define SMH_GRAM_PAIR2_SPLIT 14 /* patterns at least this long have all eight planes */
 #define SMH_GRAM_BYTES (128u * 1024u)
 /* 24-bit multiplier of the byte-gram index (v_mul_u32_u24).  Round 3: 0xD6E8FF instead of the golden-ratio constant

@@ -430,33 +430,33 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
     return 0;
 }
 
-int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns, const uint32_t *lengths, int p_size)
+static int const_getenv_has(const char *var, const char *word)
 {
-    if (!suffix || suffix->alphabet != 4 || p_size < 1) return 1;
-    uint32_t minlen = UINT32_MAX;
-    int short_ones = 0;
+    const char *t = getenv(var);
+    return t && strstr(t, word);
+}
+
+/* the two groups' per-gram plane bytes for one way of splitting the set -- group A = the patterns of `split` symbols and more
+ * with JA = min(8, shortest of them - 6) planes (the deeper planes accept every gram, so the eight-plane recurrence of the lane code
+ * decides on JA), group B = the shorter ones with JB = min(5, shortest - 6) -- and the candidates per column on pseudo-random text */
+static double grouped_planes(const unsigned char *patterns, const uint32_t *lengths, int p_size, uint32_t split, uint8_t *gA, uint8_t *gB, int *JB_out)
+{
+    uint32_t minA = UINT32_MAX, minB = UINT32_MAX;
     for (int p = 0; p < p_size; ++p) {
-        if (lengths[p] < minlen) minlen = lengths[p];
-        if (lengths[p] < SMH_GRAM_PAIR2_SPLIT) ++short_ones;
+        if (lengths[p] >= split) { if (lengths[p] < minA) minA = lengths[p]; }
+        else if (lengths[p] < minB) minB = lengths[p];
     }
-    if (minlen < 8) return 1; /* a pattern of 7 symbols has one plane: nothing to chain */
-    int JB = 0;
-    if (short_ones) {
-        JB = (int)minlen - 6;
-        if (JB > 5) JB = 5;
-    }
-    const int bsh = JB ? JB + 1 : 0;
-    uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES + 32768u);
-    uint8_t *gA = (uint8_t *)malloc(16384), *gB = (uint8_t *)malloc(16384);
-    if (!tab || !gA || !gB) { free(tab); free(gA); free(gB); return -1; }
-    memset(gA, 0xFF, 16384);                       /* bit 7-j SET = the gram is not in plane j of group A */
-    memset(gB, JB ? (1 << JB) - 1 : 0, 16384);     /* bit JB-1-j SET = not in plane j of group B */
+    int JA = minA == UINT32_MAX ? 8 : (int)minA - 6, JB = minB == UINT32_MAX ? 0 : (int)minB - 6;
+    if (JA > 8) JA = 8;
+    if (JB > 5) JB = 5;
+    memset(gA, minA == UINT32_MAX ? 0xFF : 0xFF & ~((1 << (8 - JA)) - 1), 16384); /* bit 7-j SET = the gram is not in plane j of group A */
+    memset(gB, JB ? (1 << JB) - 1 : 0, 16384);                                   /* bit JB-1-j SET = not in plane j of group B */
     uint64_t off = 0;
     for (int p = 0; p < p_size; ++p) {
         const uint32_t L = lengths[p];
         const unsigned char *pat = patterns + off;
         off += L;
-        const int isA = L >= SMH_GRAM_PAIR2_SPLIT, J = isA ? 8 : JB;
+        const int isA = L >= split, J = isA ? JA : JB;
         for (int j = 0; j < J; ++j) {
             const unsigned char *g = pat + (L - 7 - (uint32_t)j);
             uint32_t code = 0;
@@ -465,13 +465,6 @@ int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns
             else gB[code] &= (uint8_t)~(1u << (JB - 1 - j));
         }
     }
-    for (uint32_t x = 0; x < 65536; ++x) {
-        const uint32_t eA = ((uint32_t)gA[x >> 2] << 1) | gA[x & 0x3FFFu], eB = ((uint32_t)gB[x >> 2] << 1) | gB[x & 0x3FFFu];
-        tab[x] = (uint16_t)((eA << bsh) | eB);
-    }
-    uint16_t *gx = (uint16_t *)((uint8_t *)tab + SMH_GRAM_BYTES);
-    for (uint32_t c = 0; c < 16384; ++c) gx[c] = (uint16_t)(gA[c] | ((uint32_t)gB[c] << 8));
-    /* candidates per column on pseudo-random text, both states */
     enum { COLS = 1 << 18 };
     uint64_t seed = 0x5EEDull, hits = 0;
     uint32_t SA = ~0u, SB = ~0u, code = 0;
@@ -481,10 +474,46 @@ int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns
         SB = (SB << 1) | gB[code];
         if (x >= 16) hits += (((SA >> 7) & 1u) ^ 1u) | (JB ? ((SB >> (JB - 1)) & 1u) ^ 1u : 0u);
     }
-    const double dens = (double)hits / (double)(COLS - 16);
+    *JB_out = JB;
+    return (double)hits / (double)(COLS - 16);
+}
+
+int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns, const uint32_t *lengths, int p_size)
+{
+    if (!suffix || suffix->alphabet != 4 || p_size < 1) return 1;
+    uint32_t minlen = UINT32_MAX;
+    for (int p = 0; p < p_size; ++p)
+        if (lengths[p] < minlen) minlen = lengths[p];
+    if (minlen < 8) return 1; /* a pattern of 7 symbols has one plane: nothing to chain */
+    uint16_t *tab = (uint16_t *)malloc(SMH_GRAM_BYTES + 32768u);
+    uint8_t *gA = (uint8_t *)malloc(16384), *gB = (uint8_t *)malloc(16384);
+    if (!tab || !gA || !gB) { free(tab); free(gA); free(gB); return -1; }
+    /* Round 5: where the set is split is chosen, not fixed at SMH_GRAM_PAIR2_SPLIT.  Group B's depth is its SHORTEST pattern's, so
+     * with lengths 8..32 a split at 14 tests the 200 patterns of 9..13 symbols on their last eight only (0.0039 candidates per
+     * column); split at 10 or 11 they join group A with 4 or 5 planes and the 80 or 120 shortest are left to B: 0.0020. */
+    uint32_t split = SMH_GRAM_PAIR2_SPLIT;
+    int JB = 0;
+    double dens = 2.0;
+    for (uint32_t sp = 9; sp <= SMH_GRAM_PAIR2_SPLIT; ++sp) {
+        if (sp != SMH_GRAM_PAIR2_SPLIT && sp <= minlen) continue; /* (no pattern below it: the same as any other such split) */
+        int jb;
+        const double d = grouped_planes(patterns, lengths, p_size, sp, gA, gB, &jb);
+        if (d < dens) { dens = d; split = sp; }
+    }
+    if (const_getenv_has("SMH_WM_TUNE", "split14")) split = SMH_GRAM_PAIR2_SPLIT; /* development knob: the round-4 split */
+    dens = grouped_planes(patterns, lengths, p_size, split, gA, gB, &JB);
+    int short_ones = 0;
+    for (int p = 0; p < p_size; ++p) short_ones += lengths[p] < split;
+    const int bsh = JB ? JB + 1 : 0;
+    for (uint32_t x = 0; x < 65536; ++x) {
+        const uint32_t eA = ((uint32_t)gA[x >> 2] << 1) | gA[x & 0x3FFFu], eB = ((uint32_t)gB[x >> 2] << 1) | gB[x & 0x3FFFu];
+        tab[x] = (uint16_t)((eA << bsh) | eB);
+    }
+    uint16_t *gx = (uint16_t *)((uint8_t *)tab + SMH_GRAM_BYTES);
+    for (uint32_t c = 0; c < 16384; ++c) gx[c] = (uint16_t)(gA[c] | ((uint32_t)gB[c] << 8));
     free(gA); free(gB);
     if (getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "debug"))
-        fprintf(stderr, "grouped pair-gram filter: %d short patterns with %d planes, candidates %.6f per column\n", short_ones, JB, dens);
+        fprintf(stderr, "grouped pair-gram filter: split at %u, %d short patterns with %d planes, candidates %.6f per column\n", split, short_ones, JB, dens);
     /* every candidate is looked up in the suffix index (window from HBM, one record), and a group's planes together are
      * as selective as an exact match of its shortest pattern's length: with many SHORT patterns the candidates are
      * mostly real matches of those classes and an automaton counts them in line, cheaper (pset_host.c falls back) */
@@ -509,7 +538,7 @@ int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns
         uint32_t *slot = (uint32_t *)((uint8_t *)tab + base), *ent = slot + 65536u * 8u, *pw = ent + (size_t)p_size * 8u;
         memset(slot, 0, total - base);
         uint32_t n_ent = 0, dw = 0;
-        off = 0;
+        uint64_t off = 0;
         for (int p = 0; p < p_size; ++p) {
             const uint32_t L = lengths[p], nd = (L + 3u) >> 2;
             const unsigned char *pat = patterns + off;

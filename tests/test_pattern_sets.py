@@ -252,10 +252,12 @@ def _random_dna_set(seed):
     return text, patterns, lengths, classes, want_pos
 
 
+@pytest.mark.parametrize("tune", ["grouped=force", "grouped=force,split14"], ids=["split_chosen", "split_at_14"])
 @pytest.mark.parametrize("seed", range(10))
-def test_grouped_pair_gram_filter_on_random_dna_sets(seed, monkeypatch):
+def test_grouped_pair_gram_filter_on_random_dna_sets(seed, tune, monkeypatch):
     """the one-pass form of SMH_ALGO_WM sets on the 4-letter alphabet (emulated lane code) against the definition
-    (sum over length classes)"""
+    (sum over length classes); the two groups split where the builder estimates the fewest candidates (round 5) and at the
+    fixed length of round 4"""
     text, patterns, lengths, classes, want_pos = _random_dna_set(seed)
     want = len(want_pos)
     Lmin = min(classes)
@@ -265,7 +267,7 @@ def test_grouped_pair_gram_filter_on_random_dna_sets(seed, monkeypatch):
         off += int(L)
     suffix = S.WmTables.from_patterns(np.concatenate(suf), Lmin, len(lengths), 4)
     handles = [S.WmTables.from_patterns(classes[L], L, len(classes[L]) // L, 4) for L in sorted(classes)]
-    monkeypatch.setenv("SMH_WM_TUNE", "grouped=force")  # whatever the candidate rate: the count must not depend on it
+    monkeypatch.setenv("SMH_WM_TUNE", tune)  # whatever the candidate rate: the count must not depend on it
     assert E.build_gram_mixed(suffix, patterns, lengths) == 0
     assert E.wm_scan_multi(suffix, handles, text, None, 2) == want
     total, got = E.wm_scan_multi(suffix, handles, text, want + 3, 3)
