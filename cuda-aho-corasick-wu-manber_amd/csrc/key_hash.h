@@ -31,7 +31,10 @@ struct smh_key_params {
                         * numbers differ by y' - y) */
     uint32_t mask_lo, mask_hi; /* the key's bits in the rolling code */
     uint32_t mul[4];   /* A, B, C (24 bits, odd): h1 = (f & 0xFFFFFF) * A + ((f >> 8) & 0xFFFFFF) * B, h2 = (h1 & 0xFFFFFF) * C  (mod 2^32); [3] unused */
-    uint32_t fold[2];  /* wide keys: f = lo + (hi & 0xFFFFFF) * C + ((hi >> 8) & 0xFFFFFF) * D */
+    uint32_t fold[2];  /* 64-bit keys (wide == 1): the hash is ROLLED along the text with the window, symbol by symbol -- f = sum of
+                        * sym_i * B^(m-1-i) mod 2^24 -- [0] = B (odd, 24 bits), [1] = 2^24 - B^m mod 2^24 (what removes the symbol that
+                        * leaves); h1 = f, h2 = (f & 0xFFFFFF) * C.  (Until round 5's last build: f = lo + hi * C + (hi >> 8) * D and h1 mixed f
+                        * again -- 8 vector instructions per column where the rolled hash takes 4; the 64-bit class is bound by them) */
     uint32_t slots;    /* per table; any number below 65536: slot_t = ((h_t & 0xFFFFFF) * slots) >> 24 (one v_mul_hi_u32_u24 with slots << 8: it takes the low 24 bits of h_t by itself) */
     uint32_t pad;      /* quotient keys: extra slots behind each table's `slots` (2^(m * bits - 32)), else 0 */
     uint32_t base2;    /* byte offset of table 2 in the image (table 1 at 0) = (slots + pad) * slot bytes */
@@ -54,20 +57,25 @@ SMH_KEY_FN uint32_t smh_key_mul24(uint32_t a, uint32_t b) { return (uint32_t)((u
 SMH_KEY_FN uint32_t smh_key_mulhi24(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) >> 32); }
 #endif
 
-/* 64-bit key -> the 32 bits both hashes are taken from */
-SMH_KEY_FN uint32_t smh_key_fold(uint32_t lo, uint32_t hi, uint32_t c, uint32_t d)
+/* 64-bit keys: one symbol enters the rolled hash / the symbol m places back leaves it (only the low 24 bits mean anything) */
+SMH_KEY_FN uint32_t smh_key_poly_in(uint32_t h, uint32_t sym, uint32_t base) { return smh_key_mul24(h, base) + sym; }
+SMH_KEY_FN uint32_t smh_key_poly_out(uint32_t h, uint32_t sym, uint32_t neg_bm) { return smh_key_mul24(sym, neg_bm) + h; }
+/* ... and the same hash of a whole key (oldest symbol in the highest bits): what the host builder places a pattern by */
+SMH_KEY_FN uint32_t smh_key_poly(uint64_t key, const struct smh_key_params *K)
 {
-    return lo + smh_key_mul24(hi, c) + smh_key_mul24(hi >> 8, d);
+    uint32_t h = 0;
+    for (int i = K->m - 1; i >= 0; --i) h = smh_key_poly_in(h, (uint32_t)(key >> (K->bits * i)) & ((1u << K->bits) - 1u), K->fold[0]);
+    return h;
 }
 /* The two hashes of f (a 32-bit key, or a 64-bit key folded): h1 = (f & 0xFFFFFF) * A + (f >> 8) * B -- every bit of f reaches it
  * through one of the two products -- and h2 = (h1 & 0xFFFFFF) * C, which re-spreads h1's low 24 bits: keys that share slot 1 (h1
  * within one 2^24 / slots wide range) land all over table 2.  Four VALU for both. */
 
-/* byte offsets of a key's two slots in the image; f = the 32 bits the hashes are taken from (the key, a wide key folded, a quotient
+/* byte offsets of a key's two slots in the image; f = the 32 bits the hashes are taken from (the key, a 64-bit key's rolled hash, a quotient
  * key's low half), y = a quotient key's high bits (else 0) */
 SMH_KEY_FN void smh_key_slots(uint32_t f, uint32_t y, const struct smh_key_params *K, uint32_t *o1, uint32_t *o2)
 {
-    const uint32_t h1 = smh_key_mul24(f, K->mul[0]) + smh_key_mul24(f >> 8, K->mul[1]), h2 = smh_key_mul24(h1, K->mul[2]);
+    const uint32_t h1 = K->wide == 1 ? f : smh_key_mul24(f, K->mul[0]) + smh_key_mul24(f >> 8, K->mul[1]), h2 = smh_key_mul24(h1, K->mul[2]);
     const uint32_t ns = K->slots << 8, wsh = K->wide == 1 ? 3u : 2u;
     *o1 = (smh_key_mulhi24(h1, ns) + y) << wsh;
     *o2 = ((smh_key_mulhi24(h2, ns) + y) << wsh) + K->base2;

@@ -40,7 +40,7 @@ static int cmp_u64(const void *a, const void *b)
 
 static uint32_t key_f(uint64_t key, const struct smh_key_params *K)
 {
-    return K->wide == 1 ? smh_key_fold((uint32_t)key, (uint32_t)(key >> 32), K->fold[0], K->fold[1]) : (uint32_t)key;
+    return K->wide == 1 ? smh_key_poly(key, K) : (uint32_t)key;
 }
 static uint32_t key_y(uint64_t key, const struct smh_key_params *K) { return K->wide == 2 ? (uint32_t)(key >> 32) : 0u; }
 
@@ -146,7 +146,10 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
     int placed = 0;
     for (int t = 0; t < SMH_KEY_TRIES && !placed; ++t) {
         for (int q = 0; q < 4; ++q) K.mul[q] = ((uint32_t)splitmix(&seed) & 0xFFFFFFu) | 0x800001u; /* odd, top bit set */
-        for (int q = 0; q < 2; ++q) K.fold[q] = ((uint32_t)splitmix(&seed) & 0xFFFFFFu) | 0x800001u;
+        K.fold[0] = ((uint32_t)splitmix(&seed) & 0xFFFFFFu) | 0x800001u; /* B of the 64-bit keys' rolled hash, and 2^24 - B^m */
+        uint32_t bm = 1;
+        for (int i = 0; i < m; ++i) bm = (uint32_t)(((uint64_t)bm * K.fold[0]) & 0xFFFFFFu);
+        K.fold[1] = (0x1000000u - bm) & 0xFFFFFFu;
         placed = cuckoo_place(keys, n, &K, slot_of);
     }
     if (!placed) { free(keys); free(slot_of); free(k); free(image); *why = "no cuckoo placement found"; return NULL; }

@@ -17,7 +17,7 @@
 #include "wm_lane.h" /* smh_prev_lane_word, smh_lds_u32x2 */
 #include "key_hash.h"
 
-struct smh_key_code { uint32_t lo, hi; };
+struct smh_key_code { uint32_t lo, hi, h; }; /* h: 64-bit keys only, the window's rolled hash (key_hash.h smh_key_poly_*) */
 
 /* acc += the number of lanes of the wave whose `hit` is set, on the scalar unit (one s_bcnt1 + s_add per column instead of a
  * v_cndmask / v_addc pair: the loop is VALU-issue bound); acc is wave-uniform.  The emulation runs one lane at a time. */
@@ -35,9 +35,14 @@ SMH_LANE uint32_t smh_key_count_mine(uint32_t acc) { return acc; }
 
 /* KC = the key class (smh_key_params.wide): 0 = 32-bit keys, 1 = 64-bit keys in 8-byte slots, 2 = quotient keys (33..42 bits,
  * the low 32 in a 4-byte slot, the high bits added to the slot number) */
-template <int KC>
-SMH_LANE void smh_key_roll(smh_key_code &c, uint32_t sym, uint32_t bits)
+template <int KC, bool FULL = false>
+SMH_LANE void smh_key_roll(smh_key_code &c, uint32_t sym, uint32_t bits, const smh_key_params &K)
 {
+    if constexpr (KC == 1) {
+        /* the symbol that leaves the window sits in the code's top symbol (m * bits > 42 and bits <= 8: always in the high register) */
+        const uint32_t out = FULL ? c.hi >> (32u - bits) : smh_bfe(c.hi, (uint32_t)K.m * bits - bits - 32u, bits);
+        c.h = smh_key_poly_out(smh_key_poly_in(c.h, sym, K.fold[0]), out, K.fold[1]);
+    }
     if constexpr (KC != 0) {
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         c.hi = __builtin_amdgcn_alignbit(c.hi, c.lo, 32u - bits);
@@ -57,8 +62,8 @@ SMH_LANE smh_key_probe smh_key_address(const smh_key_code &c, const smh_key_para
     smh_key_probe p;
     p.klo = FULL || KC == 2 ? c.lo : (c.lo & K.mask_lo);
     p.khi = KC != 0 ? (FULL ? c.hi : (c.hi & K.mask_hi)) : 0u;
-    const uint32_t f = KC == 1 ? smh_key_fold(p.klo, p.khi, K.fold[0], K.fold[1]) : p.klo;
-    const uint32_t h1 = smh_key_mul24(f, K.mul[0]) + smh_key_mul24(f >> 8, K.mul[1]), h2 = smh_key_mul24(h1, K.mul[2]);
+    const uint32_t f = KC == 1 ? c.h : p.klo;
+    const uint32_t h1 = KC == 1 ? f : smh_key_mul24(f, K.mul[0]) + smh_key_mul24(f >> 8, K.mul[1]), h2 = smh_key_mul24(h1, K.mul[2]);
     const uint32_t ns = K.slots << 8;
     if constexpr (KC == 2) { /* the key's high bits move the slot (one v_add_lshl per table instead of the shift) */
         p.o1 = (smh_key_mulhi24(h1, ns) + p.khi) << 2;
@@ -117,12 +122,12 @@ SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint3
                                     const void *tab, const smh_key_params &K, const smh_pos_out *po)
 {
     const uint32_t bits = (uint32_t)K.bits;
-    smh_key_code c = {0u, 0u};
+    smh_key_code c = {0u, 0u, 0u};
 #pragma unroll
     for (int q = 0; q < 4 * HP; ++q) {
         const uint32_t pw = smh_prev_lane_word(w[16 - 4 * HP + q], edge[q], text, a - 16u * HP + 4u * q);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) smh_key_roll<KC>(c, smh_bfe(pw, 8u * k, bits), bits);
+        for (int k = 0; k < 4; ++k) smh_key_roll<KC, FULL>(c, smh_bfe(pw, 8u * k, bits), bits, K);
     }
     uint32_t cnt = 0, mlo = 0, mhi = 0;
 #pragma unroll
@@ -131,7 +136,7 @@ SMH_LANE uint32_t smh_key_lane_fast(const uint8_t *text, uint64_t a, const uint3
         smh_key_slots2 r[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            smh_key_roll<KC>(c, smh_bfe(w[q], 8u * k, bits), bits);
+            smh_key_roll<KC, FULL>(c, smh_bfe(w[q], 8u * k, bits), bits, K);
             p[k] = smh_key_address<KC, FULL>(c, K);
         }
 #pragma unroll
@@ -164,11 +169,11 @@ SMH_LANE uint32_t smh_key_lane_slow(const uint8_t *text, uint64_t n, uint64_t a,
     if (e0 < (uint64_t)(K.m - 1)) e0 = (uint64_t)(K.m - 1);
     if (e0 >= end) return 0;
     const uint32_t bits = (uint32_t)K.bits, smask = (1u << bits) - 1u;
-    smh_key_code c = {0u, 0u};
+    smh_key_code c = {0u, 0u, 0u};
     uint32_t cnt = 0;
-    for (uint64_t i = e0 - (uint64_t)(K.m - 1); i < e0; ++i) smh_key_roll<KC>(c, text[i] & smask, bits);
+    for (uint64_t i = e0 - (uint64_t)(K.m - 1); i < e0; ++i) smh_key_roll<KC>(c, text[i] & smask, bits, K);
     for (uint64_t e = e0; e < end; ++e) {
-        smh_key_roll<KC>(c, text[e] & smask, bits);
+        smh_key_roll<KC>(c, text[e] & smask, bits, K);
         const uint32_t hit = smh_key_test<KC>(c, tab, K);
         cnt += hit;
         if (match_mask && hit) *match_mask |= 1ull << (e - a);

@@ -16,6 +16,7 @@ ap.add_argument("libs", nargs=2)
 ap.add_argument("--mib", type=int, default=1024)
 ap.add_argument("--sets", default="ac:1000:8,ac:1000:16,ac:1000:32,ac:8000:16")
 ap.add_argument("--reps", type=int, default=40)
+ap.add_argument("--engine", type=int, default=-1, help="smh_*_set_scan_engine value forced on both handles (3 = key table, 4 = window hash)")
 args = ap.parse_args()
 
 
@@ -54,6 +55,9 @@ for spec in args.sets.split(","):
     for L in libs:
         h = (L.smh_ac_compile_patterns if algo == "ac" else L.smh_wm_compile)(pat.ctypes.data_as(S.u8p), m, p, sigma)
         assert h, L.smh_last_error()
+        if args.engine >= 0:
+            rc = (L.smh_ac_set_scan_engine if algo == "ac" else L.smh_wm_set_scan_engine)(C.c_void_p(h), args.engine)
+            assert rc == 0, L.smh_last_error()
         hs.append(C.c_void_p(h))
     ts = [[], []]
     counts = [None, None]
