@@ -184,7 +184,7 @@ struct smh_keys {
 #define SMH_KEYS_LDS_BUDGET (156u * 1024u)
 #define SMH_KEYS_MS_NARROW 0.40 /* ms per GiB at steady state, 4-byte slots (32-bit and quotient keys): measured on MI355X whatever text and set (profiles/r05_keys) */
 #define SMH_KEYS_MS_QUOT 0.46   /* quotient keys: two registers of rolling code, 4-byte slots */
-#define SMH_KEYS_MS_WIDE 0.54   /* 8-byte slots */
+#define SMH_KEYS_MS_WIDE 0.51   /* 8-byte slots */
 struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p_size, int alphabet, uint32_t lds_budget, const char **why);
 void smh_keys_free(struct smh_keys *k);
 int smh_keys_contains(const struct smh_keys *k, uint64_t key);
