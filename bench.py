@@ -180,7 +180,7 @@ def compact_line(out, detail_path=None, detail_sha=None):
         optional.append(("stream_read", _pick(out["stream_read"], ("GBps", "hbm_frac"))))
     for key in ("cpu_baseline_wm", "cpu_baseline_all_cores"):
         if key in out:
-            optional.append((key, _pick(out[key], ("value", "unit", "cores", "kind", "counts_match"))))
+            optional.append((key, _pick(out[key], ("value", "unit", "cores", "cpu_quota", "kind", "counts_match"))))
     if "host_pointer_path" in out:
         optional.append(("host_pointer_path", _pick(out["host_pointer_path"], ("GBps", "first_call_GBps", "count_matches"))))
     sk = out.get("skewed")
@@ -244,6 +244,22 @@ def cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def cpu_quota():
+    """CPUs' worth of run time the container's cgroup grants this process (cpu.max / cfs quota), None = no limit.  A box of this
+    pool shows 256 CPUs and grants 16: 256 threads of search_ac then deliver 16 threads' worth (13.7 Gbit/s = 16 x 0.87)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / per, 2)
+    except (OSError, ValueError):
+        return None
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -1082,10 +1098,11 @@ def main():
         if cpu.kind == "reference":
             secs, ok, wall = cpu.ac_all_cores_reference(pats, AC_PATTERNS, SIGMA, prefix, cpu_counts)
             allc = dict(value=round(8.0 * sample * len(pats) / secs / 1e9, 3), unit="Gbit/s", cores=cpu.all_cores, kind="reference",
-                        cpu=cpu.model, host_cpus=cpu.host_cpus, counts_match=ok,
+                        cpu=cpu.model, host_cpus=cpu.host_cpus, cpu_quota=cpu_quota(), counts_match=ok,
                         sample="same sample as byte-range shards (main.c:467-477) on %d threads = every thread this process may run on "
-                               "(%d CPUs in the machine); time = slowest shard's search_ac per set, summed (%.2f s; %.1f s wall with "
-                               "preproc_ac repeated per shard as every MPI rank of the reference does)" % (cpu.all_cores, cpu.host_cpus, secs, wall))
+                               "(%d CPUs in the machine, cgroup quota %s CPUs); time = slowest shard's search_ac per set, summed (%.2f s; %.1f s wall with "
+                               "preproc_ac repeated per shard as every MPI rank of the reference does)"
+                               % (cpu.all_cores, cpu.host_cpus, cpu_quota() if cpu_quota() is not None else "none", secs, wall))
             if wpat is not None:
                 wsecs, wok = cpu.wm_all_cores_reference(wpat, WM_LENGTH, WM_PATTERNS, SIGMA, host_text[:wsample], wcnt)
                 allc["wm"] = dict(value=round(8.0 * wsample / wsecs / 1e9, 3), unit="Gbit/s", counts_match=wok,
