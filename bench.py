@@ -505,7 +505,9 @@ def main():
     shard = args.shard_mib << 20
     # N > 1: what a rank's share of the host threads recounts in about a minute per 32 GB configuration -- 8 MiB per thread,
     # 128..512 MiB of every 4 GiB shard (6 ranks on one box: 153 s of wall at 512 MiB, 149 s of it this; profiles/r05_final/rehearse6*)
-    auto_mib = max(128, min(512, 8 * max(1, len(os.sched_getaffinity(0)) // max(world, 1))))
+    # (threads the container's CPU quota does not back recount nothing: a box of this pool shows 256 CPUs and grants 16)
+    eff_cpus = len(os.sched_getaffinity(0)) if cpu_quota() is None else min(len(os.sched_getaffinity(0)), max(1, int(cpu_quota() + 0.5)))
+    auto_mib = max(128, min(512, 8 * max(1, eff_cpus // max(world, 1))))
     verify_budget = (args.verify_mib << 20) if args.verify_mib >= 0 else (0 if world == 1 else auto_mib << 20)
     stream = torch.cuda.current_stream().cuda_stream
     ev = lambda: torch.cuda.Event(enable_timing=True)
