@@ -137,8 +137,8 @@ smh_pset *smh_pset_compile(const unsigned char *patterns, const uint32_t *length
      * full patterns, (B) the automaton with joined output counts, (C) block filter over the patterns' last min-length
      * symbols while it is sparse, (D) split form: (A) for the long patterns + (B) for the short ones.  SMH_ALGO_AC
      * sets: (B). ---- */
-    const int no_gram = getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "nogram");
-    const int no_acm = getenv("SMH_PSET_TUNE") && strstr(getenv("SMH_PSET_TUNE"), "classes");
+    const int no_gram = smh_tune_has(SMH_TUNE_PSET, "nogram");
+    const int no_acm = smh_tune_has(SMH_TUNE_PSET, "classes");
     int grouped = 1;
     if (algorithm == SMH_ALGO_WM && n_classes >= 2 && n_classes <= SMH_PSET_MAX_ONE_PASS_CLASSES && set->cls[0].length >= 3) {
         const uint32_t Lmin = set->cls[0].length;

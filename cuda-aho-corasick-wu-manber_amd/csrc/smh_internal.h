@@ -9,6 +9,7 @@
 #include <stddef.h>
 #include "../../include/smatcher.h"
 #include "../../include/smatcher_hip.h"
+#include "smh_tune.h" /* development knobs: constants unless -DSMH_TESTING */
 
 #ifdef __cplusplus
 extern "C" {

@@ -15,6 +15,7 @@
 #include "key_hash.h"
 #include "hash_lane.h"
 #include "smh_stats.h"
+#include "smh_tune.h" /* development knobs: constants unless -DSMH_TESTING */
 
 #define SMH_BLOCK_THREADS 1024
 #define SMH_LDS_BUDGET (156u * 1024u) /* of the 160 KiB per CU; the rest is left to the runtime */

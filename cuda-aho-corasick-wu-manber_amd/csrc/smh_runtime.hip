@@ -849,7 +849,7 @@ static int ac_launch_own(struct smh_ac *ac, const unsigned char *d_text, uint64_
     /* development knob SMH_AC_TUNE="nohalo=1": no lane ever counts as deep enough for a halo step, so the scan does NONE of its
      * K - 1 warm-up steps -- counts are wrong; the launch time is the bound on what shrinking the halo share could buy
      * (profiles/r05_final/notes/ab_automaton_halo.log) */
-    if (const char *t = getenv("SMH_AC_TUNE"); t && strstr(t, "nohalo=1"))
+    if (smh_tune_has(SMH_TUNE_AC, "nohalo=1")) /* testing library only (smh_tune.h) */
         for (int i = 0; i < SMH_AC_DF_LEN; ++i) L.df.v[i] = 0xFFFFFFFFu;
     L.d_count = d_count; L.n_cus = n_cus;
     L.V.pos.out = NULL; L.V.pos.capacity = 0; L.V.pos.cursor = NULL;
@@ -1169,14 +1169,31 @@ static void host_ws_release(smh_host_ws *w)
     g_ws_free = w;
 }
 
+/* piece size of the host-pointer path: SMH_HOST_PIECE, or SMH_HOST_PIECE_KIB from the environment READ ONCE per process, or what
+ * smh_host_path_set_piece() last set.  It moves no count: pieces overlap by m - 1 bytes whatever their size. */
+static std::atomic<uint64_t> g_host_piece{0};
+
 static uint64_t host_piece_bytes(void)
 {
-    uint64_t p = SMH_HOST_PIECE;
-    if (const char *e = getenv("SMH_HOST_PIECE_KIB")) {
-        const long long v = atoll(e);
-        if (v >= 4) p = ((uint64_t)v << 10) & ~(uint64_t)4095;
-    }
-    return p;
+    uint64_t p = g_host_piece.load(std::memory_order_relaxed);
+    if (p) return p;
+    static const uint64_t from_env = [] {
+        uint64_t v = SMH_HOST_PIECE;
+        if (const char *e = getenv("SMH_HOST_PIECE_KIB")) {
+            const long long kib = atoll(e);
+            if (kib >= 4) v = ((uint64_t)kib << 10) & ~(uint64_t)4095;
+        }
+        return v;
+    }();
+    return from_env;
+}
+
+extern "C" uint64_t smh_host_path_set_piece(uint64_t bytes)
+{
+    const uint64_t before = host_piece_bytes();
+    if (bytes == 0) g_host_piece.store(0, std::memory_order_relaxed); /* back to the default / the environment's value */
+    else g_host_piece.store(bytes < 4096 ? 4096 : bytes & ~(uint64_t)4095, std::memory_order_relaxed);
+    return before;
 }
 
 /* shared by the *_count_host helpers.  m = the pattern length (pieces overlap by m - 1 bytes); prepare() = table uploads,
@@ -1746,8 +1763,7 @@ static int keys_ensure_device(struct smh_keys *k, smh_keys_dev **out)
 
 static int keys_wg_per_cu()
 {
-    static const int v = [] { const char *t = getenv("SMH_KEY_TUNE"); return t && strstr(t, "wg=") ? atoi(strstr(t, "wg=") + 3) : 0; }();
-    return v;
+    return smh_tune_int(SMH_TUNE_KEY, "wg=", 0);
 }
 
 /* one launch over [d_text, d_text + n): END columns counted into *d_count, or appended to po */
@@ -1854,8 +1870,7 @@ static int hash_launch(struct smh_hashes *k, const unsigned char *d_text, uint64
     if ((rc = hash_ensure_device(k, &dv)) != SMH_OK) return rc;
     smh_hash_launch L = {};
     L.C.text = d_text; L.C.n = n; L.C.P = k->P; L.C.table = reinterpret_cast<const uint8_t *>(dv->d_table);
-    static const uint32_t drop = [] { const char *t = getenv("SMH_HASH_TUNE"); return t && strstr(t, "drop=1") ? 1u : 0u; }();
-    L.C.drop = drop;
+    L.C.drop = smh_tune_has(SMH_TUNE_HASH, "drop=1") ? 1u : 0u; /* testing library only: stage 1 alone, counts wrong (smh_tune.h) */
     L.d_bloom = reinterpret_cast<const uint32_t *>(dv->d_bloom); L.d_count = d_count; L.n_cus = n_cus; L.stats = SA;
     if (po) {
         L.po = *po;

@@ -249,11 +249,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
     uint32_t best_bytes = 0;
     double best_ms = other_ms, best_dens = 0.0;
     /* development knob: SMH_WM_TUNE="gram=K" keeps form K whenever the set can use it (0: never a gram filter) */
-    int force = -1;
-    {
-        const char *t = getenv("SMH_WM_TUNE"), *g = t ? strstr(t, "gram=") : NULL;
-        if (g) force = atoi(g + 5);
-    }
+    const int force = smh_tune_int(SMH_TUNE_WM, "gram=", -1);
     if (force == 0) return 0;
     if (force > 0) best_ms = 1e30;
 #define GRAM_WANTED(kind) (force < 0 || force == (kind))
@@ -378,7 +374,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
                 tab[prod >> 15] &= (uint8_t)~(1u << ((prod >> 12) & 7u));
             }
-        if (getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "debug")) {
+        if (smh_tune_has(SMH_TUNE_WM, "debug")) {
             uint64_t zeros = 0;
             for (uint32_t i = 0; i < SMH_GRAM_BYTES; ++i) zeros += 8u - (uint32_t)__builtin_popcount(tab[i]);
             fprintf(stderr, "flat byte grams: %d patterns x %d grams, %.1f %% of the 2^20 bits in the set\n", d, J, 100.0 * (double)zeros / 1048576.0);
@@ -399,8 +395,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                         t2[prod >> 15] &= (uint8_t)~((1u << ((prod >> 12) & 7u)) | (1u << ((prod >> 9) & 7u)));
                     }
                 const double d2 = gram_survivors(SMH_GRAM_FLAT_K2, t2, wm->alphabet, J), ms2 = SMH_GRAM_FLAT_MS + 0.01 + gram_verify_ms(m, d2);
-                const char *tune = getenv("SMH_WM_TUNE"); /* development knob "flatk=1|2": one / two bits per gram regardless */
-                const int fk = tune && strstr(tune, "flatk=") ? atoi(strstr(tune, "flatk=") + 6) : 0;
+                const int fk = smh_tune_int(SMH_TUNE_WM, "flatk=", 0); /* development knob "flatk=1|2": one / two bits per gram regardless */
                 if (fk == 2 || (fk != 1 && ms2 < ms)) {
                     free(tab);
                     tab = t2; dens = d2; ms = ms2; k2 = 1;
@@ -418,7 +413,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
         }
     }
 #undef GRAM_WANTED
-    if (getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "debug"))
+    if (smh_tune_has(SMH_TUNE_WM, "debug"))
         fprintf(stderr, "gram filter: block filter est %.3f ms/GiB; kept form %d, %d planes, survivors %.5f, est %.3f ms/GiB\n",
                 other_ms, best_kind, best_planes, best_dens, best_ms);
     wm->gram_kind = best_kind;
@@ -428,12 +423,6 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
     wm->gram_density = best_dens;
     wm->scan_ms_est = best_ms;
     return 0;
-}
-
-static int const_getenv_has(const char *var, const char *word)
-{
-    const char *t = getenv(var);
-    return t && strstr(t, word);
 }
 
 /* the two groups' per-gram plane bytes for one way of splitting the set -- group A = the patterns of `split` symbols and more
@@ -500,7 +489,7 @@ int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns
         const double d = grouped_planes(patterns, lengths, p_size, sp, gA, gB, &jb);
         if (d < dens) { dens = d; split = sp; }
     }
-    if (const_getenv_has("SMH_WM_TUNE", "split14")) split = SMH_GRAM_PAIR2_SPLIT; /* development knob: the round-4 split */
+    if (smh_tune_has(SMH_TUNE_WM, "split14")) split = SMH_GRAM_PAIR2_SPLIT; /* development knob: the round-4 split */
     dens = grouped_planes(patterns, lengths, p_size, split, gA, gB, &JB);
     int short_ones = 0;
     for (int p = 0; p < p_size; ++p) short_ones += lengths[p] < split;
@@ -512,12 +501,12 @@ int smh_wm_build_gram_mixed(struct smh_wm *suffix, const unsigned char *patterns
     uint16_t *gx = (uint16_t *)((uint8_t *)tab + SMH_GRAM_BYTES);
     for (uint32_t c = 0; c < 16384; ++c) gx[c] = (uint16_t)(gA[c] | ((uint32_t)gB[c] << 8));
     free(gA); free(gB);
-    if (getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "debug"))
+    if (smh_tune_has(SMH_TUNE_WM, "debug"))
         fprintf(stderr, "grouped pair-gram filter: split at %u, %d short patterns with %d planes, candidates %.6f per column\n", split, short_ones, JB, dens);
     /* every candidate is looked up in the suffix index (window from HBM, one record), and a group's planes together are
      * as selective as an exact match of its shortest pattern's length: with many SHORT patterns the candidates are
      * mostly real matches of those classes and an automaton counts them in line, cheaper (pset_host.c falls back) */
-    if (dens > SMH_PSET_GROUPED_DENSITY && !(getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "grouped=force"))) { free(tab); return 1; }
+    if (dens > SMH_PSET_GROUPED_DENSITY && !smh_tune_has(SMH_TUNE_WM, "grouped=force")) { free(tab); return 1; }
     /* The verify stage's index (round 4): every pattern keyed by its LAST EIGHT symbols -- what every candidate column of
      * either group has matched at the least.  One 32-byte record per 8-symbol code: {next record + 1, length, where the whole
      * pattern lies, 0, the pattern's last 16 bytes END-aligned}; patterns that share their last eight symbols chain through
@@ -830,7 +819,7 @@ struct smh_wm *smh_wm_compile_impl(const unsigned char *pattern_flat, int m, int
          * un-pipelined trip is what is left exposed -- 2.6 slots per pattern: 7 % of the windows, four: 1 % -- and the same
          * 2 MiB table is 8-11 % faster, 100 000 byte patterns over 4 GiB 1.53 / 1.26 / 1.20 / 1.21 -> 1.42 / 1.15 / 1.08 / 1.07 ms
          * at m = 5 / 8 / 12 / 20; 4 MiB: no better.  SMH_WM_TUNE="vt=1m" restores the old cap.) */
-        const size_t vt_cap = getenv("SMH_WM_TUNE") && strstr(getenv("SMH_WM_TUNE"), "vt=1m") ? (size_t)1 << 20 : (size_t)2 << 20;
+        const size_t vt_cap = smh_tune_has(SMH_TUNE_WM, "vt=1m") ? (size_t)1 << 20 : (size_t)2 << 20;
         if (((size_t)4 << lg) > vt_cap) lg = ceil_log2_u32((uint32_t)d * 2u);
         if (lg < 4) lg = 4;
         wm->verify_log2 = lg;

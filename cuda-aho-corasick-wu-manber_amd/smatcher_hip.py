@@ -16,7 +16,11 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsmatcher_hip.so")
+# the product library -- unless this file is executed by load_testing() below, which presets LIB_PATH
+LIB_PATH = globals().get("LIB_PATH") or os.path.join(HERE, "libsmatcher_hip.so")
+TESTING_LIB_PATH = os.path.join(os.path.dirname(HERE), "tests", "emu", "libsmatcher_hip_testing.so")
+IS_TESTING_LIB = os.path.basename(LIB_PATH) != "libsmatcher_hip.so"
+TUNE_WM, TUNE_AC, TUNE_HASH, TUNE_KEY, TUNE_PSET = range(5)  # csrc/smh_tune.h
 
 SMH_OK = 0
 VARIANT_TUNED = 0
@@ -110,7 +114,7 @@ LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_s
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
                "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
-               "smh_stream_read_probe_variant", "smh_host_path_release",
+               "smh_stream_read_probe_variant", "smh_host_path_release", "smh_host_path_set_piece",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_corpus_text_host_kind", "smh_corpus_text_device_kind", "smh_corpus_patterns_kind",
                "smh_shard_range", "smh_ac_compile_tables",
@@ -148,6 +152,8 @@ def _load():
     lib.smh_stream_read_probe_variant.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
     lib.smh_host_path_release.restype = None
     lib.smh_host_path_release.argtypes = []
+    lib.smh_host_path_set_piece.restype = C.c_uint64
+    lib.smh_host_path_set_piece.argtypes = [C.c_uint64]
     lib.smh_splitmix64_at.restype = C.c_uint64
     lib.smh_splitmix64_at.argtypes = [C.c_uint64, C.c_uint64]
     lib.smh_corpus_text_host.restype = None
@@ -289,6 +295,53 @@ def _load():
 
 
 lib = _load()
+
+
+def load_testing():
+    """A second copy of this module bound to tests/emu/libsmatcher_hip_testing.so: the product's sources built with -DSMH_TESTING,
+    the only build that has the development knobs (csrc/smh_tune.h) and the runtime's test hooks.  Tests and tools that force a
+    code path or run a timing experiment use it (`T = S.load_testing(); T.tune(T.TUNE_WM, "gram=6")`); everything else -- and
+    every number on a bench record -- goes through the product library, which reads no knob."""
+    import importlib.util
+    import sys
+    name = __name__ + "_testing"
+    if name in sys.modules:
+        return sys.modules[name]
+    if not os.path.exists(TESTING_LIB_PATH):
+        raise SmhError("%s is not built; run `make -C %s emu`" % (TESTING_LIB_PATH, HERE))
+    spec = importlib.util.spec_from_file_location(name, os.path.abspath(__file__))
+    mod = importlib.util.module_from_spec(spec)
+    mod.LIB_PATH = TESTING_LIB_PATH
+    sys.modules[name] = mod
+    try:
+        spec.loader.exec_module(mod)
+    except BaseException:
+        del sys.modules[name]
+        raise
+    return mod
+
+
+def for_tools():
+    """development micro-drivers (tools/): the testing twin when a knob variable is exported, the product library otherwise"""
+    import sys
+    if any(os.environ.get(v) for v in ("SMH_WM_TUNE", "SMH_AC_TUNE", "SMH_HASH_TUNE", "SMH_KEY_TUNE", "SMH_PSET_TUNE")):
+        print("[tools] development knob exported: running tests/emu/libsmatcher_hip_testing.so, not the product library", file=sys.stderr)
+        return load_testing()
+    return sys.modules[__name__]
+
+
+def tune(which, text=None):
+    """testing library only: set (or clear, text=None) one knob string -- smh_test_tune_set, csrc/smh_tune.c"""
+    if not IS_TESTING_LIB:
+        raise SmhError("the product library has no development knobs; use load_testing().tune(...)")
+    lib.smh_test_tune_set.argtypes = [C.c_int, C.c_char_p]
+    if lib.smh_test_tune_set(which, text.encode() if text else None) != 0:
+        raise SmhError("smh_test_tune_set(%r): no such knob class" % (which,))
+
+
+def tune_clear():
+    for which in range(5):
+        tune(which, None)
 
 
 def _check(rc, what):

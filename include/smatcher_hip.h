@@ -77,6 +77,21 @@ int smh_stream_read_probe_variant(const void *d_buf, uint64_t bytes, uint64_t *d
  * nothing and needs 2 x (64 MiB + m) of device memory whatever the text's length.  The workspaces stay allocated
  * between calls; this frees them (call it with no *_count_host / legacy call in flight). */
 void smh_host_path_release(void);
+/* Piece size of that path in bytes (rounded down to 4 KiB, at least 4 KiB); 0 = back to the default.  Returns the size in
+ * force before the call.  Tests shrink the pieces so that a small text has hundreds of piece boundaries; counts never depend
+ * on it.  Takes effect for calls that start afterwards. */
+uint64_t smh_host_path_set_piece(uint64_t bytes);
+
+/* ---- Environment.  The library reads exactly these variables -- never on the path of a scan or a launch -- and none of them can
+ * change a count:
+ *   SMH_ADAPT=0                 read once per process: handles keep the engine their compile chose (no adaptive switching, no
+ *                               reporting launches)
+ *   SMH_HOST_PIECE_KIB=N        read once per process: default piece size of the host-pointer path (smh_host_path_set_piece
+ *                               overrides it)
+ *   SMH_MULTI_SHARE_DEVICE=1    read by smh_multi_create: logical shards share the visible devices (one-card rehearsal), same
+ *                               as the SMH_MULTI_SHARE_DEVICE flag
+ * Nothing else is read: the development knobs of earlier rounds (SMH_WM_TUNE, SMH_AC_TUNE, SMH_HASH_TUNE, SMH_KEY_TUNE,
+ * SMH_PSET_TUNE) exist only in tests/emu/libsmatcher_hip_testing.so, built with -DSMH_TESTING (csrc/smh_tune.h). ---- */
 
 /* ---- synthetic corpus (clean-room stand-in for the reference's missing helper.c:
  *      load_files / create_multiple_pattern_with_hits, main.c:49,453) ----

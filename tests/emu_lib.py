@@ -136,16 +136,16 @@ def wm_scan_multi(suffix, classes, text, capacity=None, blocks=0):
 
 
 # ---- grouped pair-gram filter of a mixed-length set (csrc/wm_host.c): internal entry point, bound for the tests
-S.lib.smh_wm_build_gram_mixed.restype = C.c_int
-S.lib.smh_wm_build_gram_mixed.argtypes = [C.c_void_p, S.u8p, C.POINTER(C.c_uint32), C.c_int]
-
-
-def build_gram_mixed(suffix, patterns, lengths):
-    """attach the grouped pair-gram filter over the FULL patterns to the suffix handle; 0 = built, 1 = not applicable"""
+def build_gram_mixed(suffix, patterns, lengths, lib=None):
+    """attach the grouped pair-gram filter over the FULL patterns to the suffix handle; 0 = built, 1 = not applicable.
+    lib: the library whose builder runs (the testing twin's obeys the development knobs); default the product's"""
+    lib = lib or S.lib
+    lib.smh_wm_build_gram_mixed.restype = C.c_int
+    lib.smh_wm_build_gram_mixed.argtypes = [C.c_void_p, S.u8p, C.POINTER(C.c_uint32), C.c_int]
     patterns = np.ascontiguousarray(patterns, dtype=np.uint8)
     lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
-    return int(S.lib.smh_wm_build_gram_mixed(suffix.h, patterns.ctypes.data_as(S.u8p),
-                                             lengths.ctypes.data_as(C.POINTER(C.c_uint32)), len(lengths)))
+    return int(lib.smh_wm_build_gram_mixed(suffix.h, patterns.ctypes.data_as(S.u8p),
+                                           lengths.ctypes.data_as(C.POINTER(C.c_uint32)), len(lengths)))
 
 
 # ---- mixed-length automaton (csrc/acm_host.c): internal entry points of the library, bound here for the tests

@@ -176,14 +176,11 @@ def run(cases, seed, verbose=True):
                     # the grouped pair-gram form forced whatever its candidate rate, its verify stage by the suffix index and
                     # class by class: same count, same END columns
                     ref = np.sort(out[:wantset].cpu().numpy())
+                    T = S.load_testing()  # the knobs exist only in the testing build (csrc/smh_tune.h)
                     for tune in ("grouped=force", "grouped=force,sfx=0"):
-                        os.environ["SMH_WM_TUNE"] = tune
+                        T.tune(T.TUNE_WM, tune)  # read by the table builder and by the launcher
                         try:
-                            pg = S.PatternSet(mpat, mlen, sigma, algo)
-                        finally:
-                            del os.environ["SMH_WM_TUNE"]
-                        os.environ["SMH_WM_TUNE"] = tune  # the launcher reads the knob too
-                        try:
+                            pg = T.PatternSet(mpat, mlen, sigma, algo)
                             assert pg.count_host(text)[0] == wantset, (tag, "pset", tune, lens)
                             cur.zero_()
                             out.zero_()
@@ -191,7 +188,7 @@ def run(cases, seed, verbose=True):
                                                 torch.cuda.current_stream().cuda_stream)
                             torch.cuda.synchronize()
                         finally:
-                            del os.environ["SMH_WM_TUNE"]
+                            T.tune(T.TUNE_WM, None)
                         assert int(cur.item()) == wantset and np.array_equal(np.sort(out[:wantset].cpu().numpy()), ref), (tag, "pset positions", tune, lens)
                         pg.close()
                         checks += 2

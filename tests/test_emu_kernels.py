@@ -128,11 +128,12 @@ def test_grid_size_does_not_change_the_count():
                                             (5, 4, 11, 30), (5, 4, 12, 200), (5, 4, 16, 8000), (5, 4, 17, 500), (5, 4, 18, 3000), (5, 4, 23, 20000), (5, 4, 24, 100), (5, 4, 33, 50),
                                             (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
                                             (2, 128, 7, 100)])
-def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
+def test_gram_filter_forms(kind, sigma, m, p, knob):
     """The three q-gram shift-or forms (symbol pairs, 8-symbol grams, hashed byte grams), each forced with the
     development knob so the test does not depend on the cost model: random text with planted occurrences,
     including ones that straddle segment / wave-chunk boundaries and the text's first and last columns."""
-    monkeypatch.setenv("SMH_WM_TUNE", "gram=%d" % kind)
+    S = knob.T  # the testing build: the knobs below exist only there
+    knob.wm("gram=%d" % kind)
     rng = np.random.RandomState(1000 * kind + m)
     n = 3 * 4096 + 777
     text = rng.randint(0, sigma, size=n).astype(np.uint8)
@@ -156,9 +157,10 @@ def test_gram_filter_forms(kind, sigma, m, p, monkeypatch):
 
 
 @pytest.mark.parametrize("kind,m,p", [(6, 5, 300), (6, 8, 5000), (6, 17, 400), (6, 20, 500), (2, 5, 300), (2, 12, 3000), (2, 17, 300), (2, 33, 200)])
-def test_byte_gram_forms_staged_and_from_l2(kind, m, p, monkeypatch):
+def test_byte_gram_forms_staged_and_from_l2(kind, m, p, knob):
     """The byte forms' two verify modes (round 4: windows from L2, the default; SMH_WM_TUNE="l2=0": the chunk staged in LDS)
     give the count of the definition; the window request bends dwords the window does not reach back onto its last one."""
+    S = knob.T  # the testing build: the knobs below exist only there
     rng = np.random.RandomState(31 * kind + m)
     n = 3 * 4096 + 999
     text = rng.randint(0, 256, size=n).astype(np.uint8)
@@ -167,7 +169,7 @@ def test_byte_gram_forms_staged_and_from_l2(kind, m, p, monkeypatch):
         text[off:off + m] = pat[(7 * i) % p]
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
     for tune in ("gram=%d" % kind, "gram=%d,l2=0" % kind):
-        monkeypatch.setenv("SMH_WM_TUNE", tune)
+        knob.wm(tune)
         wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, 256)
         assert wm.info().gram_kind == kind
         for blocks in (1, 3):
@@ -177,11 +179,12 @@ def test_byte_gram_forms_staged_and_from_l2(kind, m, p, monkeypatch):
 
 
 @pytest.mark.parametrize("m,p", [(5, 300), (5, 20000), (6, 3000), (7, 100), (7, 9000)])
-def test_flat_byte_grams_with_two_bits_per_gram(m, p, monkeypatch):
+def test_flat_byte_grams_with_two_bits_per_gram(m, p, knob):
     """Round 4: patterns of 5..7 bytes may keep TWO bits per gram in the flat Bloom set (a blocked Bloom filter with 8-bit
     blocks: wm_lane.h smh_flat_addr<true>); forced here with the development knob, against brute force, both block counts,
     positions mode, and the bounds-checked first / last chunks."""
-    monkeypatch.setenv("SMH_WM_TUNE", "gram=6,flatk=2")
+    S = knob.T  # the testing build: the knobs below exist only there
+    knob.wm("gram=6,flatk=2")
     rng = np.random.RandomState(77 * m + p)
     n = 3 * 4096 + 555
     text = rng.randint(0, 256, size=n).astype(np.uint8)
@@ -196,19 +199,20 @@ def test_flat_byte_grams_with_two_bits_per_gram(m, p, monkeypatch):
         assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want
     total, pos = E.wm_positions(wm, text, want + 8, 2)
     assert total == want and len(set(pos.tolist())) == want
-    monkeypatch.setenv("SMH_WM_TUNE", "gram=6,flatk=1")
+    knob.wm("gram=6,flatk=1")
     one = S.WmTables.from_patterns(pat.reshape(-1), m, p, 256)
     assert E.wm_scan(one, text, S.VARIANT_TUNED, 2) == want
 
 
 @pytest.mark.parametrize("kind", [1, 5])
 @pytest.mark.parametrize("m", [11, 12, 13, 14, 16, 17, 18, 21, 24, 29, 32, 33])
-def test_in_register_verify_every_column_and_length(m, kind, monkeypatch):
+def test_in_register_verify_every_column_and_length(m, kind, knob):
     """Round 3: the pair form's in-register verify (wm_lane.h smh_regv_tag: the window's dwords selected out of the lane's
     text registers and the previous lane's tail by a barrel of conditional moves).  One occurrence ending at EVERY column
     residue 0..63 of a segment -- in lane 0 of a wave-chunk (window out of the halo), in lanes 1 and 63, across a chunk
     boundary -- for every window length class (whole dwords, +1, +2, +3 bytes; 16 and 32 bytes of halo); forced on, forced off
     (staged verify), both equal to the definition."""
+    S = knob.T  # the testing build: the knobs below exist only there
     sigma, p = 4, 64 * 4
     rng = np.random.RandomState(500 + m)
     n = 4 * 4096 + 100
@@ -223,7 +227,7 @@ def test_in_register_verify_every_column_and_length(m, kind, monkeypatch):
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
     assert want >= len(set(ends))
     for tune in ("gram=%d,regv=1" % kind, "gram=%d,regv=0" % kind):
-        monkeypatch.setenv("SMH_WM_TUNE", tune)
+        knob.wm(tune)
         wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
         if wm.info().scan_engine != S.ALGO_WM:
             wm.set_scan_engine(S.ALGO_WM)

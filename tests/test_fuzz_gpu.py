@@ -13,18 +13,14 @@ def test_random_sets_agree_with_the_oracle(seed):
 
 
 @pytest.mark.parametrize("m,p", [(12, 3000), (16, 1000), (16, 8000), (24, 8000), (32, 1000), (33, 300)])
-def test_long_texts_with_every_verify_mode_and_engine_forced(m, p, monkeypatch):
+def test_long_texts_with_every_verify_mode_and_engine_forced(m, p, knob):
     """Texts of several MiB -- many consecutive fast chunks per wave, pending columns carried from chunk to chunk -- with the
     pair-gram kernels' verify forced in registers, staged, and staged with the drain from HBM, and with every engine an
     Aho-Corasick handle keeps forced in turn (the automaton kernels, the filter kernels, the plain stride-1 automaton); a
     stretch of back-to-back repeats of one pattern and a poly-symbol run give some chunks hundreds of surviving columns."""
-    import os
-    import sys
     import numpy as np
-    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd"))
     import oracle_lib as O
-    import smatcher_hip as S
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
     sigma = 4
     n = (7 << 20) + 12345 + 64 * m
     text = S.corpus_text(n, 1000 + m, sigma)
@@ -37,9 +33,9 @@ def test_long_texts_with_every_verify_mode_and_engine_forced(m, p, monkeypatch):
     wm = S.WmTables.from_patterns(pat, m, p, sigma)
     wm.set_scan_engine(S.ALGO_WM)
     for tune in ("", "regv=1", "regv=0", "regv=0,hd=1", "regv=0,hd=0", "stage=0"):
-        monkeypatch.setenv("SMH_WM_TUNE", tune)
+        knob.wm(tune)
         assert wm.count_host(text)[0] == want, tune
-    monkeypatch.delenv("SMH_WM_TUNE")
+    knob.wm(None)
     ac = S.AcAutomaton.from_patterns(pat, m, p, sigma)
     assert ac.count_host(text)[0] == want
     forced = 0

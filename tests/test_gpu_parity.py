@@ -239,11 +239,12 @@ def test_every_scan_plan_gives_the_same_count(name):
 
 
 @pytest.mark.parametrize("tune", ["clamp=0", "clamp=1", "clamp=0,nch=3", "clamp=1,nch=3", "clamp=0,nch=2", "clamp=1,nch=2", "nch=1"])
-def test_hybrid_kernel_instantiations_agree(tune, monkeypatch):
+def test_hybrid_kernel_instantiations_agree(tune, knob):
     """Every instantiation of the hybrid-image kernels gives the reference's count: the unclamped full-row lookup (run only
     after the per-device probe smh_lds_oob_reads_zero has seen out-of-range LDS reads return 0) and its clamped twin, two
     chains with the register prefetch and three without, exact and depth-cut plans, 4 MiB of text with planted matches."""
-    monkeypatch.setenv("SMH_AC_TUNE", tune)
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
+    knob.ac(tune)
     sigma, n = 4, (4 << 20) + 12345
     text = O.gen_text(n, 77, sigma)
     for m, p, plans in ((12, 1000, [(3, 12 | (9 << 8)), (3, 12 | (6 << 8)), (3, 9 | (5 << 8))]),
@@ -395,12 +396,13 @@ def test_ascii_100k_patterns_against_bruteforce(m):
 
 @pytest.mark.parametrize("lane0", [0, 1])
 @pytest.mark.parametrize("m,p", [(11, 3000), (13, 500), (16, 3000), (17, 8000), (18, 3000), (21, 200), (27, 5000), (32, 8000), (33, 3000)])
-def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, monkeypatch):
+def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, knob):
     """Pair-gram filter: the shift-or state that lane 0 of a wave-chunk inherits is either assumed (every plane alive)
     or worked out from the 16 / 32 bytes in front of the chunk (wm_lane.h; the launcher's choice, forced both ways
     here).  Occurrences END in each of the first 15 columns of a chunk -- the columns that state decides -- in every
     chunk of the text, with enough patterns that lane 0 has early flags in most chunks."""
-    monkeypatch.setenv("SMH_WM_TUNE", "gram=1,lane0=%d" % lane0)
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
+    knob.wm("gram=1,lane0=%d" % lane0)
     rng = np.random.RandomState(77 * m + p)
     n = 48 * 4096 + 123
     text = rng.randint(0, 4, size=n).astype(np.uint8)
@@ -427,17 +429,17 @@ def test_pair_gram_lane0_state_on_the_gpu(m, p, lane0, monkeypatch):
 
 @pytest.mark.parametrize("kind,m,p", [(6, 5, 3000), (6, 6, 100000), (6, 8, 30000), (6, 17, 1000), (6, 33, 2000), (2, 5, 3000), (2, 12, 30000),
                                       (2, 17, 100000), (2, 18, 1000), (2, 33, 2000)])
-def test_byte_gram_forms_with_the_staged_verify_on_the_gpu(kind, m, p, monkeypatch):
+def test_byte_gram_forms_with_the_staged_verify_on_the_gpu(kind, m, p, knob):
     """Round 4: the byte forms take their survivors' windows from L2 (a two-stage pipeline across chunks, wm_lane.h
     smh_wm_l2_columns; what the default / hbm_windows / staged / in_registers ids below run for kinds 2 and 6); this is the
     round-3 staged verify (the chunk copied to LDS) on the same texts."""
-    test_gram_filter_forms_on_the_gpu(kind, 256, m, p, ",l2=0", monkeypatch)
+    test_gram_filter_forms_on_the_gpu(kind, 256, m, p, ",l2=0", knob)
 
 
 @pytest.mark.parametrize("m,p", [(5, 3000), (6, 100000), (7, 100)])
-def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, monkeypatch):
+def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, knob):
     """the flat form of 5..7-byte patterns with two bits per gram forced (round 4): same text, same checks as below"""
-    test_gram_filter_forms_on_the_gpu(6, 256, m, p, ",flatk=2", monkeypatch)
+    test_gram_filter_forms_on_the_gpu(6, 256, m, p, ",flatk=2", knob)
 
 
 @pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1"], ids=["default", "hbm_windows", "staged", "in_registers"])
@@ -447,13 +449,14 @@ def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, monkeypatch):
                                             (5, 4, 11, 30), (5, 4, 16, 8000), (5, 4, 17, 6000), (5, 4, 18, 300), (5, 4, 23, 20000), (5, 4, 33, 50),
                                             (2, 256, 12, 30000), (2, 256, 17, 100000), (2, 256, 18, 1000), (2, 256, 33, 2000),
                                             (2, 256, 34, 2000), (2, 128, 7, 100)])
-def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, monkeypatch):
+def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
     """Each q-gram shift-or form forced (development knob), with the staged verify (window hashes from the LDS copy
     of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them), with the pair form's
     in-register verify forced on and off (round 3; the stretch where every column survives gives a lane 64 rounds of it)
     and with windows re-read from HBM; texts with planted occurrences at chunk / segment boundaries and a stretch where EVERY column
     survives the filter (a pattern repeated back to back), so lists overflow and are flushed mid-chunk."""
-    monkeypatch.setenv("SMH_WM_TUNE", "gram=%d%s" % (kind, stage))
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
+    knob.wm("gram=%d%s" % (kind, stage))
     rng = np.random.RandomState(1000 * kind + m)
     n = 9 * 4096 + 777
     text = rng.randint(0, sigma, size=n).astype(np.uint8)

@@ -1,6 +1,6 @@
 """The legacy host-pointer path (search_ac / search_wu / cuda_* and the *_count_host helpers): the text crosses PCIe in
 pieces through two device buffers of a pooled workspace, piece k+1 copying while piece k is scanned, pieces overlapping by
-m - 1 bytes (main.c:467-477).  SMH_HOST_PIECE_KIB shrinks the pieces so that a small text has hundreds of boundaries."""
+m - 1 bytes (main.c:467-477).  smh_host_path_set_piece shrinks the pieces so that a small text has hundreds of boundaries."""
 import os
 import sys
 
@@ -21,14 +21,26 @@ def test_release_entry_point_exists_and_is_harmless_without_a_device():
     S.lib.smh_host_path_release()
 
 
+def test_piece_size_setter_rounds_and_restores():
+    default = S.lib.smh_host_path_set_piece(0)
+    assert default >= 4096 and default % 4096 == 0
+    assert S.lib.smh_host_path_set_piece(5000) == default
+    assert S.lib.smh_host_path_set_piece(1) == 4096      # 5000 rounded down to 4 KiB
+    assert S.lib.smh_host_path_set_piece(0) == 4096      # 1 raised to the 4 KiB floor
+    assert S.lib.smh_host_path_set_piece(0) == default
+
+
+@pytest.fixture
+def piece():
+    yield lambda kib: S.lib.smh_host_path_set_piece(kib << 10)
+    S.lib.smh_host_path_set_piece(0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("piece_kib", [4, 8, 64, 0])
 @pytest.mark.parametrize("m,p,sigma", [(8, 300, 4), (16, 500, 4), (33, 200, 4), (5, 2000, 256), (12, 3000, 256), (65, 20, 4)])
-def test_counts_across_piece_boundaries(monkeypatch, piece_kib, m, p, sigma):
-    if piece_kib:
-        monkeypatch.setenv("SMH_HOST_PIECE_KIB", str(piece_kib))
-    else:
-        monkeypatch.delenv("SMH_HOST_PIECE_KIB", raising=False)
+def test_counts_across_piece_boundaries(piece, piece_kib, m, p, sigma):
+    piece(piece_kib)  # 0: the default, 64 MiB
     for n in (1_000_003, 4096 * 7, 4096 * 7 + m - 1, 4096 * 7 + m - 2, 4095, m, m - 1, 0):
         text = S.corpus_text(n, 42, sigma)
         pat = S.corpus_patterns(m, p, 7, sigma, 42, max(n, m), 2)
@@ -54,8 +66,8 @@ def test_counts_across_piece_boundaries(monkeypatch, piece_kib, m, p, sigma):
 
 
 @pytest.mark.gpu
-def test_siblings_and_legacy_names_through_the_pieces(monkeypatch):
-    monkeypatch.setenv("SMH_HOST_PIECE_KIB", "4")
+def test_siblings_and_legacy_names_through_the_pieces(piece):
+    piece(4)
     n, m, p, sigma = 300_001, 8, 200, 4
     text = S.corpus_text(n, 42, sigma)
     pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)

@@ -122,6 +122,40 @@ def test_product_library_has_no_test_hooks():
     assert _testing_lib().smh_dev_build_peak(0) == 0
 
 
+def test_product_library_reads_no_development_knob():
+    """Round 6: SMH_WM_TUNE / SMH_AC_TUNE / SMH_HASH_TUNE / SMH_KEY_TUNE / SMH_PSET_TUNE -- some of whose words change the COUNT
+    ("nohalo=1", "stmin=-1", "drop=1": timing experiments) -- are compiled only into the testing twin (csrc/smh_tune.h).  The product
+    binary holds none of the names, no setter, and the only environment variables it knows are the three count-preserving ones
+    include/smatcher_hip.h lists."""
+    import re
+    blob = open(S.LIB_PATH, "rb").read()
+    words = set(w.decode() for w in re.findall(rb"[ -~]{4,}", blob))
+    bad = [w for w in words if re.search(r"nohalo|stmin=|drop=1|SMH_(WM|AC|HASH|KEY|PSET)_TUNE|SMH_TEST|gram=|grouped=force|flatk=|regv=|lane0=", w)]
+    assert bad == []
+    env_names = sorted(w for w in words if re.fullmatch(r"SMH_[A-Z0-9_]+", w))
+    assert env_names == ["SMH_ADAPT", "SMH_HOST_PIECE_KIB", "SMH_MULTI_SHARE_DEVICE"]
+    with pytest.raises(AttributeError):
+        S.lib.smh_test_tune_set
+    with pytest.raises(S.SmhError):
+        S.tune(S.TUNE_WM, "gram=6")
+    # ... and the testing twin does have them
+    T = S.load_testing()
+    tblob = open(T.LIB_PATH, "rb").read()
+    assert b"SMH_WM_TUNE" in tblob and b"nohalo=1" in tblob
+    T.tune(T.TUNE_WM, "gram=0")
+    T.tune_clear()
+
+
+def test_knob_forces_a_form_in_the_testing_twin_only(knob, monkeypatch):
+    """the same patterns compiled by both libraries with SMH_WM_TUNE exported AND the twin's knob set: only the twin obeys"""
+    T = knob.T
+    knob.wm("gram=2")  # hashed byte grams where the cost model takes the flat form
+    pat = S.corpus_patterns(6, 100000, 7, 256, 42, 1 << 20, 2)
+    forced = T.WmTables.from_patterns(pat, 6, 100000, 256)
+    plain = S.WmTables.from_patterns(pat, 6, 100000, 256)
+    assert forced.info().gram_kind == 2 and plain.info().gram_kind == 6
+
+
 @pytest.mark.gpu
 def test_table_sets_of_two_handles_are_built_side_by_side(monkeypatch):
     """ensure_device_set builds outside the process-wide mutex: two host threads preparing two handles overlap

@@ -53,9 +53,10 @@ def test_oracle_and_lane_code_reproduce_every_class(vec):
 
 @pytest.mark.parametrize("vec", [v for v in MIXED if min(c[0] for c in v["classes"]) >= 3],
                          ids=[v["name"] for v in MIXED if min(c[0] for c in v["classes"]) >= 3])
-def test_one_pass_lane_code_reproduces_the_decomposition(vec, monkeypatch):
+def test_one_pass_lane_code_reproduces_the_decomposition(vec, knob):
     """SMH_ALGO_WM sets are scanned in ONE pass: a block filter over the patterns' last min-length symbols
     proposes END columns, every survivor is verified per length class.  Same total, same positions."""
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
     text, patterns, lengths = cases.build_mixed(vec)
     sigma = vec["sigma"]
     classes = cases.split_classes(patterns, lengths)
@@ -73,15 +74,15 @@ def test_one_pass_lane_code_reproduces_the_decomposition(vec, monkeypatch):
     if sigma == 4 and Lmin >= 8:
         # grouped pair-gram filter over the FULL patterns (two shift-or states per lane), same total and positions;
         # forced: with 200 patterns of 8 symbols the set itself takes the automaton (one column in 160 a candidate)
-        assert E.build_gram_mixed(suffix, patterns, lengths) == 1
-        monkeypatch.setenv("SMH_WM_TUNE", "grouped=force")
-        assert E.build_gram_mixed(suffix, patterns, lengths) == 0 and suffix.info().gram_planes == 8
+        assert E.build_gram_mixed(suffix, patterns, lengths, S.lib) == 1
+        knob.wm("grouped=force")
+        assert E.build_gram_mixed(suffix, patterns, lengths, S.lib) == 0 and suffix.info().gram_planes == 8
         for blocks in (1, 3):
             assert E.wm_scan_multi(suffix, handles, text, None, blocks) == vec["total"]
         total, got = E.wm_scan_multi(suffix, handles, text, vec["total"] + 3, 2)
         assert total == vec["total"] and np.array_equal(np.sort(got).astype(np.int64), want_pos)
     # the handle takes the one-pass form only while the suffix filter lets few columns through
-    monkeypatch.delenv("SMH_WM_TUNE", raising=False)
+    knob.wm(None)
     assert S.PatternSet(patterns, lengths, sigma, S.ALGO_WM).info().one_pass == (1 if vec["name"] in ONE_PASS | ONE_PASS_AC else 0)
     assert S.PatternSet(patterns, lengths, sigma, S.ALGO_AC).info().one_pass == (1 if vec["name"] in ONE_PASS_AC else 0)
 
@@ -254,10 +255,11 @@ def _random_dna_set(seed):
 
 @pytest.mark.parametrize("tune", ["grouped=force", "grouped=force,split14"], ids=["split_chosen", "split_at_14"])
 @pytest.mark.parametrize("seed", range(10))
-def test_grouped_pair_gram_filter_on_random_dna_sets(seed, tune, monkeypatch):
+def test_grouped_pair_gram_filter_on_random_dna_sets(seed, tune, knob):
     """the one-pass form of SMH_ALGO_WM sets on the 4-letter alphabet (emulated lane code) against the definition
     (sum over length classes); the two groups split where the builder estimates the fewest candidates (round 5) and at the
     fixed length of round 4"""
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
     text, patterns, lengths, classes, want_pos = _random_dna_set(seed)
     want = len(want_pos)
     Lmin = min(classes)
@@ -267,26 +269,27 @@ def test_grouped_pair_gram_filter_on_random_dna_sets(seed, tune, monkeypatch):
         off += int(L)
     suffix = S.WmTables.from_patterns(np.concatenate(suf), Lmin, len(lengths), 4)
     handles = [S.WmTables.from_patterns(classes[L], L, len(classes[L]) // L, 4) for L in sorted(classes)]
-    monkeypatch.setenv("SMH_WM_TUNE", tune)  # whatever the candidate rate: the count must not depend on it
-    assert E.build_gram_mixed(suffix, patterns, lengths) == 0
+    knob.wm(tune)  # whatever the candidate rate: the count must not depend on it
+    assert E.build_gram_mixed(suffix, patterns, lengths, S.lib) == 0
     assert E.wm_scan_multi(suffix, handles, text, None, 2) == want
     total, got = E.wm_scan_multi(suffix, handles, text, want + 3, 3)
     assert total == want and np.array_equal(np.sort(got).astype(np.int64), want_pos)
-    monkeypatch.delenv("SMH_WM_TUNE")
+    knob.wm(None)
     assert S.PatternSet(patterns, lengths, 4, S.ALGO_WM).info().one_pass == 1  # grouped filter or automaton
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("force", [True, False], ids=["grouped_forced", "as_chosen"])
 @pytest.mark.parametrize("seed", range(10))
-def test_gpu_grouped_pair_gram_filter_on_random_dna_sets(seed, force, monkeypatch):
+def test_gpu_grouped_pair_gram_filter_on_random_dna_sets(seed, force, knob):
     """the same sets through smh_pset_* on the device: count and positions of SMH_ALGO_WM sets, with the grouped
     pair-gram filter forced and with whatever one-pass form the set chose"""
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
     import torch
     text, patterns, lengths, classes, want_pos = _random_dna_set(seed)
     want, n = len(want_pos), len(text)
     if force:
-        monkeypatch.setenv("SMH_WM_TUNE", "grouped=force")
+        knob.wm("grouped=force")
     ps = S.PatternSet(patterns, lengths, 4, S.ALGO_WM)
     assert ps.info().one_pass == 1
     assert ps.count_host(text)[0] == want
@@ -326,7 +329,8 @@ def _nested_suffix_set(seed=5):
 
 
 @pytest.mark.parametrize("tune", ["grouped=force", "grouped=force,sfx=0"], ids=["suffix_index", "class_by_class"])
-def test_suffix_index_chains_nested_and_long_patterns(tune, monkeypatch):
+def test_suffix_index_chains_nested_and_long_patterns(tune, knob):
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
     text, patterns, lengths, classes, want_pos = _nested_suffix_set()
     want = len(want_pos)
     assert want > 50 and len(np.unique(want_pos)) < want  # several patterns end at one column
@@ -337,8 +341,8 @@ def test_suffix_index_chains_nested_and_long_patterns(tune, monkeypatch):
         off += int(L)
     suffix = S.WmTables.from_patterns(np.concatenate(suf), Lmin, len(lengths), 4)
     handles = [S.WmTables.from_patterns(classes[L], L, len(classes[L]) // L, 4) for L in sorted(classes)]
-    monkeypatch.setenv("SMH_WM_TUNE", tune)
-    assert E.build_gram_mixed(suffix, patterns, lengths) == 0
+    knob.wm(tune)
+    assert E.build_gram_mixed(suffix, patterns, lengths, S.lib) == 0
     assert E.wm_scan_multi(suffix, handles, text, None, 2) == want
     total, got = E.wm_scan_multi(suffix, handles, text, want + 3, 3)
     assert total == want and np.array_equal(np.sort(got).astype(np.int64), want_pos)
@@ -346,11 +350,12 @@ def test_suffix_index_chains_nested_and_long_patterns(tune, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("tune", ["grouped=force", "grouped=force,sfx=0"], ids=["suffix_index", "class_by_class"])
-def test_gpu_suffix_index_chains_nested_and_long_patterns(tune, monkeypatch):
+def test_gpu_suffix_index_chains_nested_and_long_patterns(tune, knob):
+    S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
     import torch
     text, patterns, lengths, classes, want_pos = _nested_suffix_set()
     want, n = len(want_pos), len(text)
-    monkeypatch.setenv("SMH_WM_TUNE", tune)
+    knob.wm(tune)
     ps = S.PatternSet(patterns, lengths, 4, S.ALGO_WM)
     assert ps.info().one_pass == 1
     assert ps.count_host(text)[0] == want

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch
 sys.path.insert(0, os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd"))
 import smatcher_hip as S
+S = S.for_tools()  # knobs exist only in the testing twin (csrc/smh_tune.h)
 mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n = mib << 20
 dev = torch.device("cuda", 0)

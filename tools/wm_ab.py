@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch
 sys.path.insert(0, os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd"))
 import smatcher_hip as S
+S = S.load_testing()  # knobs exist only in the testing twin (csrc/smh_tune.h)
 m, p, mib, sigma = (int(x) for x in sys.argv[1:5])
 tunes = sys.argv[5:7]
 n = mib << 20
@@ -20,7 +21,7 @@ ts = {t: [] for t in tunes}
 counts = {}
 for it in range(43):
     for t in tunes:
-        os.environ["SMH_WM_TUNE"] = t
+        S.tune(S.TUNE_WM, t)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         cnt.zero_(); a.record(); wm.scan_device(text.data_ptr(), n, cnt.data_ptr(), 0, st); b.record()
         torch.cuda.synchronize()

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch
 sys.path.insert(0, os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd"))
 import smatcher_hip as S
+S = S.for_tools()  # knobs exist only in the testing twin (csrc/smh_tune.h)
 m, p, mib, sigma = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 variant = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 n = mib << 20
