@@ -130,7 +130,7 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
     if (N < 16u) N = 16u;
     if (N < 4u * K.pad) N = 4u * K.pad; /* quotient keys: a free slot's filler must hash outside the pad slots in front of it -- possible only while the table is longer than its padding */
     if (N > cap) { free(keys); *why = "more keys than two tables in LDS hold"; return NULL; }
-    if (N > 65535u) N = 65535u;
+    if (N > 65534u) N = 65534u; /* rounded up to even below: stays under 65536 (slots << 8 must fit the 24-bit multiply, key_hash.h) */
     if ((double)n > 0.485 * 2.0 * (double)N) { free(keys); *why = "more keys than two tables in LDS hold"; return NULL; }
     N = (N + 1u) & ~1u; /* table 2 starts 8-byte aligned */
     K.slots = N;

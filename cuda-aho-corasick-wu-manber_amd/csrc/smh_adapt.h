@@ -212,7 +212,10 @@ static smh_stats_arg adapt_arg(smh_adapt_dev *A, uint64_t n, int engine, void *s
     const bool unreliable = A->unordered != 0;
     const uint32_t k = A->launches++;
     if (n < SMH_ADAPT_MIN_BYTES) return sa;
-    if (k < 4u || (engine >= 0 && engine < SMH_ENGINES && A->n[engine] < 2) || (k & 7u) == 0u) sa = adapt_slot(A, n, engine, unreliable);
+    /* (an unreliable launch's record is never counted into A->n, so the "series incomplete" rule must not apply to it: a handle that
+     * is only ever launched unordered -- inside captures -- would otherwise pay the report on every launch, for ever) */
+    const bool series_open = !unreliable && engine >= 0 && engine < SMH_ENGINES && A->n[engine] < 2;
+    if (k < 4u || series_open || (k & 7u) == 0u) sa = adapt_slot(A, n, engine, unreliable);
     return sa;
 }
 

@@ -481,7 +481,7 @@ static smh_adapt_dev *adapt_find(smh_adapt_dev *const *head)
  * depth-cut automaton kernels' candidate queue, the report slots -- and its measured rates are only its own while its launches do
  * not run beside each other.  Same stream as the previous launch: in order anyway, nothing to do, nothing recorded (the
  * single-stream caller pays nothing).  The first time a second stream shows up nothing was recorded behind the earlier launches:
- * one hipDeviceSynchronize, once per handle and device.  From then on every launch records an event behind itself and a launch
+ * an event is recorded on the previous stream then (once per handle and device; the host does not block).  From then on every launch records an event behind itself and a launch
  * on another stream than the previous one waits for it on the device (the host never blocks).  Not inside a stream capture.
  * Called with A->mu held. */
 static int adapt_order_before(smh_adapt_dev *A, void *stream)
@@ -495,12 +495,22 @@ static int adapt_order_before(smh_adapt_dev *A, void *stream)
         return SMH_OK;
     }
     if (!A->multi_stream) {
-        HIP_TRY(hipDeviceSynchronize());
+        /* first change of stream: nothing has been recorded behind the earlier launches yet.  Round 6: an event recorded NOW on the
+         * previous stream stands behind all of them; the new stream waits for it on the device.  (Round 5 did a hipDeviceSynchronize
+         * here: it blocked the host with A->mu held and failed -- invalidating the capture -- when ANY stream of the process was
+         * capturing in global mode.)  A previous stream that is capturing, or that the caller has destroyed since, cannot take the
+         * record: this launch then goes unordered, as inside a capture, and its duration is not used. */
         hipEvent_t ev;
         HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         A->order_ev = (void *)ev;
         A->multi_stream = 1;
-        return SMH_OK;
+        hipStreamCaptureStatus prev = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)A->last_stream, &prev) != hipSuccess || prev != hipStreamCaptureStatusNone ||
+            hipEventRecord(ev, (hipStream_t)A->last_stream) != hipSuccess) {
+            (void)hipGetLastError();
+            A->unordered = 1;
+            return SMH_OK;
+        }
     }
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)A->order_ev, 0));
     return SMH_OK;
@@ -1320,6 +1330,10 @@ static int wm_ensure_device(struct smh_wm *wm, smh_wm_dev **out)
             for (int j = 0; j < wm->distinct; ++j) memcpy(padded.data() + (size_t)j * row, wm->pat_sorted + (size_t)j * wm->m, (size_t)wm->m);
             if ((rc = upload((void **)&d->d_pat_sorted, padded.data(), (size_t)wm->distinct * row, 16)) != SMH_OK) return rc;
         }
+        /* room for a mixed-length set's class table (768 bytes; filled by wm_multi_launch when this handle is a set's suffix filter):
+         * allocated with the set so that no scan ever allocates -- a scan may run inside a stream capture */
+        HIP_TRY(hipMalloc((void **)&d->d_classes, sizeof(smh_wm_class) * SMH_WM_MAX_CLASSES));
+        d->n_classes_up = 0;
         return SMH_OK;
     }, out);
 }
@@ -1526,6 +1540,8 @@ extern "C" int smh_wm_get_adapt(smh_wm *wm, smh_adapt_info *out)
     return SMH_OK;
 }
 
+static int wm_positions_impl(smh_wm *wm, int engine, const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                             uint64_t *d_cursor, void *stream);
 extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_t n, uint64_t *d_positions,
                                 uint64_t capacity, uint64_t *d_cursor, void *stream)
 {
@@ -1534,7 +1550,24 @@ extern "C" int smh_wm_positions(smh_wm *wm, const unsigned char *d_text, uint64_
         return SMH_EINVAL;
     }
     if (n < (uint64_t)wm->m) return SMH_OK;
-    if (const int engine = wm_engine_now(wm); engine == SMH_ALGO_AC)
+    /* a handle that smh_wm_scan serialises and orders (same test as there) gets the same for its positions launches: they share the
+     * per-device survivor queue with the scans and must not run beside them (round 6) */
+    if (!(adapt_enabled() && (wm_engines(wm) || wm_reports(wm))))
+        return wm_positions_impl(wm, wm_engine_static(wm), d_text, n, d_positions, capacity, d_cursor, stream);
+    smh_adapt_dev *A = NULL;
+    int rc = adapt_get(&wm->adapt, &A);
+    if (rc != SMH_OK) return rc;
+    const int engine = wm_engine_now(wm); /* (takes A->mu itself) */
+    std::lock_guard<std::mutex> adapt_lock(*A->mu);
+    if ((rc = adapt_order_before(A, stream)) != SMH_OK) return rc;
+    rc = wm_positions_impl(wm, engine, d_text, n, d_positions, capacity, d_cursor, stream);
+    const int rc_after = adapt_order_after(A, stream);
+    return rc != SMH_OK ? rc : rc_after;
+}
+static int wm_positions_impl(smh_wm *wm, int engine, const unsigned char *d_text, uint64_t n, uint64_t *d_positions, uint64_t capacity,
+                             uint64_t *d_cursor, void *stream)
+{
+    if (engine == SMH_ALGO_AC)
         return smh_ac_positions(wm_automaton_engine(wm), d_text, n, d_positions, capacity, d_cursor, stream);
     else if (engine == SMH_ENGINE_AC_FLAT && wm->flex_ac && wm->flex_ac->flat_ac)
         return ac_flat_positions(wm->flex_ac, d_text, n, d_positions, capacity, d_cursor, stream);
@@ -1614,19 +1647,22 @@ static int wm_multi_launch(smh_wm *suffix, smh_wm *const *classes, int n_classes
         host[c].pat_sorted = kdv->d_pat_sorted;
     }
     {
-        /* Round 5: the class table goes up when it has changed -- once per set -- and synchronously, so that a later launch on
-         * another stream finds it there.  It used to go up with EVERY scan, from this function's stack (pageable: the runtime
-         * stages such a copy before it returns): 29 us in front of a 240 us kernel, 0.267 ms per scan of the 8..32 set where
-         * the kernel trace said 0.238. */
-        std::lock_guard<std::mutex> lock(g_dev_mu);
-        if (!sdv->d_classes) {
-            HIP_TRY(hipMalloc((void **)&sdv->d_classes, sizeof host));
-            sdv->n_classes_up = 0;
-        }
+        /* The class table goes up when it has changed -- once per set and device (round 5; it used to go up with EVERY scan, from
+         * this function's stack: 29 us in front of a 240 us kernel).  Round 6: with hipMemcpyAsync on the CALLER'S stream
+         * out of the handle's own persistent copy (h_classes) and under a mutex of its own -- round 5 used a blocking copy on the
+         * null stream with the process-wide g_dev_mu held, which (a) was an illegal synchronous call inside a stream capture,
+         * (b) did not order behind launches on non-blocking streams and (c) stalled every other handle's ensure_device.  A pset's
+         * scans must not overlap (include/smatcher_hip.h), so the stream that carries the scan is the stream the table must be
+         * ordered on.  Inside a capture the copy becomes a node of the graph (it re-reads h_classes at every replay: same bytes)
+         * and the table does not count as uploaded -- the first scan outside a capture still sends it. */
+        static std::mutex classes_mu;
+        std::lock_guard<std::mutex> lock(classes_mu);
         if (sdv->n_classes_up != n_classes || memcmp(sdv->h_classes, host, sizeof(smh_wm_class) * (size_t)n_classes) != 0) {
-            HIP_TRY(hipMemcpy(sdv->d_classes, host, sizeof(smh_wm_class) * (size_t)n_classes, hipMemcpyHostToDevice));
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing((hipStream_t)stream, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
             memcpy(sdv->h_classes, host, sizeof(smh_wm_class) * (size_t)n_classes);
-            sdv->n_classes_up = n_classes;
+            HIP_TRY(hipMemcpyAsync(sdv->d_classes, sdv->h_classes, sizeof(smh_wm_class) * (size_t)n_classes, hipMemcpyHostToDevice, (hipStream_t)stream));
+            sdv->n_classes_up = cap == hipStreamCaptureStatusNone ? n_classes : 0;
         }
     }
     int n_cus = 0;

@@ -240,7 +240,8 @@ int smh_ac_set_scan_engine(smh_ac *ac, int engine);
  * state -- the depth-cut kernels' candidate queue, the report slots of the adaptive engine -- so the library (i) serialises the
  * host side of those calls per handle and device with a mutex and (ii) ORDERS the handle's launches on the device: a launch on
  * another stream than the handle's previous one first waits (hipStreamWaitEvent, the host does not block) for that one.  The same
- * stream as before costs nothing; the first change of stream costs one hipDeviceSynchronize, once per handle and device.  Launches
+ * stream as before costs nothing; the first change of stream costs one event created and recorded on the previous stream, once per handle and device (the
+ * host never blocks).  Launches
  * of DIFFERENT handles are independent.  Exceptions: inside a stream capture no ordering is applied (capture a handle on one
  * stream only); smh_pset handles and SMH_ADAPT=0 processes keep the old rule -- scans of the same handle must not overlap.
  * smh_*_free must not run beside any other call on the handle.

@@ -86,3 +86,66 @@ def test_two_threads_two_streams_one_handle(entry):
             for i in range(2):
                 assert np.all(counts[i].cpu().numpy() == want[name]), (name, "automaton kernels", i)
         h.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sigma,m,p", [(256, 12, 10000), (4, 16, 8000)])
+def test_scans_and_positions_of_one_handle_on_two_streams(sigma, m, p):
+    """Round 6: smh_wm_positions shares the handle's per-device survivor queue with smh_wm_scan, so it takes the
+    same mutex and the same ordering across streams.  One thread scans, the other asks for positions, same handle, filter
+    kernels forced (the queue's users), 40 launches each: every count and every position list equals the single-stream one."""
+    n, launches = 16 << 20, 40
+    dev = torch.device("cuda", 0)
+    t = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    S.corpus_text_device(t.data_ptr(), n, 42, sigma, 0, S.CORPUS_UNIFORM, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n, 2)
+    h = S.WmTables.from_patterns(pat, m, p, sigma)
+    h.set_scan_engine(S.ALGO_WM)
+    one = torch.zeros(1, dtype=torch.int64, device=dev)
+    h.scan_device(t.data_ptr(), n, one.data_ptr(), S.VARIANT_TUNED, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = int(one.item())
+    assert want == O.oracle_wu(pat, m, p, sigma, t[:n].cpu().numpy())[0] and want > 100
+    ref = torch.zeros(want + 8, dtype=torch.int64, device=dev)
+    cur = torch.zeros(1, dtype=torch.int64, device=dev)
+    h.positions_device(t.data_ptr(), n, ref.data_ptr(), want + 8, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(cur.item()) == want
+    ref_sorted = np.sort(ref[:want].cpu().numpy())
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    counts = torch.zeros(launches, dtype=torch.int64, device=dev)
+    cursors = torch.zeros(launches, dtype=torch.int64, device=dev)
+    outs = torch.zeros((launches, want + 8), dtype=torch.int64, device=dev)
+    errors = []
+
+    def scans():
+        try:
+            torch.cuda.set_device(0)
+            for k in range(launches):
+                h.scan_device(t.data_ptr(), n, counts.data_ptr() + 8 * k, S.VARIANT_TUNED, streams[0].cuda_stream)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def positions():
+        try:
+            torch.cuda.set_device(0)
+            for k in range(launches):
+                h.positions_device(t.data_ptr(), n, outs[k].data_ptr(), want + 8, cursors.data_ptr() + 8 * k, streams[1].cuda_stream)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=scans), threading.Thread(target=positions)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert np.all(counts.cpu().numpy() == want), np.unique(counts.cpu().numpy())
+    assert np.all(cursors.cpu().numpy() == want), np.unique(cursors.cpu().numpy())
+    got = outs.cpu().numpy()
+    for k in range(launches):
+        assert np.array_equal(np.sort(got[k, :want]), ref_sorted), k
+    h.close()
+
