@@ -39,6 +39,20 @@ struct smh_key_params {
     uint32_t pad;      /* quotient keys: extra slots behind each table's `slots` (2^(m * bits - 32)), else 0 */
     uint32_t base2;    /* byte offset of table 2 in the image (table 1 at 0) = (slots + pad) * slot bytes */
     uint32_t bytes;    /* the image: both tables, padded to 16 */
+    /* ---- round 6: the BUCKET image (layout 1; below) -- one LDS read per column instead of two ---- */
+    uint32_t layout;      /* 0 = the two-table cuckoo image above; 1 = bucket image */
+    uint32_t bk_mul;      /* A << bk_sh, 24 bits: the rolled image H = (H << bits) + symbol * bk_mul  (mod 2^32) */
+    uint32_t bk_sh;       /* 32 - bk_r * bits: H's low bk_sh bits are always zero */
+    uint32_t bk_r;        /* symbols H covers: min(m, floor(32 / bits)), or floor(30 / bits) when the window is longer than that */
+    uint32_t bk_old;      /* 0: m <= bk_r, H is the whole window.  else = bk_r: the older m - bk_r symbols come from the H of bk_r columns ago */
+    uint32_t bk_q;        /* F = (H_old << bk_q) + H: the older symbols' image lands in F's top (m - bk_r) * bits bits */
+    uint32_t bk_log2;     /* primary table: 2^bk_log2 buckets of 8 bytes {S0, S1} at offset 0; bucket = F >> (32 - bk_log2) */
+    uint32_t bk2_log2;    /* overflow table: 2^bk2_log2 buckets of 16 bytes (four slots) at bk2_base; bucket = (F + (F << bk2_z)) >> (32 - bk2_log2) */
+    uint32_t bk2_z, bk2_base;
+    uint32_t bk_sentinel; /* S0 == sentinel: the bucket holds three keys or more -- S0 is no key, S1 is one of them, the others sit in the overflow table */
+    uint32_t bk_symmask;  /* ((1 << bits) - 1) * 0x01010101: text dwords are masked once, then a symbol is a byte */
+    uint32_t bk_overflow; /* keys in the overflow table (statistics) */
+    uint32_t bk_crowded;  /* buckets that hold a sentinel */
 };
 
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -79,6 +93,35 @@ SMH_KEY_FN void smh_key_slots(uint32_t f, uint32_t y, const struct smh_key_param
     const uint32_t ns = K->slots << 8, wsh = K->wide == 1 ? 3u : 2u;
     *o1 = (smh_key_mulhi24(h1, ns) + y) << wsh;
     *o2 = ((smh_key_mulhi24(h2, ns) + y) << wsh) + K->base2;
+}
+
+/* ---- The bucket image (round 6).
+ *
+ * The cuckoo image costs a column two random LDS reads (2 x 6.7 LDS-array cycles per wave-lookup, counters in DESIGN.md 9) and 12
+ * vector instructions, both units full.  This image costs ONE 8-byte read and 7-8 instructions:
+ *
+ *   H  = sum over the window's last r symbols of symbol_i * A * 2^(sh + bits * i)  (mod 2^32), i = 0 the newest.  Rolled along
+ *        the text in two instructions, (H << bits) + symbol * (A << sh): what is older than r symbols has left through the top
+ *        (r * bits + sh = 32).  A is odd, so H >> sh is a BIJECTIVE image of those r symbols: equal H, equal symbols.
+ *   F  = H when the window is r symbols or fewer.  Longer windows (e = m - r more symbols, e * bits <= bk_log2): the H of r
+ *        columns ago holds, in its bits [sh, sh + e * bits), a bijective image E of exactly those e older symbols (the low bits of
+ *        the rolled sum depend on the newest symbols only); F = (H_old << q) + H adds E into H's top e * bits bits.
+ *   bucket = the top bk_log2 bits of F; each of its two slots holds the H of a key.  "slot == H" in the bucket of F says that
+ *        H and the top bits of F are a key's, hence E, hence all m symbols: exact, no verify stage.
+ *   Three keys or more in a bucket (1.4 % of the buckets at 8000 keys in 2^14): slot 0 holds the sentinel, slot 1 one key, the
+ *        rest go to a small overflow table of four-slot buckets indexed by the top bits of F * (2^z + 1) -- an odd multiple, so the
+ *        same argument makes "slot == H" there exact while its bucket bits are at least e * bits.  Only lanes that read a sentinel
+ *        look there, behind a wave-uniform branch.
+ *   Free slots hold a value no probe of that bucket carries: 2 when sh >= 2 (every H has its low bits clear), else (sh < 2 only
+ *        when F = H) one whose bucket bits differ.  Sentinel: 1 when sh >= 2, else 0 -- and the builder keeps a key whose H is 0 out
+ *        of slot 0. */
+SMH_KEY_FN uint32_t smh_keyb_roll(uint32_t H, uint32_t sym, uint32_t bits, uint32_t mul) { return (H << bits) + smh_key_mul24(sym, mul); }
+SMH_KEY_FN uint32_t smh_keyb_mix(uint32_t H, uint32_t Hold, const struct smh_key_params *K) { return K->bk_old ? (Hold << K->bk_q) + H : H; }
+SMH_KEY_FN uint32_t smh_keyb_off1(uint32_t F, const struct smh_key_params *K) { return (F >> (29u - K->bk_log2)) & ~7u; }
+SMH_KEY_FN uint32_t smh_keyb_off2(uint32_t F, const struct smh_key_params *K)
+{
+    const uint32_t G = (F << K->bk2_z) + F;
+    return ((G >> (28u - K->bk2_log2)) & ~15u) | K->bk2_base;
 }
 
 #endif

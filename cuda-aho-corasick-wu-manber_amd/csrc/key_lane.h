@@ -231,4 +231,249 @@ SMH_LANE uint32_t smh_key_thread(uint64_t gthread, const smh_chunk_sched &S, con
     return cnt;
 }
 
+/* ------------------------------------------------------------------ the bucket image (key_hash.h "The bucket image"; round 6)
+ *
+ * Per column: the image H rolled by one symbol (v_mul_u32_u24 on the symbol's byte + v_lshl_add), F for windows longer than the
+ * image (one v_lshl_add with the H of R columns ago, kept in registers: the loop is unrolled, the delay line is indexed by
+ * constants), the bucket's byte offset (shift + and), ONE ds_read_b64, three compares (slot 0, slot 1, sentinel) whose results
+ * go to the scalar unit as lane masks.  Lanes that read a sentinel -- the bucket held three keys or more -- look into the
+ * overflow table behind a wave-uniform branch. */
+struct smh_keyb_slots { uint32_t s0, s1; };
+SMH_LANE smh_keyb_slots smh_keyb_read(const void *tab, uint32_t off)
+{
+    smh_keyb_slots r;
+    smh_lds_u32x2(tab, off, r.s0, r.s1);
+    return r;
+}
+/* the four slots of an overflow bucket hold H? */
+SMH_LANE bool smh_keyb_overflow_has(const void *tab, uint32_t F, uint32_t H, const smh_key_params &K)
+{
+    const uint32_t off = smh_keyb_off2(F, &K);
+    uint32_t a, b, c, d;
+    smh_lds_u32x2(tab, off, a, b);
+    smh_lds_u32x2(tab, off + 8u, c, d);
+    return (a == H) | (b == H) | (c == H) | (d == H);
+}
+/* the whole test for one window, any lane by itself: the bounds-checked path and the model the fast path must equal */
+SMH_LANE bool smh_keyb_hit(const void *tab, uint32_t H, uint32_t Hold, const smh_key_params &K)
+{
+    const uint32_t F = smh_keyb_mix(H, Hold, &K);
+    const smh_keyb_slots r = smh_keyb_read(tab, smh_keyb_off1(F, &K));
+    if (r.s0 != K.bk_sentinel) return (r.s0 == H) | (r.s1 == H);
+    return (r.s1 == H) || smh_keyb_overflow_has(tab, F, H, K); /* (H is never the sentinel here: key_hash.h) */
+}
+
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+typedef uint64_t smh_keyb_mask;
+SMH_LANE smh_keyb_mask smh_keyb_ballot(bool x) { return __builtin_amdgcn_ballot_w64(x); }
+SMH_LANE uint32_t smh_keyb_popc(smh_keyb_mask x) { return (uint32_t)__builtin_popcountll(x); }
+SMH_LANE bool smh_keyb_mine(smh_keyb_mask x) { return (x >> (threadIdx.x & 63u)) & 1u; }
+#else
+typedef uint32_t smh_keyb_mask; /* the emulation runs one lane at a time: a mask is that lane's bit */
+SMH_LANE smh_keyb_mask smh_keyb_ballot(bool x) { return x ? 1u : 0u; }
+SMH_LANE uint32_t smh_keyb_popc(smh_keyb_mask x) { return x; }
+SMH_LANE bool smh_keyb_mine(smh_keyb_mask x) { return x != 0; }
+#endif
+
+#ifndef SMH_KEYB_GROUP
+#define SMH_KEYB_GROUP 2
+#endif
+/* The overflow path is DEFERRED (counting kernels on the GPU).  Looking into the overflow table the moment a lane reads a sentinel
+ * costs the whole wave ten instructions and an LDS round trip for the one lane in 64 that needs it -- 1.4 % of the lanes, hence six
+ * columns in ten: measured 0.57 against 0.34 ms/GiB without (profiles/r06_key/notes/ab_key_bucket_image.log).  Instead the lanes that
+ * read a sentinel append their (H, F) to a queue of the wave in LDS (ballot + mbcnt: the wave's entries are contiguous), and the
+ * queue is drained 64 entries per step -- every lane one entry, one overflow-table read in flight per lane -- whenever 64 more
+ * might not fit, and at the end of the segment.  Slot 1 of the crowded bucket has been compared in line; a window is a key in one
+ * place at most, so the drain's hits are simply added. */
+#define SMH_KEYB_QCAP 96u /* entries per wave: 4 bytes each (H), 8 where F != H */
+#define SMH_KEYB_QBYTES(R) (16u * SMH_KEYB_QCAP * ((R) > 0 ? 8u : 4u)) /* per 1024-thread workgroup */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+struct smh_keyb_queue { uint32_t off; uint32_t count; uint32_t hits; }; /* off: LDS byte offset of this wave's entries; count, hits: wave-uniform */
+template <int R>
+SMH_LANE void smh_keyb_drain(smh_keyb_queue &Q, const void *tab, const smh_key_params &K)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = 0; base < Q.count; base += 64u) { /* wave-uniform */
+        bool more = false;
+        if (base + lane < Q.count) {
+            const uint32_t H = smh_lds_u32(tab, Q.off + 4u * (base + lane));
+            const uint32_t F = R > 0 ? smh_lds_u32(tab, Q.off + 4u * SMH_KEYB_QCAP + 4u * (base + lane)) : H;
+            more = smh_keyb_overflow_has(tab, F, H, K);
+        }
+        Q.hits += smh_keyb_popc(smh_keyb_ballot(more));
+    }
+    Q.count = 0u;
+}
+/* the lanes of `mf` (a sentinel in slot 0) queue their window; mf != 0, wave-uniform.  false: the queue is full (the caller looks
+ * into the overflow table in line -- only a text that keeps hitting crowded buckets gets there) */
+template <int R>
+SMH_LANE bool smh_keyb_defer(smh_keyb_queue &Q, smh_keyb_mask mf, bool mine, uint32_t H, uint32_t F)
+{
+    const uint32_t more = smh_keyb_popc(mf);
+    if (Q.count + more > SMH_KEYB_QCAP) return false;
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf, 0u));
+    if (mine) {
+        const uint32_t at = Q.off + 4u * (Q.count + before);
+        *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(at) = H;
+        if constexpr (R > 0) *reinterpret_cast<__attribute__((address_space(3))) uint32_t *>(at + 4u * SMH_KEYB_QCAP) = F;
+    }
+    Q.count += more;
+    return true;
+}
+#endif
+/* R = the delay line's length (smh_key_params.bk_old: 0, 15 or 6); the 16 * HP bytes in front of the segment prime image and line */
+template <int R, int HP, bool POS>
+SMH_LANE uint32_t smh_keyb_lane_fast(const uint8_t *text, uint64_t a, const uint32_t (&w)[16], const uint32_t (&edge)[4 * HP],
+                                     const void *tab, const smh_key_params &K, const smh_pos_out *po, uint32_t queue_off)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    smh_keyb_queue Q = {queue_off, 0u, 0u};
+#else
+    (void)queue_off;
+#endif
+    static_assert(R <= 16 * HP, "the halo fills the delay line");
+    const uint32_t bits = (uint32_t)K.bits, mul = K.bk_mul, smask = K.bk_symmask;
+    uint32_t H = 0;
+    uint32_t line[R > 0 ? R : 1];
+#pragma unroll
+    for (int q = 0; q < 4 * HP; ++q) {
+        const uint32_t pw = smh_prev_lane_word(w[16 - 4 * HP + q], edge[q], text, a - 16u * HP + 4u * q) & smask;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            H = smh_keyb_roll(H, smh_byte_of(pw, k), bits, mul);
+            if constexpr (R > 0) line[(4 * q + k) % R] = H;
+        }
+    }
+    uint32_t cnt = 0, mlo = 0, mhi = 0;
+    constexpr int G = SMH_KEYB_GROUP; /* text dwords per step: 4 * G columns' reads in flight, then the compares, then ONE look at the sentinels */
+#pragma unroll
+    for (int q = 0; q < 16; q += G) {
+        uint32_t Hk[4 * G], Fk[4 * G];
+        smh_keyb_slots r[4 * G];
+#pragma unroll
+        for (int j = 0; j < 4 * G; ++j) {
+            const uint32_t ww = w[q + j / 4] & smask;
+            H = smh_keyb_roll(H, smh_byte_of(ww, j % 4), bits, mul);
+            Hk[j] = Fk[j] = H;
+            if constexpr (R > 0) {
+                const int at = (16 * HP + 4 * q + j) % R; /* a constant once the loops are unrolled; this slot took its value R columns ago */
+                Fk[j] = (line[at] << K.bk_q) + H;
+                line[at] = H;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4 * G; ++j) r[j] = smh_keyb_read(tab, smh_keyb_off1(Fk[j], &K));
+        /* a sentinel is no probe's H (key_hash.h; key_host.c keeps the one bucket where it could be from overflowing), so slot 0's
+         * compare needs no mask: a lane that reads a sentinel can only hit in slot 1 or in the overflow table */
+        /* ... and a window is a key in ONE place at most: hits of the two slots and hits of the overflow table are counted
+         * separately, and no lane mask outlives its column (masks are scalar register pairs: eight columns' worth spill) */
+        uint32_t bits4 = 0; /* positions mode: this lane's hits of the step's columns */
+        smh_keyb_mask any = 0;
+#pragma unroll
+        for (int j = 0; j < 4 * G; ++j) {
+            if constexpr (POS) bits4 |= (((r[j].s0 == Hk[j]) | (r[j].s1 == Hk[j])) ? 1u : 0u) << j;
+            else cnt += smh_keyb_popc(smh_keyb_ballot(r[j].s0 == Hk[j]) | smh_keyb_ballot(r[j].s1 == Hk[j]));
+            any |= smh_keyb_ballot(r[j].s0 == K.bk_sentinel);
+        }
+        if (any) { /* wave-uniform: some lane of the wave read a sentinel in one of the step's columns (the builder keeps that rare) */
+#pragma unroll
+            for (int j = 0; j < 4 * G; ++j) {
+                const bool crowded = r[j].s0 == K.bk_sentinel;
+                const smh_keyb_mask mf = smh_keyb_ballot(crowded);
+                if (!mf) continue; /* wave-uniform */
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+                if constexpr (!POS) {
+                    if (smh_keyb_defer<R>(Q, mf, crowded, Hk[j], Fk[j])) continue;
+                }
+#endif
+                bool more = false;
+                if (crowded) more = smh_keyb_overflow_has(tab, Fk[j], Hk[j], K);
+                if constexpr (POS) bits4 |= (more ? 1u : 0u) << j;
+                else cnt += smh_keyb_popc(smh_keyb_ballot(more));
+            }
+        }
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+        if constexpr (!POS) {
+            if (q + G == 8) smh_keyb_drain<R>(Q, tab, K); /* mid-segment; the other drain is at its end */
+        }
+#endif
+        if constexpr (POS) {
+            if (4 * q < 32) mlo |= bits4 << (4 * q);
+            else mhi |= bits4 << (4 * q - 32);
+        }
+    }
+    if constexpr (POS) return smh_append_bits(((uint64_t)mhi << 32) | mlo, a, *po);
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    smh_keyb_drain<R>(Q, tab, K);
+    cnt += Q.hits;
+#endif
+    return smh_key_count_mine(cnt);
+}
+
+/* bounds-checked path: END columns [max(a, m - 1), min(a + 64, n)) byte by byte from memory; a second image lags bk_old symbols behind */
+SMH_LANE uint32_t smh_keyb_lane_slow(const uint8_t *text, uint64_t n, uint64_t a, const void *tab, const smh_key_params &K,
+                                     uint64_t *match_mask = nullptr)
+{
+    if (match_mask) *match_mask = 0;
+    if (a >= n) return 0;
+    uint64_t end = a + SMH_SEG;
+    if (end > n) end = n;
+    uint64_t e0 = a;
+    if (e0 < (uint64_t)(K.m - 1)) e0 = (uint64_t)(K.m - 1);
+    if (e0 >= end) return 0;
+    const uint32_t bits = (uint32_t)K.bits, smask = (1u << bits) - 1u, R = K.bk_old;
+    uint32_t H = 0, Hold = 0, cnt = 0;
+    const uint64_t first = e0 - (uint64_t)(K.m - 1); /* the first window's first symbol */
+    for (uint64_t i = first; i < e0; ++i) H = smh_keyb_roll(H, text[i] & smask, bits, K.bk_mul);
+    if (R) for (uint64_t i = first; i + R < e0; ++i) Hold = smh_keyb_roll(Hold, text[i] & smask, bits, K.bk_mul);
+    for (uint64_t e = e0; e < end; ++e) {
+        H = smh_keyb_roll(H, text[e] & smask, bits, K.bk_mul);
+        if (R) Hold = smh_keyb_roll(Hold, text[e - R] & smask, bits, K.bk_mul);
+        const bool hit = smh_keyb_hit(tab, H, Hold, K);
+        cnt += hit ? 1u : 0u;
+        if (match_mask && hit) *match_mask |= 1ull << (e - a);
+    }
+    return cnt;
+}
+
+template <int R, int HP, bool POS>
+SMH_LANE uint32_t smh_keyb_thread(uint64_t gthread, const smh_chunk_sched &S, const uint8_t *text, uint64_t n, const void *tab,
+                                  const smh_key_params &K, const smh_pos_out *po = nullptr, uint32_t queue_off = 0u)
+{
+    if (n < (uint64_t)K.m) return 0;
+    const uint64_t chunk_bytes = (uint64_t)SMH_SEG * 64u;
+    const uint64_t n_chunks = (n + chunk_bytes - 1) / chunk_bytes;
+    const uint32_t lane = (uint32_t)(gthread & 63u);
+    uint32_t cnt = 0;
+    uint32_t cur[16], edge[4 * HP];
+    auto is_fast = [&](uint64_t kk) { return kk >= 1 && kk < n_chunks && (kk + 1) * chunk_bytes <= n; };
+    uint64_t k = S.take(n_chunks);
+    while (k < n_chunks) {
+        const uint64_t base = smh_uniform64(k * chunk_bytes);
+        const uint64_t a = base + (uint64_t)lane * SMH_SEG;
+        if (is_fast(k)) {
+            const uint8_t *p = text + a;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const smh_u32x4 t = smh_load16(p + 16u * q);
+                cur[4 * q + 0] = t.v[0]; cur[4 * q + 1] = t.v[1]; cur[4 * q + 2] = t.v[2]; cur[4 * q + 3] = t.v[3];
+            }
+#pragma unroll
+            for (int q = 0; q < HP; ++q) { /* the bytes in front of the wave-chunk, same address in every lane */
+                const smh_u32x4 t = smh_load16(text + base - 16u * (uint32_t)(HP - q));
+                edge[4 * q + 0] = t.v[0]; edge[4 * q + 1] = t.v[1]; edge[4 * q + 2] = t.v[2]; edge[4 * q + 3] = t.v[3];
+            }
+            cnt += smh_keyb_lane_fast<R, HP, POS>(text, a, cur, edge, tab, K, po, queue_off);
+        } else if (POS) {
+            uint64_t mm;
+            smh_keyb_lane_slow(text, n, a, tab, K, &mm);
+            cnt += smh_append_bits(mm, a, *po);
+        } else {
+            cnt += smh_keyb_lane_slow(text, n, a, tab, K);
+        }
+        k = S.take(n_chunks);
+    }
+    return cnt;
+}
+
 #endif

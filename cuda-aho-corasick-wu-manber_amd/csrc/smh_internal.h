@@ -186,6 +186,10 @@ struct smh_keys {
 #define SMH_KEYS_MS_NARROW 0.40 /* ms per GiB at steady state, 4-byte slots (32-bit and quotient keys): measured on MI355X whatever text and set (profiles/r05_keys) */
 #define SMH_KEYS_MS_QUOT 0.46   /* quotient keys: two registers of rolling code, 4-byte slots */
 #define SMH_KEYS_MS_WIDE 0.51   /* 8-byte slots */
+#define SMH_KEYS_MS_BUCKET 0.285      /* round 6, bucket image (key_hash.h): one LDS read per column; window within the 32-bit image */
+#define SMH_KEYS_MS_BUCKET_OLD 0.30   /* ... window longer than the image: one more instruction per column */
+#define SMH_KEYS_MS_CROWDED_STEP 0.16 /* ... plus the crowded buckets' cost (key_host.c): per step of eight columns / per column with a sentinel in the wave */
+#define SMH_KEYS_MS_CROWDED_COL 0.15
 struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p_size, int alphabet, uint32_t lds_budget, const char **why);
 void smh_keys_free(struct smh_keys *k);
 int smh_keys_contains(const struct smh_keys *k, uint64_t key);

@@ -12,6 +12,7 @@
  * API returns SMH_ENODEV and the legacy names print the reason and exit(1).
  */
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1814,6 +1815,7 @@ static int keys_launch(struct smh_keys *k, const unsigned char *d_text, uint64_t
     smh_key_launch L = {};
     L.d_text = d_text; L.n = n; L.K = k->P; L.d_image = reinterpret_cast<const uint32_t *>(dv->d_image);
     L.d_count = d_count; L.n_cus = n_cus; L.wg_per_cu = keys_wg_per_cu(); L.stats = SA;
+    if (smh_tune_has(SMH_TUNE_KEY, "noover=1")) L.K.bk_sentinel = 0xFFFFFFFEu; /* testing library only: no lane ever sees a sentinel -- the bucket image's scan without its overflow path, counts wrong (timing experiment) */
     if (po) {
         L.po = *po;
         HIP_TRY(smh_launch_keys_positions(L, (hipStream_t)stream));
@@ -1845,13 +1847,16 @@ extern "C" int smh_keys_positions(struct smh_keys *k, const unsigned char *d_tex
 
 extern "C" int smh_keys_get_info(const struct smh_keys *k, smh_keys_info *out)
 {
-    if (!k || k->magic != SMH_MAGIC_KEYS || !out || out->struct_size != sizeof *out) {
+    const uint32_t r5_size = (uint32_t)offsetof(smh_keys_info, layout); /* the struct of round 5 ends in front of `layout` */
+    if (!k || k->magic != SMH_MAGIC_KEYS || !out || (out->struct_size != sizeof *out && out->struct_size != r5_size)) {
         smh_set_error("smh_keys_get_info: bad arguments (set struct_size = sizeof(smh_keys_info))");
         return SMH_EINVAL;
     }
     out->alphabet = (uint32_t)k->alphabet; out->m = (uint32_t)k->m; out->keys = k->n_keys;
-    out->key_bits = (uint32_t)(k->P.m * k->P.bits); out->slot_bytes = k->P.wide == 1 ? 8u : 4u; out->slots = k->P.slots;
+    out->key_bits = (uint32_t)(k->P.m * k->P.bits); out->slot_bytes = k->P.wide == 1 ? 8u : 4u;
+    out->slots = k->P.slots; /* bucket image: buckets of the primary table (two slots each) */
     out->lds_bytes = k->P.bytes; out->est_ms_per_gib = k->ms_est;
+    if (out->struct_size == sizeof *out) { out->layout = k->P.layout; out->overflow_keys = k->P.layout == 1 ? k->P.bk_overflow : 0u; }
     return SMH_OK;
 }
 

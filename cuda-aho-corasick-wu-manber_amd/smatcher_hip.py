@@ -74,7 +74,7 @@ class AdaptInfo(C.Structure):
 class KeysInfo(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("alphabet", C.c_uint32), ("m", C.c_uint32), ("keys", C.c_uint32),
                 ("key_bits", C.c_uint32), ("slot_bytes", C.c_uint32), ("slots", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("est_ms_per_gib", C.c_double)]
+                ("est_ms_per_gib", C.c_double), ("layout", C.c_uint32), ("overflow_keys", C.c_uint32)]
 
 
 class PsetInfo(C.Structure):

@@ -441,6 +441,10 @@ typedef struct smh_keys_info {
     uint32_t slots;        /* per table (two tables) */
     uint32_t lds_bytes;    /* the image */
     double est_ms_per_gib;
+    /* round 6 (struct_size 48; a caller compiled against the 40-byte struct of round 5 gets the fields above only) */
+    uint32_t layout;       /* 0 = two-table cuckoo hash: two LDS reads per column; 1 = bucket image: one 8-byte read per column, `slots` = the
+                            * two-slot buckets of the primary table, keys of buckets with three or more in a small overflow table (csrc/key_hash.h) */
+    uint32_t overflow_keys;
 } smh_keys_info;
 smh_keys *smh_keys_compile_patterns(const unsigned char *pattern_flat, int m, int p_size, int alphabet);
 int smh_keys_get_info(const smh_keys *k, smh_keys_info *out);

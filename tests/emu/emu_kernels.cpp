@@ -607,8 +607,26 @@ static uint64_t keys_grid(const smh_keys *k, const uint8_t *text, uint64_t n, ui
     }
     return cursor ? *cursor : total;
 }
+template <int R, int HP>
+static uint64_t keyb_grid(const smh_keys *k, const uint8_t *text, uint64_t n, uint64_t blocks, uint64_t *out, uint64_t capacity, uint64_t *cursor)
+{
+    const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
+    uint64_t total = 0;
+    smh_pos_out po{out, capacity, cursor};
+    for (uint64_t t = 0; t < nthreads; ++t) {
+        const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
+        if (cursor) smh_keyb_thread<R, HP, true>(t, S, text, n, k->image, k->P, &po);
+        else total += smh_keyb_thread<R, HP, false>(t, S, text, n, k->image, k->P, nullptr);
+    }
+    return cursor ? *cursor : total;
+}
 static uint64_t keys_any(const smh_keys *k, const uint8_t *text, uint64_t n, uint64_t blocks, uint64_t *out, uint64_t capacity, uint64_t *cursor)
 {
+    if (k->P.layout == 1) { /* the bucket image: as key_kernels.hip launch_any */
+        if (k->P.bk_old == 15) return keyb_grid<15, 2>(k, text, n, blocks, out, capacity, cursor);
+        if (k->P.bk_old == 6) return keyb_grid<6, 1>(k, text, n, blocks, out, capacity, cursor);
+        return k->P.m - 1 > 16 ? keyb_grid<0, 2>(k, text, n, blocks, out, capacity, cursor) : keyb_grid<0, 1>(k, text, n, blocks, out, capacity, cursor);
+    }
     const bool hp2 = k->P.m - 1 > 16;
     const int kb = k->P.m * k->P.bits; /* as key_kernels.hip launch_any: keys that fill their slot run the instantiation without the mask */
     if (kb == 64) return hp2 ? keys_grid<1, 2, true>(k, text, n, blocks, out, capacity, cursor) : keys_grid<1, 1, true>(k, text, n, blocks, out, capacity, cursor);

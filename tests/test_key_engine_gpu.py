@@ -10,7 +10,7 @@ import torch
 import oracle_lib as O
 import emu_lib  # noqa: F401  (puts the package directory on sys.path)
 import smatcher_hip as S
-from test_key_engine import SETS, _text_and_patterns
+from test_key_engine import BUCKET_SETS, SETS, _text_and_patterns
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -36,6 +36,34 @@ def test_kernel_counts_what_the_definition_counts(sigma, m, p):
     for cut in (0, 1, m - 1, m, 63, 4096, 4097, 8192 + 17):  # tails and texts shorter than a wave-chunk
         assert _count(k, text[:cut]) == O.count_bruteforce(pat, m, p, text[:cut]), cut
     k.close()
+
+
+@pytest.mark.parametrize("sigma,m,p", BUCKET_SETS)
+def test_both_images_of_a_set_count_the_same_on_the_device(sigma, m, p, knob):
+    """round 6: the bucket image (one LDS read per column, overflow table behind a wave-uniform branch) and the cuckoo image of the same
+    set, each forced in the testing twin, against the definition: 1 MiB with every second pattern cut from the text, ragged tails,
+    positions"""
+    T = knob.T
+    n = (1 << 20) + 4321
+    text, pat = _text_and_patterns(sigma, m, p, n)
+    want = O.count_bruteforce(pat, m, p, text)
+    for layout in (1, 0):
+        knob.set(T.TUNE_KEY, "layout=%d" % layout)
+        k = T.KeyTable(pat, m, p, sigma)
+        assert k.info().layout == layout
+        assert _count(k, text) == want > 0, layout
+        for cut in (0, m - 1, m, 4096, 4097, 8192 + 17, 3 * 4096 + 5):
+            assert _count(k, text[:cut]) == O.count_bruteforce(pat, m, p, text[:cut]), (layout, cut)
+        dev = torch.device("cuda", 0)
+        t = torch.zeros(((n + 15) // 16) * 16 + 64, dtype=torch.uint8, device=dev)
+        t[:n] = torch.from_numpy(np.ascontiguousarray(text)).to(dev)
+        out = torch.zeros(want + 8, dtype=torch.int64, device=dev)
+        cur = torch.zeros(1, dtype=torch.int64, device=dev)
+        k.positions_device(t.data_ptr(), n, out.data_ptr(), want + 8, cur.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(cur.item()) == want
+        assert np.array_equal(np.sort(out[:want].cpu().numpy()), np.sort(np.asarray(O.positions_bruteforce(pat, m, p, text), dtype=np.int64))), layout
+        k.close()
 
 
 def test_golden_vectors_of_the_reference():

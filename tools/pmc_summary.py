@@ -11,7 +11,7 @@ for path in sys.argv[1:]:
         agg = collections.OrderedDict()
         for r in rows:
             name = r["Kernel_Name"]
-            if not any(k in name for k in ("ac_dfa", "wm_block", "wm_pair", "wm_gram", "acm_kernel", "key_kernel", "hash_kernel", "k_", "stream_read")):
+            if not any(k in name for k in ("ac_dfa", "wm_block", "wm_pair", "wm_gram", "acm_kernel", "key_kernel", "keyb_kernel", "hash_kernel", "k_", "stream_read")):
                 continue
             short = name.split("(")[0].replace("void ", "")
             agg.setdefault(short, collections.OrderedDict()).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
