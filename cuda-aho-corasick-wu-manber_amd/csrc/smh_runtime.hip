@@ -206,6 +206,15 @@ extern "C" int smh_device_name(char *buf, size_t cap)
     return SMH_OK;
 }
 
+extern "C" int smh_device_pci_bus_id(char *buf, size_t cap)
+{
+    if (!buf || cap < 16) { smh_set_error("smh_device_pci_bus_id: buffer of 16 bytes or more"); return SMH_EINVAL; }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetPCIBusId(buf, (int)cap, dev));
+    return SMH_OK;
+}
+
 extern "C" int smh_device_malloc(void **dptr, uint64_t bytes)
 {
     if (!dptr) { smh_set_error("smh_device_malloc: NULL"); return SMH_EINVAL; }
@@ -1110,8 +1119,10 @@ static void host_ws_destroy(smh_host_ws *w)
 }
 
 /* frees the pooled workspaces of every device (they are kept between calls otherwise); for leak checks and tidy exits */
+static void legacy_release(void); /* the handles the legacy GPU names keep between calls (end of this file) */
 extern "C" void smh_host_path_release(void)
 {
+    legacy_release();
     smh_host_ws *w;
     {
         std::lock_guard<std::mutex> lock(g_ws_mu);
@@ -2195,11 +2206,66 @@ extern "C" unsigned search_ac(unsigned char *text, int n, struct ac_table *table
     return (unsigned)count;
 }
 
+/* The legacy GPU names take the caller's TABLES with every call (cuda/cuda_ac.cu:594, cuda/cuda_wm.cu:183) and main.c:583-592,
+ * 623-648 calls the five variants back to back on the same tables.  Until round 5 every call compiled a handle from them, sent
+ * its table set to the device and freed it.  Round 6: the last handle of each family is kept, keyed on the caller's pointers and
+ * shapes AND a digest of everything the reference's search reads from them (the transition / supply / final arrays; the patterns,
+ * SHIFT, PREFIX_size and the used entries of PREFIX_value / PREFIX_index) -- a caller that rewrites its arrays in place gets a new
+ * handle.  smh_host_path_release() frees the kept handles; smh_legacy_handle_builds() counts the compiles (tests, bench). */
+static uint64_t digest_words(uint64_t h, const void *data, size_t bytes)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+    }
+    uint64_t tail = 0;
+    if (i < bytes) memcpy(&tail, p + i, bytes - i);
+    h = (h ^ tail ^ ((uint64_t)bytes << 56)) * 0xBF58476D1CE4E5B9ull;
+    return h ^ (h >> 32);
+}
+struct legacy_key {
+    const void *ptr[5];
+    int m, p_size, alphabet;
+    uint64_t digest;
+    bool operator==(const legacy_key &o) const { return memcmp(ptr, o.ptr, sizeof ptr) == 0 && m == o.m && p_size == o.p_size && alphabet == o.alphabet && digest == o.digest; }
+};
+static std::mutex g_legacy_mu; /* the legacy names are the reference's single-threaded API: one call at a time */
+static smh_ac *g_legacy_ac = NULL;
+static smh_wm *g_legacy_wm = NULL;
+static legacy_key g_legacy_ac_key, g_legacy_wm_key;
+static std::atomic<uint64_t> g_legacy_builds{0};
+extern "C" uint64_t smh_legacy_handle_builds(void) { return g_legacy_builds.load(); }
+static void legacy_release(void)
+{
+    std::lock_guard<std::mutex> lock(g_legacy_mu);
+    if (g_legacy_ac) smh_ac_free(g_legacy_ac);
+    if (g_legacy_wm) smh_wm_free(g_legacy_wm);
+    g_legacy_ac = NULL;
+    g_legacy_wm = NULL;
+}
+
 static void cuda_ac_any(int k, int variant, int m, unsigned char *text, int n, int p_size, int alphabet,
                         int *state_transition, unsigned int *state_supply, unsigned int *state_final)
 {
-    smh_ac *ac = smh_ac_compile_tables(state_transition, state_supply, state_final, (uint64_t)m * p_size + 1,
-                                       alphabet, m);
+    std::lock_guard<std::mutex> lock(g_legacy_mu);
+    const uint64_t rows = (uint64_t)m * (uint64_t)p_size + 1u;
+    legacy_key key = {{state_transition, state_supply, state_final, NULL, NULL}, m, p_size, alphabet, 0};
+    if (state_transition && state_supply && state_final && m > 0 && p_size > 0 && alphabet > 0) {
+        key.digest = digest_words(0x5EED, state_transition, (size_t)rows * (size_t)alphabet * sizeof(int));
+        key.digest = digest_words(key.digest, state_supply, (size_t)rows * sizeof(unsigned int));
+        key.digest = digest_words(key.digest, state_final, (size_t)rows * sizeof(unsigned int));
+    }
+    if (!g_legacy_ac || !(key == g_legacy_ac_key)) {
+        if (g_legacy_ac) smh_ac_free(g_legacy_ac);
+        g_legacy_ac = smh_ac_compile_tables(state_transition, state_supply, state_final, rows, alphabet, m);
+        g_legacy_ac_key = key;
+        g_legacy_builds++;
+    }
+    smh_ac *ac = g_legacy_ac;
     if (!ac) die_with_error("cuda_ac");
     uint64_t count = 0;
     double secs = 0.0;
@@ -2208,7 +2274,6 @@ static void cuda_ac_any(int k, int variant, int m, unsigned char *text, int n, i
     /* cuda/cuda_ac.cu:675 */
     printf("Kernel %d matches \t%i\t time \t%f\n", k, (int)count, secs);
     fflush(stdout);
-    smh_ac_free(ac);
 }
 
 #define SMH_CUDA_AC(K, VARIANT)                                                                            \
@@ -2236,14 +2301,33 @@ static int alphabet_from_shiftsize(void)
 
 static unsigned int wm_any(const unsigned char *flat, int m, int p_size, int alphabet, unsigned char *text, int n,
                            int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size, int variant,
-                           double *secs)
+                           double *secs, const void *pattern_identity)
 {
-    smh_wm *wm = smh_wm_compile_tables(flat, m, p_size, alphabet, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
+    std::lock_guard<std::mutex> lock(g_legacy_mu);
+    legacy_key key = {{pattern_identity, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size}, m, p_size, alphabet, 0};
+    const uint32_t buckets = alphabet > 0 ? smh_wu_shiftsize_for(alphabet) : 0u;
+    if (flat && SHIFT && PREFIX_value && PREFIX_index && PREFIX_size && m > 0 && p_size > 0 && buckets) {
+        key.digest = digest_words(0x5EED, flat, (size_t)m * (size_t)p_size);
+        key.digest = digest_words(key.digest, SHIFT, (size_t)buckets * sizeof(int));
+        key.digest = digest_words(key.digest, PREFIX_size, (size_t)buckets * sizeof(int));
+        for (uint32_t h = 0; h < buckets; ++h) { /* the entries search_wu reads: PREFIX_size[h] of them per bucket (wu/wu.c:76-80) */
+            const int used = PREFIX_size[h] < 0 ? 0 : (PREFIX_size[h] > p_size ? p_size : PREFIX_size[h]);
+            if (!used) continue;
+            key.digest = digest_words(key.digest, PREFIX_value + (size_t)h * (size_t)p_size, (size_t)used * sizeof(int));
+            key.digest = digest_words(key.digest, PREFIX_index + (size_t)h * (size_t)p_size, (size_t)used * sizeof(int));
+        }
+    }
+    if (!g_legacy_wm || !(key == g_legacy_wm_key)) {
+        if (g_legacy_wm) smh_wm_free(g_legacy_wm);
+        g_legacy_wm = smh_wm_compile_tables(flat, m, p_size, alphabet, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size);
+        g_legacy_wm_key = key;
+        g_legacy_builds++;
+    }
+    smh_wm *wm = g_legacy_wm;
     if (!wm) die_with_error("wu-manber");
     uint64_t count = 0;
     if (smh_wm_count_host(wm, text, n < 0 ? 0 : (uint64_t)n, variant, &count, secs) != SMH_OK)
         die_with_error("wu-manber");
-    smh_wm_free(wm);
     return (unsigned int)count;
 }
 
@@ -2252,7 +2336,7 @@ extern "C" unsigned int search_wu2(unsigned char *pattern_flat, int m, int p_siz
                                    int *SHIFT, int *PREFIX_value, int *PREFIX_index, int *PREFIX_size)
 {
     return wm_any(pattern_flat, m, p_size, alphabet_from_shiftsize(), text, n, SHIFT, PREFIX_value, PREFIX_index,
-                  PREFIX_size, SMH_VARIANT_TUNED, NULL);
+                  PREFIX_size, SMH_VARIANT_TUNED, NULL, pattern_flat);
 }
 
 /* smatcher.h:105 / wu/wu.c:49-107 */
@@ -2262,7 +2346,7 @@ extern "C" unsigned int search_wu(unsigned char **pattern, int m, int p_size, un
     std::vector<unsigned char> flat((size_t)m * (size_t)p_size);
     for (int j = 0; j < p_size; ++j) memcpy(flat.data() + (size_t)j * m, pattern[j], (size_t)m);
     return wm_any(flat.data(), m, p_size, alphabet_from_shiftsize(), text, n, SHIFT, PREFIX_value, PREFIX_index,
-                  PREFIX_size, SMH_VARIANT_TUNED, NULL);
+                  PREFIX_size, SMH_VARIANT_TUNED, NULL, pattern);
 }
 
 #define SMH_CUDA_WM(K, VARIANT)                                                                              \
@@ -2273,7 +2357,7 @@ extern "C" unsigned int search_wu(unsigned char **pattern, int m, int p_size, un
         (void)B;                                                                                             \
         double secs = 0.0;                                                                                   \
         unsigned int c = wm_any(pattern_flat, m, p_size, alphabet, text, n, SHIFT, PREFIX_value, PREFIX_index, \
-                                PREFIX_size, VARIANT, &secs);                                                \
+                                PREFIX_size, VARIANT, &secs, pattern_flat);                                  \
         if (gpuTime) *gpuTime = secs; /* cuda/cuda_wm.cu:302 */                                              \
         return (int)c;                                                                                       \
     }

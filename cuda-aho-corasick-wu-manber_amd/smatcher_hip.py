@@ -112,9 +112,9 @@ LEGACY_SYMBOLS = (["fail", "preproc_ac", "search_ac", "free_ac", "wu_determine_s
                   + ["preproc_sbom", "search_sbom", "free_sbom", "pointer_array"] + ["cuda_sbom%d" % k for k in range(1, 6)]
                   + ["preproc_sog8", "search_sog8"] + ["cuda_sog%d" % k for k in range(1, 6)])
 EXT_SYMBOLS = ["smh_version", "smh_last_error", "smh_device_count", "smh_set_device",
-               "smh_device_name", "smh_device_malloc", "smh_device_free", "smh_device_memset",
+               "smh_device_name", "smh_device_pci_bus_id", "smh_device_malloc", "smh_device_free", "smh_device_memset",
                "smh_copy_to_device", "smh_copy_to_host", "smh_stream_synchronize", "smh_stream_read_probe",
-               "smh_stream_read_probe_variant", "smh_host_path_release", "smh_host_path_set_piece",
+               "smh_stream_read_probe_variant", "smh_host_path_release", "smh_host_path_set_piece", "smh_legacy_handle_builds",
                "smh_splitmix64_at", "smh_corpus_text_host", "smh_corpus_text_device",
                "smh_corpus_patterns", "smh_corpus_text_host_kind", "smh_corpus_text_device_kind", "smh_corpus_patterns_kind",
                "smh_shard_range", "smh_ac_compile_tables",
@@ -142,6 +142,7 @@ def _load():
     lib.smh_device_count.restype = C.c_int
     lib.smh_set_device.argtypes = [C.c_int]
     lib.smh_device_name.argtypes = [C.c_char_p, C.c_size_t]
+    lib.smh_device_pci_bus_id.argtypes = [C.c_char_p, C.c_size_t]
     lib.smh_device_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
     lib.smh_device_free.argtypes = [C.c_void_p]
     lib.smh_device_memset.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p]
@@ -152,6 +153,8 @@ def _load():
     lib.smh_stream_read_probe_variant.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
     lib.smh_host_path_release.restype = None
     lib.smh_host_path_release.argtypes = []
+    lib.smh_legacy_handle_builds.restype = C.c_uint64
+    lib.smh_legacy_handle_builds.argtypes = []
     lib.smh_host_path_set_piece.restype = C.c_uint64
     lib.smh_host_path_set_piece.argtypes = [C.c_uint64]
     lib.smh_splitmix64_at.restype = C.c_uint64
@@ -365,6 +368,13 @@ def device_count():
 def device_name():
     buf = C.create_string_buffer(256)
     _check(lib.smh_device_name(buf, 256), "smh_device_name")
+    return buf.value.decode()
+
+
+def device_pci_bus_id():
+    """domain:bus:device.function of the current device"""
+    buf = C.create_string_buffer(64)
+    _check(lib.smh_device_pci_bus_id(buf, 64), "smh_device_pci_bus_id")
     return buf.value.decode()
 
 

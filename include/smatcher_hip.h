@@ -55,6 +55,8 @@ const char *smh_last_error(void);
 int smh_device_count(void); /* 0 when there is no GPU or no HIP runtime */
 int smh_set_device(int device);
 int smh_device_name(char *buf, size_t cap);
+/* "domain:bus:device.function" of the CURRENT device (hipDeviceGetPCIBusId): what tells two ranks' cards apart in a record */
+int smh_device_pci_bus_id(char *buf, size_t cap);
 int smh_device_malloc(void **dptr, uint64_t bytes);
 int smh_device_free(void *dptr);
 int smh_device_memset(void *dptr, int value, uint64_t bytes, void *stream);
@@ -77,6 +79,11 @@ int smh_stream_read_probe_variant(const void *d_buf, uint64_t bytes, uint64_t *d
  * nothing and needs 2 x (64 MiB + m) of device memory whatever the text's length.  The workspaces stay allocated
  * between calls; this frees them (call it with no *_count_host / legacy call in flight). */
 void smh_host_path_release(void);
+/* The legacy GPU names of smatcher.h (cuda_ac1..5, cuda_wm1..5, search_wu, search_wu2) take the caller's tables with every call; the
+ * library keeps the handle it compiled from them (and its table set on the device) until a call arrives with other pointers,
+ * shapes or contents -- main.c:583-592,623-648 runs the five variants back to back on the same tables: one compile, one upload.
+ * smh_host_path_release() frees the kept handles as well.  This counts the compiles so far (tests, bench.py `preproc`). */
+uint64_t smh_legacy_handle_builds(void);
 /* Piece size of that path in bytes (rounded down to 4 KiB, at least 4 KiB); 0 = back to the default.  Returns the size in
  * force before the call.  Tests shrink the pieces so that a small text has hundreds of piece boundaries; counts never depend
  * on it.  Takes effect for calls that start afterwards. */

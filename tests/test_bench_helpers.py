@@ -71,3 +71,37 @@ def test_last_line_is_short_and_carries_roofline_and_cpu_baseline():
     fat["config"] = dict(rec["config"], workload="x" * 5000)
     line = bench.compact_line(fat, "bench_detail.json", "0" * 64)
     assert len(line) < 4096 and {"roofline", "cpu_baseline", "value"} <= set(json.loads(line))
+
+
+def test_line_says_who_ran_and_whether_the_run_held():
+    """Round 6: the N > 1 record carries the backend and world size torch.distributed reports
+    and one card identity per rank; `parity_ok` / `smh_multi_ok` / `error` are in the part of the line that is never dropped."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_final", "bench_detail.json")))
+    ranks = [dict(rank=i, local_rank=i, device=i, pci_bus_id="0000:%02x:00.0" % (0x10 + i), uuid="GPU-%d" % i, host="node", pid=100 + i) for i in range(8)]
+    rec.update(parity_ok=True, smh_multi_ok=False, error="x" * 2000,
+               world=dict(world_size=8, backend="nccl", distinct_cards=8, rehearsal=False, ranks=ranks))
+    rec["skewed"] = dict(rec["skewed"], **{"corpus%d" % i: rec["skewed"]["dna_repeats"] for i in range(200)})  # bloat: optional groups go
+    got = json.loads(bench.compact_line(rec, "bench_detail.json", "0" * 64))
+    assert got["parity_ok"] is True and got["smh_multi_ok"] is False and len(got["error"]) == 300
+    w = got["world"]
+    assert w["world_size"] == 8 and w["backend"] == "nccl" and w["distinct_cards"] == 8 and w["rehearsal"] is False
+    assert [r["pci_bus_id"] for r in w["ranks"]] == [r["pci_bus_id"] for r in ranks] and set(w["ranks"][0]) == {"rank", "local_rank", "device", "pci_bus_id"}
+    # the six-rank one-card rehearsal: six identical bus ids, gloo, flagged
+    reh = dict(rec, world=dict(world_size=6, backend="gloo", distinct_cards=1, rehearsal=True, ranks=[dict(r, local_rank=0, device=0, pci_bus_id="0000:75:00.0") for r in ranks[:6]]))
+    w = json.loads(bench.compact_line(reh))["world"]
+    assert w["backend"] == "gloo" and w["rehearsal"] is True and w["distinct_cards"] == 1 and len({r["pci_bus_id"] for r in w["ranks"]}) == 1
+
+
+def test_sharding_label_names_the_collective_that_ran():
+    assert "no collective" in bench.sharding_label(1, None, False)
+    assert "RCCL" in bench.sharding_label(8, "nccl", False) and "x8" in bench.sharding_label(8, "nccl", False)
+    lab = bench.sharding_label(6, "gloo", True)
+    assert "gloo" in lab and "RCCL" not in lab and "REHEARSAL" in lab
+
+
+def test_small_text_and_preproc_reach_the_line():
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r05_final", "bench_detail.json")))
+    rec["small_text"] = {"workload": "w", "E.coli": {"bytes": 4628736, "alphabet": 4, "ac_1000_m8": {"of_gib_rate": 0.2}, "wm_8000_m8": {"of_gib_rate": 0.19}}}
+    rec["preproc"] = {"what": "w", "sets": {"ac_1000_m8": {"preproc_s": 0.01}}}
+    got = json.loads(bench.compact_line(rec))
+    assert got["small_text_of_gib_rate"] == {"E.coli": [0.2, 0.19]} and got["preproc_s"] == {"ac_1000_m8": 0.01}

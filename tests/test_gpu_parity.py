@@ -83,9 +83,13 @@ def test_legacy_api_reads_like_the_reference_driver(capfd):
     assert S.lib.search_ac(tp, n, tab) == want
     S.lib.free_ac(tab, sigma)
     capfd.readouterr()
+    S.lib.smh_host_path_release()
+    builds = S.lib.smh_legacy_handle_builds()
     for k in range(1, 6):
         getattr(S.lib, "cuda_ac%d" % k)(m, tp, n, p, sigma, t.state_transition.ctypes.data_as(S.i32p),
                                         t.state_supply.ctypes.data_as(S.u32p), t.state_final.ctypes.data_as(S.u32p))
+    # round 6: main.c:583-592's five back-to-back calls on the same tables compile ONE handle and send ONE table set
+    assert S.lib.smh_legacy_handle_builds() == builds + 1
     lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("Kernel")]
     assert len(lines) == 5
     for k, ln in enumerate(lines, 1):
@@ -101,10 +105,27 @@ def test_legacy_api_reads_like_the_reference_driver(capfd):
     for j in range(p):
         parr[j] = C.cast(prow[j].ctypes.data, S.u8p)
     assert S.lib.search_wu(parr, m, p, tp, n, *w.ptrs()) == want
+    builds = S.lib.smh_legacy_handle_builds()
     for k in range(1, 6):
         secs = C.c_double(0)
         got = getattr(S.lib, "cuda_wm%d" % k)(pat.ctypes.data_as(S.u8p), m, tp, n, p, sigma, 3, *w.ptrs(), C.byref(secs))
         assert got == want and secs.value > 0
+    # main.c:623-648: ONE handle serves all five (search_wu above came with another pattern pointer: cuda_wm1 compiled, 2..5 reused)
+    assert S.lib.smh_legacy_handle_builds() == builds + 1
+    # the caller rewrites its arrays IN PLACE (same pointers): other contents, another handle, the other count
+    half = p // 2
+    pat2 = pat.copy()
+    pat2[half * m:] = pat2[:(p - half) * m]  # the second half repeats the first: fewer distinct patterns
+    pat[:] = pat2
+    w2 = O.WMTables(m, p, sigma, S.shiftsize_global())
+    S.lib.preproc_wu2(pat.ctypes.data_as(S.u8p), m, p, sigma, 3, *w2.ptrs())
+    for name in ("SHIFT", "PREFIX_value", "PREFIX_index", "PREFIX_size"):
+        getattr(w, name)[:] = getattr(w2, name)
+    want2 = O.count_bruteforce(pat, m, p, text)
+    secs = C.c_double(0)
+    assert S.lib.cuda_wm5(pat.ctypes.data_as(S.u8p), m, tp, n, p, sigma, 3, *w.ptrs(), C.byref(secs)) == want2 != want
+    assert S.lib.smh_legacy_handle_builds() == builds + 2
+    S.lib.smh_host_path_release()
 
 
 def test_device_resident_text_and_streams():
