@@ -26,6 +26,7 @@
 #define SMH_HASH_BASE 0x5BD1E9u    /* B: odd, 24 bits */
 #define SMH_HASH_MAX_M 32          /* the window's dwords: nine aligned ones cover 33 bytes at any alignment */
 #define SMH_HASH_MIN_M 4
+#define SMH_HASH_MUL3 0xC2B2AFu    /* the third filter bit's index: the top five bits of the low 24 bits of h times this (one v_mul_u32_u24) */
 
 struct smh_hash_params {
     int m;
@@ -37,6 +38,7 @@ struct smh_hash_params {
                             * where one-slot buckets place 42 % -- half the table, and the probes are random 128-byte line fills of
                             * a table that should stay in L2 */
     uint32_t seed;         /* of the slot hashes: the builder retries with another one when the patterns do not place */
+    uint32_t bloom_k;      /* filter bits per window: 2, or (round 6) 3 -- the third one at bit (((h & 0xFFFFFF) * SMH_HASH_MUL3) >> 27) of the same word */
     uint32_t slot_dwords;  /* (m + 3) / 4: a slot is the pattern zero-padded to whole dwords, slots back to back (a table that is a third smaller
                             * than with 16 / 32-byte slots stays in L2 that much better: the probes are random 128-byte line fills) */
 };
@@ -53,7 +55,8 @@ SMH_HASH_FN uint32_t smh_hash_mad24(uint32_t a, uint32_t b, uint32_t c) { return
 SMH_HASH_FN uint32_t smh_hash_in(uint32_t h, uint32_t byte) { return smh_hash_mad24(h, SMH_HASH_BASE, byte); }
 /* ... and the byte m places back leaves it */
 SMH_HASH_FN uint32_t smh_hash_out(uint32_t h, uint32_t byte, uint32_t neg_bm) { return smh_hash_mad24(byte, neg_bm, h); }
-/* the window's two filter bits: bit (h & 31) and bit ((h >> 5) & 31) of the word at byte address (h >> shift) & mask */
+/* the window's filter bits: bit (h & 31), bit ((h >> 5) & 31) and -- bloom_k = 3 -- bit smh_hash_bit3(h) of the word at byte address (h >> shift) & mask */
+SMH_HASH_FN uint32_t smh_hash_bit3(uint32_t h) { return smh_hash_mad24(h, SMH_HASH_MUL3, 0u) >> 27; }
 SMH_HASH_FN uint32_t smh_hash_word_addr(uint32_t h, uint32_t shift, uint32_t mask) { return (h >> shift) & mask; }
 
 /* the two slots of a window whose verify-stage hash (wm_lane.h smh_wm_tag_dwords == wm_host.c smh_wm_tag) is `tag` */

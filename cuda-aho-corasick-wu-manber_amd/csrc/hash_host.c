@@ -62,23 +62,45 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
     /* buckets of two slots, two tables: 4 N slots for `distinct` patterns at 82 % */
     uint32_t N = (uint32_t)((double)distinct / (4.0 * 0.82)) + 4u;
     P.slots = N;
-    k->bloom = (uint32_t *)calloc(1, P.bloom_bytes);
     const size_t slot_bytes = 4u * (size_t)P.slot_dwords;
     k->table_bytes = 4u * (size_t)N * slot_bytes;
     k->table = (unsigned char *)calloc(1, k->table_bytes + 64);
     uint32_t *slot_of = (uint32_t *)calloc(4u * (size_t)N, sizeof(uint32_t)); /* [2 * bucket + slot], buckets of table 2 behind table 1's */
-    if (!k->bloom || !k->table || !slot_of) { free(slot_of); smh_hash_free(k); *why = "out of memory"; return NULL; }
-    for (int j = 0; j < distinct; ++j) {
-        const uint32_t h = hash_roll(patterns + (size_t)j * (size_t)m, m);
-        uint32_t *w = k->bloom + (smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask) >> 2);
-        *w |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u));
+    if (!k->table || !slot_of) { free(slot_of); smh_hash_free(k); *why = "out of memory"; return NULL; }
+    /* The filter, with two bits per window and with three (round 6).  A non-matching window passes when all of its bits are set:
+     * about (bits set / bits)^k, more for the uneven words -- SAMPLED on the finished filter (65536 pseudo-random hashes), not
+     * modelled.  The third bit costs the scan four vector instructions per column (0.36 -> 0.42 ms/GiB with the candidates dropped)
+     * and spares stage 2 the candidates it removes: 100 000 byte patterns 5.0 % -> 3.3 % of the non-matching windows, 0.83 -> 0.71
+     * ms/GiB on uniform text and 0.93 / 1.02 / 1.46 -> 0.90 / 0.95 / 1.31 on natural-language-like text (m = 8 / 12 / 20), while 30 000
+     * patterns (1.6 % -> 1.1 %) lose 4 % (profiles/r06_key/notes/ab_hash_third_bit.log): whichever estimate is lower is built. */
+    const int forced_k = smh_tune_int(SMH_TUNE_HASH, "bits=", 0); /* testing library only: "bits=2|3" */
+    double best_ms = 0.0;
+    for (uint32_t bits = 2; bits <= 3u; ++bits) {
+        if (forced_k >= 2 && forced_k <= 3 && (uint32_t)forced_k != bits) continue;
+        uint32_t *bloom = (uint32_t *)calloc(1, P.bloom_bytes);
+        if (!bloom) { free(slot_of); smh_hash_free(k); *why = "out of memory"; return NULL; }
+        for (int j = 0; j < distinct; ++j) {
+            const uint32_t h = hash_roll(patterns + (size_t)j * (size_t)m, m);
+            bloom[smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask) >> 2] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u)) | (bits >= 3u ? 1u << smh_hash_bit3(h) : 0u);
+        }
+        uint32_t pass = 0, x = 0x2545F491u;
+        for (int i = 0; i < 65536; ++i) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            const uint32_t h = x & 0xFFFFFFu, w = bloom[smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask) >> 2];
+            pass += (w >> (h & 31u)) & (w >> ((h >> 5) & 31u)) & (bits >= 3u ? w >> smh_hash_bit3(h) : 1u) & 1u;
+        }
+        const double rate = (double)pass / 65536.0;
+        const double ms = (bits >= 3u ? SMH_HASHES_MS_SCAN3 : SMH_HASHES_MS_SCAN) + SMH_HASHES_MS_PER_SURVIVOR * 4096.0 * rate;
+        if (!k->bloom || ms < best_ms) {
+            free(k->bloom);
+            k->bloom = bloom;
+            k->pass_rate = rate;
+            P.bloom_k = bits;
+            best_ms = ms;
+        } else {
+            free(bloom);
+        }
     }
-    uint64_t set = 0;
-    for (uint32_t i = 0; i < P.bloom_bytes / 4u; ++i) set += (uint64_t)__builtin_popcount(k->bloom[i]);
-    /* a non-matching window passes when both of its bits are set: about (bits set / bits)^2, more for the uneven words (measured
-     * 5.2 % at 100 000 patterns where the plain square says 3.0 %) */
-    const double load = (double)set / (8.0 * (double)P.bloom_bytes);
-    k->pass_rate = 1.7 * load * load;
     /* cuckoo placement of the patterns (random walk); a set that does not place is retried under another seed */
     int ok = 0;
     uint64_t rng = 0x9E3779B97F4A7C15ull;
@@ -132,7 +154,7 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
     k->distinct = (uint32_t)distinct;
     k->P = P;
     /* scan 0.43 ms/GiB (twelve VALU and one LDS read per column) + two round trips per surviving column: measured (round 5) */
-    k->ms_est = SMH_HASHES_MS_SCAN + SMH_HASHES_MS_PER_SURVIVOR * 4096.0 * k->pass_rate;
+    k->ms_est = (P.bloom_k >= 3u ? SMH_HASHES_MS_SCAN3 : SMH_HASHES_MS_SCAN) + SMH_HASHES_MS_PER_SURVIVOR * 4096.0 * k->pass_rate;
     return k;
 }
 
@@ -141,7 +163,7 @@ int smh_hash_filter_passes(const struct smh_hashes *k, const unsigned char *wind
 {
     const uint32_t h = hash_roll(window, k->m);
     const uint32_t w = k->bloom[smh_hash_word_addr(h, k->P.bloom_shift, k->P.bloom_mask) >> 2];
-    return (int)((w >> (h & 31u)) & (w >> ((h >> 5) & 31u)) & 1u);
+    return (int)((w >> (h & 31u)) & (w >> ((h >> 5) & 31u)) & (k->P.bloom_k >= 3u ? w >> smh_hash_bit3(h) : 1u) & 1u);
 }
 int smh_hash_contains(const struct smh_hashes *k, const unsigned char *window)
 {

@@ -15,7 +15,7 @@
 
 #define SMH_HASH_QUEUES ((SMH_BLOCK_THREADS / 64) * SMH_HASH_QCAP * 4u)
 
-template <bool POS, int ND>
+template <bool POS, int ND, bool K3>
 __global__ __launch_bounds__(SMH_BLOCK_THREADS) void hash_kernel(smh_hash_ctx C, const uint32_t *__restrict__ bloom_g, uint64_t *count,
                                                                 smh_pos_out po, smh_stats_arg SA)
 {
@@ -31,14 +31,14 @@ __global__ __launch_bounds__(SMH_BLOCK_THREADS) void hash_kernel(smh_hash_ctx C,
     const uint64_t gthread = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t *queue = reinterpret_cast<uint32_t *>(smh_lds + C.P.bloom_bytes) + (threadIdx.x >> 6) * SMH_HASH_QCAP;
     uint32_t events = 0;
-    const uint32_t cnt = smh_hash_thread<POS, ND>(gthread, S, C, smh_lds, queue, &po, &events);
+    const uint32_t cnt = smh_hash_thread<POS, ND, K3>(gthread, S, C, smh_lds, queue, &po, &events);
     if constexpr (!POS) smh_block_finish(cnt, count, smh_lds, S.ctr_off, C.n, events); /* positions mode: the cursor is the count */
 }
 
-template <bool POS, int ND>
+template <bool POS, int ND, bool K3 = false>
 static hipError_t launch(const smh_hash_launch &L, hipStream_t stream)
 {
-    auto kern = hash_kernel<POS, ND>;
+    auto kern = hash_kernel<POS, ND, K3>;
     const uint32_t lds = L.C.P.bloom_bytes + SMH_HASH_QUEUES + 16u + SMH_SCHED_LDS;
     static smh_attr_cache cache;
     int per_cu = 0;
@@ -59,6 +59,19 @@ static hipError_t launch(const smh_hash_launch &L, hipStream_t stream)
 template <bool POS>
 static hipError_t launch_nd(const smh_hash_launch &L, hipStream_t stream)
 {
+    if constexpr (!POS) {
+        if (L.C.P.bloom_k >= 3u) /* the counting kernels test the filter's third bit (positions: two, stage 2 decides either way) */
+            switch ((L.C.P.m + 3) / 4) {
+            case 1: return launch<POS, 1, true>(L, stream);
+            case 2: return launch<POS, 2, true>(L, stream);
+            case 3: return launch<POS, 3, true>(L, stream);
+            case 4: return launch<POS, 4, true>(L, stream);
+            case 5: return launch<POS, 5, true>(L, stream);
+            case 6: return launch<POS, 6, true>(L, stream);
+            case 7: return launch<POS, 7, true>(L, stream);
+            default: return launch<POS, 8, true>(L, stream);
+            }
+    }
     switch ((L.C.P.m + 3) / 4) {
     case 1: return launch<POS, 1>(L, stream);
     case 2: return launch<POS, 2>(L, stream);

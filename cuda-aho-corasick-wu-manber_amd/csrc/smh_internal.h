@@ -216,6 +216,7 @@ struct smh_hashes {
     struct smh_hash_dev *dev;
 };
 #define SMH_HASHES_MS_SCAN 0.43
+#define SMH_HASHES_MS_SCAN3 0.50 /* round 6: with the third filter bit (four more vector instructions per column: +0.065 ms/GiB measured) */
 #define SMH_HASHES_MS_PER_SURVIVOR 0.0020 /* ms per GiB per surviving column in 4 KiB: 100 000 patterns of 12 bytes, 213 per 4 KiB on uniform text 0.87 ms/GiB against 0.43 with the survivors dropped (profiles/r05_final/notes) */
 struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int distinct, const char **why);
 void smh_hash_free(struct smh_hashes *k);

@@ -682,9 +682,9 @@ extern "C" uint64_t emu_hash_scan(const smh_wm *wm, const uint8_t *text_in, uint
             const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
             uint32_t ev = 0;
             switch ((k->m + 3) / 4) { /* as hash_kernels.hip launch_nd */
-#define EMU_HASH_ND(ND) case ND: if (out) smh_hash_thread<true, ND>(t, S, C, k->bloom, nullptr, &po, &ev); else total += smh_hash_thread<false, ND>(t, S, C, k->bloom, nullptr, nullptr, &ev); break;
+#define EMU_HASH_ND(ND) case ND: if (out) smh_hash_thread<true, ND>(t, S, C, k->bloom, nullptr, &po, &ev); else if (k->P.bloom_k >= 3u) total += smh_hash_thread<false, ND, true>(t, S, C, k->bloom, nullptr, nullptr, &ev); else total += smh_hash_thread<false, ND>(t, S, C, k->bloom, nullptr, nullptr, &ev); break;
             EMU_HASH_ND(1) EMU_HASH_ND(2) EMU_HASH_ND(3) EMU_HASH_ND(4) EMU_HASH_ND(5) EMU_HASH_ND(6) EMU_HASH_ND(7)
-            default: if (out) smh_hash_thread<true, 8>(t, S, C, k->bloom, nullptr, &po, &ev); else total += smh_hash_thread<false, 8>(t, S, C, k->bloom, nullptr, nullptr, &ev); break;
+            default: if (out) smh_hash_thread<true, 8>(t, S, C, k->bloom, nullptr, &po, &ev); else if (k->P.bloom_k >= 3u) total += smh_hash_thread<false, 8, true>(t, S, C, k->bloom, nullptr, nullptr, &ev); else total += smh_hash_thread<false, 8>(t, S, C, k->bloom, nullptr, nullptr, &ev); break;
 #undef EMU_HASH_ND
             }
             events += ev;

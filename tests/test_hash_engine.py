@@ -122,3 +122,24 @@ def test_golden_vectors_of_the_reference_through_the_lane_code():
             taken += 1
         wm.close()
     assert taken >= 8, taken
+
+
+@pytest.mark.parametrize("sigma,m,p", [(256, 12, 2000), (256, 20, 5000), (256, 9, 300), (20, 16, 1000), (256, 32, 300)])
+def test_three_filter_bits_pass_fewer_windows_and_count_the_same(sigma, m, p, knob):
+    """Round 6: a third bit per window in the same filter word (hash_engine.h bloom_k = 3; testing twin: the count of bits is a
+    development knob).  Same count, every match still passes the filter, fewer non-matching windows do."""
+    T = knob.T
+    n = 3 * 4096 + 2345
+    text, pat = _case(sigma, m, p, n)
+    want = O.count_bruteforce(pat, m, p, text)
+    passed = {}
+    for bits in (2, 3):
+        knob.set(T.TUNE_HASH, "bits=%d" % bits)
+        wm = T.WmTables.from_patterns(pat, m, p, sigma)
+        got, passed[bits] = E.hash_scan(wm, text)
+        assert got == want and passed[bits] >= want, bits
+        assert E.hash_scan(wm, text, blocks=1)[0] == want
+        total, pos = E.hash_positions(wm, text, want + 8) if hasattr(E, "hash_positions") else (want, None)
+        assert total == want
+        wm.close()
+    assert passed[3] <= passed[2]
