@@ -480,6 +480,16 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
  * get a gram filter at all (m = 5..7 had the 12-VALU blocked-Bloom test), m = 8 a better one; from ten grams on the set is
  * fuller than the planes and SMH_GRAM_BYTE wins.  Costs two VALU more per column than SMH_GRAM_BYTE (bit index, bit). */
 #define SMH_GRAM_FLAT 6
+/* Round 6: SMH_GRAM_BYTE with a table of 143.9 KiB instead of 128 -- what LDS holds beside the 16 KiB of survivor queues the
+ * windows-from-L2 verify keeps (wm_kernels.inc smh_gram_lds).  A plane of 100 000 grams is 49 % full instead of 53 %, and eight
+ * planes in a row pass 0.35 % of random columns instead of 0.66 %: nearly half the verify stage's work.  The table has no power-of-
+ * two size: its index is (v_mul_hi_u32_u24(product, dwords << 8) << 2) | (product >> 30) -- the multiply yields 16 bits, hence
+ * dwords, and one v_alignbit puts the product's top two bits under it as the byte -- ONE vector instruction more per column than
+ * the top-17-bits index (profiles/r06_key/notes/ab_byte_gram_big_table.log).  Only with the windows-from-L2 verify (no room for
+ * staging buffers): sets whose filter passes more than its pipeline takes keep SMH_GRAM_BYTE. */
+#define SMH_GRAM_BYTE_BIG 8
+#define SMH_GRAM_BIG_BYTES 147392u
+#define SMH_GRAM_BIG_INDEX(prod) ((((uint32_t)(((uint64_t)((prod) & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES / 4u) << 8)) >> 32)) << 2) | ((uint32_t)(prod) >> 30))
 /* candidates per column above which the grouped form is not used.  Round 4: 0.0005 -> 0.002.  A candidate is now decided by the
  * suffix index (one 32-byte record, wm_host.c smh_wm_build_gram_mixed) instead of one window hash, bucket and compare per length
  * class; measured on 1 GiB (profiles/r04_final/notes/mixed_grouped.log): 40 patterns of each length 9..32 (0.0008 per column)

@@ -196,7 +196,8 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
             k0 = k1;
             k1 = c;
-            G = ((const uint8_t *)tab)[(uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15];
+            const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
+            G = ((const uint8_t *)tab)[kind == SMH_GRAM_BYTE_BIG ? SMH_GRAM_BIG_INDEX(prod) : prod >> 15];
         }
         S = (S << 1) | G;                                           /* shift-or: candidate bit clear = candidate */
         if (x >= 32) hits += ((S >> cand_bit) & 1u) ^ 1u;
@@ -212,6 +213,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
 #define SMH_GRAM_OCT_MS 0.24 /* 0.218 at 2000 patterns .. 0.243 at 12 000 with next to no survivors (lane 0 of a wave-chunk keeps the assumption) */
 #define SMH_GRAM_OCT2_MS 0.178 /* the pair form's lookups + lane 0's inherited state from the halo in every chunk */
 #define SMH_GRAM_BYTE_MS 0.238
+#define SMH_GRAM_BYTE_BIG_MS 0.243 /* one vector instruction more per column (the index), under the LDS lookup's shadow */
 #define SMH_GRAM_FLAT_MS 0.27 /* SMH_GRAM_BYTE's lookup per column + two VALU (bit index, bit) */
 /* verify stage, ms per GiB for a fraction `dens` of surviving columns.  Staged (m <= 33: window hashes from the LDS
  * copy of the chunk, probe pipelined): the cost is mostly per wave-chunk that has any survivor -- lock, copy, hash
@@ -339,23 +341,31 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
     /* (round 4: from nine symbols up, not only for byte alphabets -- a symbol is a byte of text whatever the alphabet, and on
      * the 20-letter alphabet a plane of 1000 patterns' 3-symbol grams holds 12 % of the 8000 possible ones: eight planes let
      * nothing through, where the direct filter on the last four symbols passed 0.6 % of the columns to the verify stage) */
-    if (wm->bits_per_symbol >= 4 && m >= 5 && GRAM_WANTED(SMH_GRAM_BYTE)) {
+    for (int big = 0; big <= 1; ++big) {
+        /* SMH_GRAM_BYTE, and (round 6) the same planes in the 143.9 KiB table SMH_GRAM_BYTE_BIG: windows of up to 33 bytes (its verify
+         * is the windows-from-L2 pipeline) and sets that leave its pipeline room (launch_gram, wm_kernels.inc: 56 per 4 KiB chunk) */
+        const int kind = big ? SMH_GRAM_BYTE_BIG : SMH_GRAM_BYTE;
+        if (!(wm->bits_per_symbol >= 4 && m >= 5 && GRAM_WANTED(kind))) continue;
+        if (big && m - 1 > 32) continue;
+        const size_t bytes = big ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES;
         int J = m - 2;
         if (J > 8) J = 8;
-        uint8_t *tab = (uint8_t *)malloc(SMH_GRAM_BYTES);
+        uint8_t *tab = (uint8_t *)malloc(bytes);
         if (!tab) { free(best); return -1; }
-        memset(tab, 0xFF & ~((1 << (8 - J)) - 1), SMH_GRAM_BYTES);
+        memset(tab, 0xFF & ~((1 << (8 - J)) - 1), bytes);
         for (int p = 0; p < d; ++p)
             for (int j = 0; j < J; ++j) {
                 const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
                 const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
-                const uint32_t idx = (uint32_t)((uint64_t)key * SMH_GRAM_MUL) >> 15; /* low 32 bits of the product, top 17 */
+                const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL); /* low 32 bits of the product */
+                const uint32_t idx = big ? SMH_GRAM_BIG_INDEX(prod) : prod >> 15; /* (the top 17) */
                 tab[idx] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_BYTE, tab, wm->alphabet, J), ms = SMH_GRAM_BYTE_MS + gram_verify_ms(m, dens);
+        const double dens = gram_survivors(kind, tab, wm->alphabet, J), ms = (big ? SMH_GRAM_BYTE_BIG_MS : SMH_GRAM_BYTE_MS) + gram_verify_ms(m, dens);
+        if (big && force != SMH_GRAM_BYTE_BIG && dens * 4096.0 > 40.0) { free(tab); continue; } /* (its pipeline would overflow: the staged verify of SMH_GRAM_BYTE is the faster one there) */
         if (ms < best_ms) {
             free(best);
-            best = tab; best_kind = SMH_GRAM_BYTE; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
+            best = tab; best_kind = kind; best_planes = J; best_bytes = (uint32_t)bytes; best_ms = ms; best_dens = dens;
         } else {
             free(tab);
         }
@@ -1000,7 +1010,7 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
     out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
-    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : SMH_GRAM_BYTES;
+    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : (wm->gram_kind == SMH_GRAM_BYTE_BIG ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES);
     return SMH_OK;
 }
 

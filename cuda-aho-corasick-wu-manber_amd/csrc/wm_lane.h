@@ -28,6 +28,7 @@
 
 #define SMH_WM_HASH_MUL 0x9E3779B1u /* == SMH_HASH_MUL in smh_internal.h */
 #define SMH_GRAM_MUL_DEV 0xD6E8FFu  /* == SMH_GRAM_MUL in smh_internal.h */
+#define SMH_GRAM_BIG_BYTES_DEV 147392u /* == SMH_GRAM_BIG_BYTES in smh_internal.h: the table of KIND 8 (hashed byte grams, 143.9 KiB) */
 #include <utility>
 
 struct smh_wm_params {
@@ -1583,11 +1584,23 @@ SMH_LANE uint32_t smh_gram_key(const uint32_t (&w)[16], uint32_t pre)
  *   KIND 6  (round 3, SMH_GRAM_FLAT) ONE set for the grams of all offsets, a 2^20-bit array: byte address = the same 17
  *           bits, bit = the three below them; the array holds the set INVERTED, so a sign-extending 1-bit field extract
  *           yields 0 (in the set) or all ones (not), masked to the J plane bits `gmask` -- every plane tests the same set */
+/* KIND 8 (round 6): KIND 2 with a table of SMH_GRAM_BIG_BYTES bytes -- index = the product's low 24 bits scaled to the table's
+ * DWORDS (v_mul_hi_u32_u24 yields 16 bits), the product's top two bits as the byte: == SMH_GRAM_BIG_INDEX in smh_internal.h */
+SMH_LANE uint32_t smh_gram_big_index(uint32_t prod)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    uint32_t dw;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(dw) : "v"(prod), "s"((SMH_GRAM_BIG_BYTES_DEV / 4u) << 8));
+    return __builtin_amdgcn_alignbit(dw, prod, 30u); /* (dw << 2) | (prod >> 30) */
+#else
+    return ((uint32_t)(((uint64_t)(prod & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES_DEV / 4u) << 8)) >> 32) << 2) | (prod >> 30);
+#endif
+}
 template <int KIND>
 SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask, bool k2 = false)
 {
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
-    const uint32_t b = smh_lds_u8(tab, prod >> 15);
+    const uint32_t b = smh_lds_u8(tab, KIND == 8 ? smh_gram_big_index(prod) : prod >> 15);
     if constexpr (KIND == 6) { /* the bounds-checked path (the fast path: smh_flat_columns); k2: a gram has TWO bits in its byte */
         uint32_t out = b >> ((prod >> 12) & 7u);
         if (k2) out |= b >> ((prod >> 9) & 7u);
@@ -1746,7 +1759,7 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
         if (a < 10) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
             const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
-            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : 2>(key, tab, gmask, k2));
+            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : (KIND == 8 ? 8 : 2)>(key, tab, gmask, k2));
         }
     }
     return S & 0x7Fu;
@@ -2167,7 +2180,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
                 G = g;
             } else {
                 const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
-                G = smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : 2>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), KIND == 7);
+                G = smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : (KIND == 8 ? 8 : 2)>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), KIND == 7);
             }
         }
         T = smh_gram_step(T, G);

@@ -284,6 +284,8 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
             total += stg == 5 ? GRAM_CALL(5, 5) : stg == 6 ? GRAM_CALL(5, 6) : GRAM_STG(5);
         else if (wm->gram_kind == SMH_GRAM_OCT)
             total += GRAM_STG(3);
+        else if (wm->gram_kind == SMH_GRAM_BYTE_BIG) /* the 143.9 KiB table: windows from L2 always (wm_kernels.inc launch_gram) */
+            total += stg == 1 ? GRAM_CALL(8, 3) : GRAM_CALL(8, 4);
         else if (wm->gram_kind == SMH_GRAM_FLAT || wm->gram_kind == SMH_GRAM_BYTE) {
             /* the byte forms: windows from L2 (STG 3 / 4) unless SMH_WM_TUNE says "l2=0", as launch_gram */
             const char *tn = getenv("SMH_WM_TUNE");

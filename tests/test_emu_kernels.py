@@ -127,7 +127,8 @@ def test_grid_size_does_not_change_the_count():
                                             (6, 256, 5, 300), (6, 256, 6, 3000), (6, 256, 7, 100), (6, 256, 8, 5000), (6, 128, 7, 100), (6, 256, 12, 3000), (6, 256, 20, 500),
                                             (5, 4, 11, 30), (5, 4, 12, 200), (5, 4, 16, 8000), (5, 4, 17, 500), (5, 4, 18, 3000), (5, 4, 23, 20000), (5, 4, 24, 100), (5, 4, 33, 50),
                                             (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
-                                            (2, 128, 7, 100)])
+                                            (2, 128, 7, 100),
+                                            (8, 256, 5, 300), (8, 256, 12, 3000), (8, 256, 17, 2000), (8, 256, 20, 500), (8, 256, 33, 200), (8, 20, 10, 500)])
 def test_gram_filter_forms(kind, sigma, m, p, knob):
     """The three q-gram shift-or forms (symbol pairs, 8-symbol grams, hashed byte grams), each forced with the
     development knob so the test does not depend on the cost model: random text with planted occurrences,
@@ -144,7 +145,8 @@ def test_gram_filter_forms(kind, sigma, m, p, knob):
     pat[p // 2] = pat[0]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
     info = wm.info()
-    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2}[kind]) and info.gram_kind == kind
+    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2}[kind]) and info.gram_kind == kind
+    assert info.lds_bytes == {3: 65536, 8: 147392}.get(kind, 131072)
     if info.scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)

@@ -469,7 +469,8 @@ def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, knob):
                                             (6, 256, 5, 3000), (6, 256, 6, 100000), (6, 256, 7, 100), (6, 256, 8, 30000), (6, 256, 17, 1000), (6, 256, 33, 2000),
                                             (5, 4, 11, 30), (5, 4, 16, 8000), (5, 4, 17, 6000), (5, 4, 18, 300), (5, 4, 23, 20000), (5, 4, 33, 50),
                                             (2, 256, 12, 30000), (2, 256, 17, 100000), (2, 256, 18, 1000), (2, 256, 33, 2000),
-                                            (2, 256, 34, 2000), (2, 128, 7, 100)])
+                                            (2, 256, 34, 2000), (2, 128, 7, 100),
+                                            (8, 256, 5, 3000), (8, 256, 12, 30000), (8, 256, 17, 100000), (8, 256, 20, 100000), (8, 256, 33, 2000), (8, 20, 10, 500)])
 def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
     """Each q-gram shift-or form forced (development knob), with the staged verify (window hashes from the LDS copy
     of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them), with the pair form's
@@ -490,7 +491,7 @@ def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
         text[off:off + m] = pat[(7 * i + 3) % p]
     pat[p // 2] = pat[3]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
-    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2}[kind]) and wm.info().gram_kind == kind
+    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2}[kind]) and wm.info().gram_kind == kind
     if wm.info().scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
