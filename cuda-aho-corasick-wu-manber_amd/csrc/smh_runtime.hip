@@ -1453,7 +1453,7 @@ static int wm_launch_own(struct smh_wm *wm, const unsigned char *d_text, uint64_
     L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
     L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify; L.d_verify_ck = dv->d_verify_ck; L.ck_buckets = wm->ck_buckets; L.ck_seed = wm->ck_seed;
     L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind; L.gram_density = density < 0 ? (float)wm->gram_density : density; L.gram_lane0 = (float)wm->gram_lane0; L.gram_planes = wm->gram_planes;
-    if (wm->gram_kind == SMH_GRAM_FLAT) L.gram_jb = wm->gram_jb; /* 1: two bits per gram */
+    if (wm->gram_kind == SMH_GRAM_FLAT || wm->gram_kind == SMH_GRAM_FLAT_BIG) L.gram_jb = wm->gram_jb; /* 1: two bits per gram */
     L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = d_count; L.n_cus = n_cus;
     L.po.out = NULL; L.po.capacity = 0; L.po.cursor = NULL;
     L.stats = SA;
@@ -1603,7 +1603,7 @@ static int wm_positions_impl(smh_wm *wm, int engine, const unsigned char *d_text
         L.filter_log2 = wm->filter_log2; L.filter_hashed = wm->filter_hashed; L.filter_k = wm->filter_k; L.filter_le4 = wm->filter_le4; L.filter_exact = wm->filter_exact;
         L.d_filter = dv->d_filter; L.d_pair = dv->d_pair; L.verify_log2 = wm->verify_log2; L.d_verify = dv->d_verify; L.d_verify_ck = dv->d_verify_ck; L.ck_buckets = wm->ck_buckets; L.ck_seed = wm->ck_seed;
         L.d_gram = dv->d_gram; L.gram_kind = wm->gram_kind; L.gram_density = (float)wm->gram_density; L.gram_lane0 = (float)wm->gram_lane0; L.gram_planes = wm->gram_planes;
-        if (wm->gram_kind == SMH_GRAM_FLAT) L.gram_jb = wm->gram_jb;
+        if (wm->gram_kind == SMH_GRAM_FLAT || wm->gram_kind == SMH_GRAM_FLAT_BIG) L.gram_jb = wm->gram_jb;
         L.d_pat_sorted = dv->d_pat_sorted; L.d_queue = dv->d_queue; L.d_count = NULL; L.n_cus = n_cus;
         L.po.out = d_positions; L.po.capacity = capacity; L.po.cursor = d_cursor;
         HIP_TRY(smh_launch_wm_block_positions(L, (hipStream_t)stream));

@@ -160,6 +160,7 @@ static uint64_t gram_rng(uint64_t *s)
 }
 
 #define SMH_GRAM_FLAT_K2 (-6) /* gram_survivors only: the flat form with two bits per gram */
+#define SMH_GRAM_FLAT_BIG_K2 (-9) /* ... in the 143.9 KiB table */
 static double gram_survivors(int kind, const void *tab, int alphabet, int planes)
 {
     enum { COLS = 1 << 18 };
@@ -184,13 +185,21 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
         } else if (kind == SMH_GRAM_OCT) {
             code = ((code << 2) | c) & 0xFFFFu;
             G = ((const uint8_t *)tab)[code];
-        } else if (kind == SMH_GRAM_FLAT || kind == SMH_GRAM_FLAT_K2) {
+        } else if (kind == SMH_GRAM_FLAT || kind == SMH_GRAM_FLAT_K2 || kind == SMH_GRAM_FLAT_BIG || kind == SMH_GRAM_FLAT_BIG_K2) {
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
             k0 = k1;
             k1 = c;
+            const int fbig = kind == SMH_GRAM_FLAT_BIG || kind == SMH_GRAM_FLAT_BIG_K2, fk2 = kind == SMH_GRAM_FLAT_K2 || kind == SMH_GRAM_FLAT_BIG_K2;
             const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
-            const uint32_t b = ((const uint8_t *)tab)[prod >> 15];
-            const uint32_t out = (b >> ((prod >> 12) & 7u)) | (kind == SMH_GRAM_FLAT_K2 ? b >> ((prod >> 9) & 7u) : 0u);
+            uint32_t out;
+            if (fbig) { /* a dword of the set, bit = the product's low five bits (wm_lane.h smh_flat_group) */
+                uint32_t word;
+                memcpy(&word, (const uint8_t *)tab + SMH_GRAM_BIG_DWORD(prod), 4);
+                out = (word >> (prod & 31u)) | (fk2 ? word >> ((prod >> 5) & 31u) : 0u);
+            } else {
+                const uint32_t b = ((const uint8_t *)tab)[prod >> 15];
+                out = (b >> ((prod >> 12) & 7u)) | (fk2 ? b >> ((prod >> 9) & 7u) : 0u);
+            }
             G = (out & 1u) ? (0xFFu & ~((1u << (8 - planes)) - 1u)) : 0u;
         } else {
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
@@ -214,6 +223,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
 #define SMH_GRAM_OCT2_MS 0.178 /* the pair form's lookups + lane 0's inherited state from the halo in every chunk */
 #define SMH_GRAM_BYTE_MS 0.238
 #define SMH_GRAM_BYTE_BIG_MS 0.243 /* one vector instruction more per column (the index), under the LDS lookup's shadow */
+#define SMH_GRAM_FLAT_BIG_MS 0.272 /* the same instruction count as SMH_GRAM_FLAT (the set is read a dword at a time) */
 #define SMH_GRAM_FLAT_MS 0.27 /* SMH_GRAM_BYTE's lookup per column + two VALU (bit index, bit) */
 /* verify stage, ms per GiB for a fraction `dens` of surviving columns.  Staged (m <= 33: window hashes from the LDS
  * copy of the chunk, probe pipelined): the cost is mostly per wave-chunk that has any survivor -- lock, copy, hash
@@ -222,6 +232,11 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
  * 0.11 / 0.15 at 12 / 20 symbols, 116 -> 0.28, 690 -> 1.28; gpurun_out/r02_s, r02_z .. r02_ac).  Windows re-read from HBM (longer patterns): linear in
  * the survivors and the window the stage has to fetch and hash (fits to 8000 DNA patterns / 100 000 byte patterns
  * before staging: 0.49 / 0.72, 0.63 / 0.82). */
+/* the flat set in the big table: clear bit `bit` (0..31) of the little-endian dword the product selects */
+static void flat_big_clear(uint8_t *tab, uint32_t prod, uint32_t bit)
+{
+    tab[SMH_GRAM_BIG_DWORD(prod) + (bit >> 3)] &= (uint8_t)~(1u << (bit & 7u));
+}
 static double gram_verify_ms(int m, double dens)
 {
     if (m > 33) return (12.0 + 3.0 * m) * dens;
@@ -370,41 +385,49 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
             free(tab);
         }
     }
-    if (wm->bits_per_symbol >= 4 && m >= 5 && GRAM_WANTED(SMH_GRAM_FLAT)) {
-        /* one Bloom set for the grams of all offsets (smh_internal.h SMH_GRAM_FLAT); bit = 1: NOT in the set */
+    for (int big = 0; big <= 1; ++big) {
+        /* one Bloom set for the grams of all offsets (smh_internal.h SMH_GRAM_FLAT); bit = 1: NOT in the set.  Round 6: also in the
+         * 143.9 KiB table (SMH_GRAM_FLAT_BIG: windows of up to 33 bytes, sets that leave the L2 pipeline room, as SMH_GRAM_BYTE_BIG) */
+        const int kind = big ? SMH_GRAM_FLAT_BIG : SMH_GRAM_FLAT;
+        if (!(wm->bits_per_symbol >= 4 && m >= 5 && GRAM_WANTED(kind))) continue;
+        if (big && m - 1 > 32) continue;
+        const size_t bytes = big ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES;
         int J = m - 2;
         if (J > 8) J = 8;
-        uint8_t *tab = (uint8_t *)malloc(SMH_GRAM_BYTES);
+        uint8_t *tab = (uint8_t *)malloc(bytes);
         if (!tab) { free(best); return -1; }
-        memset(tab, 0xFF, SMH_GRAM_BYTES);
+        memset(tab, 0xFF, bytes);
         for (int p = 0; p < d; ++p)
             for (int j = 0; j < J; ++j) {
                 const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
                 const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
                 const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
-                tab[prod >> 15] &= (uint8_t)~(1u << ((prod >> 12) & 7u));
+                if (big) flat_big_clear(tab, prod, prod & 31u);
+                else tab[prod >> 15] &= (uint8_t)~(1u << ((prod >> 12) & 7u));
             }
         if (smh_tune_has(SMH_TUNE_WM, "debug")) {
             uint64_t zeros = 0;
-            for (uint32_t i = 0; i < SMH_GRAM_BYTES; ++i) zeros += 8u - (uint32_t)__builtin_popcount(tab[i]);
-            fprintf(stderr, "flat byte grams: %d patterns x %d grams, %.1f %% of the 2^20 bits in the set\n", d, J, 100.0 * (double)zeros / 1048576.0);
+            for (uint32_t i = 0; i < bytes; ++i) zeros += 8u - (uint32_t)__builtin_popcount(tab[i]);
+            fprintf(stderr, "flat byte grams: %d patterns x %d grams, %.1f %% of the %zu bits in the set\n", d, J, 100.0 * (double)zeros / (8.0 * (double)bytes), 8 * bytes);
         }
-        double dens = gram_survivors(SMH_GRAM_FLAT, tab, wm->alphabet, J), ms = SMH_GRAM_FLAT_MS + gram_verify_ms(m, dens);
+        const double flat_ms = big ? SMH_GRAM_FLAT_BIG_MS : SMH_GRAM_FLAT_MS;
+        double dens = gram_survivors(big ? SMH_GRAM_FLAT_BIG : SMH_GRAM_FLAT, tab, wm->alphabet, J), ms = flat_ms + gram_verify_ms(m, dens);
         int k2 = 0;
         if (J <= 5) {
-            /* round 4: two bits per gram in its byte (wm_lane.h smh_flat_addr<true>) while the grams are few enough for the fuller
+            /* round 4: two bits per gram in its byte (wm_lane.h smh_flat_group<.., K2>) while the grams are few enough for the fuller
              * array to pay -- 100 000 patterns of 5 bytes: 1.6 % -> 0.7 % of random columns pass; kept when it measures better */
-            uint8_t *t2 = (uint8_t *)malloc(SMH_GRAM_BYTES);
+            uint8_t *t2 = (uint8_t *)malloc(bytes);
             if (t2) {
-                memset(t2, 0xFF, SMH_GRAM_BYTES);
+                memset(t2, 0xFF, bytes);
                 for (int p = 0; p < d; ++p)
                     for (int j = 0; j < J; ++j) {
                         const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
                         const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
                         const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
-                        t2[prod >> 15] &= (uint8_t)~((1u << ((prod >> 12) & 7u)) | (1u << ((prod >> 9) & 7u)));
+                        if (big) { flat_big_clear(t2, prod, prod & 31u); flat_big_clear(t2, prod, (prod >> 5) & 31u); }
+                        else t2[prod >> 15] &= (uint8_t)~((1u << ((prod >> 12) & 7u)) | (1u << ((prod >> 9) & 7u)));
                     }
-                const double d2 = gram_survivors(SMH_GRAM_FLAT_K2, t2, wm->alphabet, J), ms2 = SMH_GRAM_FLAT_MS + 0.01 + gram_verify_ms(m, d2);
+                const double d2 = gram_survivors(big ? SMH_GRAM_FLAT_BIG_K2 : SMH_GRAM_FLAT_K2, t2, wm->alphabet, J), ms2 = flat_ms + 0.01 + gram_verify_ms(m, d2);
                 const int fk = smh_tune_int(SMH_TUNE_WM, "flatk=", 0); /* development knob "flatk=1|2": one / two bits per gram regardless */
                 if (fk == 2 || (fk != 1 && ms2 < ms)) {
                     free(tab);
@@ -414,9 +437,10 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 }
             }
         }
+        if (big && force != SMH_GRAM_FLAT_BIG && dens * 4096.0 > 40.0) { free(tab); continue; } /* (the L2 pipeline would overflow: SMH_GRAM_FLAT's staged verify) */
         if (ms < best_ms) {
             free(best);
-            best = tab; best_kind = SMH_GRAM_FLAT; best_planes = J; best_bytes = SMH_GRAM_BYTES; best_ms = ms; best_dens = dens;
+            best = tab; best_kind = kind; best_planes = J; best_bytes = (uint32_t)bytes; best_ms = ms; best_dens = dens;
             wm->gram_jb = k2;
         } else {
             free(tab);
@@ -1010,7 +1034,7 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
     out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
-    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : (wm->gram_kind == SMH_GRAM_BYTE_BIG ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES);
+    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : (wm->gram_kind == SMH_GRAM_BYTE_BIG || wm->gram_kind == SMH_GRAM_FLAT_BIG ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES);
     return SMH_OK;
 }
 

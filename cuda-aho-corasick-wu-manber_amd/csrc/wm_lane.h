@@ -1584,6 +1584,13 @@ SMH_LANE uint32_t smh_gram_key(const uint32_t (&w)[16], uint32_t pre)
  *   KIND 6  (round 3, SMH_GRAM_FLAT) ONE set for the grams of all offsets, a 2^20-bit array: byte address = the same 17
  *           bits, bit = the three below them; the array holds the set INVERTED, so a sign-extending 1-bit field extract
  *           yields 0 (in the set) or all ones (not), masked to the J plane bits `gmask` -- every plane tests the same set */
+/* kernel KINDs of the byte-gram forms: 2 = hashed planes, 6 / 7 = flat set with one / two bits per gram; round 6: 8 / 9 / 10 = the same three
+ * in the 143.9 KiB table (SMH_GRAM_BIG_BYTES) */
+constexpr bool smh_kind_flat(int k) { return k == 6 || k == 7 || k == 9 || k == 10; }
+constexpr bool smh_kind_flat_k2(int k) { return k == 7 || k == 10; }
+constexpr bool smh_kind_big(int k) { return k == 8 || k == 9 || k == 10; }
+/* the instance of smh_gram_byte_G that looks a column up for kernel KIND k: 2 / 8 the planes, 6 / 9 the flat set */
+constexpr int smh_kind_lookup(int k) { return smh_kind_flat(k) ? (smh_kind_big(k) ? 9 : 6) : (k == 8 ? 8 : 2); }
 /* KIND 8 (round 6): KIND 2 with a table of SMH_GRAM_BIG_BYTES bytes -- index = the product's low 24 bits scaled to the table's
  * DWORDS (v_mul_hi_u32_u24 yields 16 bits), the product's top two bits as the byte: == SMH_GRAM_BIG_INDEX in smh_internal.h */
 SMH_LANE uint32_t smh_gram_big_index(uint32_t prod)
@@ -1596,13 +1603,32 @@ SMH_LANE uint32_t smh_gram_big_index(uint32_t prod)
     return ((uint32_t)(((uint64_t)(prod & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES_DEV / 4u) << 8)) >> 32) << 2) | (prod >> 30);
 #endif
 }
+/* the flat set in the big table (KIND 9 / 10) is read a DWORD at a time: byte address = the dword index << 2, bit = the product's low
+ * five bits (second bit: the next five) -- v_lshrrev takes a shift's low five bits by itself, so the form costs what the 128 KiB one
+ * costs: mul, mul_hi, shift, [ds_read_b32], shift, alignbit */
+SMH_LANE uint32_t smh_gram_big_dword(uint32_t prod)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    uint32_t dw;
+    asm("v_mul_hi_u32_u24 %0, %1, %2" : "=v"(dw) : "v"(prod), "s"((SMH_GRAM_BIG_BYTES_DEV / 4u) << 8));
+    return dw << 2;
+#else
+    return (uint32_t)(((uint64_t)(prod & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES_DEV / 4u) << 8)) >> 32) << 2;
+#endif
+}
 template <int KIND>
 SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask, bool k2 = false)
 {
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
+    if constexpr (KIND == 9) { /* the flat set in the big table (bounds-checked path) */
+        const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
+        uint32_t out = word >> (prod & 31u);
+        if (k2) out |= word >> ((prod >> 5) & 31u);
+        return (out & 1u) ? gmask : 0u;
+    }
     const uint32_t b = smh_lds_u8(tab, KIND == 8 ? smh_gram_big_index(prod) : prod >> 15);
     if constexpr (KIND == 6) { /* the bounds-checked path (the fast path: smh_flat_columns); k2: a gram has TWO bits in its byte */
-        uint32_t out = b >> ((prod >> 12) & 7u);
+        uint32_t out = b >> ((prod >> 12) & 7u); /* bit indices: product bits 12..14 and 9..11, under the 17 address bits */
         if (k2) out |= b >> ((prod >> 9) & 7u);
         return (out & 1u) ? gmask : 0u;
     } else {
@@ -1658,15 +1684,19 @@ SMH_LANE uint32_t smh_flat_idx(uint32_t prod)
     return (prod >> OFF) & 7u;
 #endif
 }
-SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2)
+SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2, bool big)
 {
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
+    if (big) {
+        const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
+        return k2 ? (word >> (prod & 31u)) | (word >> ((prod >> 5) & 31u)) : word >> (prod & 31u);
+    }
     const uint32_t b = smh_lds_u8(tab, prod >> 15);
     return k2 ? (b >> smh_flat_idx<12>(prod)) | (b >> smh_flat_idx<9>(prod)) : b >> smh_flat_idx<12>(prod);
 }
 /* eight columns: the products, the eight lookups in flight together, then the bits (only the products and the bytes live
  * across the lookups: with the indices kept beside them the two-bit variant ran out of registers) */
-template <int G, bool K2>
+template <int G, bool K2, bool BIG>
 SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H)
 {
     uint32_t prod[8], b[8];
@@ -1679,11 +1709,17 @@ SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *
     prod[6] = smh_mul24(smh_gram_key<8 * G + 6>(w, pre), SMH_GRAM_MUL_DEV);
     prod[7] = smh_mul24(smh_gram_key<8 * G + 7>(w, pre), SMH_GRAM_MUL_DEV);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = smh_lds_u8(tab, prod[j] >> 15);
+    for (int j = 0; j < 8; ++j) b[j] = BIG ? smh_lds_u32(tab, smh_gram_big_dword(prod[j])) : smh_lds_u8(tab, prod[j] >> 15);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        uint32_t t = b[j] >> smh_flat_idx<12>(prod[j]);
-        if constexpr (K2) t |= b[j] >> smh_flat_idx<9>(prod[j]);
+        uint32_t t;
+        if constexpr (BIG) { /* a dword of the set: the bit index is the product's low five bits, the shift takes them by itself */
+            t = b[j] >> (prod[j] & 31u);
+            if constexpr (K2) t |= b[j] >> ((prod[j] >> 5) & 31u);
+        } else {
+            t = b[j] >> smh_flat_idx<12>(prod[j]);
+            if constexpr (K2) t |= b[j] >> smh_flat_idx<9>(prod[j]);
+        }
         H = smh_flat_push(H, t);
     }
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -1692,17 +1728,17 @@ SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-template <bool K2>
+template <bool K2, bool BIG>
 SMH_LANE void smh_flat_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H0, uint32_t &H1)
 {
-    smh_flat_group<0, K2>(w, pre, tab, H0);
-    smh_flat_group<1, K2>(w, pre, tab, H0);
-    smh_flat_group<2, K2>(w, pre, tab, H0);
-    smh_flat_group<3, K2>(w, pre, tab, H0);
-    smh_flat_group<4, K2>(w, pre, tab, H1);
-    smh_flat_group<5, K2>(w, pre, tab, H1);
-    smh_flat_group<6, K2>(w, pre, tab, H1);
-    smh_flat_group<7, K2>(w, pre, tab, H1);
+    smh_flat_group<0, K2, BIG>(w, pre, tab, H0);
+    smh_flat_group<1, K2, BIG>(w, pre, tab, H0);
+    smh_flat_group<2, K2, BIG>(w, pre, tab, H0);
+    smh_flat_group<3, K2, BIG>(w, pre, tab, H0);
+    smh_flat_group<4, K2, BIG>(w, pre, tab, H1);
+    smh_flat_group<5, K2, BIG>(w, pre, tab, H1);
+    smh_flat_group<6, K2, BIG>(w, pre, tab, H1);
+    smh_flat_group<7, K2, BIG>(w, pre, tab, H1);
 }
 /* (hi:lo) << k for 0 < k < 32: bit i of the result = bit i - k of the 64-bit sequence whose upper word is hi */
 SMH_LANE uint32_t smh_shl_across(uint32_t hi, uint32_t lo, uint32_t k) { return (hi << k) | (lo >> (32u - k)); }
@@ -1727,12 +1763,12 @@ SMH_LANE uint64_t smh_flat_candidates(uint32_t Z0, uint32_t Z1, uint32_t Z2, uin
     return ~(((uint64_t)Z2 << 32) | Z1);
 }
 /* the 32 bits in front of the segment at a, true values (the emulator; the GPU takes the previous lane's H1) */
-SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const void *tab, bool k2)
+SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const void *tab, bool k2, bool big)
 {
     uint32_t H = 0;
     for (uint64_t x = a >= 32 ? a - 32 : 0; x < a; ++x) {
         uint32_t t = 0; /* a column without a whole gram in front of it cannot be ruled out */
-        if (x >= 2) t = smh_flat_bit((uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16), tab, k2);
+        if (x >= 2) t = smh_flat_bit((uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16), tab, k2, big);
         H = smh_flat_push(H, t);
     }
     return H; /* (a < 32 never reaches the fast path: chunk 0 is bounds-checked) */
@@ -1759,7 +1795,7 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
         if (a < 10) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
             const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
-            S = smh_gram_step(S, smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : (KIND == 8 ? 8 : 2)>(key, tab, gmask, k2));
+            S = smh_gram_step(S, smh_gram_byte_G<smh_kind_lookup(KIND)>(key, tab, gmask, k2));
         }
     }
     return S & 0x7Fu;
@@ -2012,19 +2048,19 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
             if (q == 11) fl[1] = smh_gram_flags(T, 24);
             if (q == 15) fl[2] = smh_gram_flags(T, 16);
         }
-    } else if constexpr (KIND == 6 || KIND == 7) {
+    } else if constexpr (smh_kind_flat(KIND)) {
         /* flat byte grams: the columns' bits are collected, the J-in-a-row test runs once on all of them (above).  KIND 7 = the
          * same with two bits per gram -- a kernel instance of its own: as a wave-uniform branch around two copies of the loop
          * the compiler hoisted all 64 columns' products in front of the branch (128 VGPRs and spills to scratch) */
         (void)pre0;
         uint32_t H0 = 0, H1 = 0, Hp;
-        smh_flat_columns<KIND == 7>(w, pre1, tab, H0, H1);
+        smh_flat_columns<smh_kind_flat_k2(KIND), smh_kind_big(KIND)>(w, pre1, tab, H0, H1);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         /* the 32 columns in front of the segment: the previous lane's second half; lane 0 of a wave has no neighbour and
          * assumes "all in the set" (a few more columns reach the verify stage, which is exact) */
         Hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #else
-        Hp = smh_flat_history_before(text, a, tab, KIND == 7);
+        Hp = smh_flat_history_before(text, a, tab, smh_kind_flat_k2(KIND), smh_kind_big(KIND));
 #endif
         const uint64_t msk6 = smh_flat_candidates(Hp, H0, H1, (uint32_t)P.gram_planes);
         if constexpr (smh_stg_regv(STG)) {
@@ -2164,7 +2200,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
     const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
     const uint32_t cand_bit = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u;
     uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes)
-                           : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u), KIND == 7), cnt = 0;
+                           : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u), smh_kind_flat_k2(KIND)), cnt = 0;
     for (uint64_t e = a; e < end; ++e) {
         uint32_t G = 0u; /* a column without a whole gram in front of it cannot be ruled out */
         if (e + 1 >= q) {
@@ -2180,7 +2216,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
                 G = g;
             } else {
                 const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
-                G = smh_gram_byte_G<KIND == 6 || KIND == 7 ? 6 : (KIND == 8 ? 8 : 2)>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), KIND == 7);
+                G = smh_gram_byte_G<smh_kind_lookup(KIND)>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), smh_kind_flat_k2(KIND));
             }
         }
         T = smh_gram_step(T, G);

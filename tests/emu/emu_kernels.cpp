@@ -260,7 +260,7 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     P.pat_sorted = padded.data();
     P.gram_g7 = wm->gram_kind == SMH_GRAM_PAIR ? (const uint8_t *)wm->gram_table + SMH_GRAM_BYTES : nullptr;
     P.gram_planes = wm->gram_planes;
-    if (wm->gram_kind == SMH_GRAM_FLAT) P.gram_jb = wm->gram_jb; /* 1: two bits per gram */
+    if (wm->gram_kind == SMH_GRAM_FLAT || wm->gram_kind == SMH_GRAM_FLAT_BIG) P.gram_jb = wm->gram_jb; /* 1: two bits per gram */
     const uint64_t nthreads = blocks * EMU_BLOCK_THREADS;
     uint64_t total = 0;
     /* staged verify as launch_gram (wm_kernels.inc) picks it */
@@ -286,6 +286,10 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
             total += GRAM_STG(3);
         else if (wm->gram_kind == SMH_GRAM_BYTE_BIG) /* the 143.9 KiB table: windows from L2 always (wm_kernels.inc launch_gram) */
             total += stg == 1 ? GRAM_CALL(8, 3) : GRAM_CALL(8, 4);
+        else if (wm->gram_kind == SMH_GRAM_FLAT_BIG && wm->gram_jb > 0)
+            total += stg == 1 ? GRAM_CALL(10, 3) : GRAM_CALL(10, 4);
+        else if (wm->gram_kind == SMH_GRAM_FLAT_BIG)
+            total += stg == 1 ? GRAM_CALL(9, 3) : GRAM_CALL(9, 4);
         else if (wm->gram_kind == SMH_GRAM_FLAT || wm->gram_kind == SMH_GRAM_BYTE) {
             /* the byte forms: windows from L2 (STG 3 / 4) unless SMH_WM_TUNE says "l2=0", as launch_gram */
             const char *tn = getenv("SMH_WM_TUNE");

@@ -128,7 +128,8 @@ def test_grid_size_does_not_change_the_count():
                                             (5, 4, 11, 30), (5, 4, 12, 200), (5, 4, 16, 8000), (5, 4, 17, 500), (5, 4, 18, 3000), (5, 4, 23, 20000), (5, 4, 24, 100), (5, 4, 33, 50),
                                             (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
                                             (2, 128, 7, 100),
-                                            (8, 256, 5, 300), (8, 256, 12, 3000), (8, 256, 17, 2000), (8, 256, 20, 500), (8, 256, 33, 200), (8, 20, 10, 500)])
+                                            (8, 256, 5, 300), (8, 256, 12, 3000), (8, 256, 17, 2000), (8, 256, 20, 500), (8, 256, 33, 200), (8, 20, 10, 500),
+                                            (9, 256, 5, 300), (9, 256, 6, 3000), (9, 256, 8, 5000), (9, 256, 12, 3000), (9, 256, 20, 500), (9, 128, 7, 100)])
 def test_gram_filter_forms(kind, sigma, m, p, knob):
     """The three q-gram shift-or forms (symbol pairs, 8-symbol grams, hashed byte grams), each forced with the
     development knob so the test does not depend on the cost model: random text with planted occurrences,
@@ -145,8 +146,8 @@ def test_gram_filter_forms(kind, sigma, m, p, knob):
     pat[p // 2] = pat[0]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
     info = wm.info()
-    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2}[kind]) and info.gram_kind == kind
-    assert info.lds_bytes == {3: 65536, 8: 147392}.get(kind, 131072)
+    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2, 9: 2}[kind]) and info.gram_kind == kind
+    assert info.lds_bytes == {3: 65536, 8: 147392, 9: 147392}.get(kind, 131072)
     if info.scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
@@ -180,13 +181,14 @@ def test_byte_gram_forms_staged_and_from_l2(kind, m, p, knob):
         assert total == want and len(set(pos.tolist())) == want
 
 
+@pytest.mark.parametrize("form", [6, 9])
 @pytest.mark.parametrize("m,p", [(5, 300), (5, 20000), (6, 3000), (7, 100), (7, 9000)])
-def test_flat_byte_grams_with_two_bits_per_gram(m, p, knob):
+def test_flat_byte_grams_with_two_bits_per_gram(m, p, form, knob):
     """Round 4: patterns of 5..7 bytes may keep TWO bits per gram in the flat Bloom set (a blocked Bloom filter with 8-bit
     blocks: wm_lane.h smh_flat_addr<true>); forced here with the development knob, against brute force, both block counts,
     positions mode, and the bounds-checked first / last chunks."""
     S = knob.T  # the testing build: the knobs below exist only there
-    knob.wm("gram=6,flatk=2")
+    knob.wm("gram=%d,flatk=2" % form)  # 9: the same set in the 143.9 KiB table (round 6)
     rng = np.random.RandomState(77 * m + p)
     n = 3 * 4096 + 555
     text = rng.randint(0, 256, size=n).astype(np.uint8)
@@ -194,14 +196,14 @@ def test_flat_byte_grams_with_two_bits_per_gram(m, p, knob):
     for i, off in enumerate([0, 300, 640 - m // 2, 4096 - m // 2, 8191, 8192 + 2 * m + 64, n - m]):
         text[off:off + m] = pat[(7 * i) % p]
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, 256)
-    assert wm.info().gram_kind == 6
+    assert wm.info().gram_kind == form
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
     assert want >= 7
     for blocks in (1, 3):
         assert E.wm_scan(wm, text, S.VARIANT_TUNED, blocks) == want
     total, pos = E.wm_positions(wm, text, want + 8, 2)
     assert total == want and len(set(pos.tolist())) == want
-    knob.wm("gram=6,flatk=1")
+    knob.wm("gram=%d,flatk=1" % form)
     one = S.WmTables.from_patterns(pat.reshape(-1), m, p, 256)
     assert E.wm_scan(one, text, S.VARIANT_TUNED, 2) == want
 

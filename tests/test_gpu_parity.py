@@ -457,10 +457,12 @@ def test_byte_gram_forms_with_the_staged_verify_on_the_gpu(kind, m, p, knob):
     test_gram_filter_forms_on_the_gpu(kind, 256, m, p, ",l2=0", knob)
 
 
+@pytest.mark.parametrize("form", [6, 9])
 @pytest.mark.parametrize("m,p", [(5, 3000), (6, 100000), (7, 100)])
-def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, knob):
-    """the flat form of 5..7-byte patterns with two bits per gram forced (round 4): same text, same checks as below"""
-    test_gram_filter_forms_on_the_gpu(6, 256, m, p, ",flatk=2", knob)
+def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, form, knob):
+    """the flat form of 5..7-byte patterns with two bits per gram forced (round 4; form 9, round 6: in the 143.9 KiB table): same
+    text, same checks as below"""
+    test_gram_filter_forms_on_the_gpu(form, 256, m, p, ",flatk=2", knob)
 
 
 @pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1"], ids=["default", "hbm_windows", "staged", "in_registers"])
@@ -470,7 +472,8 @@ def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, knob):
                                             (5, 4, 11, 30), (5, 4, 16, 8000), (5, 4, 17, 6000), (5, 4, 18, 300), (5, 4, 23, 20000), (5, 4, 33, 50),
                                             (2, 256, 12, 30000), (2, 256, 17, 100000), (2, 256, 18, 1000), (2, 256, 33, 2000),
                                             (2, 256, 34, 2000), (2, 128, 7, 100),
-                                            (8, 256, 5, 3000), (8, 256, 12, 30000), (8, 256, 17, 100000), (8, 256, 20, 100000), (8, 256, 33, 2000), (8, 20, 10, 500)])
+                                            (8, 256, 5, 3000), (8, 256, 12, 30000), (8, 256, 17, 100000), (8, 256, 20, 100000), (8, 256, 33, 2000), (8, 20, 10, 500),
+                                            (9, 256, 5, 3000), (9, 256, 6, 100000), (9, 256, 8, 30000), (9, 256, 9, 100000), (9, 256, 17, 1000), (9, 256, 33, 2000)])
 def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
     """Each q-gram shift-or form forced (development knob), with the staged verify (window hashes from the LDS copy
     of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them), with the pair form's
@@ -491,7 +494,7 @@ def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
         text[off:off + m] = pat[(7 * i + 3) % p]
     pat[p // 2] = pat[3]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
-    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2}[kind]) and wm.info().gram_kind == kind
+    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2, 9: 2}[kind]) and wm.info().gram_kind == kind
     if wm.info().scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
