@@ -377,7 +377,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 tab[idx] &= (uint8_t)~(1u << (7 - j));
             }
         const double dens = gram_survivors(kind, tab, wm->alphabet, J), ms = (big ? SMH_GRAM_BYTE_BIG_MS : SMH_GRAM_BYTE_MS) + gram_verify_ms(m, dens);
-        if (big && force != SMH_GRAM_BYTE_BIG && dens * 4096.0 > 40.0) { free(tab); continue; } /* (its pipeline would overflow: the staged verify of SMH_GRAM_BYTE is the faster one there) */
+        if (big && force != SMH_GRAM_BYTE_BIG && dens * 4096.0 > 56.0) { free(tab); continue; } /* (its pipeline would overflow -- launch_gram, wm_kernels.inc: 56 per chunk -- and the staged verify of SMH_GRAM_BYTE is the faster one there) */
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = kind; best_planes = J; best_bytes = (uint32_t)bytes; best_ms = ms; best_dens = dens;
@@ -437,7 +437,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 }
             }
         }
-        if (big && force != SMH_GRAM_FLAT_BIG && dens * 4096.0 > 40.0) { free(tab); continue; } /* (the L2 pipeline would overflow: SMH_GRAM_FLAT's staged verify) */
+        if (big && force != SMH_GRAM_FLAT_BIG && dens * 4096.0 > 56.0) { free(tab); continue; } /* (the L2 pipeline would overflow: SMH_GRAM_FLAT with its staged verify) */
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = kind; best_planes = J; best_bytes = (uint32_t)bytes; best_ms = ms; best_dens = dens;

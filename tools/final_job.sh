@@ -1,9 +1,9 @@
 #!/bin/bash
-# tools/final_job_r05.sh TAG -- the end-of-round evidence in one gpurun call (round 5): GPU tests (parity run, then the perf
+# tools/final_job.sh TAG -- the end-of-round evidence in one gpurun call (rounds 5, 6): GPU tests (parity run, then the perf
 # expectations enforced), the plain bench, the rocprofv3 passes over the bench INCLUDING the non-uniform corpora (that is where the
 # key and window-hash kernels run): kernel trace, two SQ passes, FETCH_SIZE and WRITE_SIZE passes (separate, as
 # MI355X_MICROARCH.md prescribes), the differential fuzz.
-TAG=${1:-r05_final}
+TAG=${1:-r06_final}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
@@ -14,8 +14,8 @@ echo "== bench"; timeout -k 10 900 python bench.py > $O/bench.json 2> $O/bench.e
 cp bench_detail.json $O/bench_detail.json
 echo "== counters"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-multi"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu --no-multi > $O/trace.log 2>&1
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu --no-multi --no-small"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu --no-multi --no-small > $O/trace.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq1 -- $BENCH > $O/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_sq2 -- $BENCH > $O/pmc_sq2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1
