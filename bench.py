@@ -1234,7 +1234,7 @@ def phase_preproc(R):
                                  % ("/".join("%.4f" % R.compile_s[m] for m in AC_LENGTHS), R.first_scans_s),
                             sets=rows,
                             legacy_cuda_wm_calls=dict(what="cuda_wm1..5 back to back on one set of caller tables (main.c:623-648), 4 MiB of text: seconds per call and "
-                                                           "handles compiled -- the first call compiles and uploads, the other four reuse",
+                                                           "handles compiled -- the first call compiles and uploads, the other four reuse its handle (cuda_wm1 / 2 walk the reference tables as given: slow by design, see table_kernels)",
                                                       seconds=[round(x, 5) for x in calls_s], handle_builds=int(S.lib.smh_legacy_handle_builds()) - builds0))
 
 

@@ -72,7 +72,7 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
      * modelled.  The third bit costs the scan four vector instructions per column (0.36 -> 0.42 ms/GiB with the candidates dropped)
      * and spares stage 2 the candidates it removes: 100 000 byte patterns 5.0 % -> 3.3 % of the non-matching windows, 0.83 -> 0.71
      * ms/GiB on uniform text and 0.93 / 1.02 / 1.46 -> 0.90 / 0.95 / 1.31 on natural-language-like text (m = 8 / 12 / 20), while 30 000
-     * patterns (1.6 % -> 1.1 %) lose 4 % (profiles/r06_key/notes/ab_hash_third_bit.log): whichever estimate is lower is built. */
+     * patterns (1.6 % -> 1.1 %) lose 4 % (profiles/r06_final/notes/ab_hash_third_bit.log): whichever estimate is lower is built. */
     const int forced_k = smh_tune_int(SMH_TUNE_HASH, "bits=", 0); /* testing library only: "bits=2|3" */
     double best_ms = 0.0;
     for (uint32_t bits = 2; bits <= 3u; ++bits) {

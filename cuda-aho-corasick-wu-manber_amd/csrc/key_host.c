@@ -302,7 +302,7 @@ struct smh_keys *smh_keys_build(const unsigned char *patterns_flat, int m, int p
             kb_handle->n_keys = n;
             kb_handle->P = K;
             kb_handle->image = bimage;
-            /* measured (profiles/r06_key/notes/ab_key_bucket_image.log): 0.285 ms/GiB for the scan itself, plus what the crowded
+            /* measured (profiles/r06_final/notes/ab_key_bucket_image.log): 0.285 ms/GiB for the scan itself, plus what the crowded
              * buckets cost -- a column in which ANY lane of the wave reads a sentinel takes the wave through the queue code, a step
              * of eight columns with one takes it through the step's second look.  With f = the crowded buckets' share, 1500 keys
              * (f = 0.01 %) +0.015, 2500 (0.05 %) +0.045, 3500 (0.13 %) +0.065, 5000 (0.36 %) +0.15, 8000 (1.4 %) +0.25. */

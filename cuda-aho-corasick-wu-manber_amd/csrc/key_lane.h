@@ -280,7 +280,7 @@ SMH_LANE bool smh_keyb_mine(smh_keyb_mask x) { return x != 0; }
 #endif
 /* The overflow path is DEFERRED (counting kernels on the GPU).  Looking into the overflow table the moment a lane reads a sentinel
  * costs the whole wave ten instructions and an LDS round trip for the one lane in 64 that needs it -- 1.4 % of the lanes, hence six
- * columns in ten: measured 0.57 against 0.34 ms/GiB without (profiles/r06_key/notes/ab_key_bucket_image.log).  Instead the lanes that
+ * columns in ten: measured 0.57 against 0.34 ms/GiB without (profiles/r06_final/notes/ab_key_bucket_image.log).  Instead the lanes that
  * read a sentinel append their (H, F) to a queue of the wave in LDS (ballot + mbcnt: the wave's entries are contiguous), and the
  * queue is drained 64 entries per step -- every lane one entry, one overflow-table read in flight per lane -- whenever 64 more
  * might not fit, and at the end of the segment.  Slot 1 of the crowded bucket has been compared in line; a window is a key in one

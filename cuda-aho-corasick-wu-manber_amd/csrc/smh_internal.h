@@ -485,7 +485,7 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
  * planes in a row pass 0.35 % of random columns instead of 0.66 %: nearly half the verify stage's work.  The table has no power-of-
  * two size: its index is (v_mul_hi_u32_u24(product, dwords << 8) << 2) | (product >> 30) -- the multiply yields 16 bits, hence
  * dwords, and one v_alignbit puts the product's top two bits under it as the byte -- ONE vector instruction more per column than
- * the top-17-bits index (profiles/r06_key/notes/ab_byte_gram_big_table.log).  Only with the windows-from-L2 verify (no room for
+ * the top-17-bits index (profiles/r06_final/notes/ab_byte_gram_big_table.log).  Only with the windows-from-L2 verify (no room for
  * staging buffers): sets whose filter passes more than its pipeline takes keep SMH_GRAM_BYTE. */
 #define SMH_GRAM_BYTE_BIG 8
 /* ... and SMH_GRAM_FLAT in the same 143.9 KiB (1 179 136 bits; read a dword at a time: bit = the product's low five bits, second bit the next five: the set of 100 000 patterns' grams is 39 % full instead of 43 % at m = 8, six in a row pass 0.34 % instead of 0.63 % */

@@ -224,7 +224,7 @@ def test_bucket_image_holds_exactly_the_set_and_counts_what_the_definition_count
 def test_bucket_image_is_the_default_where_it_is_the_faster_one():
     """sets of up to ~4000 keys whose window the image takes (alphabet 4: 10..20 symbols; 20 letters: up to 8): few crowded buckets,
     0.29-0.37 ms/GiB against the cuckoo image's 0.41-0.46; from ~4500 keys up the crowded buckets' share (8000 keys: 1.4 %) costs
-    more than the second LDS read saves (0.53 against 0.41: profiles/r06_key/notes/ab_key_bucket_image.log) -- the builder measures the
+    more than the second LDS read saves (0.53 against 0.41: profiles/r06_final/notes/ab_key_bucket_image.log) -- the builder measures the
     share and keeps the cuckoo image there"""
     for (sigma, m, p), layout in (((4, 16, 1500), 1), ((4, 16, 3500), 1), ((20, 8, 3000), 1), ((4, 20, 3000), 1), ((4, 16, 8000), 0), ((20, 8, 10000), 0),
                                   ((4, 32, 3000), 0), ((256, 8, 2000), 0), ((4, 8, 100), 0), ((20, 12, 200), 0)):
