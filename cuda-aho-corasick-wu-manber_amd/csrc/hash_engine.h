@@ -26,7 +26,7 @@
 #define SMH_HASH_BASE 0x5BD1E9u    /* B: odd, 24 bits */
 #define SMH_HASH_MAX_M 32          /* the window's dwords: nine aligned ones cover 33 bytes at any alignment */
 #define SMH_HASH_MIN_M 4
-#define SMH_HASH_MUL3 0xC2B2AFu    /* the third filter bit's index: the top five bits of the low 24 bits of h times this (one v_mul_u32_u24) */
+#define SMH_HASH_MUL3 0xC2B2AFu    /* the third filter bit's index: bits 21..25 of the low 24 bits of h times this (one v_mul_u32_u24) */
 
 struct smh_hash_params {
     int m;
@@ -38,7 +38,8 @@ struct smh_hash_params {
                             * where one-slot buckets place 42 % -- half the table, and the probes are random 128-byte line fills of
                             * a table that should stay in L2 */
     uint32_t seed;         /* of the slot hashes: the builder retries with another one when the patterns do not place */
-    uint32_t bloom_k;      /* filter bits per window: 2, or (round 6) 3 -- the third one at bit (((h & 0xFFFFFF) * SMH_HASH_MUL3) >> 27) of the same word */
+    uint32_t bloom_k;      /* filter bits per window: 2, or (round 6) 3 -- the third one at bit smh_hash_bit3(h) of the same word */
+    uint32_t bit2_shift;   /* the second filter bit's index = (h >> bit2_shift) & 31: 5, or 4 in the 2^15-word filter (below) */
     uint32_t slot_dwords;  /* (m + 3) / 4: a slot is the pattern zero-padded to whole dwords, slots back to back (a table that is a third smaller
                             * than with 16 / 32-byte slots stays in L2 that much better: the probes are random 128-byte line fills) */
 };
@@ -55,8 +56,19 @@ SMH_HASH_FN uint32_t smh_hash_mad24(uint32_t a, uint32_t b, uint32_t c) { return
 SMH_HASH_FN uint32_t smh_hash_in(uint32_t h, uint32_t byte) { return smh_hash_mad24(h, SMH_HASH_BASE, byte); }
 /* ... and the byte m places back leaves it */
 SMH_HASH_FN uint32_t smh_hash_out(uint32_t h, uint32_t byte, uint32_t neg_bm) { return smh_hash_mad24(byte, neg_bm, h); }
-/* the window's filter bits: bit (h & 31), bit ((h >> 5) & 31) and -- bloom_k = 3 -- bit smh_hash_bit3(h) of the word at byte address (h >> shift) & mask */
-SMH_HASH_FN uint32_t smh_hash_bit3(uint32_t h) { return smh_hash_mad24(h, SMH_HASH_MUL3, 0u) >> 27; }
+/* the window's filter bits: bit (h & 31), bit ((h >> bit2_shift) & 31) and -- bloom_k = 3 -- bit smh_hash_bit3(h) of the word at byte address
+ * (h >> shift) & mask.  The word address is the TOP bits of the 24 (2^15 words: bits 9..23), and the second index must end below it:
+ * bits 5..9 for every size until late in round 6, so that in the largest filter every word's second bits fell into the half that
+ * address bit 9 names -- 100 000 patterns passed 5.0 % of random windows where independent bits pass 3.8 %.  That filter now takes
+ * bits 4..8 (one bit shared with the first index: 3.9 %); the smaller ones keep bits 5..9, which they do not address with. */
+SMH_HASH_FN uint32_t smh_hash_bit2_shift(uint32_t words_log2) { return words_log2 >= 15u ? 4u : 5u; }
+SMH_HASH_FN uint32_t smh_hash_bit2(uint32_t h, uint32_t bit2_shift) { return (h >> bit2_shift) & 31u; }
+/* third index: bits 21..25 of (low 24 bits of h) x SMH_HASH_MUL3.  (First build of round 6: the product's top five bits -- within a
+ * word only h's low nine bits vary, their share of the product's top bits is nearly linear in them, and so is the second index:
+ * the third bit followed the second.  Five bits lower the low bits' share wraps many times: 100 000 patterns 3.5 % -> 3.0 % of
+ * random windows pass, against 2.6 % for three independent bits, which nine free bits per word cannot give.) */
+SMH_HASH_FN uint32_t smh_hash_bit3_raw(uint32_t h) { return smh_hash_mad24(h, SMH_HASH_MUL3, 0u) >> 21; } /* the index = its low five bits */
+SMH_HASH_FN uint32_t smh_hash_bit3(uint32_t h) { return smh_hash_bit3_raw(h) & 31u; }
 SMH_HASH_FN uint32_t smh_hash_word_addr(uint32_t h, uint32_t shift, uint32_t mask) { return (h >> shift) & mask; }
 
 /* the two slots of a window whose verify-stage hash (wm_lane.h smh_wm_tag_dwords == wm_host.c smh_wm_tag) is `tag` */

@@ -58,6 +58,7 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
     P.bloom_shift = (uint32_t)(24 - wl - 2);
     P.bloom_mask = ((1u << wl) - 1u) << 2;
     P.bloom_bytes = 4u << wl;
+    P.bit2_shift = smh_hash_bit2_shift((uint32_t)wl);
     P.slot_dwords = ((uint32_t)m + 3u) / 4u;
     /* buckets of two slots, two tables: 4 N slots for `distinct` patterns at 82 % */
     uint32_t N = (uint32_t)((double)distinct / (4.0 * 0.82)) + 4u;
@@ -69,10 +70,10 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
     if (!k->table || !slot_of) { free(slot_of); smh_hash_free(k); *why = "out of memory"; return NULL; }
     /* The filter, with two bits per window and with three (round 6).  A non-matching window passes when all of its bits are set:
      * about (bits set / bits)^k, more for the uneven words -- SAMPLED on the finished filter (65536 pseudo-random hashes), not
-     * modelled.  The third bit costs the scan four vector instructions per column (0.36 -> 0.42 ms/GiB with the candidates dropped)
-     * and spares stage 2 the candidates it removes: 100 000 byte patterns 5.0 % -> 3.3 % of the non-matching windows, 0.83 -> 0.71
-     * ms/GiB on uniform text and 0.93 / 1.02 / 1.46 -> 0.90 / 0.95 / 1.31 on natural-language-like text (m = 8 / 12 / 20), while 30 000
-     * patterns (1.6 % -> 1.1 %) lose 4 % (profiles/r06_final/notes/ab_hash_third_bit.log): whichever estimate is lower is built. */
+     * modelled.  The third bit costs the scan four vector instructions per column (0.36 -> 0.43 ms/GiB with the candidates dropped)
+     * and spares stage 2 the candidates it removes: 100 000 byte patterns 3.9 % -> 3.0 % of the non-matching windows, 0.71 -> 0.61
+     * ms/GiB on uniform text and 0.88 / 0.95 / 1.30 -> 0.84 / 0.89 / 1.12 on natural-language-like text (m = 8 / 12 / 20), while 30 000
+     * patterns (1.7 % -> 1.1 %) lose 4 % (profiles/r06_final/notes/ab_hash_third_bit.log): whichever estimate is lower is built. */
     const int forced_k = smh_tune_int(SMH_TUNE_HASH, "bits=", 0); /* testing library only: "bits=2|3" */
     double best_ms = 0.0;
     for (uint32_t bits = 2; bits <= 3u; ++bits) {
@@ -81,13 +82,13 @@ struct smh_hashes *smh_hash_build(const unsigned char *patterns, int m, int dist
         if (!bloom) { free(slot_of); smh_hash_free(k); *why = "out of memory"; return NULL; }
         for (int j = 0; j < distinct; ++j) {
             const uint32_t h = hash_roll(patterns + (size_t)j * (size_t)m, m);
-            bloom[smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask) >> 2] |= (1u << (h & 31u)) | (1u << ((h >> 5) & 31u)) | (bits >= 3u ? 1u << smh_hash_bit3(h) : 0u);
+            bloom[smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask) >> 2] |= (1u << (h & 31u)) | (1u << smh_hash_bit2(h, P.bit2_shift)) | (bits >= 3u ? 1u << smh_hash_bit3(h) : 0u);
         }
         uint32_t pass = 0, x = 0x2545F491u;
         for (int i = 0; i < 65536; ++i) {
             x ^= x << 13; x ^= x >> 17; x ^= x << 5;
             const uint32_t h = x & 0xFFFFFFu, w = bloom[smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask) >> 2];
-            pass += (w >> (h & 31u)) & (w >> ((h >> 5) & 31u)) & (bits >= 3u ? w >> smh_hash_bit3(h) : 1u) & 1u;
+            pass += (w >> (h & 31u)) & (w >> smh_hash_bit2(h, P.bit2_shift)) & (bits >= 3u ? w >> smh_hash_bit3(h) : 1u) & 1u;
         }
         const double rate = (double)pass / 65536.0;
         const double ms = (bits >= 3u ? SMH_HASHES_MS_SCAN3 : SMH_HASHES_MS_SCAN) + SMH_HASHES_MS_PER_SURVIVOR * 4096.0 * rate;
@@ -163,7 +164,7 @@ int smh_hash_filter_passes(const struct smh_hashes *k, const unsigned char *wind
 {
     const uint32_t h = hash_roll(window, k->m);
     const uint32_t w = k->bloom[smh_hash_word_addr(h, k->P.bloom_shift, k->P.bloom_mask) >> 2];
-    return (int)((w >> (h & 31u)) & (w >> ((h >> 5) & 31u)) & (k->P.bloom_k >= 3u ? w >> smh_hash_bit3(h) : 1u) & 1u);
+    return (int)((w >> (h & 31u)) & (w >> smh_hash_bit2(h, k->P.bit2_shift)) & (k->P.bloom_k >= 3u ? w >> smh_hash_bit3(h) : 1u) & 1u);
 }
 int smh_hash_contains(const struct smh_hashes *k, const unsigned char *window)
 {

@@ -210,8 +210,8 @@ SMH_LANE void smh_hash_columns(smh_hash_queue &Q, const smh_hash_ctx &C, uint64_
 SMH_LANE uint32_t smh_hash_test(uint32_t h, const void *bloom, const smh_hash_params &P, bool k3)
 {
     const uint32_t word = smh_lds_u32(bloom, smh_hash_word_addr(h, P.bloom_shift, P.bloom_mask));
-    uint32_t pass = smh_bit_at(word, h) & smh_bit_at(word, h >> 5);
-    if (k3) pass &= smh_bit_at(word, smh_hash_bit3(h)); /* round 6: four more vector instructions per column, a third fewer false candidates */
+    uint32_t pass = smh_bit_at(word, h) & smh_bit_at(word, h >> P.bit2_shift);
+    if (k3) pass &= smh_bit_at(word, smh_hash_bit3_raw(h)); /* round 6: four more vector instructions per column, a third fewer false candidates */
     return pass;
 }
 

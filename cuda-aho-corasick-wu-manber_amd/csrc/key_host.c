@@ -121,7 +121,6 @@ static int keyb_build(const uint64_t *keys, uint32_t n, int m, int bits, uint32_
     if (K->bk_old && 16u * (uint32_t)((m - 1 + 15) / 16) < K->bk_old) return 0; /* the halo primes the whole delay line */
     K->bk_sentinel = K->bk_sh >= 2u ? 1u : 0u;
     K->bk_symmask = ((1u << bits) - 1u) * 0x01010101u;
-    /* primary table: half a key per bucket when LDS allows (2^14 buckets = 128 KiB at most), never fewer bucket bits than the older symbols need */
     /* primary table: 2^14 buckets (128 KiB) from a thousand keys up -- what the lanes pay for is a CROWDED bucket (three keys or
      * more: a sentinel, a queue entry, an overflow-table look), and their share falls with the cube of the load; small sets take
      * a tenth of a key per bucket (staging the image costs the launch ~0.2 us per KiB) */

@@ -2209,28 +2209,37 @@ extern "C" unsigned search_ac(unsigned char *text, int n, struct ac_table *table
 /* The legacy GPU names take the caller's TABLES with every call (cuda/cuda_ac.cu:594, cuda/cuda_wm.cu:183) and main.c:583-592,
  * 623-648 calls the five variants back to back on the same tables.  Until round 5 every call compiled a handle from them, sent
  * its table set to the device and freed it.  Round 6: the last handle of each family is kept, keyed on the caller's pointers and
- * shapes AND a digest of everything the reference's search reads from them (the transition / supply / final arrays; the patterns,
+ * shapes AND a 128-bit digest of everything the reference's search reads from them (the transition / supply / final arrays; the patterns,
  * SHIFT, PREFIX_size and the used entries of PREFIX_value / PREFIX_index) -- a caller that rewrites its arrays in place gets a new
  * handle.  smh_host_path_release() frees the kept handles; smh_legacy_handle_builds() counts the compiles (tests, bench). */
-static uint64_t digest_words(uint64_t h, const void *data, size_t bytes)
+struct legacy_digest { /* 128 bits: two independent multiply-xorshift lanes over the same words */
+    uint64_t a, b;
+    bool operator==(const legacy_digest &o) const { return a == o.a && b == o.b; }
+};
+static legacy_digest digest_words(legacy_digest h, const void *data, size_t bytes)
 {
     const unsigned char *p = (const unsigned char *)data;
     size_t i = 0;
     for (; i + 8 <= bytes; i += 8) {
         uint64_t w;
         memcpy(&w, p + i, 8);
-        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
-        h ^= h >> 29;
+        h.a = (h.a ^ w) * 0x9E3779B97F4A7C15ull;
+        h.a ^= h.a >> 29;
+        h.b = (h.b + w) * 0xD6E8FEB86659FD93ull;
+        h.b ^= h.b >> 32;
     }
     uint64_t tail = 0;
     if (i < bytes) memcpy(&tail, p + i, bytes - i);
-    h = (h ^ tail ^ ((uint64_t)bytes << 56)) * 0xBF58476D1CE4E5B9ull;
-    return h ^ (h >> 32);
+    h.a = (h.a ^ tail ^ ((uint64_t)bytes << 56)) * 0xBF58476D1CE4E5B9ull;
+    h.a ^= h.a >> 32;
+    h.b = (h.b + tail + (uint64_t)bytes) * 0x94D049BB133111EBull;
+    h.b ^= h.b >> 31;
+    return h;
 }
 struct legacy_key {
     const void *ptr[5];
     int m, p_size, alphabet;
-    uint64_t digest;
+    legacy_digest digest;
     bool operator==(const legacy_key &o) const { return memcmp(ptr, o.ptr, sizeof ptr) == 0 && m == o.m && p_size == o.p_size && alphabet == o.alphabet && digest == o.digest; }
 };
 static std::mutex g_legacy_mu; /* the legacy names are the reference's single-threaded API: one call at a time */
@@ -2253,9 +2262,9 @@ static void cuda_ac_any(int k, int variant, int m, unsigned char *text, int n, i
 {
     std::lock_guard<std::mutex> lock(g_legacy_mu);
     const uint64_t rows = (uint64_t)m * (uint64_t)p_size + 1u;
-    legacy_key key = {{state_transition, state_supply, state_final, NULL, NULL}, m, p_size, alphabet, 0};
+    legacy_key key = {{state_transition, state_supply, state_final, NULL, NULL}, m, p_size, alphabet, {0, 0}};
     if (state_transition && state_supply && state_final && m > 0 && p_size > 0 && alphabet > 0) {
-        key.digest = digest_words(0x5EED, state_transition, (size_t)rows * (size_t)alphabet * sizeof(int));
+        key.digest = digest_words(legacy_digest{0x5EED, 0xFACADE}, state_transition, (size_t)rows * (size_t)alphabet * sizeof(int));
         key.digest = digest_words(key.digest, state_supply, (size_t)rows * sizeof(unsigned int));
         key.digest = digest_words(key.digest, state_final, (size_t)rows * sizeof(unsigned int));
     }
@@ -2304,10 +2313,10 @@ static unsigned int wm_any(const unsigned char *flat, int m, int p_size, int alp
                            double *secs, const void *pattern_identity)
 {
     std::lock_guard<std::mutex> lock(g_legacy_mu);
-    legacy_key key = {{pattern_identity, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size}, m, p_size, alphabet, 0};
+    legacy_key key = {{pattern_identity, SHIFT, PREFIX_value, PREFIX_index, PREFIX_size}, m, p_size, alphabet, {0, 0}};
     const uint32_t buckets = alphabet > 0 ? smh_wu_shiftsize_for(alphabet) : 0u;
     if (flat && SHIFT && PREFIX_value && PREFIX_index && PREFIX_size && m > 0 && p_size > 0 && buckets) {
-        key.digest = digest_words(0x5EED, flat, (size_t)m * (size_t)p_size);
+        key.digest = digest_words(legacy_digest{0x5EED, 0xFACADE}, flat, (size_t)m * (size_t)p_size);
         key.digest = digest_words(key.digest, SHIFT, (size_t)buckets * sizeof(int));
         key.digest = digest_words(key.digest, PREFIX_size, (size_t)buckets * sizeof(int));
         for (uint32_t h = 0; h < buckets; ++h) { /* the entries search_wu reads: PREFIX_size[h] of them per bucket (wu/wu.c:76-80) */

@@ -195,7 +195,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
             if (fbig) { /* a dword of the set, bit = the product's low five bits (wm_lane.h smh_flat_group) */
                 uint32_t word;
                 memcpy(&word, (const uint8_t *)tab + SMH_GRAM_BIG_DWORD(prod), 4);
-                out = (word >> (prod & 31u)) | (fk2 ? word >> ((prod >> 5) & 31u) : 0u);
+                out = (word >> (prod & 31u)) | (fk2 ? word >> (prod >> 27) : 0u);
             } else {
                 const uint32_t b = ((const uint8_t *)tab)[prod >> 15];
                 out = (b >> ((prod >> 12) & 7u)) | (fk2 ? b >> ((prod >> 9) & 7u) : 0u);
@@ -424,12 +424,18 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                         const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
                         const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
                         const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
-                        if (big) { flat_big_clear(t2, prod, prod & 31u); flat_big_clear(t2, prod, (prod >> 5) & 31u); }
+                        if (big) { flat_big_clear(t2, prod, prod & 31u); flat_big_clear(t2, prod, prod >> 27); }
                         else t2[prod >> 15] &= (uint8_t)~((1u << ((prod >> 12) & 7u)) | (1u << ((prod >> 9) & 7u)));
                     }
-                const double d2 = gram_survivors(big ? SMH_GRAM_FLAT_BIG_K2 : SMH_GRAM_FLAT_K2, t2, wm->alphabet, J), ms2 = flat_ms + 0.01 + gram_verify_ms(m, d2);
+                /* what the second bit costs the scan: 0.01 ms/GiB in the byte-addressed form (round 4), 0.022 in the big table (filter
+                 * alone 0.916 -> 1.004 ms per 4 GiB).  The big form's windows-from-L2 verify costs about the same at 16 and at 28
+                 * survivors per chunk (0.05 / 0.057 ms/GiB) and twice that at 46, where its queue overflows: there the second bit
+                 * pays (100 000 patterns, m = 5: 46 -> 21 per chunk, 1.45 -> 1.21 ms per 4 GiB) and below it loses (m = 6: 28 -> 16,
+                 * 1.15 -> 1.21; m = 7: 1.09 -> 1.23) -- profiles/r06_final/notes/ab_byte_gram_big_table.log */
+                const double d2 = gram_survivors(big ? SMH_GRAM_FLAT_BIG_K2 : SMH_GRAM_FLAT_K2, t2, wm->alphabet, J), ms2 = flat_ms + (big ? 0.022 : 0.01) + gram_verify_ms(m, d2);
                 const int fk = smh_tune_int(SMH_TUNE_WM, "flatk=", 0); /* development knob "flatk=1|2": one / two bits per gram regardless */
-                if (fk == 2 || (fk != 1 && ms2 < ms)) {
+                if (smh_tune_has(SMH_TUNE_WM, "debug")) fprintf(stderr, "flat byte grams%s: one bit per gram %.5f of the columns survive, est %.3f ms/GiB; two bits %.5f, est %.3f\n", big ? " (big table)" : "", dens, ms, d2, ms2);
+                if (fk == 2 || (fk != 1 && ms2 < ms && (!big || dens * 4096.0 > 30.0))) {
                     free(tab);
                     tab = t2; dens = d2; ms = ms2; k2 = 1;
                 } else {

@@ -1604,8 +1604,11 @@ SMH_LANE uint32_t smh_gram_big_index(uint32_t prod)
 #endif
 }
 /* the flat set in the big table (KIND 9 / 10) is read a DWORD at a time: byte address = the dword index << 2, bit = the product's low
- * five bits (second bit: the next five) -- v_lshrrev takes a shift's low five bits by itself, so the form costs what the 128 KiB one
- * costs: mul, mul_hi, shift, [ds_read_b32], shift, alignbit */
+ * five bits -- v_lshrrev takes a shift's low five bits by itself, so the form costs what the 128 KiB one costs: mul, mul_hi, shift,
+ * [ds_read_b32], shift, alignbit.  Second bit (KIND 10): the product's TOP five bits (prod >> 27).  The dword index is made of the
+ * product's bits 9..23 (v_mul_hi_u32_u24 reads the low 24), so the "next five" (bits 5..9, the first build of round 6) shared
+ * bit 9 with it: within a dword every second bit fell into one half, a random gram passed the second test at 0.55 where the
+ * set is 0.37 full, and two bits filtered no better than one (m = 5: 1.05 % against 1.13 % of the columns; now 0.44 %). */
 SMH_LANE uint32_t smh_gram_big_dword(uint32_t prod)
 {
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
@@ -1623,7 +1626,7 @@ SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask,
     if constexpr (KIND == 9) { /* the flat set in the big table (bounds-checked path) */
         const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
         uint32_t out = word >> (prod & 31u);
-        if (k2) out |= word >> ((prod >> 5) & 31u);
+        if (k2) out |= word >> (prod >> 27);
         return (out & 1u) ? gmask : 0u;
     }
     const uint32_t b = smh_lds_u8(tab, KIND == 8 ? smh_gram_big_index(prod) : prod >> 15);
@@ -1689,7 +1692,7 @@ SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2, bool big)
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
     if (big) {
         const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
-        return k2 ? (word >> (prod & 31u)) | (word >> ((prod >> 5) & 31u)) : word >> (prod & 31u);
+        return k2 ? (word >> (prod & 31u)) | (word >> (prod >> 27)) : word >> (prod & 31u);
     }
     const uint32_t b = smh_lds_u8(tab, prod >> 15);
     return k2 ? (b >> smh_flat_idx<12>(prod)) | (b >> smh_flat_idx<9>(prod)) : b >> smh_flat_idx<12>(prod);
@@ -1715,7 +1718,7 @@ SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *
         uint32_t t;
         if constexpr (BIG) { /* a dword of the set: the bit index is the product's low five bits, the shift takes them by itself */
             t = b[j] >> (prod[j] & 31u);
-            if constexpr (K2) t |= b[j] >> ((prod[j] >> 5) & 31u);
+            if constexpr (K2) t |= b[j] >> (prod[j] >> 27);
         } else {
             t = b[j] >> smh_flat_idx<12>(prod[j]);
             if constexpr (K2) t |= b[j] >> smh_flat_idx<9>(prod[j]);
