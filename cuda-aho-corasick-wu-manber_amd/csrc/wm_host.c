@@ -223,7 +223,9 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
 #define SMH_GRAM_OCT2_MS 0.178 /* the pair form's lookups + lane 0's inherited state from the halo in every chunk */
 #define SMH_GRAM_BYTE_MS 0.238
 #define SMH_GRAM_BYTE_BIG_MS 0.243 /* one vector instruction more per column (the index), under the LDS lookup's shadow */
-#define SMH_GRAM_FLAT_BIG_MS 0.272 /* the same instruction count as SMH_GRAM_FLAT (the set is read a dword at a time) */
+#define SMH_GRAM_FLAT_BIG_MS 0.259 /* the same instruction count as SMH_GRAM_FLAT (the set is read a dword at a time); with the survivors dropped it runs
+                                    * 0.92 ms per 4 GiB where SMH_GRAM_BYTE_BIG runs 0.855: +0.016 ms/GiB.  (0.272 until late in round 6: m = 9 -- seven
+                                    * grams, 15 survivors per chunk against the hashed planes' 28 -- went to the planes by 0.005 and ran 9 % slower) */
 #define SMH_GRAM_FLAT_MS 0.27 /* SMH_GRAM_BYTE's lookup per column + two VALU (bit index, bit) */
 /* verify stage, ms per GiB for a fraction `dens` of surviving columns.  Staged (m <= 33: window hashes from the LDS
  * copy of the chunk, probe pipelined): the cost is mostly per wave-chunk that has any survivor -- lock, copy, hash
