@@ -488,7 +488,7 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
  * the top-17-bits index (profiles/r06_final/notes/ab_byte_gram_big_table.log).  Only with the windows-from-L2 verify (no room for
  * staging buffers): sets whose filter passes more than its pipeline takes keep SMH_GRAM_BYTE. */
 #define SMH_GRAM_BYTE_BIG 8
-/* ... and SMH_GRAM_FLAT in the same 143.9 KiB (1 179 136 bits; read a dword at a time: bit = the product's low five bits, second bit its top five: the set of 100 000 patterns' grams is 39 % full instead of 43 % at m = 8, six in a row pass 0.34 % instead of 0.63 % */
+/* ... and SMH_GRAM_FLAT in the same 143.9 KiB (1 179 136 bits; read a dword at a time: bit = the product's low five bits, second bit its bits 24..28: the set of 100 000 patterns' grams is 39 % full instead of 43 % at m = 8, six in a row pass 0.34 % instead of 0.63 % */
 #define SMH_GRAM_FLAT_BIG 9
 #define SMH_GRAM_BIG_BYTES 147392u
 #define SMH_GRAM_BIG_DWORD(prod) (((uint32_t)(((uint64_t)((prod) & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES / 4u) << 8)) >> 32)) << 2) /* byte offset of the dword */

@@ -195,7 +195,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
             if (fbig) { /* a dword of the set, bit = the product's low five bits (wm_lane.h smh_flat_group) */
                 uint32_t word;
                 memcpy(&word, (const uint8_t *)tab + SMH_GRAM_BIG_DWORD(prod), 4);
-                out = (word >> (prod & 31u)) | (fk2 ? word >> (prod >> 27) : 0u);
+                out = (word >> (prod & 31u)) | (fk2 ? word >> ((prod >> 24) & 31u) : 0u);
             } else {
                 const uint32_t b = ((const uint8_t *)tab)[prod >> 15];
                 out = (b >> ((prod >> 12) & 7u)) | (fk2 ? b >> ((prod >> 9) & 7u) : 0u);
@@ -426,7 +426,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                         const unsigned char *g = pats + (size_t)p * m + (m - 3 - j);
                         const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16);
                         const uint32_t prod = (uint32_t)((uint64_t)key * SMH_GRAM_MUL);
-                        if (big) { flat_big_clear(t2, prod, prod & 31u); flat_big_clear(t2, prod, prod >> 27); }
+                        if (big) { flat_big_clear(t2, prod, prod & 31u); flat_big_clear(t2, prod, (prod >> 24) & 31u); }
                         else t2[prod >> 15] &= (uint8_t)~((1u << ((prod >> 12) & 7u)) | (1u << ((prod >> 9) & 7u)));
                     }
                 /* what the second bit costs the scan: 0.01 ms/GiB in the byte-addressed form (round 4), 0.022 in the big table (filter

@@ -1605,7 +1605,7 @@ SMH_LANE uint32_t smh_gram_big_index(uint32_t prod)
 }
 /* the flat set in the big table (KIND 9 / 10) is read a DWORD at a time: byte address = the dword index << 2, bit = the product's low
  * five bits -- v_lshrrev takes a shift's low five bits by itself, so the form costs what the 128 KiB one costs: mul, mul_hi, shift,
- * [ds_read_b32], shift, alignbit.  Second bit (KIND 10): the product's TOP five bits (prod >> 27).  The dword index is made of the
+ * [ds_read_b32], shift, alignbit.  Second bit (KIND 10): the product's bits 24..28 (smh_flat_big_second).  The dword index is made of the
  * product's bits 9..23 (v_mul_hi_u32_u24 reads the low 24), so the "next five" (bits 5..9, the first build of round 6) shared
  * bit 9 with it: within a dword every second bit fell into one half, a random gram passed the second test at 0.55 where the
  * set is 0.37 full, and two bits filtered no better than one (m = 5: 1.05 % against 1.13 % of the columns; now 0.44 %). */
@@ -1619,6 +1619,18 @@ SMH_LANE uint32_t smh_gram_big_dword(uint32_t prod)
     return (uint32_t)(((uint64_t)(prod & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES_DEV / 4u) << 8)) >> 32) << 2;
 #endif
 }
+/* KIND 10's second bit: bit (product bits 24..28) of the dword -- the shift takes the index out of the product's top BYTE by itself
+ * (SDWA byte select; the shift uses an amount's low five bits), so the second bit costs a shift and an or */
+SMH_LANE uint32_t smh_flat_big_second(uint32_t word, uint32_t prod)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    uint32_t t;
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(t) : "v"(prod), "v"(word));
+    return t;
+#else
+    return word >> ((prod >> 24) & 31u);
+#endif
+}
 template <int KIND>
 SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask, bool k2 = false)
 {
@@ -1626,7 +1638,7 @@ SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask,
     if constexpr (KIND == 9) { /* the flat set in the big table (bounds-checked path) */
         const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
         uint32_t out = word >> (prod & 31u);
-        if (k2) out |= word >> (prod >> 27);
+        if (k2) out |= smh_flat_big_second(word, prod);
         return (out & 1u) ? gmask : 0u;
     }
     const uint32_t b = smh_lds_u8(tab, KIND == 8 ? smh_gram_big_index(prod) : prod >> 15);
@@ -1692,7 +1704,7 @@ SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2, bool big)
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
     if (big) {
         const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
-        return k2 ? (word >> (prod & 31u)) | (word >> (prod >> 27)) : word >> (prod & 31u);
+        return k2 ? (word >> (prod & 31u)) | smh_flat_big_second(word, prod) : word >> (prod & 31u);
     }
     const uint32_t b = smh_lds_u8(tab, prod >> 15);
     return k2 ? (b >> smh_flat_idx<12>(prod)) | (b >> smh_flat_idx<9>(prod)) : b >> smh_flat_idx<12>(prod);
@@ -1718,7 +1730,7 @@ SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *
         uint32_t t;
         if constexpr (BIG) { /* a dword of the set: the bit index is the product's low five bits, the shift takes them by itself */
             t = b[j] >> (prod[j] & 31u);
-            if constexpr (K2) t |= b[j] >> (prod[j] >> 27);
+            if constexpr (K2) t |= smh_flat_big_second(b[j], prod[j]);
         } else {
             t = b[j] >> smh_flat_idx<12>(prod[j]);
             if constexpr (K2) t |= b[j] >> smh_flat_idx<9>(prod[j]);
