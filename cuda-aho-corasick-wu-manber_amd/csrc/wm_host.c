@@ -430,9 +430,9 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                         else t2[prod >> 15] &= (uint8_t)~((1u << ((prod >> 12) & 7u)) | (1u << ((prod >> 9) & 7u)));
                     }
                 /* what the second bit costs the scan: 0.01 ms/GiB in the byte-addressed form (round 4), 0.022 in the big table (filter
-                 * alone 0.916 -> 1.004 ms per 4 GiB).  The big form's windows-from-L2 verify costs about the same at 16 and at 28
+                 * alone 0.894 -> 0.953 ms per 4 GiB).  The big form's windows-from-L2 verify costs about the same at 16 and at 28
                  * survivors per chunk (0.05 / 0.057 ms/GiB) and twice that at 46, where its queue overflows: there the second bit
-                 * pays (100 000 patterns, m = 5: 46 -> 21 per chunk, 1.45 -> 1.21 ms per 4 GiB) and below it loses (m = 6: 28 -> 16,
+                 * pays (100 000 patterns, m = 5: 46 -> 26 per chunk, 1.44 -> 1.19 ms per 4 GiB) and below it loses (m = 6: 28 -> 16,
                  * 1.15 -> 1.21; m = 7: 1.09 -> 1.23) -- profiles/r06_final/notes/ab_byte_gram_big_table.log */
                 const double d2 = gram_survivors(big ? SMH_GRAM_FLAT_BIG_K2 : SMH_GRAM_FLAT_K2, t2, wm->alphabet, J), ms2 = flat_ms + (big ? 0.022 : 0.01) + gram_verify_ms(m, d2);
                 const int fk = smh_tune_int(SMH_TUNE_WM, "flatk=", 0); /* development knob "flatk=1|2": one / two bits per gram regardless */

@@ -1608,7 +1608,9 @@ SMH_LANE uint32_t smh_gram_big_index(uint32_t prod)
  * [ds_read_b32], shift, alignbit.  Second bit (KIND 10): the product's bits 24..28 (smh_flat_big_second).  The dword index is made of the
  * product's bits 9..23 (v_mul_hi_u32_u24 reads the low 24), so the "next five" (bits 5..9, the first build of round 6) shared
  * bit 9 with it: within a dword every second bit fell into one half, a random gram passed the second test at 0.55 where the
- * set is 0.37 full, and two bits filtered no better than one (m = 5: 1.05 % against 1.13 % of the columns; now 0.44 %). */
+ * set is 0.37 full, and two bits filtered no better than one (m = 5: 1.05 % against 1.13 % of the columns).  Bits 27..31 pass 0.52 %
+ * (independent bits: 0.47 %) at three instructions for the second bit; bits 24..28 -- bit 24 is a weaker one -- 0.64 % at two, which
+ * measured 1.3 % faster: kept. */
 SMH_LANE uint32_t smh_gram_big_dword(uint32_t prod)
 {
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)

@@ -1,9 +1,10 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
+M=${1:-12}   # pattern length: traffic_ck.sh [m]
 O=$R/gpurun_out/r06_o; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for t in ck=0 ck=1 none; do
   export SMH_WM_TUNE=$t
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$t -- python3 $R/tools/wmbench.py 12 100000 4096 256 > $O/wmbench_$t.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch_$t -- python3 $R/tools/wmbench.py $M 100000 4096 256 > $O/wmbench_$t.log 2>&1
   tail -2 $O/wmbench_$t.log
 done
 cd $R
