@@ -1,0 +1,74 @@
+"""Filters pass what their bits can hold -- not more.  Round 6 found two filters whose extra bit indices were drawn from bits
+that their word address already used (csrc/wm_lane.h smh_flat_big_second, csrc/hash_engine.h smh_hash_bit2_shift): every count
+was right and every parity test green, the extra bits simply filtered next to nothing.  These tests hold the pass rates
+against what independent indices give, so that the next such overlap shows up on the CPU."""
+import math
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import emu_lib as E
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "cuda-aho-corasick-wu-manber_amd")
+
+
+def _blocked_bloom_pass(keys_per_word, k, bits=32, trials=200000, seed=1):
+    """pass rate of a random key against a filter whose words hold Poisson(keys_per_word) keys of k independent bits each"""
+    rng = np.random.default_rng(seed)
+    load = rng.poisson(keys_per_word, trials)
+    fill = 1.0 - np.exp(-load * k / bits)  # expected fraction of a word's bits set (a key's bits may coincide)
+    return float(np.mean(fill ** k))
+
+
+@pytest.mark.parametrize("p,bits,slack", [(100000, 2, 1.12), (100000, 3, 1.30), (30000, 2, 1.12)])
+def test_window_hash_filter_passes_what_independent_bits_pass(p, bits, slack, knob):
+    """hash_engine.h: `bits` indices into one 32-bit word.  With the second index on address bit 9 the 2^15-word filter of 100 000
+    patterns passed 5.0 % of random windows (independent: 3.8 %); the third index, nearly linear in the bits that vary within
+    a word, 3.3 % where bits 21..25 of the product give 3.0 % (independent: 2.6 % -- nine free bits per word cannot give that:
+    hence the wider slack for three)."""
+    T = knob.T
+    m, sigma, n = 8, 256, 128 << 10
+    rng = np.random.default_rng(11)
+    pat = rng.integers(0, sigma, m * p, dtype=np.uint8)
+    text = rng.integers(0, sigma, n, dtype=np.uint8)
+    knob.set(T.TUNE_HASH, "bits=%d" % bits)
+    wm = T.WmTables.from_patterns(pat, m, p, sigma)
+    assert wm.info().hash_slots, "the handle keeps no window-hash engine"
+    got, passed = E.hash_scan(wm, text)
+    wm.close()
+    words_log2 = 8
+    while words_log2 < 15 and (32 << words_log2) < 10 * p:
+        words_log2 += 1  # hash_host.c: 10 bits per key, 2^15 words at most
+    ideal = _blocked_bloom_pass(p / float(1 << words_log2), bits)
+    rate = (passed - got) / float(n)
+    assert rate <= slack * ideal, "the filter passes %.4f of random windows, independent indices pass %.4f" % (rate, ideal)
+    assert rate >= 0.8 * ideal  # (and the estimate above is the right one)
+
+
+def test_flat_set_second_bit_halves_the_survivors():
+    """wm_host.c build_gram_filter, the flat set in the 143.9 KiB table, 100 000 patterns of 5 bytes: a second bit per gram takes
+    the set from 22 % to 39 % full and a gram's pass rate from 0.22 to about 0.17 -- three grams in a row: 1.13 % -> 0.5-0.65 %
+    of the columns.  (With the second index on the dword index's own bits it was 1.05 %.)  The builder prints both under the
+    testing twin's "debug" knob."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, smatcher_hip as S\n"
+        "T = S.load_testing()\n"
+        "T.tune(T.TUNE_WM, 'debug')\n"
+        "pat = np.random.default_rng(5).integers(0, 256, 5 * 100000, dtype=np.uint8)\n"
+        "T.WmTables.from_patterns(pat, 5, 100000, 256)\n" % PKG
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    mt = re.search(r"\(big table\): one bit per gram ([0-9.]+) of the columns survive.*two bits ([0-9.]+)", out.stderr)
+    assert mt, out.stderr[-2000:]
+    one, two = float(mt.group(1)), float(mt.group(2))
+    fill1 = 1.0 - math.exp(-300000.0 / 1179136.0)
+    assert abs(one - fill1 ** 3) < 0.15 * fill1 ** 3, (one, fill1 ** 3)
+    assert two <= 0.62 * one, "two bits per gram pass %.5f of the columns, one bit %.5f" % (two, one)
+    assert "kept form 9" in out.stderr
