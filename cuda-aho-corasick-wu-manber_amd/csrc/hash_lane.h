@@ -109,51 +109,7 @@ SMH_LANE void smh_hash_verify(const smh_hash_ctx &C, const uint64_t (&e)[NCH], b
 #pragma unroll
     for (int c = 0; c < NCH; ++c) smh_hash_slots(smh_wm_tag_dwords<9>(d[c], sh[c], C.P.m), C.P.seed, C.P.slots, &s1[c], &s2[c]);
     const uint32_t last_mask = (C.P.m & 3) ? (1u << (8 * (C.P.m & 3))) - 1u : 0xFFFFFFFFu;
-    if constexpr (ND >= 3) {
-        /* Two looks (late round 6).  The stage is bound by the rate at which the L1 takes a wave's scattered 16-byte requests, and a
-         * bucket of two slots of ND dwords is 2 or 3 of them.  The FIRST request of a bucket holds dwords 0 and 1 of both of its slots
-         * (the slots are interleaved dword by dword): a window that is no pattern differs from a slot there but once in 2^64, so only
-         * lanes whose window agrees with a slot in its first eight bytes -- the true matches -- ask for the rest, and only of that
-         * bucket.  Requests per window and slot pair, m = 12 / 16 / 20: 5 / 6 / 8 before; a non-match 3 / 4 / 4, a match 4 / 5 / 6. */
-        uint32_t a[NCH][4], b[NCH][4];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            smh_hash_load_bucket<4>(C.table + 8u * ND * (uint64_t)s1[c], a[c]);
-            smh_hash_load_bucket<4>(C.table + 8u * ND * (uint64_t)s2[c], b[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const uint32_t v0 = smh_hash_window_dword(d[c], sh[c], 0), v1 = smh_hash_window_dword(d[c], sh[c], 1);
-            uint32_t d0 = (v0 ^ a[c][0]) | (v1 ^ a[c][2]), d1 = (v0 ^ a[c][1]) | (v1 ^ a[c][3]);
-            uint32_t d2 = (v0 ^ b[c][0]) | (v1 ^ b[c][2]), d3 = (v0 ^ b[c][1]) | (v1 ^ b[c][3]);
-            hit[c] = 0u;
-            if ((d0 == 0u) | (d1 == 0u)) { /* per lane: the rest of the first bucket */
-                uint32_t r[2 * ND - 4];
-                smh_hash_load_bucket<2 * ND - 4>(C.table + 8u * ND * (uint64_t)s1[c] + 16u, r);
-#pragma unroll
-                for (int j = 2; j < ND; ++j) {
-                    uint32_t v = smh_hash_window_dword(d[c], sh[c], j);
-                    if (j == ND - 1) v &= last_mask;
-                    d0 |= v ^ r[2 * j - 4];
-                    d1 |= v ^ r[2 * j - 3];
-                }
-                hit[c] |= ((d0 == 0u) | (d1 == 0u)) ? 1u : 0u;
-            }
-            if ((d2 == 0u) | (d3 == 0u)) {
-                uint32_t r[2 * ND - 4];
-                smh_hash_load_bucket<2 * ND - 4>(C.table + 8u * ND * (uint64_t)s2[c] + 16u, r);
-#pragma unroll
-                for (int j = 2; j < ND; ++j) {
-                    uint32_t v = smh_hash_window_dword(d[c], sh[c], j);
-                    if (j == ND - 1) v &= last_mask;
-                    d2 |= v ^ r[2 * j - 4];
-                    d3 |= v ^ r[2 * j - 3];
-                }
-                hit[c] |= ((d2 == 0u) | (d3 == 0u)) ? 1u : 0u;
-            }
-        }
-    } else {
-    uint32_t a[NCH][2 * ND], b[NCH][2 * ND]; /* the two buckets, each two slots interleaved dword by dword: one request each */
+    uint32_t a[NCH][2 * ND], b[NCH][2 * ND]; /* the two buckets, each two slots interleaved dword by dword */
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         smh_hash_load_bucket<2 * ND>(C.table + 8u * ND * (uint64_t)s1[c], a[c]);
@@ -173,7 +129,6 @@ SMH_LANE void smh_hash_verify(const smh_hash_ctx &C, const uint64_t (&e)[NCH], b
             d3 |= v ^ b[c][2 * j + 1];
         }
         hit[c] = ((d0 == 0u) | (d1 == 0u) | (d2 == 0u) | (d3 == 0u)) ? 1u : 0u;
-    }
     }
 }
 
