@@ -72,3 +72,37 @@ def test_flat_set_second_bit_halves_the_survivors():
     assert abs(one - fill1 ** 3) < 0.15 * fill1 ** 3, (one, fill1 ** 3)
     assert two <= 0.62 * one, "two bits per gram pass %.5f of the columns, one bit %.5f" % (two, one)
     assert "kept form 9" in out.stderr
+
+
+def _builder_debug(m, p, sigma=256, seed=5):
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, smatcher_hip as S\n"
+        "T = S.load_testing()\n"
+        "T.tune(T.TUNE_WM, 'debug')\n"
+        "pat = np.random.default_rng(%d).integers(0, %d, %d * %d, dtype=np.uint8)\n"
+        "T.WmTables.from_patterns(pat, %d, %d, %d)\n" % (PKG, seed, sigma, m, p, m, p, sigma)
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stderr
+
+
+@pytest.mark.parametrize("m,form,grams", [(12, 8, 8), (9, 9, 7), (8, 9, 6)])
+def test_byte_gram_filters_of_the_big_table_pass_what_their_bits_hold(m, form, grams):
+    """BASELINE configs[4] (100 000 byte patterns): the hashed planes (form 8: a plane = 100 000 grams over 147 392 bytes, eight
+    planes in a row) and the one-bit flat set (form 9: all offsets' grams over 1 179 136 bits, m - 2 of them in a row) against
+    the rates independent hashing gives -- and against the bound of any Bloom-type filter of that size, 0.6185^(bits per
+    pattern): the forms sit within a fifth of it, which is why DESIGN.md section 9 calls the filter closed."""
+    err = _builder_debug(m, 100000)
+    mt = re.search(r"kept form (\d+), (\d+) planes, survivors ([0-9.]+)", err)
+    assert mt, err[-2000:]
+    assert (int(mt.group(1)), int(mt.group(2))) == (form, grams), mt.group(0)
+    got = float(mt.group(3))
+    if form == 8:
+        ideal = (1.0 - math.exp(-100000.0 / 147392.0)) ** grams
+    else:
+        ideal = (1.0 - math.exp(-100000.0 * grams / 1179136.0)) ** grams
+    assert abs(got - ideal) <= 0.15 * ideal, (got, ideal)
+    bound = 0.6185 ** (1179136.0 / 100000.0)
+    assert got <= 1.45 * bound, (got, bound)
