@@ -158,6 +158,9 @@ def compact_line(out, detail_path=None, detail_sha=None):
         line["world"] = dict(world_size=w.get("world_size"), backend=w.get("backend"), distinct_cards=w.get("distinct_cards"),
                              rehearsal=w.get("rehearsal"),
                              ranks=[_pick(r, ("rank", "local_rank", "device", "pci_bus_id")) for r in w.get("ranks", [])][:16])
+        buses = {r.get("pci_bus_id") for r in w.get("ranks", [])}
+        if w.get("distinct_cards") and len(buses) != w.get("distinct_cards"):  # cards told apart by UUID (rank_identity): say so
+            line["world"]["ranks"] = [_pick(r, ("rank", "local_rank", "device", "pci_bus_id", "uuid")) for r in w.get("ranks", [])][:16]
     roof = _pick(out.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_instance", "launch_ms",
                                            "algorithmic_bytes_per_launch", "of_stream_read", "chosen_engine"))
     roof["traffic_source"] = str(out.get("roofline", {}).get("traffic_source", ""))[:140]
@@ -650,7 +653,9 @@ def rank_identity(R):
     mine = dict(rank=R.rank, local_rank=R.local_rank, device=int(torch.cuda.current_device()), pci_bus_id=S.device_pci_bus_id(),
                 uuid=str(getattr(props, "uuid", "")), host=socket.gethostname(), pid=os.getpid())
     ranks = R.sharded.gather_objects(mine)
-    cards = {(r["host"], r["pci_bus_id"]) for r in ranks}
+    # a card = (host, PCI bus id, device UUID): two ranks share one only when all three agree (partitioned devices may report
+    # one bus id for several logical devices; their UUIDs differ)
+    cards = {(r["host"], r["pci_bus_id"], r["uuid"]) for r in ranks}
     if len(cards) != len(ranks) and not R.args.share_device:
         raise SystemExit("bench.py: %d ranks on %d distinct cards %r -- every rank needs a card of its own (--share-device rehearses the "
                          "flow on one card)" % (len(ranks), len(cards), sorted(cards)))

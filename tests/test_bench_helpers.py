@@ -105,3 +105,16 @@ def test_small_text_and_preproc_reach_the_line():
     rec["preproc"] = {"what": "w", "sets": {"ac_1000_m8": {"preproc_s": 0.01}}}
     got = json.loads(bench.compact_line(rec))
     assert got["small_text_of_gib_rate"] == {"E.coli": [0.2, 0.19]} and got["preproc_s"] == {"ac_1000_m8": 0.01}
+
+
+def test_cards_that_share_a_bus_id_are_told_apart_by_uuid_and_the_line_says_so():
+    """rank_identity counts (host, PCI bus id, UUID): logical devices of a partitioned card may report one bus id.  The compact
+    line then carries the UUIDs as well, so that the reader can see why distinct_cards exceeds the distinct bus ids."""
+    ranks = [dict(rank=i, local_rank=i, device=i, pci_bus_id="0000:75:00.0", uuid="GPU-%d" % i, host="node", pid=100 + i) for i in range(2)]
+    rec = dict(metric="Gbit/s", value=1.0, unit="Gbit/s", n_gpus=2, steps=1, warmup=0, ms_per_step=1.0, higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="u8", data="synthetic", config=dict(workload="w"), parity_ok=True, smh_multi_ok=True,
+               roofline=dict(bound="hbm", achieved=1.0, peak=8000.0, unit="GB/s", frac=0.1, traffic=None),
+               cpu_baseline=dict(value=1.0, unit="Gbit/s", cores=1, kind="reference", sample="s"),
+               world=dict(world_size=2, backend="nccl", distinct_cards=2, rehearsal=False, ranks=ranks))
+    w = json.loads(bench.compact_line(rec))["world"]
+    assert w["distinct_cards"] == 2 and [r["uuid"] for r in w["ranks"]] == ["GPU-0", "GPU-1"]
