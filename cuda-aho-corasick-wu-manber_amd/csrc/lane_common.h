@@ -45,6 +45,12 @@
 /* (8000 x 16 at 4.4 per chunk: in registers 10 % faster than staged; 0.2 per chunk and below: 0-2.5 % faster; between 0.5
  * and 3 per chunk against the staged kernel that also drains sparse chunks from HBM: -3 % .. +2 %, within the noise of the
  * interleaved A/Bs -- profiles/r03_experiments/regv_ab_threshold.log, gram_forms_ab.log; 20 per chunk: 12 % slower) */
+#ifndef SMH_L2_MIN_PER_CHUNK
+#define SMH_L2_MIN_PER_CHUNK 0.02 /* == smh_internal.h: surviving columns per wave-chunk from which the DNA forms verify through the windows-from-L2 pipeline */
+#endif
+#ifndef SMH_L2_DNA_MAX_PER_CHUNK
+#define SMH_L2_DNA_MAX_PER_CHUNK 40.0 /* (both headers) ... up to here: at 46 per chunk the staged verify measured 3 % faster again */
+#endif
 #ifndef SMH_REGV_WANTED
 #define SMH_REGV_WANTED(per_chunk) ((per_chunk) <= SMH_REGV_MAX_PER_CHUNK)
 #endif

@@ -153,6 +153,12 @@ extern _Thread_local int smh_alt_engine_depth;
 #ifndef SMH_REGV_MAX_PER_CHUNK
 #define SMH_REGV_MAX_PER_CHUNK 8.0 /* == lane_common.h; surviving columns per 4 KiB wave-chunk up to which the pair-gram kernels verify in registers (wm_lane.h smh_wm_regv_columns) */
 #endif
+#ifndef SMH_L2_MIN_PER_CHUNK
+#define SMH_L2_MIN_PER_CHUNK 0.02 /* == lane_common.h; from here up (to SMH_L2_DNA_MAX_PER_CHUNK) the DNA gram forms verify through the windows-from-L2 pipeline (wm_kernels.inc launch_gram) */
+#endif
+#ifndef SMH_L2_DNA_MAX_PER_CHUNK
+#define SMH_L2_DNA_MAX_PER_CHUNK 40.0 /* (both headers) ... up to here: at 46 per chunk the staged verify measured 3 % faster again */
+#endif
 #ifndef SMH_REGV_WANTED
 #define SMH_REGV_WANTED(per_chunk) ((per_chunk) <= SMH_REGV_MAX_PER_CHUNK) /* == lane_common.h */
 #endif

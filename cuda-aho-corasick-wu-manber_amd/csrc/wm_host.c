@@ -253,8 +253,21 @@ static double gram_verify_ms(int m, double dens)
 static double gram_verify_ms_pairlike(int m, double dens)
 {
     const double pc = dens * 4096.0;
+    /* late round 6: between SMH_L2_MIN_PER_CHUNK and 40 survivors per chunk these forms verify through the windows-from-L2 pipeline
+     * (wm_kernels.inc launch_gram), fit on 13 DNA sets x 3 forms pinned to the filter kernels (tools/l2_fit.py,
+     * profiles/r06_final/notes/ab_dna_l2_verify.log): 0.014 / 0.037 / 0.079 / 0.082 / 0.158 ms/GiB over the bare scan at 1.2 / 6.2 /
+     * 13.8 / 19.9 / 34 per chunk */
+    if (m <= 33 && pc >= SMH_L2_MIN_PER_CHUNK && pc <= SMH_L2_DNA_MAX_PER_CHUNK) return 0.01 + 0.0045 * pc;
     const double f = m > 33 ? 1.0 : pc <= SMH_REGV_MAX_PER_CHUNK ? 0.7 : pc <= 40.0 ? 1.2 : 1.0;
     return f * gram_verify_ms(m, dens);
+}
+/* the 8-symbol-gram form (one lookup per column) with that pipeline: 0.029 / 0.033 / 0.060 / 0.125 over its bare 0.215 at 0.25 / 1.7 /
+ * 5.9 / 36 per chunk -- over SMH_GRAM_OCT_MS, which holds 0.025 of it */
+static double gram_verify_ms_oct(int m, double dens)
+{
+    const double pc = dens * 4096.0;
+    if (m <= 33 && pc >= SMH_L2_MIN_PER_CHUNK && pc <= SMH_L2_DNA_MAX_PER_CHUNK) return 0.005 + 0.0027 * pc;
+    return gram_verify_ms(m, dens);
 }
 #define SMH_HASHED_VERIFY_MS(m) (6.0 + 1.05 * (m))
 #define SMH_DIRECT_VERIFY_MS(m) ((m) > 4 ? 1.9 * (m) - 3.0 : 4.6)
@@ -323,7 +336,7 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
                 for (int i = 0; i < 8; ++i) code = (code << 2) | g[i];
                 tab[code] &= (uint8_t)~(1u << (7 - j));
             }
-        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4, J), ms = SMH_GRAM_OCT_MS + gram_verify_ms(m, dens);
+        const double dens = gram_survivors(SMH_GRAM_OCT, tab, 4, J), ms = SMH_GRAM_OCT_MS + gram_verify_ms_oct(m, dens);
         if (ms < best_ms) {
             free(best);
             best = tab; best_kind = SMH_GRAM_OCT; best_planes = J; best_bytes = 65536; best_ms = ms; best_dens = dens;

@@ -272,12 +272,21 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
         if (strstr(tn, "regv=0")) regv = false;
         if (strstr(tn, "regv=1")) regv = pairlike && stg > 0;
     }
-    if (regv) stg += 4;
+    /* the DNA forms through the windows-from-L2 pipeline (STG 3 / 4) from SMH_L2_MIN_PER_CHUNK to SMH_L2_DNA_MAX_PER_CHUNK
+     * survivors per chunk, as launch_gram (late round 6); SMH_WM_TUNE "l2=0|1" as there */
+    const bool l2_dna = wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2 || wm->gram_kind == SMH_GRAM_OCT;
+    bool l2p = l2_dna && stg > 0 && wm->gram_density * 4096.0 >= SMH_L2_MIN_PER_CHUNK && wm->gram_density * 4096.0 <= SMH_L2_DNA_MAX_PER_CHUNK;
+    if (const char *tn = getenv("SMH_WM_TUNE")) {
+        if (strstr(tn, "l2=0")) l2p = false;
+        if (strstr(tn, "l2=1")) l2p = l2_dna && stg > 0;
+    }
+    if (l2p) stg += 2; /* 3 / 4 */
+    else if (regv) stg += 4;
     for (uint64_t t = 0; t < nthreads; ++t) {
         const smh_chunk_sched S = smh_sched_static(t >> 6, nthreads >> 6);
 #define GRAM_CALL(KIND, STG) (po ? smh_wm_gram_thread<KIND, true, STG>(t, S, text, n, wm->gram_table, P, nullptr, po) \
                                  : smh_wm_gram_thread<KIND, false, STG>(t, S, text, n, wm->gram_table, P, nullptr, po))
-#define GRAM_STG(KIND) (stg == 1 ? GRAM_CALL(KIND, 1) : stg == 2 ? GRAM_CALL(KIND, 2) : GRAM_CALL(KIND, 0))
+#define GRAM_STG(KIND) (stg == 1 ? GRAM_CALL(KIND, 1) : stg == 2 ? GRAM_CALL(KIND, 2) : stg == 3 ? GRAM_CALL(KIND, 3) : stg == 4 ? GRAM_CALL(KIND, 4) : GRAM_CALL(KIND, 0))
         if (wm->gram_kind == SMH_GRAM_PAIR)
             total += stg == 5 ? GRAM_CALL(1, 5) : stg == 6 ? GRAM_CALL(1, 6) : GRAM_STG(1);
         else if (wm->gram_kind == SMH_GRAM_OCT2)
