@@ -96,7 +96,8 @@ def ac_kernel_name(info):
     if info.scan_dense:  # the dense plan: the pair lookup kernel with the automaton's accepting-bit set
         return "wm_pair_kernel<false, 1024>"
     if info.scan_engine == 1:  # SMH_ALGO_WM: the pair-gram filter scans (ac_host.c, end of the compile); STG = halo staged / 16
-        return "wm_gram_kernel<%d, false, %d, false>" % (info.gram_kind, (1 if info.m <= 17 else 2) + (4 if info.verify_in_registers else 0))
+        # verify stage: 1 = in registers (STG 5 / 6), 2 = windows from L2 (STG 3 / 4), 0 = staged (STG 1 / 2): smh_wm_info.verify_in_registers
+        return "wm_gram_kernel<%d, false, %d, false>" % (info.gram_kind, (1 if info.m <= 17 else 2) + {0: 0, 1: 4, 2: 2}[int(info.verify_in_registers)])
     halo = info.scan_depth - 1
     hc = 1 if halo <= 16 else (2 if halo <= 32 else 4)
     entry = "unsigned short" if (info.scan_stride == 2 or info.lds_rows <= 32768) else "unsigned int"

@@ -48,6 +48,9 @@
 #ifndef SMH_L2_MIN_PER_CHUNK
 #define SMH_L2_MIN_PER_CHUNK 0.02 /* == smh_internal.h: surviving columns per wave-chunk from which the DNA forms verify through the windows-from-L2 pipeline */
 #endif
+#ifndef SMH_L2_MIN_PER_CHUNK_REGV
+#define SMH_L2_MIN_PER_CHUNK_REGV 0.25 /* (both headers) ... for the forms that can verify in registers (pair form, two-column 8-grams): below it -- the headline sets, 0.003-0.03 per chunk -- the in-register instance is 2 % faster (no pipeline to move along) */
+#endif
 #ifndef SMH_L2_DNA_MAX_PER_CHUNK
 #define SMH_L2_DNA_MAX_PER_CHUNK 40.0 /* (both headers) ... up to here: at 46 per chunk the staged verify measured 3 % faster again */
 #endif

@@ -156,6 +156,9 @@ extern _Thread_local int smh_alt_engine_depth;
 #ifndef SMH_L2_MIN_PER_CHUNK
 #define SMH_L2_MIN_PER_CHUNK 0.02 /* == lane_common.h; from here up (to SMH_L2_DNA_MAX_PER_CHUNK) the DNA gram forms verify through the windows-from-L2 pipeline (wm_kernels.inc launch_gram) */
 #endif
+#ifndef SMH_L2_MIN_PER_CHUNK_REGV
+#define SMH_L2_MIN_PER_CHUNK_REGV 0.25 /* (both headers) ... for the forms that can verify in registers (pair form, two-column 8-grams): below it -- the headline sets, 0.003-0.03 per chunk -- the in-register instance is 2 % faster (no pipeline to move along) */
+#endif
 #ifndef SMH_L2_DNA_MAX_PER_CHUNK
 #define SMH_L2_DNA_MAX_PER_CHUNK 40.0 /* (both headers) ... up to here: at 46 per chunk the staged verify measured 3 % faster again */
 #endif

@@ -257,7 +257,7 @@ static double gram_verify_ms_pairlike(int m, double dens)
      * (wm_kernels.inc launch_gram), fit on 13 DNA sets x 3 forms pinned to the filter kernels (tools/l2_fit.py,
      * profiles/r06_final/notes/ab_dna_l2_verify.log): 0.014 / 0.037 / 0.079 / 0.082 / 0.158 ms/GiB over the bare scan at 1.2 / 6.2 /
      * 13.8 / 19.9 / 34 per chunk */
-    if (m <= 33 && pc >= SMH_L2_MIN_PER_CHUNK && pc <= SMH_L2_DNA_MAX_PER_CHUNK) return 0.01 + 0.0045 * pc;
+    if (m <= 33 && pc >= SMH_L2_MIN_PER_CHUNK_REGV && pc <= SMH_L2_DNA_MAX_PER_CHUNK) return 0.01 + 0.0045 * pc;
     const double f = m > 33 ? 1.0 : pc <= SMH_REGV_MAX_PER_CHUNK ? 0.7 : pc <= 40.0 ? 1.2 : 1.0;
     return f * gram_verify_ms(m, dens);
 }
@@ -1054,7 +1054,13 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
     out->verify_ck_slots = wm->verify_ck ? 4u * wm->ck_buckets : 0u;
     out->gram_planes = wm->gram_kind != SMH_GRAM_NONE ? (uint32_t)wm->gram_planes : 0u;
     out->gram_kind = (uint32_t)wm->gram_kind;
-    out->verify_in_registers = (wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2) && wm->m <= 33 && SMH_REGV_WANTED(wm->gram_density * 4096.0);
+    { /* which verify stage a launch over text like the compile's takes (wm_kernels.inc launch_gram): 1 in registers, 2 windows from L2, 0 staged / other */
+        const double pc = wm->gram_density * 4096.0;
+        const int pairlike = wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2, dna = pairlike || wm->gram_kind == SMH_GRAM_OCT;
+        out->verify_in_registers = 0;
+        if (dna && wm->m <= 33 && pc >= (pairlike ? SMH_L2_MIN_PER_CHUNK_REGV : SMH_L2_MIN_PER_CHUNK) && pc <= SMH_L2_DNA_MAX_PER_CHUNK) out->verify_in_registers = 2;
+        else if (pairlike && wm->m <= 33 && SMH_REGV_WANTED(pc)) out->verify_in_registers = 1;
+    }
     if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : (wm->gram_kind == SMH_GRAM_BYTE_BIG || wm->gram_kind == SMH_GRAM_FLAT_BIG ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES);
     return SMH_OK;
 }

@@ -291,9 +291,12 @@ typedef struct smh_wm_info {
                                * than a non-exact direct filter; same count) -- see smh_wm_set_scan_engine */
     uint32_t gram_planes;     /* > 0: the scan runs the q-gram shift-or filter with this many positional planes
                                * (one lookup per column, or per two columns on the 4-letter alphabet) */
-    uint32_t verify_in_registers; /* 1: pair form (4-letter alphabet) with few surviving columns per 4 KiB of text and
-                               * m <= 33: a survivor's window is hashed by its own lane out of the text registers
-                               * (kernel instance wm_gram_kernel<1 | 5, ., 5 | 6, false>), not from a staged LDS copy */
+    uint32_t verify_in_registers; /* the verify stage a launch takes on text like the compile's.  1: pair-like form (4-letter alphabet) with
+                               * next to no surviving columns (under 0.25 per 4 KiB) and m <= 33: a survivor's window is hashed by its
+                               * own lane out of the text registers (kernel instance wm_gram_kernel<1 | 5, ., 5 | 6, false>).  2 (round
+                               * 6): the 4-letter forms with up to 40 survivors per 4 KiB: survivors queued across chunks, their windows
+                               * re-read from L2, probes pipelined (wm_gram_kernel<1 | 3 | 5, ., 3 | 4, false>).  0: a staged LDS copy
+                               * of the chunk, or the form's own stage (byte forms) */
     uint32_t gram_kind;       /* form of the q-gram filter (== the kernels' KIND template value): 0 none, 1 symbol pairs (7-symbol
                                * grams, two columns per lookup), 2 hashed byte grams (one plane per offset), 3 8-symbol grams, 5 8-symbol
                                * grams at two columns per lookup, 6 flat byte grams (one Bloom set for all offsets) */

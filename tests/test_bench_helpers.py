@@ -25,6 +25,8 @@ def test_kernel_instance_names():
     assert bench.ac_kernel_name(_info(m=32, scan_engine=1, verify_in_registers=1)) == "wm_gram_kernel<1, false, 6, false>"
     assert bench.ac_kernel_name(_info(m=32, scan_engine=1)) == "wm_gram_kernel<1, false, 2, false>"
     assert bench.ac_kernel_name(_info(scan_engine=1, verify_in_registers=1, gram_kind=5)) == "wm_gram_kernel<5, false, 5, false>"
+    assert bench.ac_kernel_name(_info(scan_engine=1, verify_in_registers=2, gram_kind=5)) == "wm_gram_kernel<5, false, 3, false>"  # windows from L2 (round 6)
+    assert bench.ac_kernel_name(_info(m=32, scan_engine=1, verify_in_registers=2, gram_kind=1)) == "wm_gram_kernel<1, false, 4, false>"
     assert bench.ac_kernel_name(_info()) == "ac_dfa_kernel<unsigned short, 4, 4, 1, false,"          # hybrid, depth-cut
     assert bench.ac_kernel_name(_info(scan_full_rows=0, scan_exact=1, scan_depth=8)) == "ac_dfa_kernel<unsigned short, 4, 2, 1, true,"
 
