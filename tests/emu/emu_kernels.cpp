@@ -277,7 +277,7 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
     const bool l2_dna = wm->gram_kind == SMH_GRAM_PAIR || wm->gram_kind == SMH_GRAM_OCT2 || wm->gram_kind == SMH_GRAM_OCT;
     bool l2p = l2_dna && stg > 0 && wm->gram_density * 4096.0 >= (pairlike ? SMH_L2_MIN_PER_CHUNK_REGV : SMH_L2_MIN_PER_CHUNK) && wm->gram_density * 4096.0 <= SMH_L2_DNA_MAX_PER_CHUNK;
     if (const char *tn = getenv("SMH_WM_TUNE")) {
-        if (strstr(tn, "l2=0")) l2p = false;
+        if (strstr(tn, "l2=0") || strstr(tn, "regv=") || strstr(tn, "hd=")) l2p = false; /* (the knobs that name another stage) */
         if (strstr(tn, "l2=1")) l2p = l2_dna && stg > 0;
     }
     if (l2p) stg += 2; /* 3 / 4 */

@@ -230,7 +230,7 @@ def test_in_register_verify_every_column_and_length(m, kind, knob):
     pat = np.stack([text[e - m + 1:e + 1] for e in ends]).astype(np.uint8)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
     assert want >= len(set(ends))
-    for tune in ("gram=%d,regv=1" % kind, "gram=%d,regv=0" % kind):
+    for tune in ("gram=%d,regv=1" % kind, "gram=%d,regv=0" % kind, "gram=%d,l2=1" % kind):  # (l2=1, late round 6: the windows-from-L2 pipeline)
         knob.wm(tune)
         wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
         if wm.info().scan_engine != S.ALGO_WM:

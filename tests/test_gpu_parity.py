@@ -465,7 +465,7 @@ def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, form, knob):
     test_gram_filter_forms_on_the_gpu(form, 256, m, p, ",flatk=2", knob)
 
 
-@pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1"], ids=["default", "hbm_windows", "staged", "in_registers"])
+@pytest.mark.parametrize("stage", ["", ",stage=0", ",regv=0", ",regv=1", ",l2=1"], ids=["default", "hbm_windows", "staged", "in_registers", "windows_from_l2"])
 @pytest.mark.parametrize("kind,sigma,m,p", [(1, 4, 11, 40), (1, 4, 16, 300), (1, 4, 17, 6000), (1, 4, 33, 50), (1, 4, 40, 50),
                                             (3, 4, 11, 200), (3, 4, 16, 20000), (3, 4, 32, 500), (2, 256, 5, 3000),
                                             (6, 256, 5, 3000), (6, 256, 6, 100000), (6, 256, 7, 100), (6, 256, 8, 30000), (6, 256, 17, 1000), (6, 256, 33, 2000),
@@ -477,8 +477,8 @@ def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, form, knob):
 def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
     """Each q-gram shift-or form forced (development knob), with the staged verify (window hashes from the LDS copy
     of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them), with the pair form's
-    in-register verify forced on and off (round 3; the stretch where every column survives gives a lane 64 rounds of it)
-    and with windows re-read from HBM; texts with planted occurrences at chunk / segment boundaries and a stretch where EVERY column
+    in-register verify forced on and off (round 3; the stretch where every column survives gives a lane 64 rounds of it),
+    with windows re-read from HBM and -- late round 6, the 4-letter forms too -- through the windows-from-L2 pipeline; texts with planted occurrences at chunk / segment boundaries and a stretch where EVERY column
     survives the filter (a pattern repeated back to back), so lists overflow and are flushed mid-chunk."""
     S = knob.T  # the testing build: the development knobs exist only there (csrc/smh_tune.h)
     knob.wm("gram=%d%s" % (kind, stage))
