@@ -2,7 +2,7 @@
 """DNA sets x the three pair-like gram forms (testing twin, "gram=1|3|5"), the handle pinned to its filter kernels (no adaptive
 switching), 1 GiB: median scan time beside the survivors per chunk the compile simulated -- what wm_host.c's
 gram_verify_ms_pairlike is fitted to.  Bare scans of the forms (no survivors): pair form 0.173, two-column 8-grams 0.173, 8-grams
-0.215 ms/GiB.  usage: l2_fit.py [l2=0|l2=1]"""
+0.215 ms/GiB.  usage: l2_fit.py [l2=0|l2=1|regv=1|""] [m:p,m:p,...]"""
 import ctypes as C, os, re, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import torch
@@ -34,7 +34,10 @@ def compile_with_debug(pat, m, p, tune):
         return h, tmp.read()
 
 
-for m, p in [(10, 2000), (12, 2000), (12, 4000), (12, 8000), (13, 8000), (14, 8000), (14, 20000), (16, 8000), (16, 20000), (16, 40000), (18, 40000), (20, 40000), (24, 40000)]:
+SETS = [(10, 2000), (12, 2000), (12, 4000), (12, 8000), (13, 8000), (14, 8000), (14, 20000), (16, 8000), (16, 20000), (16, 40000), (18, 40000), (20, 40000), (24, 40000)]
+if len(sys.argv) > 2:  # "16:2000,16:4000"
+    SETS = [tuple(int(x) for x in t.split(":")) for t in sys.argv[2].split(",")]
+for m, p in SETS:
     pat = T.corpus_patterns(m, p, 7, 4, 42, n, 2)
     for g in (1, 3, 5):
         h, err = compile_with_debug(pat, m, p, "gram=%d" % g)
