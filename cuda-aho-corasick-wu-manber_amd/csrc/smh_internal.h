@@ -499,6 +499,12 @@ uint32_t smh_wu_shiftsize_for(int alphabet); /* 0 if unsupported */
 #define SMH_GRAM_BYTE_BIG 8
 /* ... and SMH_GRAM_FLAT in the same 143.9 KiB (1 179 136 bits; read a dword at a time: bit = the product's low five bits, second bit its bits 24..28: the set of 100 000 patterns' grams is 39 % full instead of 43 % at m = 8, six in a row pass 0.34 % instead of 0.63 % */
 #define SMH_GRAM_FLAT_BIG 9
+/* ... and (late round 6) the one-bit flat set over FOUR-byte grams: three symbols of a 20-letter alphabet are 8000 grams, which a few thousand
+ * patterns fill completely (10 000 protein patterns of 8: every 3-gram filter passes 13 % of the columns); four are 160 000.  Product =
+ * low three bytes x SMH_GRAM_MUL + fourth byte x SMH_GRAM_MUL4 (one SDWA multiply and one multiply-add), then as SMH_GRAM_FLAT_BIG. */
+#define SMH_GRAM_FLAT4_BIG 11
+#define SMH_GRAM_MUL4 0x9E3779u
+#define SMH_GRAM_PROD4(key32) ((uint32_t)((uint64_t)((key32) & 0xFFFFFFu) * SMH_GRAM_MUL) + (uint32_t)((uint64_t)((uint32_t)(key32) >> 24) * SMH_GRAM_MUL4))
 #define SMH_GRAM_BIG_BYTES 147392u
 #define SMH_GRAM_BIG_DWORD(prod) (((uint32_t)(((uint64_t)((prod) & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES / 4u) << 8)) >> 32)) << 2) /* byte offset of the dword */
 #define SMH_GRAM_BIG_INDEX(prod) ((((uint32_t)(((uint64_t)((prod) & 0xFFFFFFu) * (uint64_t)((SMH_GRAM_BIG_BYTES / 4u) << 8)) >> 32)) << 2) | ((uint32_t)(prod) >> 30))

@@ -165,7 +165,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
 {
     enum { COLS = 1 << 18 };
     uint64_t seed = 0x5EEDull, hits = 0;
-    uint32_t S = ~0u, code = 0, k0 = 0, k1 = 0;
+    uint32_t S = ~0u, code = 0, k0 = 0, k1 = 0, k2s = 0;
     const int cand_bit = kind == SMH_GRAM_PAIR ? planes - 1 : 7; /* the pair form holds J-bit values, candidate = bit J-1 */
     if (kind == SMH_GRAM_OCT2) { /* a lookup every second column, two END columns decided per lookup */
         for (int x = 0; x < COLS; ++x) {
@@ -185,6 +185,15 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
         } else if (kind == SMH_GRAM_OCT) {
             code = ((code << 2) | c) & 0xFFFFu;
             G = ((const uint8_t *)tab)[code];
+        } else if (kind == SMH_GRAM_FLAT4_BIG) { /* the flat set over four-byte grams (a dword of the set, bit = the product's low five bits) */
+            const uint32_t key = k0 | (k1 << 8) | (k2s << 16) | (c << 24);
+            k0 = k1;
+            k1 = k2s;
+            k2s = c;
+            const uint32_t prod = SMH_GRAM_PROD4(key);
+            uint32_t word;
+            memcpy(&word, (const uint8_t *)tab + SMH_GRAM_BIG_DWORD(prod), 4);
+            G = ((word >> (prod & 31u)) & 1u) ? (0xFFu & ~((1u << (8 - planes)) - 1u)) : 0u;
         } else if (kind == SMH_GRAM_FLAT || kind == SMH_GRAM_FLAT_K2 || kind == SMH_GRAM_FLAT_BIG || kind == SMH_GRAM_FLAT_BIG_K2) {
             const uint32_t key = k0 | (k1 << 8) | (c << 16);
             k0 = k1;
@@ -227,6 +236,7 @@ static double gram_survivors(int kind, const void *tab, int alphabet, int planes
                                     * 0.92 ms per 4 GiB where SMH_GRAM_BYTE_BIG runs 0.855: +0.016 ms/GiB.  (0.272 until late in round 6: m = 9 -- seven
                                     * grams, 15 survivors per chunk against the hashed planes' 28 -- went to the planes by 0.005 and ran 9 % slower) */
 #define SMH_GRAM_FLAT_MS 0.27 /* SMH_GRAM_BYTE's lookup per column + two VALU (bit index, bit) */
+#define SMH_GRAM_FLAT4_BIG_MS 0.272 /* SMH_GRAM_FLAT_BIG + one vector instruction per column (the fourth byte's multiply; the add rides on the first) */
 /* verify stage, ms per GiB for a fraction `dens` of surviving columns.  Staged (m <= 33: window hashes from the LDS
  * copy of the chunk, probe pipelined): the cost is mostly per wave-chunk that has any survivor -- lock, copy, hash
  * round trips -- and grows slowly with their number (pair form, 16 symbols, survivors per 4 KiB chunk -> ms/GiB over the
@@ -463,6 +473,31 @@ static int build_gram_filter(struct smh_wm *wm, double other_ms)
             free(best);
             best = tab; best_kind = kind; best_planes = J; best_bytes = (uint32_t)bytes; best_ms = ms; best_dens = dens;
             wm->gram_jb = k2;
+        } else {
+            free(tab);
+        }
+    }
+    /* late round 6: the flat set over FOUR-byte grams (smh_internal.h SMH_GRAM_FLAT4_BIG), one bit per gram, in the 143.9 KiB table with its
+     * windows-from-L2 verify: for alphabets whose three-symbol grams the set saturates.  J = m - 3 grams in a row. */
+    if (wm->bits_per_symbol >= 4 && m >= 6 && m - 1 <= 32 && GRAM_WANTED(SMH_GRAM_FLAT4_BIG)) {
+        int J = m - 3;
+        if (J > 8) J = 8;
+        uint8_t *tab = (uint8_t *)malloc(SMH_GRAM_BIG_BYTES);
+        if (!tab) { free(best); return -1; }
+        memset(tab, 0xFF, SMH_GRAM_BIG_BYTES);
+        for (int p = 0; p < d; ++p)
+            for (int j = 0; j < J; ++j) {
+                const unsigned char *g = pats + (size_t)p * m + (m - 4 - j);
+                const uint32_t key = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
+                const uint32_t prod = SMH_GRAM_PROD4(key);
+                flat_big_clear(tab, prod, prod & 31u);
+            }
+        const double dens = gram_survivors(SMH_GRAM_FLAT4_BIG, tab, wm->alphabet, J), ms = SMH_GRAM_FLAT4_BIG_MS + gram_verify_ms(m, dens);
+        if (smh_tune_has(SMH_TUNE_WM, "debug")) fprintf(stderr, "flat four-byte grams (big table): %.5f of the columns survive, est %.3f ms/GiB\n", dens, ms);
+        if ((force == SMH_GRAM_FLAT4_BIG || dens * 4096.0 <= 56.0) && ms < best_ms) {
+            free(best);
+            best = tab; best_kind = SMH_GRAM_FLAT4_BIG; best_planes = J; best_bytes = SMH_GRAM_BIG_BYTES; best_ms = ms; best_dens = dens;
+            wm->gram_jb = 0;
         } else {
             free(tab);
         }
@@ -1061,7 +1096,7 @@ int smh_wm_get_info(const smh_wm *wm, smh_wm_info *out)
         if (dna && wm->m <= 33 && pc >= (pairlike ? SMH_L2_MIN_PER_CHUNK_REGV : SMH_L2_MIN_PER_CHUNK) && pc <= SMH_L2_DNA_MAX_PER_CHUNK) out->verify_in_registers = 2;
         else if (pairlike && wm->m <= 33 && SMH_REGV_WANTED(pc)) out->verify_in_registers = 1;
     }
-    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : (wm->gram_kind == SMH_GRAM_BYTE_BIG || wm->gram_kind == SMH_GRAM_FLAT_BIG ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES);
+    if (wm->gram_kind != SMH_GRAM_NONE) out->lds_bytes = wm->gram_kind == SMH_GRAM_OCT ? 65536u : (wm->gram_kind == SMH_GRAM_BYTE_BIG || wm->gram_kind == SMH_GRAM_FLAT_BIG || wm->gram_kind == SMH_GRAM_FLAT4_BIG ? SMH_GRAM_BIG_BYTES : SMH_GRAM_BYTES);
     return SMH_OK;
 }
 

@@ -1579,6 +1579,31 @@ SMH_LANE uint32_t smh_gram_key(const uint32_t (&w)[16], uint32_t pre)
     }
 }
 
+/* the FOUR bytes that end at column i (KIND 11): the dword at byte offset i - 3 of the segment */
+template <int I>
+SMH_LANE uint32_t smh_gram_key4(const uint32_t (&w)[16], uint32_t pre)
+{
+    if constexpr (I < 3) return smh_alignbyte(w[0], pre, (uint32_t)(I + 1));
+    else {
+        constexpr int first = I - 3, d = first >> 2, r = first & 3;
+        if constexpr (r == 0) return w[d];
+        else return smh_alignbyte(w[d + 1], w[d], (uint32_t)r); /* d + 1 <= 15: the gram ENDS inside the segment */
+    }
+}
+/* its product: low three bytes x SMH_GRAM_MUL + fourth byte x SMH_GRAM_MUL4 (== SMH_GRAM_PROD4): an SDWA multiply on the top byte and a
+ * multiply-add -- one vector instruction more than the three-byte gram's */
+SMH_LANE uint32_t smh_gram_prod4(uint32_t key32)
+{
+#if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
+    uint32_t t;
+    const uint32_t mul4 = 0x9E3779u; /* SMH_GRAM_MUL4 */
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(t) : "v"(key32), "v"(mul4));
+    return __umul24(key32, SMH_GRAM_MUL_DEV) + t;
+#else
+    return (uint32_t)((uint64_t)(key32 & 0xFFFFFFu) * SMH_GRAM_MUL_DEV) + (uint32_t)((uint64_t)(key32 >> 24) * 0x9E3779u);
+#endif
+}
+
 /* G of a byte-gram column from its key (the three bytes that end there, in the low 24 bits).
  *   KIND 2  one plane per offset: the table byte at the top 17 bits of key * SMH_GRAM_MUL
  *   KIND 6  (round 3, SMH_GRAM_FLAT) ONE set for the grams of all offsets, a 2^20-bit array: byte address = the same 17
@@ -1586,11 +1611,12 @@ SMH_LANE uint32_t smh_gram_key(const uint32_t (&w)[16], uint32_t pre)
  *           yields 0 (in the set) or all ones (not), masked to the J plane bits `gmask` -- every plane tests the same set */
 /* kernel KINDs of the byte-gram forms: 2 = hashed planes, 6 / 7 = flat set with one / two bits per gram; round 6: 8 / 9 / 10 = the same three
  * in the 143.9 KiB table (SMH_GRAM_BIG_BYTES) */
-constexpr bool smh_kind_flat(int k) { return k == 6 || k == 7 || k == 9 || k == 10; }
+constexpr bool smh_kind_flat(int k) { return k == 6 || k == 7 || k == 9 || k == 10 || k == 11; }
 constexpr bool smh_kind_flat_k2(int k) { return k == 7 || k == 10; }
-constexpr bool smh_kind_big(int k) { return k == 8 || k == 9 || k == 10; }
+constexpr bool smh_kind_big(int k) { return k == 8 || k == 9 || k == 10 || k == 11; }
+constexpr bool smh_kind_wide(int k) { return k == 11; } /* late round 6: FOUR-byte grams (smh_internal.h SMH_GRAM_FLAT4_BIG) */
 /* the instance of smh_gram_byte_G that looks a column up for kernel KIND k: 2 / 8 the planes, 6 / 9 the flat set */
-constexpr int smh_kind_lookup(int k) { return smh_kind_flat(k) ? (smh_kind_big(k) ? 9 : 6) : (k == 8 ? 8 : 2); }
+constexpr int smh_kind_lookup(int k) { return k == 11 ? 11 : smh_kind_flat(k) ? (smh_kind_big(k) ? 9 : 6) : (k == 8 ? 8 : 2); }
 /* KIND 8 (round 6): KIND 2 with a table of SMH_GRAM_BIG_BYTES bytes -- index = the product's low 24 bits scaled to the table's
  * DWORDS (v_mul_hi_u32_u24 yields 16 bits), the product's top two bits as the byte: == SMH_GRAM_BIG_INDEX in smh_internal.h */
 SMH_LANE uint32_t smh_gram_big_index(uint32_t prod)
@@ -1636,6 +1662,10 @@ SMH_LANE uint32_t smh_flat_big_second(uint32_t word, uint32_t prod)
 template <int KIND>
 SMH_LANE uint32_t smh_gram_byte_G(uint32_t key, const void *tab, uint32_t gmask, bool k2 = false)
 {
+    if constexpr (KIND == 11) { /* four-byte grams, one bit (bounds-checked path): key = all four bytes */
+        const uint32_t prod4 = smh_gram_prod4(key);
+        return ((smh_lds_u32(tab, smh_gram_big_dword(prod4)) >> (prod4 & 31u)) & 1u) ? gmask : 0u;
+    }
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
     if constexpr (KIND == 9) { /* the flat set in the big table (bounds-checked path) */
         const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
@@ -1701,8 +1731,12 @@ SMH_LANE uint32_t smh_flat_idx(uint32_t prod)
     return (prod >> OFF) & 7u;
 #endif
 }
-SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2, bool big)
+SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2, bool big, bool wide = false)
 {
+    if (wide) { /* KIND 11: key = the four bytes, one bit, big table */
+        const uint32_t prod4 = smh_gram_prod4(key);
+        return smh_lds_u32(tab, smh_gram_big_dword(prod4)) >> (prod4 & 31u);
+    }
     const uint32_t prod = smh_mul24(key, SMH_GRAM_MUL_DEV);
     if (big) {
         const uint32_t word = smh_lds_u32(tab, smh_gram_big_dword(prod));
@@ -1713,10 +1747,20 @@ SMH_LANE uint32_t smh_flat_bit(uint32_t key, const void *tab, bool k2, bool big)
 }
 /* eight columns: the products, the eight lookups in flight together, then the bits (only the products and the bytes live
  * across the lookups: with the indices kept beside them the two-bit variant ran out of registers) */
-template <int G, bool K2, bool BIG>
+template <int G, bool K2, bool BIG, bool WIDE = false>
 SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H)
 {
     uint32_t prod[8], b[8];
+    if constexpr (WIDE) { /* four-byte grams (KIND 11) */
+        prod[0] = smh_gram_prod4(smh_gram_key4<8 * G + 0>(w, pre));
+        prod[1] = smh_gram_prod4(smh_gram_key4<8 * G + 1>(w, pre));
+        prod[2] = smh_gram_prod4(smh_gram_key4<8 * G + 2>(w, pre));
+        prod[3] = smh_gram_prod4(smh_gram_key4<8 * G + 3>(w, pre));
+        prod[4] = smh_gram_prod4(smh_gram_key4<8 * G + 4>(w, pre));
+        prod[5] = smh_gram_prod4(smh_gram_key4<8 * G + 5>(w, pre));
+        prod[6] = smh_gram_prod4(smh_gram_key4<8 * G + 6>(w, pre));
+        prod[7] = smh_gram_prod4(smh_gram_key4<8 * G + 7>(w, pre));
+    } else {
     prod[0] = smh_mul24(smh_gram_key<8 * G + 0>(w, pre), SMH_GRAM_MUL_DEV);
     prod[1] = smh_mul24(smh_gram_key<8 * G + 1>(w, pre), SMH_GRAM_MUL_DEV);
     prod[2] = smh_mul24(smh_gram_key<8 * G + 2>(w, pre), SMH_GRAM_MUL_DEV);
@@ -1725,6 +1769,7 @@ SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *
     prod[5] = smh_mul24(smh_gram_key<8 * G + 5>(w, pre), SMH_GRAM_MUL_DEV);
     prod[6] = smh_mul24(smh_gram_key<8 * G + 6>(w, pre), SMH_GRAM_MUL_DEV);
     prod[7] = smh_mul24(smh_gram_key<8 * G + 7>(w, pre), SMH_GRAM_MUL_DEV);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = BIG ? smh_lds_u32(tab, smh_gram_big_dword(prod[j])) : smh_lds_u8(tab, prod[j] >> 15);
 #pragma unroll
@@ -1745,17 +1790,17 @@ SMH_LANE void smh_flat_group(const uint32_t (&w)[16], uint32_t pre, const void *
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
-template <bool K2, bool BIG>
+template <bool K2, bool BIG, bool WIDE = false>
 SMH_LANE void smh_flat_columns(const uint32_t (&w)[16], uint32_t pre, const void *tab, uint32_t &H0, uint32_t &H1)
 {
-    smh_flat_group<0, K2, BIG>(w, pre, tab, H0);
-    smh_flat_group<1, K2, BIG>(w, pre, tab, H0);
-    smh_flat_group<2, K2, BIG>(w, pre, tab, H0);
-    smh_flat_group<3, K2, BIG>(w, pre, tab, H0);
-    smh_flat_group<4, K2, BIG>(w, pre, tab, H1);
-    smh_flat_group<5, K2, BIG>(w, pre, tab, H1);
-    smh_flat_group<6, K2, BIG>(w, pre, tab, H1);
-    smh_flat_group<7, K2, BIG>(w, pre, tab, H1);
+    smh_flat_group<0, K2, BIG, WIDE>(w, pre, tab, H0);
+    smh_flat_group<1, K2, BIG, WIDE>(w, pre, tab, H0);
+    smh_flat_group<2, K2, BIG, WIDE>(w, pre, tab, H0);
+    smh_flat_group<3, K2, BIG, WIDE>(w, pre, tab, H0);
+    smh_flat_group<4, K2, BIG, WIDE>(w, pre, tab, H1);
+    smh_flat_group<5, K2, BIG, WIDE>(w, pre, tab, H1);
+    smh_flat_group<6, K2, BIG, WIDE>(w, pre, tab, H1);
+    smh_flat_group<7, K2, BIG, WIDE>(w, pre, tab, H1);
 }
 /* (hi:lo) << k for 0 < k < 32: bit i of the result = bit i - k of the 64-bit sequence whose upper word is hi */
 SMH_LANE uint32_t smh_shl_across(uint32_t hi, uint32_t lo, uint32_t k) { return (hi << k) | (lo >> (32u - k)); }
@@ -1780,11 +1825,14 @@ SMH_LANE uint64_t smh_flat_candidates(uint32_t Z0, uint32_t Z1, uint32_t Z2, uin
     return ~(((uint64_t)Z2 << 32) | Z1);
 }
 /* the 32 bits in front of the segment at a, true values (the emulator; the GPU takes the previous lane's H1) */
-SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const void *tab, bool k2, bool big)
+SMH_LANE uint32_t smh_flat_history_before(const uint8_t *text, uint64_t a, const void *tab, bool k2, bool big, bool wide = false)
 {
     uint32_t H = 0;
     for (uint64_t x = a >= 32 ? a - 32 : 0; x < a; ++x) {
         uint32_t t = 0; /* a column without a whole gram in front of it cannot be ruled out */
+        if (wide) {
+            if (x >= 3) t = smh_flat_bit((uint32_t)text[x - 3] | ((uint32_t)text[x - 2] << 8) | ((uint32_t)text[x - 1] << 16) | ((uint32_t)text[x] << 24), tab, false, true, true);
+        } else
         if (x >= 2) t = smh_flat_bit((uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16), tab, k2, big);
         H = smh_flat_push(H, t);
     }
@@ -1809,9 +1857,10 @@ SMH_LANE uint32_t smh_gram_state_before(const uint8_t *text, uint64_t a, const v
         /* J - 1 columns of history (J = planes, handed over in place of a table pointer's companion: see callers) */
         return 0u; /* the pair form has its own routine: smh_gram1_state_before */
     } else {
-        if (a < 10) return S;
+        if (a < 11) return S;
         for (uint64_t x = a - 7; x < a; ++x) {
-            const uint32_t key = (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
+            const uint32_t key = smh_kind_wide(KIND) ? (uint32_t)text[x - 3] | ((uint32_t)text[x - 2] << 8) | ((uint32_t)text[x - 1] << 16) | ((uint32_t)text[x] << 24)
+                                                     : (uint32_t)text[x - 2] | ((uint32_t)text[x - 1] << 8) | ((uint32_t)text[x] << 16);
             S = smh_gram_step(S, smh_gram_byte_G<smh_kind_lookup(KIND)>(key, tab, gmask, k2));
         }
     }
@@ -2071,13 +2120,13 @@ SMH_LANE void smh_wm_gram_lane_fast(const uint8_t *text, uint64_t a, const uint3
          * the compiler hoisted all 64 columns' products in front of the branch (128 VGPRs and spills to scratch) */
         (void)pre0;
         uint32_t H0 = 0, H1 = 0, Hp;
-        smh_flat_columns<smh_kind_flat_k2(KIND), smh_kind_big(KIND)>(w, pre1, tab, H0, H1);
+        smh_flat_columns<smh_kind_flat_k2(KIND), smh_kind_big(KIND), smh_kind_wide(KIND)>(w, pre1, tab, H0, H1);
 #if defined(__HIPCC__) && !defined(SMH_HOST_EMU)
         /* the 32 columns in front of the segment: the previous lane's second half; lane 0 of a wave has no neighbour and
          * assumes "all in the set" (a few more columns reach the verify stage, which is exact) */
         Hp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 #else
-        Hp = smh_flat_history_before(text, a, tab, smh_kind_flat_k2(KIND), smh_kind_big(KIND));
+        Hp = smh_flat_history_before(text, a, tab, smh_kind_flat_k2(KIND), smh_kind_big(KIND), smh_kind_wide(KIND));
 #endif
         const uint64_t msk6 = smh_flat_candidates(Hp, H0, H1, (uint32_t)P.gram_planes);
         if constexpr (smh_stg_regv(STG)) {
@@ -2214,7 +2263,7 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
         }
         return cnt5;
     }
-    const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : 3u);
+    const uint64_t q = KIND == 1 ? 7u : (KIND == 3 ? 8u : (smh_kind_wide(KIND) ? 4u : 3u));
     const uint32_t cand_bit = KIND == 1 ? (uint32_t)P.gram_planes - 1u : 7u;
     uint32_t T = KIND == 1 ? smh_gram1_state_before(text, a, P.gram_g7, P.gram_planes)
                            : smh_gram_state_before<KIND>(text, a, tab, P.gram_g7, 0xFFu & ~((1u << (8 - (KIND == 1 ? 8 : P.gram_planes))) - 1u), smh_kind_flat_k2(KIND)), cnt = 0;
@@ -2232,7 +2281,8 @@ SMH_LANE uint32_t smh_wm_gram_lane_slow(const uint8_t *text, uint64_t n, uint64_
                 memcpy(&g, P.gram_g7 + 2u * code, 2);
                 G = g;
             } else {
-                const uint32_t key = (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
+                const uint32_t key = smh_kind_wide(KIND) ? (uint32_t)text[e - 3] | ((uint32_t)text[e - 2] << 8) | ((uint32_t)text[e - 1] << 16) | ((uint32_t)text[e] << 24)
+                                                         : (uint32_t)text[e - 2] | ((uint32_t)text[e - 1] << 8) | ((uint32_t)text[e] << 16);
                 G = smh_gram_byte_G<smh_kind_lookup(KIND)>(key, tab, 0xFFu & ~((1u << (8 - P.gram_planes)) - 1u), smh_kind_flat_k2(KIND));
             }
         }

@@ -299,7 +299,8 @@ typedef struct smh_wm_info {
                                * of the chunk, or the form's own stage (byte forms) */
     uint32_t gram_kind;       /* form of the q-gram filter (== the kernels' KIND template value): 0 none, 1 symbol pairs (7-symbol
                                * grams, two columns per lookup), 2 hashed byte grams (one plane per offset), 3 8-symbol grams, 5 8-symbol
-                               * grams at two columns per lookup, 6 flat byte grams (one Bloom set for all offsets) */
+                               * grams at two columns per lookup, 6 flat byte grams (one Bloom set for all offsets); round 6: 8 / 9 = forms 2 / 6 in a 143.9 KiB
+                               * table, 11 = the flat set over four-byte grams (alphabets whose three-symbol grams a set saturates) */
     uint32_t adaptive;        /* as smh_ac_info.adaptive: this handle also holds an automaton engine and follows the launches' reports */
     uint32_t key_slots;       /* round 5: as smh_ac_info.key_slots */
     uint32_t hash_slots;      /* round 5: slots of the window-hash engine's pattern table (SMH_ENGINE_HASH); 0: the handle keeps none */

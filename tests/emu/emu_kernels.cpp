@@ -295,6 +295,8 @@ static uint64_t wm_gram_grid(const smh_wm *wm, const uint8_t *text, uint64_t n, 
             total += GRAM_STG(3);
         else if (wm->gram_kind == SMH_GRAM_BYTE_BIG) /* the 143.9 KiB table: windows from L2 always (wm_kernels.inc launch_gram) */
             total += stg == 1 ? GRAM_CALL(8, 3) : GRAM_CALL(8, 4);
+        else if (wm->gram_kind == SMH_GRAM_FLAT4_BIG) /* four-byte grams (late round 6) */
+            total += stg == 1 ? GRAM_CALL(11, 3) : GRAM_CALL(11, 4);
         else if (wm->gram_kind == SMH_GRAM_FLAT_BIG && wm->gram_jb > 0)
             total += stg == 1 ? GRAM_CALL(10, 3) : GRAM_CALL(10, 4);
         else if (wm->gram_kind == SMH_GRAM_FLAT_BIG)

@@ -129,7 +129,8 @@ def test_grid_size_does_not_change_the_count():
                                             (3, 4, 32, 500), (2, 256, 5, 300), (2, 256, 12, 3000), (2, 256, 20, 500),
                                             (2, 128, 7, 100),
                                             (8, 256, 5, 300), (8, 256, 12, 3000), (8, 256, 17, 2000), (8, 256, 20, 500), (8, 256, 33, 200), (8, 20, 10, 500),
-                                            (9, 256, 5, 300), (9, 256, 6, 3000), (9, 256, 8, 5000), (9, 256, 12, 3000), (9, 256, 20, 500), (9, 128, 7, 100)])
+                                            (9, 256, 5, 300), (9, 256, 6, 3000), (9, 256, 8, 5000), (9, 256, 12, 3000), (9, 256, 20, 500), (9, 128, 7, 100),
+                                            (11, 20, 8, 10000), (11, 20, 6, 300), (11, 20, 12, 3000), (11, 256, 7, 3000), (11, 256, 20, 500), (11, 128, 33, 100)])
 def test_gram_filter_forms(kind, sigma, m, p, knob):
     """The three q-gram shift-or forms (symbol pairs, 8-symbol grams, hashed byte grams), each forced with the
     development knob so the test does not depend on the cost model: random text with planted occurrences,
@@ -146,8 +147,8 @@ def test_gram_filter_forms(kind, sigma, m, p, knob):
     pat[p // 2] = pat[0]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
     info = wm.info()
-    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2, 9: 2}[kind]) and info.gram_kind == kind
-    assert info.lds_bytes == {3: 65536, 8: 147392, 9: 147392}.get(kind, 131072)
+    assert info.gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2, 9: 2, 11: 3}[kind]) and info.gram_kind == kind
+    assert info.lds_bytes == {3: 65536, 8: 147392, 9: 147392, 11: 147392}.get(kind, 131072)
     if info.scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)

@@ -473,7 +473,8 @@ def test_flat_byte_grams_two_bits_per_gram_on_the_gpu(m, p, form, knob):
                                             (2, 256, 12, 30000), (2, 256, 17, 100000), (2, 256, 18, 1000), (2, 256, 33, 2000),
                                             (2, 256, 34, 2000), (2, 128, 7, 100),
                                             (8, 256, 5, 3000), (8, 256, 12, 30000), (8, 256, 17, 100000), (8, 256, 20, 100000), (8, 256, 33, 2000), (8, 20, 10, 500),
-                                            (9, 256, 5, 3000), (9, 256, 6, 100000), (9, 256, 8, 30000), (9, 256, 9, 100000), (9, 256, 17, 1000), (9, 256, 33, 2000)])
+                                            (9, 256, 5, 3000), (9, 256, 6, 100000), (9, 256, 8, 30000), (9, 256, 9, 100000), (9, 256, 17, 1000), (9, 256, 33, 2000),
+                                            (11, 20, 8, 10000), (11, 20, 6, 300), (11, 20, 12, 30000), (11, 256, 7, 3000), (11, 256, 17, 100000), (11, 128, 33, 2000)])
 def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
     """Each q-gram shift-or form forced (development knob), with the staged verify (window hashes from the LDS copy
     of the chunk, 16- and 32-byte halo, m = 17 / 33 at their limits, m = 34 / 40 beyond them), with the pair form's
@@ -494,7 +495,7 @@ def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
         text[off:off + m] = pat[(7 * i + 3) % p]
     pat[p // 2] = pat[3]  # a duplicate pattern: a column is counted once
     wm = S.WmTables.from_patterns(pat.reshape(-1), m, p, sigma)
-    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2, 9: 2}[kind]) and wm.info().gram_kind == kind
+    assert wm.info().gram_planes == min({1: 15, 5: 16}.get(kind, 8), m - {1: 6, 3: 7, 2: 2, 5: 7, 6: 2, 8: 2, 9: 2, 11: 3}[kind]) and wm.info().gram_kind == kind
     if wm.info().scan_engine != S.ALGO_WM:
         wm.set_scan_engine(S.ALGO_WM)
     want = O.count_bruteforce(pat.reshape(-1), m, p, text)
