@@ -71,6 +71,7 @@ for label, ms_, inst in (("configs[4] WM 100 000, m = 5, 4 GiB", (5,), "wm_gram_
                  traffic(inst, 4).replace(" / ", " (cuckoo verify entries) / ") + (" (m = 6: bucket table)" if " / " in traffic(inst, 4) else "")))
 for label, corpus, sets in (("skewed DNA 8000 × 16 / 32", "dna_repeats", ("ac_8000_m16", "ac_8000_m32")), ("skewed proteins 10 000 × 8 / 1000 × 8 (round 5: 0.449 / 0.452 ms)", "protein_skewed", ("wm_10000_m8", "ac_1000_m8")),
                             ("skewed bytes 100 000 × 8 / 12 / 20 (150–230 true matches per 4 KiB)", "ascii_skewed", ("wm_100000_m8", "wm_100000_m12", "wm_100000_m20")),
+                            ("uniform proteins 10 000 × 8 (round 5: key table, 0.453 ms)", "protein_uniform", ("wm_10000_m8",)),
                             ("skewed DNA 1000 × 8 / 16", "dna_repeats", ("ac_1000_m8", "ac_1000_m16"))):
     ch = [sk[corpus][s]["chosen"] for s in sets]
     rows.append((label, " / ".join(sorted({c["engine"] for c in ch}, key=[c["engine"] for c in ch].index)), " / ".join("%.3f" % c["kernel_ms"] for c in ch) + " ms",
