@@ -1490,7 +1490,10 @@ def main():
     finish(R)
     if not R.parity_ok:
         raise SystemExit("PARITY FAILURE: GPU counts differ from the CPU reference")
-    if R.multi_ok is False:
+    if R.multi_ok is False and R.world == 1:
+        # N = 1: a leg that does not run is a defect of this tree.  N > 1: the per-rank measurement above is complete and verified by
+        # itself; the one-process side leg (a child that opens its own communicator over all devices beside the ranks') stays a flag
+        # on the record (`smh_multi_ok: false`, `smh_multi.error`) and a line on stderr, not an exit code that discards the record
         raise SystemExit("bench.py: the smh_multi leg did not complete (smh_multi_ok false on the record); --no-multi skips it")
 
 
