@@ -957,6 +957,10 @@ extern "C" int smh_ac_scan(smh_ac *ac, const unsigned char *d_text, uint64_t n, 
             } else {
                 A->engine = engine;
             }
+            /* (short texts: the key image instead of a big-table filter, as in smh_wm_scan below) */
+            if (engine == SMH_ALGO_WM && ac->engine_forced < 0 && ac->keys && n < SMH_ADAPT_MIN_BYTES &&
+                (ac_filter_engine(ac)->gram_kind == SMH_GRAM_BYTE_BIG || ac_filter_engine(ac)->gram_kind == SMH_GRAM_FLAT_BIG || ac_filter_engine(ac)->gram_kind == SMH_GRAM_FLAT4_BIG))
+                return keys_launch(ac->keys, d_text, n, d_count, NULL, stream, adapt_arg(A, n, SMH_ENGINE_KEYS, stream));
             const smh_stats_arg SA = adapt_arg(A, n, engine, stream);
             if (engine == SMH_ALGO_WM) return wm_launch_own(ac_filter_engine(ac), d_text, n, d_count, stream, SA, adapt_density(A, ac_filter_engine(ac)));
             if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(ac, d_text, n, d_count, stream, SA);
@@ -1508,6 +1512,14 @@ extern "C" int smh_wm_scan(smh_wm *wm, const unsigned char *d_text, uint64_t n, 
                     A->engine = engine;
                 }
             }
+            /* Short texts (late round 6).  The engines are ranked by ms/GiB, but a launch over a few MiB is mostly its table staging:
+             * 8000 protein patterns over the reference's 10.8 MB A.thaliana.faa take 24.8 us through the four-byte-gram filter (143.9 KiB
+             * of table per workgroup) and 19.5 through the key image (76 KiB), although the filter scans a GiB in 0.28 ms against
+             * 0.46.  The two cross near 30 MiB -- below SMH_ADAPT_MIN_BYTES, where launches do not report -- so a handle that keeps a
+             * key image beside a big-table filter scans such texts with the image.  The handle's engine (A->engine) is left alone. */
+            if (A && engine == SMH_ALGO_WM && wm->engine_forced < 0 && wm->keys && n < SMH_ADAPT_MIN_BYTES &&
+                (wm->gram_kind == SMH_GRAM_BYTE_BIG || wm->gram_kind == SMH_GRAM_FLAT_BIG || wm->gram_kind == SMH_GRAM_FLAT4_BIG))
+                return keys_launch(wm->keys, d_text, n, d_count, NULL, stream, adapt_arg(A, n, SMH_ENGINE_KEYS, stream));
             if (engine == SMH_ALGO_AC) return ac_launch_own(wm_automaton_engine(wm), d_text, n, d_count, stream, adapt_arg(A, n, engine, stream));
             if (engine == SMH_ENGINE_AC_FLAT) return ac_flat_launch(wm->flex_ac, d_text, n, d_count, stream, adapt_arg(A, n, engine, stream));
             if (engine == SMH_ENGINE_KEYS) return keys_launch(wm->keys, d_text, n, d_count, NULL, stream, adapt_arg(A, n, engine, stream));

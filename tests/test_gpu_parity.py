@@ -509,3 +509,30 @@ def test_gram_filter_forms_on_the_gpu(kind, sigma, m, p, stage, knob):
     torch.cuda.synchronize()
     assert int(cur.item()) == want
     assert sorted(out[:want].tolist()) == O.positions_bruteforce(pat.reshape(-1), m, p, text).tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("entry", ["wm", "ac"])
+def test_short_texts_of_a_big_table_handle_go_through_the_key_image(entry):
+    """Late round 6: a handle that keeps a key image beside a big-table filter (8000 protein patterns of 8: the four-byte-gram
+    form) scans texts under 32 MiB with the image -- a launch over a few MiB is mostly its table staging -- and longer ones with
+    the filter; the count is the definition's either way, and the handle's engine is left alone."""
+    import torch
+    sigma, m, p = 20, 8, 8000
+    n_small, n_big = 3 << 20, 40 << 20
+    text = S.corpus_text(n_big, 42, sigma)
+    pat = S.corpus_patterns(m, p, 7, sigma, 42, n_big, 2)
+    h = (S.WmTables if entry == "wm" else S.AcAutomaton).from_patterns(pat, m, p, sigma)
+    info = h.info()
+    assert info.key_slots > 0 and info.adaptive == 1
+    if entry == "wm":
+        assert info.gram_kind == 11
+    d_text = torch.from_numpy(text).cuda()
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (n_small, n_big, n_small):
+        cnt.zero_()
+        h.scan_device(d_text.data_ptr(), n, cnt.data_ptr(), S.VARIANT_TUNED, st)
+        torch.cuda.synchronize()
+        assert int(cnt.item()) == O.count_bruteforce(pat, m, p, text[:n]), n
+    assert h.adapt().engine == (S.ALGO_WM if entry == "wm" else h.adapt().engine)  # the short launches did not move the handle's engine
